@@ -1,0 +1,273 @@
+"""ctypes mirror of the DSV2 C ABI (reference src/dsv.h, dsv_internal.h, dsv_encoder.h,
+dsv_decoder.h).  The same declarations bind oracle/_ref/libdsv2ref.so (the real
+reference, test oracle) and digital-subband-video-2_amd/libdsv2hip.so (the product):
+the product is a drop-in, so the struct layouts are shared.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libdsv2ref.so")
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+HIP_SO = os.path.join(ROOT, "digital-subband-video-2_amd", "libdsv2hip.so")
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "dsv2_ref")
+REF_D28 = os.path.join(ROOT, "oracle", "_ref", "d28dec_ref")
+
+SUBSAMP_444, SUBSAMP_422, SUBSAMP_420 = 0x0, 0x4, 0x5
+BORDER = 32
+
+
+class META(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("width", "height", "subsamp", "fps_num", "fps_den", "aspect_num", "aspect_den",
+                 "inter_sharpen", "reserved")]
+
+
+class PLANE(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("len", C.c_int), ("format", C.c_int),
+                ("stride", C.c_int), ("w", C.c_int), ("h", C.c_int)]
+
+
+class COEFS(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_int32)), ("width", C.c_int), ("height", C.c_int)]
+
+
+class FRAME(C.Structure):
+    _fields_ = [("alloc", C.POINTER(C.c_uint8)), ("planes", PLANE * 3), ("refcount", C.c_int),
+                ("format", C.c_int), ("width", C.c_int), ("height", C.c_int), ("border", C.c_int)]
+
+
+class MV(C.Structure):
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("flags", C.c_uint32), ("err", C.c_uint16),
+                ("dc", C.c_uint16), ("submask", C.c_uint8)]
+
+
+assert C.sizeof(MV) == 16
+
+MV_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("flags", "<u4"), ("err", "<u2"), ("dc", "<u2"),
+                     ("submask", "u1"), ("pad", "u1", 3)])
+assert MV_DTYPE.itemsize == 16
+
+
+class PARAMS(C.Structure):
+    _fields_ = [("vidmeta", C.POINTER(META))] + [(n, C.c_int) for n in
+                ("effort", "do_psy", "is_ref", "has_ref", "blk_w", "blk_h", "nblocks_h", "nblocks_v",
+                 "temporal_mc", "lossless", "reserved")]
+
+
+class BUF(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("len", C.c_uint)]
+
+
+class FMETA(C.Structure):
+    _fields_ = [("params", C.POINTER(PARAMS)), ("mvs", C.POINTER(MV)), ("blockdata", C.POINTER(C.c_uint8)),
+                ("cur_plane", C.c_uint8), ("isP", C.c_uint8), ("fnum", C.c_uint32)]
+
+
+class BS(C.Structure):
+    _fields_ = [("start", C.POINTER(C.c_uint8)), ("pos", C.c_uint)]
+
+
+class STATS(C.Structure):
+    _fields_ = [(n, C.c_uint) for n in
+                ("inum", "pnum", "iqual", "pqual", "iminq", "pminq", "imaxq", "pmaxq", "isize", "psize",
+                 "imins", "pmins", "imaxs", "pmaxs", "mb", "mbI", "mbP", "mbdc", "mbsub")] + \
+               [("mbsubs", C.c_uint * 4)] + \
+               [(n, C.c_uint) for n in ("eprm", "skip", "fpx", "hpx", "qpx", "fpy", "hpy", "qpy", "ifnum", "pfnum")]
+
+
+class ENCODER(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("quality", "effort", "gop", "do_scd", "do_temporal_aq", "do_psy", "do_dark_intra_boost",
+                 "do_intra_filter", "do_inter_filter", "skip_block_thresh", "block_size_override_x",
+                 "block_size_override_y", "variable_i_interval", "rc_mode")] + \
+               [("bitrate", C.c_uint)] + \
+               [(n, C.c_int) for n in
+                ("rc_pergop", "min_q_step", "max_q_step", "min_quality", "max_quality", "min_I_frame_quality",
+                 "prev_I_frame_quality", "intra_pct_thresh", "scene_change_pct")] + \
+               [("stable_refresh", C.c_uint), ("pyramid_levels", C.c_int), ("stats", STATS),
+                ("rc_qual", C.c_uint), ("rf_total", C.c_uint), ("rf_reset", C.c_uint)] + \
+               [(n, C.c_int) for n in
+                ("rf_avg", "total_P_frame_q", "avg_P_frame_q", "prev_complexity", "curr_complexity",
+                 "curr_avgmot", "curr_intra_pct", "curr_scblocks", "prev_chaos", "motion_chaos",
+                 "motion_static", "avg_err", "auto_filter")] + \
+               [("frame_callback", C.c_void_p), ("next_fnum", C.c_uint32), ("ref", C.c_void_p),
+                ("vidmeta", META), ("prev_link", C.c_int), ("force_metadata", C.c_int),
+                ("stability", C.c_void_p), ("refresh_ctr", C.c_uint), ("blockdata", C.c_void_p),
+                ("intra_map", C.c_void_p), ("prev_gop", C.c_uint32), ("prev_quant", C.c_int)]
+
+
+class DECODER(C.Structure):
+    _fields_ = [("vidmeta", META), ("ref", C.c_void_p), ("draw_info", C.c_int), ("got_metadata", C.c_int)]
+
+
+DEC_OK, DEC_ERROR, DEC_EOS, DEC_GOT_META = 0, 1, 2, 3
+
+
+def bind_codec_api(lib):
+    """Declare the prototypes of the public + seam entry points on a loaded library."""
+    P = C.POINTER
+    lib.dsv_enc_init.argtypes = [P(ENCODER)]
+    lib.dsv_enc_free.argtypes = [P(ENCODER)]
+    lib.dsv_enc_set_metadata.argtypes = [P(ENCODER), P(META)]
+    lib.dsv_enc_force_metadata.argtypes = [P(ENCODER)]
+    lib.dsv_enc_start.argtypes = [P(ENCODER)]
+    lib.dsv_enc.argtypes = [P(ENCODER), P(FRAME), P(BUF)]
+    lib.dsv_enc.restype = C.c_int
+    lib.dsv_enc_end_of_stream.argtypes = [P(ENCODER), P(BUF)]
+    lib.dsv_dec.argtypes = [P(DECODER), P(BUF), P(P(FRAME)), P(C.c_uint32)]
+    lib.dsv_dec.restype = C.c_int
+    lib.dsv_get_metadata.argtypes = [P(DECODER)]
+    lib.dsv_get_metadata.restype = P(META)
+    lib.dsv_dec_free.argtypes = [P(DECODER)]
+    lib.dsv_mk_frame.argtypes = [C.c_int] * 4
+    lib.dsv_mk_frame.restype = P(FRAME)
+    lib.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+    lib.dsv_load_planar_frame.restype = P(FRAME)
+    lib.dsv_frame_ref_dec.argtypes = [P(FRAME)]
+    lib.dsv_frame_ref_inc.argtypes = [P(FRAME)]
+    lib.dsv_frame_ref_inc.restype = P(FRAME)
+    lib.dsv_mk_buf.argtypes = [P(BUF), C.c_int]
+    lib.dsv_buf_free.argtypes = [P(BUF)]
+    lib.dsv_alloc.argtypes = [C.c_int]
+    lib.dsv_alloc.restype = C.c_void_p
+    lib.dsv_free.argtypes = [C.c_void_p]
+    lib.dsv_set_log_level.argtypes = [C.c_int]
+    # internal seam (dsv_internal.h:112-147, dsv.h:232-237)
+    lib.dsv_fwd_sbt.argtypes = [P(PLANE), P(COEFS), P(FMETA)]
+    lib.dsv_inv_sbt.argtypes = [P(PLANE), P(COEFS), C.c_int, P(FMETA)]
+    lib.dsv_encode_plane.argtypes = [P(BS), P(COEFS), C.c_int, P(FMETA)]
+    lib.dsv_decode_plane.argtypes = [P(BS), P(COEFS), C.c_int, P(FMETA)]
+    lib.dsv_decode_plane.restype = C.c_int
+    lib.dsv_sub_pred.argtypes = [P(MV), P(PARAMS), P(FRAME), P(FRAME), P(FRAME)]
+    lib.dsv_add_pred.argtypes = [P(MV), P(FMETA), C.c_int, P(FRAME), P(FRAME), P(FRAME), C.c_int]
+    lib.dsv_add_res.argtypes = [P(MV), P(FMETA), C.c_int, P(FRAME), P(FRAME), C.c_int]
+    lib.dsv_intra_filter.argtypes = [C.c_int, P(PARAMS), P(FMETA), C.c_int, P(PLANE), C.c_int]
+    lib.dsv_intra_analysis.argtypes = [P(FRAME), P(PARAMS)]
+    lib.dsv_intra_analysis.restype = P(MV)
+    lib.dsv_ds2x_frame_luma.argtypes = [P(FRAME), P(FRAME)]
+    lib.dsv_extend_frame.argtypes = [P(FRAME)]
+    lib.dsv_extend_frame.restype = P(FRAME)
+    lib.dsv_extend_frame_luma.argtypes = [P(FRAME)]
+    lib.dsv_extend_frame_luma.restype = P(FRAME)
+    lib.dsv_frame_copy.argtypes = [P(FRAME), P(FRAME)]
+    return lib
+
+
+_libs = {}
+
+
+def load(path):
+    if path not in _libs:
+        _libs[path] = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    return _libs[path]
+
+
+def load_ref():
+    return bind_codec_api(load(REF_SO))
+
+
+def load_hip():
+    return bind_codec_api(load(HIP_SO))
+
+
+def load_oracle():
+    return load(ORACLE_SO)
+
+
+def block_geometry(w, h):
+    """Block size rule of the encoder (dsv_encoder.c:1203-1222)."""
+    def s4(d):
+        return 32 if d > 1280 else 16
+    bw, bh = s4(w), s4(h)
+    if abs(w - h) < min(w, h):
+        bw = bh = min(bw, bh)
+    return bw, bh, (w + bw - 1) // bw, (h + bh - 1) // bh
+
+
+class HostFrame:
+    """A bordered planar frame in numpy memory with the reference's layout
+    (frame.c:63-113: 32-px border, stride rounded up to 16) plus its ctypes view."""
+
+    def __init__(self, subsamp, w, h, border=True, fill=None):
+        self.subsamp, self.w, self.h = subsamp, w, h
+        hs, vs = (subsamp >> 2) & 3, subsamp & 3
+        cw, ch = (w + (1 << hs) - 1) >> hs, (h + (1 << vs) - 1) >> vs
+        ext = BORDER if border else 0
+        dims = [(w, h), (cw, ch), (cw, ch)]
+        self.dims = dims
+        self.strides = [((d[0] + 2 * ext + 15) // 16) * 16 for d in dims]
+        lens = [self.strides[i] * (dims[i][1] + 2 * ext) for i in range(3)]
+        self.lens = lens
+        self.buf = np.zeros(sum(lens) + 64, dtype=np.uint8)
+        if fill is not None:
+            self.buf[:] = fill
+        self.ext = ext
+        offs = [0, lens[0], lens[0] + lens[1]]
+        self.offs = [offs[i] + self.strides[i] * ext + ext for i in range(3)]
+        self.full = [self.buf[offs[i]:offs[i] + lens[i]].reshape(dims[i][1] + 2 * ext, self.strides[i])
+                     for i in range(3)]
+        self.c = FRAME()
+        base = self.buf.ctypes.data
+        self.c.alloc = C.cast(base, C.POINTER(C.c_uint8))
+        self.c.refcount = 1 << 20  # never freed by the library
+        self.c.format = subsamp
+        self.c.width, self.c.height = w, h
+        self.c.border = 1 if border else 0
+        for i in range(3):
+            p = self.c.planes[i]
+            p.data = C.cast(base + self.offs[i], C.POINTER(C.c_uint8))
+            p.len = lens[i]
+            p.format = subsamp
+            p.stride = self.strides[i]
+            p.w, p.h = dims[i]
+
+    def plane(self, i):
+        """Visible w x h view of plane i."""
+        e = self.ext
+        w, h = self.dims[i]
+        return self.full[i][e:e + h, e:e + w]
+
+    def set_planes(self, y, u, v):
+        for i, a in enumerate((y, u, v)):
+            self.plane(i)[:, :] = a
+
+    def plane_ptr(self, i):
+        return C.byref(self.c.planes[i])
+
+    def ptr(self):
+        return C.byref(self.c)
+
+
+def mk_params(meta, w, h, isP, lossless=0, do_psy=0xff, effort=10, temporal_mc=0, blk=None):
+    p = PARAMS()
+    p.vidmeta = C.pointer(meta)
+    p.effort, p.do_psy = effort, do_psy
+    p.is_ref, p.has_ref = 1, int(isP)
+    bw, bh, nbh, nbv = block_geometry(w, h) if blk is None else blk
+    p.blk_w, p.blk_h, p.nblocks_h, p.nblocks_v = bw, bh, nbh, nbv
+    p.temporal_mc, p.lossless = temporal_mc, lossless
+    return p
+
+
+def mk_meta(w, h, subsamp, fps=(30, 1), inter_sharpen=1):
+    m = META()
+    m.width, m.height, m.subsamp = w, h, subsamp
+    m.fps_num, m.fps_den = fps
+    m.aspect_num = m.aspect_den = 1
+    m.inter_sharpen = inter_sharpen
+    return m
+
+
+def coef_dims(subsamp, w, h):
+    """frame.c:30-60: chroma coefficient planes are rounded up to even."""
+    hs, vs = (subsamp >> 2) & 3, subsamp & 3
+    cw, ch = (w + (1 << hs) - 1) >> hs, (h + (1 << vs) - 1) >> vs
+    cw, ch = (cw + 1) & ~1, (ch + 1) & ~1
+    return [(w, h), (cw, ch), (cw, ch)]
+
+
+def np_ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
