@@ -1,0 +1,382 @@
+// api_seam.cpp -- the hot-path seam of the C ABI (include/dsv2_hip.h sections 5 and 6).
+//
+// Section 5 functions have the reference's internal signatures (dsv_internal.h:112-147):
+// operands arrive in host memory, are uploaded to HBM, processed by the HIP kernels and
+// downloaded again, so a parity test can call the reference and this library with the
+// very same arguments.  They serialise on one process-wide seam context.
+// Section 6 (dsv2hip_planeset_*) keeps operands resident in HBM for measurement.
+#include <string.h>
+
+#include <mutex>
+
+#include "dev.h"
+
+using namespace dsv2;
+
+namespace {
+
+struct SeamCtx {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    SbtScratch scratch;
+    // cached device objects, re-created when the geometry changes
+    DFrame frame[3];
+    bool frame_ok[3] = {false, false, false};
+    int32_t *coefs = nullptr;
+    size_t coefs_elems = 0;
+    uint8_t *blockdata = nullptr;
+    size_t blockdata_bytes = 0;
+    DSV_MV *mvs = nullptr;
+    size_t mvs_elems = 0;
+
+    void init()
+    {
+        ensure_device();
+        if (!stream) {
+            HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
+    }
+    DFrame *get_frame(int slot, int format, int w, int h)
+    {
+        DFrame *f = &frame[slot];
+        if (frame_ok[slot] && (f->format != format || f->w != w || f->h != h)) {
+            dframe_free(f);
+            frame_ok[slot] = false;
+        }
+        if (!frame_ok[slot]) {
+            dframe_alloc(f, format, w, h);
+            frame_ok[slot] = true;
+        }
+        return f;
+    }
+    int32_t *get_coefs(size_t n)
+    {
+        if (n > coefs_elems) {
+            if (coefs) {
+                HIPCHK(hipFree(coefs));
+            }
+            HIPCHK(hipMalloc((void **) &coefs, n * sizeof(int32_t)));
+            coefs_elems = n;
+        }
+        return coefs;
+    }
+    const uint8_t *put_blockdata(const uint8_t *host, size_t n)
+    {
+        if (!host || n == 0) {
+            return nullptr;
+        }
+        if (n > blockdata_bytes) {
+            if (blockdata) {
+                HIPCHK(hipFree(blockdata));
+            }
+            HIPCHK(hipMalloc((void **) &blockdata, n));
+            blockdata_bytes = n;
+        }
+        HIPCHK(hipMemcpyAsync(blockdata, host, n, hipMemcpyHostToDevice, stream));
+        return blockdata;
+    }
+};
+
+SeamCtx g_seam;
+
+// A DPlane for a lone host DSV_PLANE: device storage with the bordered layout, filled from
+// whatever host memory surrounds the plane when the host plane itself is bordered
+// (stride >= w + 64 is taken as "bordered": the frame layouts of frame.c:88,130).
+struct PlaneStage {
+    uint8_t *dev = nullptr;
+    size_t bytes = 0;
+    DPlane p;
+} g_pstage;
+
+void stage_plane_in(SeamCtx &c, const DSV_PLANE *hp, bool copy_in)
+{
+    int stride = (hp->w + 2 * kBorder + 15) & ~15;
+    size_t bytes = (size_t) stride * (hp->h + 2 * kBorder);
+    if (bytes + 4096 > g_pstage.bytes) {
+        if (g_pstage.dev) {
+            HIPCHK(hipFree(g_pstage.dev));
+        }
+        HIPCHK(hipMalloc((void **) &g_pstage.dev, bytes + 4096));
+        g_pstage.bytes = bytes + 4096;
+    }
+    g_pstage.p.data = g_pstage.dev + (size_t) stride * kBorder + kBorder;
+    g_pstage.p.stride = stride;
+    g_pstage.p.w = hp->w;
+    g_pstage.p.h = hp->h;
+    if (!copy_in) {
+        return;
+    }
+    bool bordered = hp->stride >= hp->w + 2 * kBorder;
+    if (bordered) {
+        // bring the border along: the transform of an odd-width chroma plane reads one column of it
+        HIPCHK(hipMemcpy2DAsync(g_pstage.dev, stride, hp->data - (size_t) hp->stride * kBorder - kBorder, hp->stride,
+                                hp->w + 2 * kBorder, hp->h + 2 * kBorder, hipMemcpyHostToDevice, c.stream));
+    } else {
+        HIPCHK(hipMemsetAsync(g_pstage.dev, 0, bytes, c.stream));
+        HIPCHK(hipMemcpy2DAsync(g_pstage.p.data, stride, hp->data, hp->stride, hp->w, hp->h, hipMemcpyHostToDevice,
+                                c.stream));
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int dsv2hip_device_ok(void)
+{
+    return device_status();
+}
+
+const char *dsv2hip_version(void) { return "dsv2hip 0.1 (DSV2 v2.8 bitstream, encoder v14 / decoder v2 semantics, gfx950)"; }
+
+int dsv2hip_set_device(int ordinal)
+{
+    ensure_device();
+    return hipSetDevice(ordinal) == hipSuccess ? 0 : -1;
+}
+
+void dsv_fwd_sbt(DSV_PLANE *src, DSV_COEFS *dst, DSV_FMETA *fm)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DSV_PARAMS *p = fm->params;
+    size_t n = (size_t) dst->width * dst->height;
+    stage_plane_in(c, src, true);
+    DCoefs dc{c.get_coefs(n), dst->width, dst->height};
+    // (rows of the coefficient plane below the picture are taken as zero: they are for every
+    // plane the codec creates -- the reference leaves the caller's values there, sbt.c:805)
+    BlockMap bm{c.put_blockdata(fm->blockdata, (size_t) p->nblocks_h * p->nblocks_v), p->nblocks_h, p->nblocks_v};
+    sbt_forward(c.stream, g_pstage.p, dc, c.scratch, fm->cur_plane, fm->isP, p->lossless, bm);
+    HIPCHK(hipMemcpyAsync(dst->data, dc.data, n * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+void dsv_inv_sbt(DSV_PLANE *dst, DSV_COEFS *src, int q, DSV_FMETA *fm)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DSV_PARAMS *p = fm->params;
+    size_t n = (size_t) src->width * src->height;
+    stage_plane_in(c, dst, false);
+    DCoefs dc{c.get_coefs(n), src->width, src->height};
+    HIPCHK(hipMemcpyAsync(dc.data, src->data, n * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+    BlockMap bm{c.put_blockdata(fm->blockdata, (size_t) p->nblocks_h * p->nblocks_v), p->nblocks_h, p->nblocks_v};
+    sbt_inverse(c.stream, g_pstage.p, dc, c.scratch, q, fm->cur_plane, fm->isP, p->lossless, bm);
+    HIPCHK(hipMemcpy2DAsync(dst->data, dst->stride, g_pstage.p.data, g_pstage.p.stride, dst->w, dst->h,
+                            hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+DSV_FRAME *dsv_extend_frame(DSV_FRAME *frame)
+{
+    if (!frame->border) {
+        return frame;
+    }
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DFrame *d = c.get_frame(0, frame->format, frame->width, frame->height);
+    dframe_upload(d, frame, c.stream);
+    extend_frame(c.stream, *d, false);
+    dframe_download_full(d, frame, c.stream);
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return frame;
+}
+
+DSV_FRAME *dsv_extend_frame_luma(DSV_FRAME *frame)
+{
+    if (!frame->border) {
+        return frame;
+    }
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DFrame *d = c.get_frame(0, frame->format, frame->width, frame->height);
+    // only the luma plane travels: upload its pixels, extend, download plane 0 with its border
+    const DSV_PLANE *hp = &frame->planes[0];
+    HIPCHK(hipMemcpy2DAsync(d->p[0].data, d->p[0].stride, hp->data, hp->stride, hp->w, hp->h, hipMemcpyHostToDevice,
+                            c.stream));
+    extend_plane(c.stream, d->p[0]);
+    HIPCHK(hipMemcpy2DAsync(hp->data - (size_t) hp->stride * kBorder - kBorder, hp->stride, d->alloc + d->plane_off[0],
+                            d->p[0].stride, hp->w + 2 * kBorder, hp->h + 2 * kBorder, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return frame;
+}
+
+void dsv_frame_copy(DSV_FRAME *dst, DSV_FRAME *src)
+{
+    // pixel copy on the host (frame.c:186-203: src width bytes for each of dst's rows) ...
+    for (int c = 0; c < 3; c++) {
+        const DSV_PLANE *sp = &src->planes[c];
+        DSV_PLANE *dp = &dst->planes[c];
+        for (int y = 0; y < dp->h; y++) {
+            memcpy(dp->data + (size_t) y * dp->stride, sp->data + (size_t) y * sp->stride, (size_t) sp->w);
+        }
+    }
+    // ... and the border synthesis on the GPU
+    if (dst->border) {
+        dsv_extend_frame(dst);
+    }
+}
+
+void dsv_ds2x_frame_luma(DSV_FRAME *dst, DSV_FRAME *src)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DFrame *s = c.get_frame(0, src->format, src->width, src->height);
+    DFrame *d = c.get_frame(1, dst->format, dst->width, dst->height);
+    const DSV_PLANE *sp = &src->planes[0];
+    DSV_PLANE *dp = &dst->planes[0];
+    if (sp->stride >= sp->w + 2 * kBorder) { // bordered source: odd sizes read one row/column of border
+        HIPCHK(hipMemcpy2DAsync(s->alloc + s->plane_off[0], s->p[0].stride, sp->data - (size_t) sp->stride * kBorder - kBorder,
+                                sp->stride, sp->w + 2 * kBorder, sp->h + 2 * kBorder, hipMemcpyHostToDevice, c.stream));
+    } else {
+        HIPCHK(hipMemcpy2DAsync(s->p[0].data, s->p[0].stride, sp->data, sp->stride, sp->w, sp->h, hipMemcpyHostToDevice,
+                                c.stream));
+    }
+    ds2x_luma(c.stream, s->p[0], d->p[0]);
+    HIPCHK(hipMemcpy2DAsync(dp->data, dp->stride, d->p[0].data, d->p[0].stride, dp->w, dp->h, hipMemcpyDeviceToHost,
+                            c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+/* ---- section 6: device-resident plane set ---- */
+
+struct dsv2hip_planeset {
+    hipStream_t stream;
+    DFrame pic;
+    int32_t *coefs[3];
+    int cw[3], ch[3];
+    SbtScratch scratch;
+    uint8_t *bd;
+    int nbh, nbv;
+    hipEvent_t e0, e1;
+};
+
+dsv2hip_planeset *dsv2hip_planeset_create(int format, int width, int height)
+{
+    ensure_device();
+    dsv2hip_planeset *ps = new dsv2hip_planeset();
+    HIPCHK(hipStreamCreateWithFlags(&ps->stream, hipStreamNonBlocking));
+    dframe_alloc(&ps->pic, format, width, height);
+    coef_dims(format, width, height, ps->cw, ps->ch);
+    for (int c = 0; c < 3; c++) {
+        size_t n = (size_t) ps->cw[c] * ps->ch[c];
+        HIPCHK(hipMalloc((void **) &ps->coefs[c], n * sizeof(int32_t)));
+        HIPCHK(hipMemset(ps->coefs[c], 0, n * sizeof(int32_t)));
+    }
+    ps->scratch.ensure((size_t) ps->cw[0] * ps->ch[0]);
+    ps->bd = nullptr;
+    ps->nbh = ps->nbv = 0;
+    HIPCHK(hipEventCreate(&ps->e0));
+    HIPCHK(hipEventCreate(&ps->e1));
+    return ps;
+}
+
+void dsv2hip_planeset_destroy(dsv2hip_planeset *ps)
+{
+    if (!ps) {
+        return;
+    }
+    HIPCHK(hipStreamSynchronize(ps->stream));
+    dframe_free(&ps->pic);
+    for (int c = 0; c < 3; c++) {
+        HIPCHK(hipFree(ps->coefs[c]));
+    }
+    ps->scratch.release();
+    if (ps->bd) {
+        HIPCHK(hipFree(ps->bd));
+    }
+    HIPCHK(hipEventDestroy(ps->e0));
+    HIPCHK(hipEventDestroy(ps->e1));
+    HIPCHK(hipStreamDestroy(ps->stream));
+    delete ps;
+}
+
+int dsv2hip_planeset_upload(dsv2hip_planeset *ps, const DSV_FRAME *frame)
+{
+    dframe_upload(&ps->pic, frame, ps->stream);
+    HIPCHK(hipStreamSynchronize(ps->stream));
+    return 0;
+}
+
+int dsv2hip_planeset_download(dsv2hip_planeset *ps, DSV_FRAME *frame)
+{
+    dframe_download(&ps->pic, frame, ps->stream);
+    HIPCHK(hipStreamSynchronize(ps->stream));
+    return 0;
+}
+
+int dsv2hip_planeset_set_blockdata(dsv2hip_planeset *ps, const uint8_t *blockdata, int nblocks_h, int nblocks_v)
+{
+    size_t n = (size_t) nblocks_h * nblocks_v;
+    if (ps->bd) {
+        HIPCHK(hipFree(ps->bd));
+    }
+    HIPCHK(hipMalloc((void **) &ps->bd, n));
+    HIPCHK(hipMemcpy(ps->bd, blockdata, n, hipMemcpyHostToDevice));
+    ps->nbh = nblocks_h;
+    ps->nbv = nblocks_v;
+    return 0;
+}
+
+int dsv2hip_planeset_fwd_sbt(dsv2hip_planeset *ps, int c, int isP, int lossless)
+{
+    sbt_forward(ps->stream, ps->pic.p[c], DCoefs{ps->coefs[c], ps->cw[c], ps->ch[c]}, ps->scratch, c, isP, lossless,
+                BlockMap{ps->bd, ps->nbh, ps->nbv});
+    return 0;
+}
+
+int dsv2hip_planeset_inv_sbt(dsv2hip_planeset *ps, int c, int q, int isP, int lossless)
+{
+    sbt_inverse(ps->stream, ps->pic.p[c], DCoefs{ps->coefs[c], ps->cw[c], ps->ch[c]}, ps->scratch, q, c, isP, lossless,
+                BlockMap{ps->bd, ps->nbh, ps->nbv});
+    return 0;
+}
+
+int dsv2hip_planeset_get_coefs(dsv2hip_planeset *ps, int c, DSV_SBC *out)
+{
+    HIPCHK(hipMemcpyAsync(out, ps->coefs[c], (size_t) ps->cw[c] * ps->ch[c] * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          ps->stream));
+    HIPCHK(hipStreamSynchronize(ps->stream));
+    return 0;
+}
+
+int dsv2hip_planeset_set_coefs(dsv2hip_planeset *ps, int c, const DSV_SBC *in)
+{
+    HIPCHK(hipMemcpyAsync(ps->coefs[c], in, (size_t) ps->cw[c] * ps->ch[c] * sizeof(int32_t), hipMemcpyHostToDevice,
+                          ps->stream));
+    HIPCHK(hipStreamSynchronize(ps->stream));
+    return 0;
+}
+
+int dsv2hip_planeset_sync(dsv2hip_planeset *ps)
+{
+    HIPCHK(hipStreamSynchronize(ps->stream));
+    return 0;
+}
+
+float dsv2hip_planeset_time_sbt(dsv2hip_planeset *ps, int c, int isP, int lossless, int inverse, int q, int iters)
+{
+    if (iters <= 0) {
+        return -1.0f;
+    }
+    HIPCHK(hipEventRecord(ps->e0, ps->stream));
+    for (int i = 0; i < iters; i++) {
+        if (inverse) {
+            dsv2hip_planeset_inv_sbt(ps, c, q, isP, lossless);
+        } else {
+            dsv2hip_planeset_fwd_sbt(ps, c, isP, lossless);
+        }
+    }
+    HIPCHK(hipEventRecord(ps->e1, ps->stream));
+    HIPCHK(hipEventSynchronize(ps->e1));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, ps->e0, ps->e1));
+    return ms / (float) iters;
+}
+
+} // extern "C"

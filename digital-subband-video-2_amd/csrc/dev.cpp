@@ -1,0 +1,169 @@
+// dev.cpp -- device memory, frame transfer and error plumbing for libdsv2hip.
+#include "dev.h"
+
+#include <mutex>
+
+namespace dsv2 {
+
+[[noreturn]] void fatal(const char *what, const char *file, int line)
+{
+    fprintf(stderr, "[dsv2hip] FATAL: %s (%s:%d)\n", what, file, line);
+    fflush(stderr);
+    abort();
+}
+
+static std::once_flag g_dev_once;
+static int g_dev_status = -1;
+
+static void probe_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_dev_status = -1;
+        return;
+    }
+    g_dev_status = 0;
+}
+
+int device_status()
+{
+    std::call_once(g_dev_once, probe_device);
+    return g_dev_status;
+}
+
+// There is deliberately no CPU path behind this: a missing GPU is a hard error.
+void ensure_device()
+{
+    if (device_status() != 0) {
+        fatal("no usable HIP device: libdsv2hip has no CPU fallback", __FILE__, __LINE__);
+    }
+}
+
+void coef_dims(int format, int w, int h, int cw[3], int ch[3]) // frame.c:30-60
+{
+    int hs = DSV_FORMAT_H_SHIFT(format), vs = DSV_FORMAT_V_SHIFT(format);
+    int c_w = (w + (1 << hs) - 1) >> hs, c_h = (h + (1 << vs) - 1) >> vs;
+    c_w = (c_w + 1) & ~1;
+    c_h = (c_h + 1) & ~1;
+    cw[0] = w;
+    ch[0] = h;
+    cw[1] = cw[2] = c_w;
+    ch[1] = ch[2] = c_h;
+}
+
+void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-113, always bordered
+{
+    ensure_device();
+    int hs = DSV_FORMAT_H_SHIFT(format), vs = DSV_FORMAT_V_SHIFT(format);
+    int cw = (w + (1 << hs) - 1) >> hs, ch = (h + (1 << vs) - 1) >> vs;
+    int pw[3] = {w, cw, cw}, ph[3] = {h, ch, ch};
+    size_t off = 0;
+    f->format = format;
+    f->w = w;
+    f->h = h;
+    for (int c = 0; c < 3; c++) {
+        int stride = (pw[c] + 2 * kBorder + 15) & ~15;
+        f->p[c].stride = stride;
+        f->p[c].w = pw[c];
+        f->p[c].h = ph[c];
+        f->plane_off[c] = off;
+        f->plane_len[c] = (size_t) stride * (ph[c] + 2 * kBorder);
+        off += f->plane_len[c];
+    }
+    f->bytes = off;
+    // slack after the last plane: block reads may run a few bytes past the final border row
+    HIPCHK(hipMalloc((void **) &f->alloc, off + 4096));
+    HIPCHK(hipMemset(f->alloc, 0, off + 4096));
+    for (int c = 0; c < 3; c++) {
+        f->p[c].data = f->alloc + f->plane_off[c] + (size_t) f->p[c].stride * kBorder + kBorder;
+    }
+}
+
+void dframe_free(DFrame *f)
+{
+    if (f->alloc) {
+        HIPCHK(hipFree(f->alloc));
+        f->alloc = nullptr;
+    }
+}
+
+void dframe_upload(DFrame *d, const DSV_FRAME *h, hipStream_t s)
+{
+    for (int c = 0; c < 3; c++) {
+        const DSV_PLANE *hp = &h->planes[c];
+        int w = hp->w < d->p[c].w ? hp->w : d->p[c].w;
+        int rows = hp->h < d->p[c].h ? hp->h : d->p[c].h;
+        HIPCHK(hipMemcpy2DAsync(d->p[c].data, d->p[c].stride, hp->data, hp->stride, w, rows, hipMemcpyHostToDevice, s));
+    }
+}
+
+void dframe_download(const DFrame *d, DSV_FRAME *h, hipStream_t s)
+{
+    for (int c = 0; c < 3; c++) {
+        DSV_PLANE *hp = &h->planes[c];
+        int w = hp->w < d->p[c].w ? hp->w : d->p[c].w;
+        int rows = hp->h < d->p[c].h ? hp->h : d->p[c].h;
+        HIPCHK(hipMemcpy2DAsync(hp->data, hp->stride, d->p[c].data, d->p[c].stride, w, rows, hipMemcpyDeviceToHost, s));
+    }
+}
+
+static bool same_layout(const DFrame *d, const DSV_FRAME *h)
+{
+    if (!h->border) {
+        return false;
+    }
+    for (int c = 0; c < 3; c++) {
+        if (h->planes[c].stride != d->p[c].stride || h->planes[c].w != d->p[c].w || h->planes[c].h != d->p[c].h) {
+            return false;
+        }
+    }
+    return true;
+}
+
+void dframe_upload_full(DFrame *d, const DSV_FRAME *h, hipStream_t s)
+{
+    if (!same_layout(d, h)) {
+        fatal("dframe_upload_full: host frame is not a bordered frame of the same geometry", __FILE__, __LINE__);
+    }
+    for (int c = 0; c < 3; c++) {
+        const uint8_t *hbase = h->planes[c].data - (size_t) h->planes[c].stride * kBorder - kBorder;
+        HIPCHK(hipMemcpyAsync(d->alloc + d->plane_off[c], hbase, d->plane_len[c], hipMemcpyHostToDevice, s));
+    }
+}
+
+void dframe_download_full(const DFrame *d, DSV_FRAME *h, hipStream_t s)
+{
+    if (!same_layout(d, h)) {
+        fatal("dframe_download_full: host frame is not a bordered frame of the same geometry", __FILE__, __LINE__);
+    }
+    for (int c = 0; c < 3; c++) {
+        uint8_t *hbase = h->planes[c].data - (size_t) h->planes[c].stride * kBorder - kBorder;
+        HIPCHK(hipMemcpyAsync(hbase, d->alloc + d->plane_off[c], d->plane_len[c], hipMemcpyDeviceToHost, s));
+    }
+}
+
+void SbtScratch::ensure(size_t n)
+{
+    if (n <= elems) {
+        return;
+    }
+    release();
+    for (int i = 0; i < 3; i++) {
+        HIPCHK(hipMalloc((void **) &t[i], n * sizeof(int32_t)));
+    }
+    elems = n;
+}
+
+void SbtScratch::release()
+{
+    for (int i = 0; i < 3; i++) {
+        if (t[i]) {
+            HIPCHK(hipFree(t[i]));
+            t[i] = nullptr;
+        }
+    }
+    elems = 0;
+}
+
+} // namespace dsv2

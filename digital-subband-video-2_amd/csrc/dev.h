@@ -1,0 +1,97 @@
+// dev.h -- device-side plumbing shared by every kernel group of libdsv2hip.
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   * pictures: planar u8, every plane surrounded by a 32-pixel border, row stride
+//     rounded up to 16 bytes -- byte-identical to the reference's host layout
+//     (frame.c:63-113) so that block reads that run into the border see the same bytes;
+//   * coefficient planes: int32, row stride = plane width, Mallat layout (frame.c:30-60);
+//   * motion vectors: 16-byte DSV_MV records, raster order; blockdata: one flag byte per block.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/dsv2_hip.h"
+
+namespace dsv2 {
+
+[[noreturn]] void fatal(const char *what, const char *file, int line);
+
+#define HIPCHK(expr)                                                   \
+    do {                                                               \
+        hipError_t e__ = (expr);                                       \
+        if (e__ != hipSuccess) {                                       \
+            fprintf(stderr, "[dsv2hip] HIP error %d (%s) ", (int) e__, \
+                    hipGetErrorString(e__));                           \
+            dsv2::fatal(#expr, __FILE__, __LINE__);                    \
+        }                                                              \
+    } while (0)
+
+constexpr int kBorder = 32; // dsv_internal.h:38
+constexpr int kBlockP = 14; // dsv_internal.h:127
+
+struct DPlane {
+    uint8_t *data; // device pointer to pixel (0,0)
+    int stride;
+    int w, h;
+};
+
+struct DFrame {
+    uint8_t *alloc = nullptr;
+    size_t bytes = 0;
+    DPlane p[3];
+    size_t plane_off[3]; // byte offset of each plane's storage (incl. border) inside alloc
+    size_t plane_len[3];
+    int format = 0, w = 0, h = 0;
+};
+
+struct DCoefs {
+    int32_t *data;
+    int w, h;
+};
+
+// per-block geometry + flags needed by adaptive stages
+struct BlockMap {
+    const uint8_t *bd; // device blockdata (may be null when unused)
+    int nbh, nbv;
+};
+
+void dframe_alloc(DFrame *f, int format, int w, int h);
+void dframe_free(DFrame *f);
+// copy between a host DSV_FRAME (any stride, bordered or not) and a device frame: visible pixels only
+void dframe_upload(DFrame *d, const DSV_FRAME *h, hipStream_t s);
+void dframe_download(const DFrame *d, DSV_FRAME *h, hipStream_t s);
+// whole storage including borders (host frame must be bordered with the reference layout)
+void dframe_upload_full(DFrame *d, const DSV_FRAME *h, hipStream_t s);
+void dframe_download_full(const DFrame *d, DSV_FRAME *h, hipStream_t s);
+
+void coef_dims(int format, int w, int h, int cw[3], int ch[3]);
+
+// scratch images for the transform: three int32 planes of the luma coefficient size
+struct SbtScratch {
+    int32_t *t[3] = {nullptr, nullptr, nullptr};
+    size_t elems = 0;
+    void ensure(size_t n);
+    void release();
+};
+
+// --- subband transform (sbt.hip) ------------------------------------------------
+// forward: u8 plane -> coefs (cw x ch).  inverse: coefs -> u8 plane (coefs preserved).
+void sbt_forward(hipStream_t s, const DPlane &src, DCoefs dst, SbtScratch &sc, int plane_idx, int isP,
+                 int lossless, BlockMap bm);
+void sbt_inverse(hipStream_t s, DPlane dst, DCoefs src, SbtScratch &sc, int q, int plane_idx, int isP,
+                 int lossless, BlockMap bm);
+
+// --- picture helpers (frame.hip) ---------------------------------------------------
+void extend_plane(hipStream_t s, const DPlane &p);
+void extend_frame(hipStream_t s, const DFrame &f, bool luma_only);
+void ds2x_luma(hipStream_t s, const DPlane &src, const DPlane &dst);
+void copy_frame_pixels(hipStream_t s, const DFrame &dst, const DFrame &src);
+void copy_frame_full(hipStream_t s, const DFrame &dst, const DFrame &src);
+
+void ensure_device();
+int device_status(); // 0 = usable HIP device present
+
+} // namespace dsv2

@@ -106,53 +106,62 @@ class DECODER(C.Structure):
 DEC_OK, DEC_ERROR, DEC_EOS, DEC_GOT_META = 0, 1, 2, 3
 
 
+def _set(lib, name, attr, value):
+    """Set a prototype if the library exports the symbol (tests/test_abi_exports.py is the strict check)."""
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        return
+    setattr(fn, attr, value)
+
+
 def bind_codec_api(lib):
     """Declare the prototypes of the public + seam entry points on a loaded library."""
     P = C.POINTER
-    lib.dsv_enc_init.argtypes = [P(ENCODER)]
-    lib.dsv_enc_free.argtypes = [P(ENCODER)]
-    lib.dsv_enc_set_metadata.argtypes = [P(ENCODER), P(META)]
-    lib.dsv_enc_force_metadata.argtypes = [P(ENCODER)]
-    lib.dsv_enc_start.argtypes = [P(ENCODER)]
-    lib.dsv_enc.argtypes = [P(ENCODER), P(FRAME), P(BUF)]
-    lib.dsv_enc.restype = C.c_int
-    lib.dsv_enc_end_of_stream.argtypes = [P(ENCODER), P(BUF)]
-    lib.dsv_dec.argtypes = [P(DECODER), P(BUF), P(P(FRAME)), P(C.c_uint32)]
-    lib.dsv_dec.restype = C.c_int
-    lib.dsv_get_metadata.argtypes = [P(DECODER)]
-    lib.dsv_get_metadata.restype = P(META)
-    lib.dsv_dec_free.argtypes = [P(DECODER)]
-    lib.dsv_mk_frame.argtypes = [C.c_int] * 4
-    lib.dsv_mk_frame.restype = P(FRAME)
-    lib.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
-    lib.dsv_load_planar_frame.restype = P(FRAME)
-    lib.dsv_frame_ref_dec.argtypes = [P(FRAME)]
-    lib.dsv_frame_ref_inc.argtypes = [P(FRAME)]
-    lib.dsv_frame_ref_inc.restype = P(FRAME)
-    lib.dsv_mk_buf.argtypes = [P(BUF), C.c_int]
-    lib.dsv_buf_free.argtypes = [P(BUF)]
-    lib.dsv_alloc.argtypes = [C.c_int]
-    lib.dsv_alloc.restype = C.c_void_p
-    lib.dsv_free.argtypes = [C.c_void_p]
-    lib.dsv_set_log_level.argtypes = [C.c_int]
+    _set(lib, 'dsv_enc_init', 'argtypes', [P(ENCODER)])
+    _set(lib, 'dsv_enc_free', 'argtypes', [P(ENCODER)])
+    _set(lib, 'dsv_enc_set_metadata', 'argtypes', [P(ENCODER), P(META)])
+    _set(lib, 'dsv_enc_force_metadata', 'argtypes', [P(ENCODER)])
+    _set(lib, 'dsv_enc_start', 'argtypes', [P(ENCODER)])
+    _set(lib, 'dsv_enc', 'argtypes', [P(ENCODER), P(FRAME), P(BUF)])
+    _set(lib, 'dsv_enc', 'restype', C.c_int)
+    _set(lib, 'dsv_enc_end_of_stream', 'argtypes', [P(ENCODER), P(BUF)])
+    _set(lib, 'dsv_dec', 'argtypes', [P(DECODER), P(BUF), P(P(FRAME)), P(C.c_uint32)])
+    _set(lib, 'dsv_dec', 'restype', C.c_int)
+    _set(lib, 'dsv_get_metadata', 'argtypes', [P(DECODER)])
+    _set(lib, 'dsv_get_metadata', 'restype', P(META))
+    _set(lib, 'dsv_dec_free', 'argtypes', [P(DECODER)])
+    _set(lib, 'dsv_mk_frame', 'argtypes', [C.c_int] * 4)
+    _set(lib, 'dsv_mk_frame', 'restype', P(FRAME))
+    _set(lib, 'dsv_load_planar_frame', 'argtypes', [C.c_int, C.c_void_p, C.c_int, C.c_int])
+    _set(lib, 'dsv_load_planar_frame', 'restype', P(FRAME))
+    _set(lib, 'dsv_frame_ref_dec', 'argtypes', [P(FRAME)])
+    _set(lib, 'dsv_frame_ref_inc', 'argtypes', [P(FRAME)])
+    _set(lib, 'dsv_frame_ref_inc', 'restype', P(FRAME))
+    _set(lib, 'dsv_mk_buf', 'argtypes', [P(BUF), C.c_int])
+    _set(lib, 'dsv_buf_free', 'argtypes', [P(BUF)])
+    _set(lib, 'dsv_alloc', 'argtypes', [C.c_int])
+    _set(lib, 'dsv_alloc', 'restype', C.c_void_p)
+    _set(lib, 'dsv_free', 'argtypes', [C.c_void_p])
+    _set(lib, 'dsv_set_log_level', 'argtypes', [C.c_int])
     # internal seam (dsv_internal.h:112-147, dsv.h:232-237)
-    lib.dsv_fwd_sbt.argtypes = [P(PLANE), P(COEFS), P(FMETA)]
-    lib.dsv_inv_sbt.argtypes = [P(PLANE), P(COEFS), C.c_int, P(FMETA)]
-    lib.dsv_encode_plane.argtypes = [P(BS), P(COEFS), C.c_int, P(FMETA)]
-    lib.dsv_decode_plane.argtypes = [P(BS), P(COEFS), C.c_int, P(FMETA)]
-    lib.dsv_decode_plane.restype = C.c_int
-    lib.dsv_sub_pred.argtypes = [P(MV), P(PARAMS), P(FRAME), P(FRAME), P(FRAME)]
-    lib.dsv_add_pred.argtypes = [P(MV), P(FMETA), C.c_int, P(FRAME), P(FRAME), P(FRAME), C.c_int]
-    lib.dsv_add_res.argtypes = [P(MV), P(FMETA), C.c_int, P(FRAME), P(FRAME), C.c_int]
-    lib.dsv_intra_filter.argtypes = [C.c_int, P(PARAMS), P(FMETA), C.c_int, P(PLANE), C.c_int]
-    lib.dsv_intra_analysis.argtypes = [P(FRAME), P(PARAMS)]
-    lib.dsv_intra_analysis.restype = P(MV)
-    lib.dsv_ds2x_frame_luma.argtypes = [P(FRAME), P(FRAME)]
-    lib.dsv_extend_frame.argtypes = [P(FRAME)]
-    lib.dsv_extend_frame.restype = P(FRAME)
-    lib.dsv_extend_frame_luma.argtypes = [P(FRAME)]
-    lib.dsv_extend_frame_luma.restype = P(FRAME)
-    lib.dsv_frame_copy.argtypes = [P(FRAME), P(FRAME)]
+    _set(lib, 'dsv_fwd_sbt', 'argtypes', [P(PLANE), P(COEFS), P(FMETA)])
+    _set(lib, 'dsv_inv_sbt', 'argtypes', [P(PLANE), P(COEFS), C.c_int, P(FMETA)])
+    _set(lib, 'dsv_encode_plane', 'argtypes', [P(BS), P(COEFS), C.c_int, P(FMETA)])
+    _set(lib, 'dsv_decode_plane', 'argtypes', [P(BS), P(COEFS), C.c_int, P(FMETA)])
+    _set(lib, 'dsv_decode_plane', 'restype', C.c_int)
+    _set(lib, 'dsv_sub_pred', 'argtypes', [P(MV), P(PARAMS), P(FRAME), P(FRAME), P(FRAME)])
+    _set(lib, 'dsv_add_pred', 'argtypes', [P(MV), P(FMETA), C.c_int, P(FRAME), P(FRAME), P(FRAME), C.c_int])
+    _set(lib, 'dsv_add_res', 'argtypes', [P(MV), P(FMETA), C.c_int, P(FRAME), P(FRAME), C.c_int])
+    _set(lib, 'dsv_intra_filter', 'argtypes', [C.c_int, P(PARAMS), P(FMETA), C.c_int, P(PLANE), C.c_int])
+    _set(lib, 'dsv_intra_analysis', 'argtypes', [P(FRAME), P(PARAMS)])
+    _set(lib, 'dsv_intra_analysis', 'restype', P(MV))
+    _set(lib, 'dsv_ds2x_frame_luma', 'argtypes', [P(FRAME), P(FRAME)])
+    _set(lib, 'dsv_extend_frame', 'argtypes', [P(FRAME)])
+    _set(lib, 'dsv_extend_frame', 'restype', P(FRAME))
+    _set(lib, 'dsv_extend_frame_luma', 'argtypes', [P(FRAME)])
+    _set(lib, 'dsv_extend_frame_luma', 'restype', P(FRAME))
+    _set(lib, 'dsv_frame_copy', 'argtypes', [P(FRAME), P(FRAME)])
     return lib
 
 
