@@ -9,7 +9,10 @@
 
 #include <mutex>
 
+#include <vector>
+
 #include "dev.h"
+#include "quant.h"
 
 using namespace dsv2;
 
@@ -28,6 +31,12 @@ struct SeamCtx {
     size_t blockdata_bytes = 0;
     DSV_MV *mvs = nullptr;
     size_t mvs_elems = 0;
+    int32_t *qv = nullptr;
+    size_t qv_elems = 0;
+    Compactor comp;
+    uint32_t *sym_pos = nullptr;
+    int32_t *sym_val = nullptr;
+    size_t sym_elems = 0;
 
     void init()
     {
@@ -59,6 +68,44 @@ struct SeamCtx {
             coefs_elems = n;
         }
         return coefs;
+    }
+    const DSV_MV *put_mvs(const DSV_MV *host, size_t n)
+    {
+        if (!host || n == 0) {
+            return nullptr;
+        }
+        if (n > mvs_elems) {
+            if (mvs) {
+                HIPCHK(hipFree(mvs));
+            }
+            HIPCHK(hipMalloc((void **) &mvs, n * sizeof(DSV_MV)));
+            mvs_elems = n;
+        }
+        HIPCHK(hipMemcpyAsync(mvs, host, n * sizeof(DSV_MV), hipMemcpyHostToDevice, stream));
+        return mvs;
+    }
+    int32_t *get_qv(size_t n)
+    {
+        if (n > qv_elems) {
+            if (qv) {
+                HIPCHK(hipFree(qv));
+            }
+            HIPCHK(hipMalloc((void **) &qv, n * sizeof(int32_t)));
+            qv_elems = n;
+        }
+        return qv;
+    }
+    void get_syms(size_t n)
+    {
+        if (n > sym_elems) {
+            if (sym_pos) {
+                HIPCHK(hipFree(sym_pos));
+                HIPCHK(hipFree(sym_val));
+            }
+            HIPCHK(hipMalloc((void **) &sym_pos, n * sizeof(uint32_t)));
+            HIPCHK(hipMalloc((void **) &sym_val, n * sizeof(int32_t)));
+            sym_elems = n;
+        }
     }
     const uint8_t *put_blockdata(const uint8_t *host, size_t n)
     {
@@ -167,6 +214,89 @@ void dsv_inv_sbt(DSV_PLANE *dst, DSV_COEFS *src, int q, DSV_FMETA *fm)
     HIPCHK(hipMemcpy2DAsync(dst->data, dst->stride, g_pstage.p.data, g_pstage.p.stride, dst->w, dst->h,
                             hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+static QuantCfg make_quant_cfg(SeamCtx &c, const DSV_COEFS *co, const DSV_FMETA *fm)
+{
+    DSV_PARAMS *p = fm->params;
+    size_t nb = (size_t) p->nblocks_h * p->nblocks_v;
+    QuantCfg cfg;
+    cfg.w = co->width;
+    cfg.h = co->height;
+    cfg.plane = fm->cur_plane;
+    cfg.isP = fm->isP;
+    cfg.lossless = p->lossless;
+    cfg.do_psy = p->do_psy;
+    cfg.hshift = DSV_FORMAT_H_SHIFT(p->vidmeta->subsamp);
+    cfg.vshift = DSV_FORMAT_V_SHIFT(p->vidmeta->subsamp);
+    cfg.blk_w = p->blk_w;
+    cfg.blk_h = p->blk_h;
+    cfg.nbh = p->nblocks_h;
+    cfg.nbv = p->nblocks_v;
+    cfg.bd = c.put_blockdata(fm->blockdata, nb);
+    cfg.mvs = fm->isP ? c.put_mvs(fm->mvs, nb) : nullptr; // I frames never dereference it (hzcc.c:367-372)
+    return cfg;
+}
+
+void dsv_encode_plane(DSV_BS *bs, DSV_COEFS *src, int q, DSV_FMETA *fm)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    size_t n = (size_t) src->width * src->height;
+    ScanGeom g;
+    make_scan(&g, src->width, src->height);
+    DCoefs dc{c.get_coefs(n), src->width, src->height};
+    HIPCHK(hipMemcpyAsync(dc.data, src->data, n * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+    QuantCfg cfg = make_quant_cfg(c, src, fm);
+    int32_t *qv = c.get_qv((size_t) g.base[10]);
+    quant_plane(c.stream, dc, qv, cfg, q);
+    c.comp.run(c.stream, qv, (size_t) g.base[10]);
+    HIPCHK(hipMemcpyAsync(src->data, dc.data, n * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    int nsym = *c.comp.h_total;
+    std::vector<uint32_t> pos((size_t) nsym);
+    std::vector<int32_t> val((size_t) nsym);
+    if (nsym) {
+        HIPCHK(hipMemcpy(pos.data(), c.comp.d_pos, (size_t) nsym * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(val.data(), c.comp.d_val, (size_t) nsym * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    BitWriter bw{bs->start, bs->pos};
+    entropy_encode_plane(bw, src->data[0], pos.data(), val.data(), nsym, g);
+    bs->pos = bw.pos;
+}
+
+int dsv_decode_plane(DSV_BS *bs, DSV_COEFS *dst, int q, DSV_FMETA *fm)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    size_t n = (size_t) dst->width * dst->height;
+    ScanGeom g;
+    make_scan(&g, dst->width, dst->height);
+    std::vector<uint32_t> pos((size_t) g.base[10]);
+    std::vector<int32_t> val((size_t) g.base[10]);
+    int seg_count[4];
+    int32_t LL = 0;
+    BitReader br{bs->start, bs->pos};
+    int ok = entropy_decode_plane(br, &LL, pos.data(), val.data(), seg_count, g);
+    bs->pos = br.pos;
+    int nsym = seg_count[0] + seg_count[1] + seg_count[2] + seg_count[3];
+    DCoefs dc{c.get_coefs(n), dst->width, dst->height};
+    HIPCHK(hipMemcpyAsync(dc.data, dst->data, n * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+    QuantCfg cfg = make_quant_cfg(c, dst, fm);
+    c.get_syms((size_t) (nsym > 0 ? nsym : 1));
+    if (nsym) {
+        HIPCHK(hipMemcpyAsync(c.sym_pos, pos.data(), (size_t) nsym * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipMemcpyAsync(c.sym_val, val.data(), (size_t) nsym * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+        dequant_plane(c.stream, dc, c.sym_pos, c.sym_val, seg_count, cfg, q);
+    }
+    HIPCHK(hipMemcpyAsync(dst->data, dc.data, n * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (ok >= 0) {
+        dst->data[0] = LL; // hzcc.c:633
+    }
+    return ok > 0;
 }
 
 DSV_FRAME *dsv_extend_frame(DSV_FRAME *frame)

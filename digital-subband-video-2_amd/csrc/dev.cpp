@@ -138,8 +138,10 @@ void dframe_download_full(const DFrame *d, DSV_FRAME *h, hipStream_t s)
         fatal("dframe_download_full: host frame is not a bordered frame of the same geometry", __FILE__, __LINE__);
     }
     for (int c = 0; c < 3; c++) {
+        // pixels + border only: the stride padding to the right of the border is left untouched
         uint8_t *hbase = h->planes[c].data - (size_t) h->planes[c].stride * kBorder - kBorder;
-        HIPCHK(hipMemcpyAsync(hbase, d->alloc + d->plane_off[c], d->plane_len[c], hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpy2DAsync(hbase, h->planes[c].stride, d->alloc + d->plane_off[c], d->p[c].stride,
+                                d->p[c].w + 2 * kBorder, d->p[c].h + 2 * kBorder, hipMemcpyDeviceToHost, s));
     }
 }
 

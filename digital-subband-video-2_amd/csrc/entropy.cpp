@@ -1,0 +1,269 @@
+// entropy.cpp -- host-side serial entropy back end: the bit codes of reference src/bs.c
+// (UEG :132, SEG :175, NEG :206, adaptive Rice :237, zero-bit RLE :284-330) and the
+// symbol-stream half of src/hzcc.c (run lengths carried across subbands :242, one adaptive
+// Rice state per plane :247, 24-bit symbol count :251/:445, end-of-plane byte 0x55 :604).
+// It consumes the scan-ordered nonzero symbols produced by quant.hip; it is not a kernel
+// because every code length depends on the adaptive state left by the previous symbol.
+#include <string.h>
+
+#include "quant.h"
+
+namespace dsv2 {
+
+void BitWriter::put_bits(unsigned n, unsigned v)
+{
+    while (n > 0) {
+        unsigned room = 8 - (pos & 7);
+        unsigned take = n < room ? n : room;
+        unsigned chunk = (v >> (n - take)) & ((1u << take) - 1);
+        start[pos >> 3] |= (uint8_t) (chunk << (room - take));
+        pos += take;
+        n -= take;
+    }
+}
+
+void BitWriter::put_ueg(unsigned v)
+{
+    v++;
+    int nb = 31 - __builtin_clz(v);
+    for (int i = nb - 1; i >= 0; i--) {
+        pos++; // a zero bit
+        put_bit((v >> i) & 1);
+    }
+    put_bit(1);
+}
+
+void BitWriter::put_seg(int v)
+{
+    int s = v < 0;
+    unsigned a = (unsigned) (s ? -v : v);
+    put_ueg(a);
+    if (a) {
+        put_bit(s);
+    }
+}
+
+void BitWriter::put_neg(int v)
+{
+    int s = v < 0;
+    unsigned a = (unsigned) (s ? -v : v);
+    put_ueg(a - 1);
+    if (a) {
+        put_bit(s);
+    }
+}
+
+void BitWriter::put_nrice(int v, int *rk, int damp)
+{
+    unsigned u = ((unsigned) (2 * v) ^ (v < 0 ? ~0u : 0u)) - 1;
+    unsigned k = (unsigned) (*rk >> damp), qq = u >> k;
+    if (qq) {
+        (*rk)++;
+    } else if (*rk > 0) {
+        (*rk)--;
+    }
+    pos += qq; // qq zero bits
+    put_bit(1);
+    if (k) {
+        put_bits(k, u & ((1u << k) - 1));
+    }
+}
+
+void BitWriter::concat(const uint8_t *data, int len)
+{
+    if (len > 0) {
+        memcpy(start + (pos >> 3), data, (size_t) len);
+        pos += (unsigned) len * 8;
+    }
+}
+
+unsigned BitReader::get_bits(unsigned n)
+{
+    unsigned out = 0;
+    while (n > 0) {
+        unsigned room = 8 - (pos & 7);
+        unsigned take = n < room ? n : room;
+        unsigned chunk = (start[pos >> 3] >> (room - take)) & ((1u << take) - 1);
+        out = (out << take) | chunk;
+        pos += take;
+        n -= take;
+    }
+    return out;
+}
+
+unsigned BitReader::get_ueg()
+{
+    unsigned v = 1;
+    while (!get_bit()) {
+        v = (v << 1) | get_bit();
+    }
+    return v - 1;
+}
+
+int BitReader::get_seg()
+{
+    int v = (int) get_ueg();
+    if (v && get_bit()) {
+        return -v;
+    }
+    return v;
+}
+
+int BitReader::get_neg()
+{
+    int v = (int) get_ueg() + 1;
+    if (v && get_bit()) {
+        return -v;
+    }
+    return v;
+}
+
+int BitReader::get_nrice(int *rk, int damp)
+{
+    int k = *rk >> damp;
+    unsigned qq = 0;
+    while (!get_bit()) {
+        qq++;
+    }
+    if (qq) {
+        (*rk)++;
+    } else if (*rk > 0) {
+        (*rk)--;
+    }
+    unsigned u = ((qq << k) | get_bits((unsigned) k)) + 1;
+    return (int) ((u >> 1) ^ (0u - (u & 1)));
+}
+
+void RleWriter::put(int b)
+{
+    if (b) {
+        bw.put_ueg((unsigned) nz);
+        nz = 0;
+    } else {
+        nz++;
+    }
+}
+
+int RleWriter::finish()
+{
+    bw.put_ueg((unsigned) nz);
+    nz = 0;
+    bw.align();
+    return (int) bw.byte_pos();
+}
+
+int RleReader::get()
+{
+    if (nz == 0) {
+        nz = (int) br.get_ueg();
+        return nz == 0;
+    }
+    nz--;
+    return nz == 0;
+}
+
+void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const int32_t *val, int n, const ScanGeom &g)
+{
+    bw.align();
+    unsigned plane_start = bw.pos;
+    bw.pos += 32; // byte length, patched below
+    bw.put_seg(LL);
+    bw.align();
+    unsigned count_at = bw.pos;
+    bw.pos += 24;
+    bw.align();
+
+    int vk = 0, seg = 0;
+    uint32_t prev_end = 0; // scan position following the previous nonzero
+    for (int i = 0; i < n; i++) {
+        uint32_t p = pos[i];
+        while (p >= (uint32_t) g.base[seg + 1]) {
+            seg++;
+        }
+        bw.put_ueg(p - prev_end);
+        if (seg == 0) {
+            bw.put_neg(val[i]);
+        } else {
+            bw.put_nrice(val[i], &vk, 3 + (seg - 1) / 3);
+        }
+        prev_end = p + 1;
+    }
+    bw.align();
+    unsigned after = bw.pos;
+    bw.pos = count_at;
+    bw.put_bits(24, (unsigned) n);
+    bw.pos = after;
+    bw.put_bits(8, 0x55);
+    bw.align();
+    unsigned plane_end = bw.pos;
+    bw.pos = plane_start;
+    bw.put_bits(32, (plane_end - plane_start) / 8 - 4);
+    bw.pos = plane_end;
+}
+
+int entropy_decode_plane(BitReader &br, int32_t *LL, uint32_t *pos, int32_t *val, int seg_count[4], const ScanGeom &g)
+{
+    seg_count[0] = seg_count[1] = seg_count[2] = seg_count[3] = 0;
+    br.align();
+    unsigned plen = br.get_bits(32);
+    br.align();
+    if (!(plen > 0 && plen < (unsigned) g.w * g.h * sizeof(int32_t) * 2)) {
+        return -1; // "plane length was strange" (hzcc.c:645): nothing is stored
+    }
+    unsigned start = br.byte_pos();
+    unsigned limit = start + plen;
+    *LL = br.get_seg();
+    br.align();
+    int runs = (int) br.get_bits(24);
+    br.align();
+
+    int vk = 0, n = 0;
+    int ok = 1;
+    // position of the next nonzero = current position + run
+    uint32_t cur = 0;
+    uint32_t total = (uint32_t) g.base[10];
+    bool truncated = false;
+    while (runs-- > 0) {
+        uint32_t run = br.get_ueg();
+        uint64_t p = (uint64_t) cur + run;
+        if (p >= total) {
+            break; // the run walks off the plane: nothing further is placed (hzcc.c:481-581 with run never reaching 0)
+        }
+        int seg = 0;
+        while (p >= (uint32_t) g.base[seg + 1]) {
+            seg++;
+        }
+        int v = seg == 0 ? br.get_neg() : br.get_nrice(&vk, 3 + (seg - 1) / 3);
+        // the reference reads the next run before its overrun check (hzcc.c:525-529), so a symbol whose
+        // successor's run crosses the plane-length limit is dropped together with everything after it
+        if (runs > 0) {
+            BitReader peek = br;
+            peek.get_ueg();
+            if (peek.byte_pos() >= limit) {
+                truncated = true;
+            }
+        } else if (br.byte_pos() >= limit) {
+            truncated = true;
+        }
+        if (truncated) {
+            break;
+        }
+        pos[n] = (uint32_t) p;
+        val[n] = v;
+        n++;
+        seg_count[seg == 0 ? 0 : 1 + (seg - 1) / 3]++;
+        cur = (uint32_t) p + 1;
+    }
+    if (!truncated) {
+        br.align();
+        if (br.get_bits(8) != 0x55) {
+            ok = 0; // "bad eop" (hzcc.c:636)
+        }
+    } else {
+        ok = 0;
+    }
+    br.pos = (start + plen) * 8;
+    return ok;
+}
+
+} // namespace dsv2

@@ -1,0 +1,590 @@
+// quant.hip -- per-subband adaptive quantisation / dequantisation ("HZCC" quant half)
+// and ordered nonzero compaction on gfx950.
+//
+// Replaces the arithmetic of reference src/hzcc.c: hzcc_enc (:235) quantise+dequantise in
+// place, lfquant (:89), hfquant (:108), TMQ4POS_P/I (:164/:171), quantSUB (:209),
+// dequantS/D (:217/:224), and the dequantisation half of hzcc_dec (:451).  The serial
+// adaptive entropy coder (zero runs + NEG / adaptive Rice) stays on the host (entropy.cpp):
+// the GPU hands it the nonzero symbols already compacted in scan order.
+//
+// Decomposition (proved bit-exact on the CPU by oracle/orc_hzcc.c):
+//   pass LL, then passes l = 0,1,2; within a pass every coefficient is independent except
+//   the "dependent" last column / row of a level whose parent cell lies in the first
+//   column / row of the same level when subband sizes are odd (the reference rounds every
+//   scanned size up, hzcc.c:40-57, so adjacent levels overlap by one line).  Dependents
+//   run as a tiny second launch of the pass.
+#include "dev.h"
+#include "quant.h"
+
+namespace dsv2 {
+
+static inline int rshift_up(int x, int s) { return (x + (1 << s) - 1) >> s; }
+static inline int h_dimat(int level, int v) { return rshift_up(v, 3 - level); }
+static inline int h_subband_off(int level, int sub, int w, int h)
+{
+    int o = 0;
+    if (sub & 1) {
+        o += rshift_up(w, 3 - level);
+    }
+    if (sub & 2) {
+        o += rshift_up(h, 3 - level) * w;
+    }
+    return o;
+}
+
+static int udiv_up(int a, int b) { return (a + b - 1) / b; }
+
+int spatial_psy_factor(int blk_w, int blk_h, int nbh, int nbv, int sub) // hzcc.c:67
+{
+    int scale, lo, hi;
+    if (sub == 1) {
+        lo = udiv_up(352, blk_w);
+        hi = udiv_up(1920, blk_w);
+        scale = nbh;
+    } else if (sub == 2) {
+        lo = udiv_up(288, blk_h);
+        hi = udiv_up(1080, blk_h);
+        scale = nbv;
+    } else {
+        lo = udiv_up(352, blk_w) * udiv_up(288, blk_h);
+        hi = udiv_up(1920, blk_w) * udiv_up(1080, blk_h);
+        scale = nbh * nbv;
+    }
+    scale = scale - lo > 0 ? scale - lo : 0;
+    return (scale << 7) / (hi - lo);
+}
+
+static int lfquant(const QuantCfg &c, int q) // hzcc.c:89
+{
+    int pf = spatial_psy_factor(c.blk_w, c.blk_h, c.nbh, c.nbv, 3);
+    q -= (q * pf >> 10);
+    q = q > 8 ? q : 8;
+    if (c.plane) {
+        if (q > 256) {
+            q = 256 + q / 4;
+        }
+        return q < 768 ? q : 768;
+    }
+    return q < 3072 ? q : 3072;
+}
+
+static int hfquant(const QuantCfg &c, int q, int s, int l) // hzcc.c:108
+{
+    bool chroma = c.plane != 0;
+    int pf = spatial_psy_factor(c.blk_w, c.blk_h, c.nbh, c.nbv, s);
+    q /= 2;
+    pf = q * pf >> (7 + (c.isP ? 0 : 1));
+    if (chroma) {
+        int tl = l - 2;
+        if (s == 1) {
+            tl += c.hshift;
+        } else if (s == 2) {
+            tl += c.vshift;
+        }
+        q = (q * 6) / (4 - tl);
+    } else if (l == 1) {
+        q += pf / 2;
+    } else if (l == 2) {
+        q += pf;
+    }
+    if (c.isP) {
+        if (l == 0) {
+            q = q * 2 - pf;
+        } else if (l == 1) {
+            q -= pf / 2;
+        }
+        q /= 4;
+        return q > 8 ? q : 8;
+    }
+    q = q * (15 + 3 * l) / 16;
+    if (!chroma) {
+        if (l == 0) {
+            q = (q * 3) / 8;
+        } else if (s == 3) {
+            q *= 2;
+        }
+    } else {
+        q /= 4;
+        if (s == 3) {
+            q *= 2;
+        }
+    }
+    return q > 8 ? q : 8;
+}
+
+void make_scan(ScanGeom *g, int w, int h) // scan order of hzcc.c:264-342
+{
+    int k = 1;
+    g->w = w;
+    g->h = h;
+    g->off[0] = 0;
+    g->sw[0] = h_dimat(0, w);
+    g->sh[0] = h_dimat(0, h);
+    for (int l = 0; l < 3; l++) {
+        for (int s = 1; s <= 3; s++, k++) {
+            g->off[k] = h_subband_off(l, s, w, h);
+            g->sw[k] = h_dimat(l, w);
+            g->sh[k] = h_dimat(l, h);
+        }
+    }
+    g->base[0] = 0;
+    for (k = 0; k < 10; k++) {
+        g->base[k + 1] = g->base[k] + g->sw[k] * g->sh[k];
+    }
+}
+
+// ---- device arithmetic ------------------------------------------------------------
+struct LevelArgs {
+    int l;
+    int sw, sh;
+    int dbx, dby;
+    int xdep, ydep;
+    int off[3], par[3], gpar[3], qp[3], base[3];
+};
+
+__device__ __forceinline__ int quant_sub(int v, int q, int sub) { return (v >= 0 ? v - sub : v + sub) / q; }
+__device__ __forceinline__ int32_t dequant_S(int v, unsigned q)
+{
+    return (int32_t) ((unsigned) v * q + ((v < 0) ? 0u - (q * 2 / 3) : (q * 2 / 3)));
+}
+__device__ __forceinline__ int32_t dequant_D(int v, unsigned q)
+{
+    return (int32_t) ((unsigned) v * q + ((v < 0) ? 0u - (q / 2) : (q / 2)));
+}
+__device__ __forceinline__ int sgn(int x) { return x < 0 ? -1 : (x > 0 ? 1 : 0); }
+
+__device__ __forceinline__ int tmq_for_P(int tmq, int flags, int parc) // hzcc.c:164
+{
+    if (parc || (flags & (DSV_IS_STABLE | DSV_IS_EPRM))) {
+        return tmq * 7 >> 3;
+    }
+    if (flags & DSV_IS_INTRA) {
+        return tmq * 6 >> 3;
+    }
+    return tmq;
+}
+
+__device__ __forceinline__ int tmq_for_I(int tmq, int flags, int parc, int l) // hzcc.c:171
+{
+    int sm = flags & (DSV_IS_STABLE | DSV_IS_MAINTAIN);
+    if (l == 0) {
+        return tmq;
+    }
+    if (sm == DSV_IS_STABLE) {
+        return (l == 2) ? (tmq >> 2) : (tmq / 3);
+    }
+    if (sm == DSV_IS_MAINTAIN) {
+        return tmq >> ((flags & DSV_IS_RINGING) ? 2 : !parc);
+    }
+    if (sm == (DSV_IS_STABLE | DSV_IS_MAINTAIN)) {
+        return (l == 2) ? (tmq >> (2 + !parc)) : (tmq >> 2);
+    }
+    return tmq;
+}
+
+__device__ __forceinline__ int quant_detail(const QuantCfg &c, int val, int qp, int l, int flags, int bi, int parc, int gparc,
+                                            int &tmq_out)
+{
+    int tmq = qp, v;
+    bool texture = !parc, gtexture = !gparc;
+    if (c.isP) {
+        tmq = tmq_for_P(tmq, flags, parc);
+        if ((c.do_psy & DSV_PSY_P_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:371-380
+            DSV_MV mv = c.mvs[bi];
+            bool small_mv = abs((int) mv.u.mv.x) < 32 && abs((int) mv.u.mv.y) < 32;
+            if ((gtexture && texture) || (mv.flags & (1u << DSV_MV_BIT_EPRM)) ||
+                ((mv.flags & (1u << DSV_MV_BIT_MAINTAIN)) && small_mv)) {
+                v = quant_sub(val, tmq, tmq >> 3);
+            } else if (texture || !(flags & DSV_IS_SIMCMPLX)) {
+                v = quant_sub(val, tmq, tmq / 6);
+            } else {
+                v = quant_sub(val, tmq, tmq >> 2);
+            }
+        } else {
+            v = val / tmq;
+        }
+    } else {
+        tmq = tmq_for_I(tmq, flags, parc, l);
+        if ((c.do_psy & DSV_PSY_I_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:387-414
+            int smf = flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE);
+            if (flags & DSV_IS_RINGING) {
+                v = quant_sub(val, tmq, -(tmq / 6));
+            } else if (l == 0) {
+                v = quant_sub(val, tmq, -(tmq >> 3));
+            } else {
+                bool edge = sgn(parc) == sgn(val);
+                int stp;
+                if (smf == 0) {
+                    stp = -tmq / 3;
+                } else if (edge && smf == DSV_IS_STABLE) {
+                    stp = tmq >> 3;
+                } else {
+                    stp = -tmq / 6;
+                }
+                v = quant_sub(val, tmq, stp);
+            }
+        } else if (c.plane) {
+            v = quant_sub(val, tmq, -(tmq >> 3));
+        } else {
+            v = val / tmq;
+        }
+    }
+    tmq_out = tmq;
+    return v;
+}
+
+// LL region: hzcc.c:308-328
+__global__ __launch_bounds__(256) void k_quant_ll(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, QuantCfg c, int sw,
+                                                  int sh, int qp)
+{
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= sw || y >= sh) {
+        return;
+    }
+    int v = 0;
+    if (x | y) { // the global DC is transmitted separately and never quantised (hzcc.c:265,599-602)
+        int32_t *cell = coefs + (size_t) y * c.w + x;
+        if (c.lossless) {
+            v = *cell;
+        } else {
+            int val = *cell;
+            v = c.isP ? (val / qp) : quant_sub(val, qp, -(qp / 6));
+            *cell = v ? (c.isP ? dequant_D(v, (unsigned) qp) : dequant_S(v, (unsigned) qp)) : 0;
+        }
+    }
+    qv[(size_t) y * sw + x] = v;
+}
+
+__device__ __forceinline__ void quant_cell(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, const QuantCfg &c,
+                                           const LevelArgs &a, int si, int x, int y)
+{
+    int32_t *cell = coefs + a.off[si] + (size_t) y * c.w + x;
+    int v;
+    if (c.lossless) {
+        v = *cell;
+    } else {
+        int bi = ((y * a.dby) >> kBlockP) * c.nbh + ((x * a.dbx) >> kBlockP);
+        int parc = coefs[a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1)];
+        int gparc = coefs[a.gpar[si] + (size_t) (y >> 2) * c.w + (x >> 2)];
+        int tmq;
+        v = quant_detail(c, *cell, a.qp[si], a.l, c.bd[bi], bi, parc, gparc, tmq);
+        *cell = v ? dequant_D(v, (unsigned) tmq) : 0;
+    }
+    qv[a.base[si] + (size_t) y * a.sw + x] = v;
+}
+
+__device__ __forceinline__ bool is_dependent(const LevelArgs &a, int s, int x, int y)
+{
+    return ((s & 1) && a.xdep && x == a.sw - 1) || ((s & 2) && a.ydep && y == a.sh - 1);
+}
+
+// phase A of a detail level: every cell that is not a dependent; blockIdx.z = subband - 1
+__global__ __launch_bounds__(256) void k_quant_level(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, QuantCfg c,
+                                                     LevelArgs a)
+{
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    int si = blockIdx.z;
+    if (x >= a.sw || y >= a.sh || is_dependent(a, si + 1, x, y)) {
+        return;
+    }
+    quant_cell(coefs, qv, c, a, si, x, y);
+}
+
+// phase B: the dependents (last column, then last row without the shared corner)
+__global__ __launch_bounds__(256) void k_quant_level_dep(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, QuantCfg c,
+                                                         LevelArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int si = blockIdx.y;
+    int x, y;
+    if (t < a.sh) {
+        x = a.sw - 1;
+        y = t;
+    } else if (t < a.sh + a.sw - 1) {
+        x = t - a.sh;
+        y = a.sh - 1;
+    } else {
+        return;
+    }
+    if (!is_dependent(a, si + 1, x, y)) {
+        return;
+    }
+    quant_cell(coefs, qv, c, a, si, x, y);
+}
+
+void quant_plane(hipStream_t s, DCoefs coefs, int32_t *qv, const QuantCfg &cfg, int q)
+{
+    ScanGeom g;
+    make_scan(&g, coefs.w, coefs.h);
+    int qf = q * 3 / 2; // fix_quant, hzcc.c:59
+    const dim3 blk(64, 4);
+    hipLaunchKernelGGL(k_quant_ll, dim3((g.sw[0] + 63) / 64, (g.sh[0] + 3) / 4), blk, 0, s, coefs.data, qv, cfg, g.sw[0], g.sh[0],
+                       cfg.lossless ? 1 : lfquant(cfg, qf));
+    for (int l = 0; l < 3; l++) {
+        LevelArgs a;
+        a.l = l;
+        a.sw = h_dimat(l, coefs.w);
+        a.sh = h_dimat(l, coefs.h);
+        a.dbx = (cfg.nbh << kBlockP) / a.sw;
+        a.dby = (cfg.nbv << kBlockP) / a.sh;
+        a.xdep = 2 * h_dimat(l - 1, coefs.w) > a.sw;
+        a.ydep = 2 * h_dimat(l - 1, coefs.h) > a.sh;
+        for (int si = 0; si < 3; si++) {
+            a.off[si] = g.off[1 + 3 * l + si];
+            a.base[si] = g.base[1 + 3 * l + si];
+            a.par[si] = h_subband_off(l - 1, si + 1, coefs.w, coefs.h);
+            a.gpar[si] = h_subband_off(l - 2, si + 1, coefs.w, coefs.h);
+            a.qp[si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
+        }
+        hipLaunchKernelGGL(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3), blk, 0, s, coefs.data, qv, cfg, a);
+        if (a.xdep || a.ydep) {
+            hipLaunchKernelGGL(k_quant_level_dep, dim3((a.sw + a.sh + 255) / 256, 3), dim3(256), 0, s, coefs.data, qv, cfg, a);
+        }
+    }
+    HIPCHK(hipGetLastError());
+}
+
+// ---- ordered compaction of the nonzero symbols ---------------------------------------
+// three small kernels: per-tile counts, one-workgroup exclusive scan of the tile counts,
+// ordered scatter.  Tiles are 1024 consecutive scan positions handled by 256 threads.
+constexpr int kTile = 1024;
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) {
+            v += t;
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_count(const int32_t *__restrict__ qv, int n, int *__restrict__ tile_count)
+{
+    __shared__ int wsum[4];
+    int base = blockIdx.x * kTile;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = base + threadIdx.x * 4 + j;
+        cnt += (i < n && qv[i] != 0);
+    }
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = wave_incl_scan(cnt, lane);
+    if (lane == 63) {
+        wsum[wv] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+// exclusive scan of up to 1024*ntile_per_thread tile counts by one workgroup; also emits the total
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ tile_count, int ntiles, int *__restrict__ tile_base,
+                                                     int *__restrict__ total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        carry = 0;
+    }
+    __syncthreads();
+    for (int start = 0; start < ntiles; start += 1024) {
+        int i = start + threadIdx.x;
+        int v = i < ntiles ? tile_count[i] : 0;
+        int inc = wave_incl_scan(v, lane);
+        if (lane == 63) {
+            wsum[wv] = inc;
+        }
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; k++) {
+            woff += wsum[k];
+        }
+        int c0 = carry;
+        if (i < ntiles) {
+            tile_base[i] = c0 + woff + inc - v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry = c0 + woff + inc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *total = carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const int32_t *__restrict__ qv, int n, const int *__restrict__ tile_base,
+                                                 uint32_t *__restrict__ out_pos, int32_t *__restrict__ out_val)
+{
+    __shared__ int wsum[4];
+    int base = blockIdx.x * kTile;
+    int vals[4];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = base + threadIdx.x * 4 + j;
+        vals[j] = (i < n) ? qv[i] : 0;
+        cnt += vals[j] != 0;
+    }
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = wave_incl_scan(cnt, lane);
+    if (lane == 63) {
+        wsum[wv] = inc;
+    }
+    __syncthreads();
+    int o = tile_base[blockIdx.x] + inc - cnt;
+    for (int k = 0; k < wv; k++) {
+        o += wsum[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (vals[j] != 0) {
+            out_pos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
+            out_val[o] = vals[j];
+            o++;
+        }
+    }
+}
+
+void Compactor::ensure(size_t n)
+{
+    if (n <= cap) {
+        return;
+    }
+    release();
+    size_t ntiles = (n + kTile - 1) / kTile;
+    HIPCHK(hipMalloc((void **) &tile_count, ntiles * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &tile_base, ntiles * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &d_total, sizeof(int)));
+    HIPCHK(hipMalloc((void **) &d_pos, n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &d_val, n * sizeof(int32_t)));
+    HIPCHK(hipHostMalloc((void **) &h_total, sizeof(int), hipHostMallocDefault));
+    cap = n;
+}
+
+void Compactor::release()
+{
+    if (!cap) {
+        return;
+    }
+    HIPCHK(hipFree(tile_count));
+    HIPCHK(hipFree(tile_base));
+    HIPCHK(hipFree(d_total));
+    HIPCHK(hipFree(d_pos));
+    HIPCHK(hipFree(d_val));
+    HIPCHK(hipHostFree(h_total));
+    cap = 0;
+}
+
+void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
+{
+    ensure(n);
+    int ntiles = (int) ((n + kTile - 1) / kTile);
+    hipLaunchKernelGGL(k_count, dim3(ntiles), dim3(256), 0, s, qv, (int) n, tile_count);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntiles, tile_base, d_total);
+    hipLaunchKernelGGL(k_scatter, dim3(ntiles), dim3(256), 0, s, qv, (int) n, tile_base, d_pos, d_val);
+    HIPCHK(hipMemcpyAsync(h_total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipGetLastError());
+}
+
+// ---- decoder side: scatter decoded symbols and dequantise (hzcc.c:451-583) -------------------
+struct DequantArgs {
+    int l;
+    int sw, sh, dbx, dby;
+    int off[3], par[3], qp[3], base[3];
+};
+
+// LL symbols: dequantL (hzcc.c:530)
+__global__ __launch_bounds__(256) void k_dequant_ll(int32_t *__restrict__ coefs, const uint32_t *__restrict__ pos,
+                                                    const int32_t *__restrict__ val, int n, QuantCfg c, int sw, int qp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    int p = (int) pos[i], v = val[i];
+    int x = p % sw, y = p / sw;
+    int32_t out = c.lossless ? v : (c.isP ? dequant_D(v, (unsigned) qp) : dequant_S(v, (unsigned) qp));
+    coefs[(size_t) y * c.w + x] = out;
+}
+
+// detail symbols of one level; `dep` selects the dependents phase (see header comment)
+__global__ __launch_bounds__(256) void k_dequant_level(int32_t *__restrict__ coefs, const uint32_t *__restrict__ pos,
+                                                       const int32_t *__restrict__ val, int n, QuantCfg c, DequantArgs a,
+                                                       int xdep, int ydep, int dep)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    int p = (int) pos[i], v = val[i];
+    int si = p >= a.base[2] ? 2 : (p >= a.base[1] ? 1 : 0);
+    int local = p - a.base[si];
+    int x = local % a.sw, y = local / a.sw;
+    int s = si + 1;
+    bool is_dep = ((s & 1) && xdep && x == a.sw - 1) || ((s & 2) && ydep && y == a.sh - 1);
+    if ((int) is_dep != dep) {
+        return;
+    }
+    int32_t out;
+    if (c.lossless) {
+        out = v;
+    } else {
+        int flags = c.bd[((y * a.dby) >> kBlockP) * c.nbh + ((x * a.dbx) >> kBlockP)];
+        int parc = coefs[a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1)];
+        int tmq = c.isP ? tmq_for_P(a.qp[si], flags, parc) : tmq_for_I(a.qp[si], flags, parc, a.l);
+        out = dequant_D(v, (unsigned) tmq);
+    }
+    coefs[a.off[si] + (size_t) y * c.w + x] = out;
+}
+
+void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int32_t *d_val, const int seg_count[4],
+                   const QuantCfg &cfg, int q)
+{
+    ScanGeom g;
+    make_scan(&g, coefs.w, coefs.h);
+    int qf = q * 3 / 2;
+    int done = 0;
+    if (seg_count[0] > 0) {
+        hipLaunchKernelGGL(k_dequant_ll, dim3((seg_count[0] + 255) / 256), dim3(256), 0, s, coefs.data, d_pos, d_val, seg_count[0],
+                           cfg, g.sw[0], cfg.lossless ? 1 : lfquant(cfg, qf));
+    }
+    done = seg_count[0];
+    for (int l = 0; l < 3; l++) {
+        int n = seg_count[1 + l];
+        if (n > 0) {
+            DequantArgs a;
+            a.l = l;
+            a.sw = h_dimat(l, coefs.w);
+            a.sh = h_dimat(l, coefs.h);
+            a.dbx = (cfg.nbh << kBlockP) / a.sw;
+            a.dby = (cfg.nbv << kBlockP) / a.sh;
+            int xdep = 2 * h_dimat(l - 1, coefs.w) > a.sw, ydep = 2 * h_dimat(l - 1, coefs.h) > a.sh;
+            for (int si = 0; si < 3; si++) {
+                a.off[si] = g.off[1 + 3 * l + si];
+                a.base[si] = g.base[1 + 3 * l + si];
+                a.par[si] = h_subband_off(l - 1, si + 1, coefs.w, coefs.h);
+                a.qp[si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
+            }
+            hipLaunchKernelGGL(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done, d_val + done, n,
+                               cfg, a, xdep, ydep, 0);
+            if (xdep || ydep) {
+                hipLaunchKernelGGL(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done,
+                                   d_val + done, n, cfg, a, xdep, ydep, 1);
+            }
+        }
+        done += n;
+    }
+    HIPCHK(hipGetLastError());
+}
+
+} // namespace dsv2
