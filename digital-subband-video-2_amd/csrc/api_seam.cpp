@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dev.h"
+#include "bmc.h"
 #include "quant.h"
 
 using namespace dsv2;
@@ -297,6 +298,88 @@ int dsv_decode_plane(DSV_BS *bs, DSV_COEFS *dst, int q, DSV_FMETA *fm)
         dst->data[0] = LL; // hzcc.c:633
     }
     return ok > 0;
+}
+
+static MCParams make_mc_params(const DSV_PARAMS *p)
+{
+    MCParams m;
+    m.blk_w = p->blk_w;
+    m.blk_h = p->blk_h;
+    m.nbh = p->nblocks_h;
+    m.nbv = p->nblocks_v;
+    m.hshift = DSV_FORMAT_H_SHIFT(p->vidmeta->subsamp);
+    m.vshift = DSV_FORMAT_V_SHIFT(p->vidmeta->subsamp);
+    m.temporal_mc = p->temporal_mc;
+    m.lossless = p->lossless;
+    return m;
+}
+
+void dsv_sub_pred(DSV_MV *mv, DSV_PARAMS *p, DSV_FRAME *pred, DSV_FRAME *resd, DSV_FRAME *ref)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DFrame *dpred = c.get_frame(0, pred->format, pred->width, pred->height);
+    DFrame *dres = c.get_frame(1, resd->format, resd->width, resd->height);
+    DFrame *dref = c.get_frame(2, ref->format, ref->width, ref->height);
+    dframe_upload_full(dpred, pred, c.stream);
+    dframe_upload_full(dres, resd, c.stream);
+    dframe_upload_full(dref, ref, c.stream);
+    const DSV_MV *dmv = c.put_mvs(mv, (size_t) p->nblocks_h * p->nblocks_v);
+    mc_sub_pred(c.stream, dmv, make_mc_params(p), *dpred, *dres, *dref);
+    dframe_download_full(dpred, pred, c.stream);
+    dframe_download_full(dres, resd, c.stream);
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+void dsv_add_res(DSV_MV *mv, DSV_FMETA *fm, int q, DSV_FRAME *resd, DSV_FRAME *pred, int do_filter)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DSV_PARAMS *p = fm->params;
+    DFrame *dpred = c.get_frame(0, pred->format, pred->width, pred->height);
+    DFrame *dres = c.get_frame(1, resd->format, resd->width, resd->height);
+    dframe_upload_full(dpred, pred, c.stream);
+    dframe_upload_full(dres, resd, c.stream);
+    const DSV_MV *dmv = c.put_mvs(mv, (size_t) p->nblocks_h * p->nblocks_v);
+    mc_add_res(c.stream, dmv, make_mc_params(p), q, *dres, *dpred, do_filter, p->vidmeta->inter_sharpen);
+    dframe_download_full(dres, resd, c.stream);
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+void dsv_add_pred(DSV_MV *mv, DSV_FMETA *fm, int q, DSV_FRAME *resd, DSV_FRAME *out, DSV_FRAME *ref, int do_filter)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DSV_PARAMS *p = fm->params;
+    DFrame *dout = c.get_frame(0, out->format, out->width, out->height);
+    DFrame *dres = c.get_frame(1, resd->format, resd->width, resd->height);
+    DFrame *dref = c.get_frame(2, ref->format, ref->width, ref->height);
+    dframe_upload_full(dout, out, c.stream);
+    dframe_upload_full(dres, resd, c.stream);
+    dframe_upload_full(dref, ref, c.stream);
+    const DSV_MV *dmv = c.put_mvs(mv, (size_t) p->nblocks_h * p->nblocks_v);
+    mc_add_pred(c.stream, dmv, make_mc_params(p), q, *dres, *dout, *dref, do_filter, p->vidmeta->inter_sharpen);
+    dframe_download_full(dout, out, c.stream);
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+void dsv_intra_filter(int q, DSV_PARAMS *p, DSV_FMETA *fm, int cpl, DSV_PLANE *dp, int do_filter)
+{
+    if (p->lossless || cpl != 0 || !do_filter) {
+        return; // bmc.c:396-404
+    }
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    stage_plane_in(c, dp, true);
+    const uint8_t *dbd = c.put_blockdata(fm->blockdata, (size_t) p->nblocks_h * p->nblocks_v);
+    intra_filter_luma(c.stream, dbd, make_mc_params(p), q, g_pstage.p);
+    HIPCHK(hipMemcpy2DAsync(dp->data, dp->stride, g_pstage.p.data, g_pstage.p.stride, dp->w, dp->h, hipMemcpyDeviceToHost,
+                            c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
 }
 
 DSV_FRAME *dsv_extend_frame(DSV_FRAME *frame)

@@ -1,0 +1,678 @@
+// bmc.hip -- block motion compensation, residual formation / reconstruction and the in-loop
+// 4x4 smoothing filters on gfx950.
+//
+// Replaces reference src/bmc.c: predict (:815) with luma_qp (:662), bilinear_sp (:773) and the
+// intra DC fills, subtract (:990), reconstruct (:926), luma_filter (:460), chroma_filter (:605),
+// dsv_intra_filter (:391) with ihfilter4x4 (:71), ivfilter4x4 (:131), artf4x4 (:253),
+// dsff4x4 (:195), degrad4x4 (:277); entry points dsv_sub_pred (:1058), dsv_add_res (:1073),
+// dsv_add_pred (:1094).
+//
+// Decomposition (proved bit-exact on the CPU by oracle/orc_bmc.c):
+//   * prediction / subtraction / reconstruction: one workgroup per (block, plane); the 2-pass
+//     quarter-pel filter is evaluated per output pixel from its 4x4 reference window (the
+//     16-bit intermediate of the reference is a pure function of one reference row);
+//   * the in-place filters are raster-order dependent in the reference.  Cell (i,j) only depends
+//     on cells (i-1,j), (i-2,j), (i-1,j-1), (i,j-1), (i+1,j-1), so all cells with equal i + 2j
+//     form a wavefront that is processed concurrently; one workgroup per plane sweeps the fronts
+//     with a workgroup barrier between them (the plane stays in L2 / the CU's L1).
+#include "dev.h"
+#include "bmc.h"
+
+namespace dsv2 {
+
+__device__ __forceinline__ int sar(int v, int s) { return v >> s; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t) (v > 255 ? 255 : (v < 0 ? 0 : v)); }
+
+struct Planes3 {
+    DPlane p[3];
+};
+
+// ---- prediction ---------------------------------------------------------------------
+
+__device__ __forceinline__ int hp_tap(int a, int b, int c, int d, bool soft)
+{
+    return soft ? (19 * (b + c) - 3 * (a + d)) : (20 * (b + c) - 4 * (a + d)); // dsv_internal.h:130-133
+}
+
+__device__ __forceinline__ int qp_blend(int f, int b, int c, int frac) // bmc.c:702-715
+{
+    switch (frac) {
+        case 0: return (64 * b + 32) >> 6;
+        case 1: return (f + 32 * b + 32) >> 6;
+        case 2: return (2 * f + 32) >> 6;
+        default: return (f + 32 * c + 32) >> 6;
+    }
+}
+
+// one luma pixel of a sub-pel block; r points at the reference sample (px-1, py-1) + (m, n)
+__device__ __forceinline__ int luma_subpel_px(const uint8_t *r, int rs, int fx, int fy, bool soft_x, bool soft_y)
+{
+    int t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint8_t *q = r + k * rs;
+        int a = q[0], b = q[1], c = q[2], d = q[3];
+        t[k] = (int) (int16_t) qp_blend(hp_tap(a, b, c, d, soft_x), b, c, fx);
+    }
+    return qp_blend(hp_tap(t[0], t[1], t[2], t[3], soft_y), t[1], t[2], fy);
+}
+
+enum { MC_PREDICT_ONLY = 0, MC_SUBTRACT = 1, MC_RECONSTRUCT = 2 };
+
+__device__ __forceinline__ uint8_t residual_px(int s, int pv, uint32_t flags, int c, int lossless) // bmc.c:1015-1050
+{
+    if (lossless) {
+        return (uint8_t) (s - pv + 128);
+    }
+    bool intra = flags & (1u << DSV_MV_BIT_INTRA), skip = flags & (1u << DSV_MV_BIT_SKIP);
+    bool noxmit = c == 0 ? (flags & (1u << DSV_MV_BIT_NOXMITY)) : (flags & (1u << DSV_MV_BIT_NOXMITC));
+    if (!intra && (skip || noxmit)) {
+        return 128;
+    }
+    if (flags & (1u << DSV_MV_BIT_EPRM)) {
+        return clamp_u8((s - pv + 256) >> 1);
+    }
+    return clamp_u8(s - pv + 128);
+}
+
+__device__ __forceinline__ uint8_t recon_px(int rv, int pv, uint32_t flags, int lossless) // bmc.c:953-983
+{
+    if (lossless) {
+        return (uint8_t) (pv + rv - 128);
+    }
+    bool plain = !(flags & (1u << DSV_MV_BIT_EPRM)) ||
+                 (!(flags & (1u << DSV_MV_BIT_INTRA)) && (flags & (1u << DSV_MV_BIT_SKIP)));
+    return plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2);
+}
+
+// grid = (nblocks_h, nblocks_v, 3); 256 threads.
+// MODE MC_SUBTRACT: pred <- prediction, res <- residual(res - pred)      (dsv_sub_pred)
+// MODE MC_RECONSTRUCT: out(=pred plane) <- recon(prediction, res)        (dsv_add_pred: prediction is
+//                      formed straight into the output frame, then overwritten by the reconstruction)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 refp, Planes3 predp,
+                                                 Planes3 resp)
+{
+    __shared__ int qsum[4];
+    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z;
+    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
+    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+    const DPlane rp = refp.p[c], dp = predp.p[c], sp = resp.p[c];
+    DSV_MV mv = mvs[i + j * p.nbh];
+    int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
+    uint32_t flags = mv.flags;
+    bool intra = flags & (1u << DSV_MV_BIT_INTRA);
+    int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
+    int x = i * bw, y = j * bh;
+    int px = x + sar(mvx, 2 + sh), py = y + sar(mvy, 2 + sv);
+    int sbw = bw >> 1, sbh = bh >> 1;
+    bool subpel_luma = (c == 0) && !intra && ((mvx | mvy) & 3);
+    if (subpel_luma) {
+        px = clampi(px - 1, -kBorder, limx);
+        py = clampi(py - 1, -kBorder, limy);
+    } else {
+        px = clampi(px, -kBorder, limx);
+        py = clampi(py, -kBorder, limy);
+    }
+    const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
+    bool need_mean = intra && !(c == 0 && mv.dc);
+    int dcq[4] = {0, 0, 0, 0};
+    if (intra) {
+        if (need_mean) {
+            if (threadIdx.x < 4) {
+                qsum[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            int part[4] = {0, 0, 0, 0};
+            for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+                int m = idx % bw, n = idx / bw;
+                int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+                part[k] += rbase[(ptrdiff_t) n * rp.stride + m];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (part[k]) {
+                    atomicAdd(&qsum[k], part[k]);
+                }
+            }
+            __syncthreads();
+            if (mv.submask == DSV_MASK_ALL_INTRA) {
+                int all = (qsum[0] + qsum[1] + qsum[2] + qsum[3]) / (bw * bh); // bmc.c:857
+                dcq[0] = dcq[1] = dcq[2] = dcq[3] = all;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    dcq[k] = qsum[k] / (sbw * sbh); // bmc.c:884
+                }
+            }
+        } else {
+            dcq[0] = dcq[1] = dcq[2] = dcq[3] = mv.dc; // transmitted DC, luma only (bmc.c:854,881)
+        }
+    }
+    int fx = 0, fy = 0;
+    bool soft_x = false, soft_y = false;
+    int f0 = 0, f1 = 0, f2 = 0, f3 = 0, sf = 0, af = 0;
+    bool chroma_frac = false;
+    if (subpel_luma) {
+        bool large = abs(mvx) >= 8 || abs(mvy) >= 8; // bmc.c:674-679
+        fx = mvx & 3;
+        fy = mvy & 3;
+        soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
+        soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
+    } else if (c != 0 && !intra) {
+        int hb = 2 + sh, vb = 2 + sv, hf = 1 << hb, vf = 1 << vb; // bmc.c:778-798
+        int dx = mvx & (hf - 1), dy = mvy & (vf - 1);
+        chroma_frac = (dx | dy) != 0;
+        f0 = (hf - dx) * (vf - dy);
+        f1 = dx * (vf - dy);
+        f2 = (hf - dx) * dy;
+        f3 = dx * dy;
+        sf = hb + vb;
+        af = 1 << (sf - 1);
+    }
+    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+        int m = idx % bw, n = idx / bw;
+        const uint8_t *r = rbase + (ptrdiff_t) n * rp.stride + m;
+        int pv;
+        if (intra) {
+            int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+            bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
+            pv = fill ? (dcq[k] & 0xff) : r[0];
+        } else if (subpel_luma) {
+            pv = clamp_u8(luma_subpel_px(r, rp.stride, fx, fy, soft_x, soft_y));
+        } else if (chroma_frac) {
+            pv = (f0 * r[0] + f1 * r[1] + f2 * r[rp.stride] + f3 * r[rp.stride + 1] + af) >> sf;
+            pv &= 0xff;
+        } else {
+            pv = r[0];
+        }
+        ptrdiff_t o = (ptrdiff_t) (y + n) * dp.stride + (x + m);
+        if (MODE == MC_SUBTRACT) {
+            dp.data[o] = (uint8_t) pv;
+            ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
+            sp.data[so] = residual_px(sp.data[so], pv, flags, c, p.lossless);
+        } else if (MODE == MC_RECONSTRUCT) {
+            ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
+            dp.data[o] = recon_px(sp.data[so], pv, flags, p.lossless);
+        } else {
+            dp.data[o] = (uint8_t) pv;
+        }
+    }
+}
+
+// encoder-side reconstruction in place: res <- recon(pred, res)   (dsv_add_res, bmc.c:1082)
+__global__ __launch_bounds__(256) void k_reconstruct(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 predp, Planes3 resp)
+{
+    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z;
+    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
+    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+    const DPlane dp = predp.p[c], sp = resp.p[c];
+    uint32_t flags = mvs[i + j * p.nbh].flags;
+    int x = i * bw, y = j * bh;
+    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+        int m = idx % bw, n = idx / bw;
+        ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
+        sp.data[so] = recon_px(sp.data[so], dp.data[(ptrdiff_t) (y + n) * dp.stride + (x + m)], flags, p.lossless);
+    }
+}
+
+// ---- 4x4 edge smoothing primitives (bmc.c:53-191) ------------------------------------------
+
+__device__ __forceinline__ bool smooth6(int e2, int e1, int e0, int i0, int i1, int i2, int t, int o[4])
+{
+    int avg = (5 * (e0 + i0) + 3 * (e1 + i1) + 8) >> 4;
+    if (abs(e0 - avg) < t && abs(i0 - avg) < t && abs(e1 - avg) < t && abs(i1 - avg) < t && abs(e2 - avg) < t &&
+        abs(i2 - avg) < t) {
+        int a5 = avg * 5;
+        o[0] = (3 * (avg + e1) + 2 * e2 + 4) >> 3;
+        o[1] = (a5 + 2 * e1 + e2 + 4) >> 3;
+        o[2] = avg;
+        o[3] = (a5 + 2 * i1 + i2 + 4) >> 3;
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void edge_filter(uint8_t *b, int across, int along, bool in_edge, int tE, int tM)
+{
+    int o[4];
+    for (int n = 0; n < 4; n++) {
+        uint8_t *p = b + (ptrdiff_t) n * along;
+        if (smooth6(p[-3 * across], p[-2 * across], p[-across], p[0], p[across], p[2 * across], tE, o)) {
+            p[-2 * across] = (uint8_t) o[0];
+            p[0] = (uint8_t) o[2];
+            p[-across] = (uint8_t) o[1];
+            p[across] = (uint8_t) o[3];
+        }
+        if (in_edge) {
+            uint8_t *k = p + 4 * across;
+            if (smooth6(k[3 * across], k[2 * across], k[across], k[0], k[-across], k[-2 * across], tM, o)) {
+                k[0] = (uint8_t) o[2];
+                k[2 * across] = (uint8_t) o[0];
+                k[-across] = (uint8_t) o[3];
+                k[across] = (uint8_t) o[1];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void hfilter(const DPlane &dp, int x, int y, bool edge, int tE, int tM)
+{
+    if (x < 4 || x > dp.w - 4 || (edge && tE <= 0) || tM <= 0) {
+        return;
+    }
+    if (!edge) {
+        tE = tM;
+    }
+    edge_filter(dp.data + (ptrdiff_t) y * dp.stride + x, 1, dp.stride, x < dp.w - 8, tE, tM);
+}
+
+__device__ __forceinline__ void vfilter(const DPlane &dp, int x, int y, bool edge, int tE, int tM)
+{
+    if (y < 4 || y > dp.h - 4 || (edge && tE <= 0) || tM <= 0) {
+        return;
+    }
+    if (!edge) {
+        tE = tM;
+    }
+    edge_filter(dp.data + (ptrdiff_t) y * dp.stride + x, dp.stride, 1, y < dp.h - 8, tE, tM);
+}
+
+__device__ __forceinline__ void ds2x2(const uint8_t *a, int as, int d[4])
+{
+    d[0] = (a[0] + a[1] + a[as] + a[as + 1] + 2) >> 2;
+    d[1] = (a[2] + a[3] + a[as + 2] + a[as + 3] + 2) >> 2;
+    a += 2 * as;
+    d[2] = (a[0] + a[1] + a[as] + a[as + 1] + 2) >> 2;
+    d[3] = (a[2] + a[3] + a[as + 2] + a[as + 3] + 2) >> 2;
+}
+
+__device__ __forceinline__ unsigned dsff(const uint8_t *a, int as) // bmc.c:194
+{
+    int d[4];
+    ds2x2(a, as, d);
+    unsigned sh = (unsigned) abs((d[0] + d[1]) - (d[3] + d[2]));
+    unsigned sv = (unsigned) abs((d[2] + d[1]) - (d[3] + d[0]));
+    if (max(sh, sv) < 8) {
+        return 0;
+    }
+    d[2] = 255 - d[2];
+    d[3] = 255 - d[3];
+    sh = (unsigned) abs(d[0] - d[1] + d[2] - d[3]);
+    sv = (unsigned) abs(d[0] + d[1] - d[2] - d[3]) >> 2;
+    return sh > sv ? (3 * sh + sv + 2) >> 2 : (3 * sv + sh + 2) >> 2;
+}
+
+__device__ __forceinline__ void artf(const uint8_t *a, int as, int &sh, int &sv, int &slh, int &slv) // bmc.c:224-270
+{
+    sh = sv = 0;
+    for (int y = 0; y < 4; y += 2) {
+        for (int x = 0; x < 4; x += 2) {
+            int x0 = a[y * as + x], x1 = a[y * as + x + 1], x2 = a[(y + 1) * as + x], x3 = a[(y + 1) * as + x + 1];
+            int hh = abs(x0 - x1 - x2 + x3) >> 1;
+            sh += abs(x0 - x1 + x2 - x3) + hh;
+            sv += abs(x0 + x1 - x2 - x3) + hh;
+        }
+    }
+    int d[4];
+    ds2x2(a, as, d);
+    int hh = abs(d[0] - d[1] - d[2] + d[3]) >> 1;
+    slh = abs(d[0] - d[1] + d[2] - d[3]) + hh;
+    slv = abs(d[0] + d[1] - d[2] - d[3]) + hh;
+}
+
+__device__ void degrad(uint8_t *a, int as) // bmc.c:276
+{
+    int px[16];
+    int lo = 16, hi = -1;
+    for (int y = 0; y < 4; y++) {
+        for (int x = 0; x < 4; x++) {
+            int v = a[y * as + x];
+            px[y * 4 + x] = v;
+            lo = min(lo, v >> 4);
+            hi = max(hi, v >> 4);
+        }
+    }
+    if (lo >= hi) {
+        return;
+    }
+    int nlo = 0, nhi = 0, slo = 0, shi = 0;
+    for (int k = 0; k < 16; k++) {
+        int b = px[k] >> 4;
+        if (b == lo) {
+            nlo++;
+            slo += px[k];
+        }
+        if (b == hi) {
+            nhi++;
+            shi += px[k];
+        }
+    }
+    int alo = slo / nlo, ahi = shi / nhi;
+    if (alo == 0) {
+        alo = 1;
+    }
+    if (ahi == 0) {
+        ahi = 1;
+    }
+    int t = (alo + ahi + 1) >> 1;
+    for (int y = 0; y < 4; y++) {
+        for (int x = 0; x < 4; x++) {
+            int os = px[y * 4 + x];
+            if (os < t) {
+                a[y * as + x] = (uint8_t) (os + (nlo * (alo - os)) / 16);
+            } else if (os > t) {
+                a[y * as + x] = (uint8_t) (os + (nhi * (ahi - os)) / 16);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int curve_tex(int tt) // bmc.c:364
+{
+    if (tt < 8) {
+        return (8 - tt) * 8;
+    }
+    if (tt > 192) {
+        return 0;
+    }
+    return tt - 7;
+}
+
+__device__ __forceinline__ void neighbordif2(const DSV_MV *v, int nbh, int x, int y, int &dx, int &dy) // dsv.c:403
+{
+    const DSV_MV *c = &v[x + y * nbh];
+    int cx = c->u.mv.x, cy = c->u.mv.y, lx = cx, ly = cy, tx = cx, ty = cy;
+    if (abs(cx) < 2 && abs(cy) < 2) {
+        dx = dy = 0;
+        return;
+    }
+    if (x > 0) {
+        const DSV_MV *m = c - 1;
+        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
+            lx = m->u.mv.x;
+            ly = m->u.mv.y;
+        }
+    }
+    if (y > 0) {
+        const DSV_MV *m = c - nbh;
+        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
+            tx = m->u.mv.x;
+            ty = m->u.mv.y;
+        }
+    }
+    dx = abs(lx - cx) + abs(ly - cy);
+    dy = abs(tx - cx) + abs(ty - cy);
+}
+
+// ---- one cell of each filter (oracle/orc_bmc.c: intra_cell, luma_cell, chroma_block) ----------
+
+__device__ void intra_cell(const DPlane &dp, const FilterParams &f, const uint8_t *bd, int i, int j, int nsbx, int nsby)
+{
+    int x = i * 4, y = j * 4;
+    if (y + 4 >= dp.h || x + 4 >= dp.w) {
+        return;
+    }
+    int flags = bd[(i * f.nbh / nsbx) + (j * f.nbv / nsby) * f.nbh];
+    if (flags & DSV_IS_RINGING) {
+        return;
+    }
+    uint8_t *a = dp.data + (ptrdiff_t) y * dp.stride + x;
+    int sh, sv, shl, svl;
+    artf(a, dp.stride, sh, sv, shl, svl);
+    int mx = max(sh, sv);
+    if (!(mx < 256 && mx > 8)) {
+        return;
+    }
+    int tt = 32;
+    if (flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE)) {
+        tt = (int) dsff(a, dp.stride);
+        if (flags & DSV_IS_STABLE) {
+            tt = tt * 5 >> 2;
+        }
+    } else {
+        tt >>= 2;
+    }
+    tt = tt * 2 / 3;
+    tt = (tt * f.q) >> 12;
+    tt = clampi(tt, 0, f.fthresh);
+    hfilter(dp, x, y, false, tt, tt);
+    vfilter(dp, x, y, false, tt, tt);
+    tt = sh > sv ? (3 * sh + sv) : (3 * sv + sh);
+    tt = curve_tex(tt);
+    tt = 16 + ((tt + 2) >> 2);
+    tt = (tt * f.q) >> 12;
+    tt = clampi(tt, 0, f.fthresh);
+    hfilter(dp, x, y, false, tt, tt);
+    vfilter(dp, x, y, false, tt, tt);
+}
+
+__device__ void luma_cell(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j, int nsbx, int nsby)
+{
+    int x = i * 4, y = j * 4;
+    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby;
+    const DSV_MV *mv = &vecs[fx + fy * f.nbh];
+    uint32_t flags = mv->flags;
+    if (y + 4 >= dp.h || (flags & (1u << DSV_MV_BIT_SKIP)) || x + 4 >= dp.w) {
+        return;
+    }
+    bool edgeh = (x % f.blk_w) == 0, edgehs = (x % (f.blk_w / 2)) == 0;
+    bool edgev = (y % f.blk_h) == 0, edgevs = (y % (f.blk_h / 2)) == 0;
+    int mvx = mv->u.mv.x, mvy = mv->u.mv.y;
+    int amx = abs(mvx), amy = abs(mvy);
+    uint8_t *a = dp.data + (ptrdiff_t) y * dp.stride + x;
+    if (flags & (1u << DSV_MV_BIT_INTRA)) {
+        int tH = clampi((64 * f.q) >> 12, 2, 32), tL = clampi((32 * f.q) >> 12, 2, 32);
+        bool eh = edgeh, ev = edgev;
+        if (mv->submask != DSV_MASK_ALL_INTRA) {
+            eh |= edgehs;
+            ev |= edgevs;
+        }
+        hfilter(dp, x, y, eh, tH, tL);
+        vfilter(dp, x, y, ev, tH, tL);
+        return;
+    }
+    if (f.do_filter) {
+        int ndx, ndy;
+        neighbordif2(vecs, f.nbh, fx, fy, ndx, ndy);
+        if (ndx || ndy) {
+            bool eprm = flags & (1u << DSV_MV_BIT_EPRM);
+            bool eh = edgeh || eprm, ev = edgev || eprm;
+            int tndc = (ndx + ndy + 1) >> 1;
+            int sh, sv, shl, svl, tt;
+            artf(a, dp.stride, sh, sv, shl, svl);
+            if (sh < 2 * sv && sv < 2 * sh) {
+                if (ndx < amx) {
+                    ndx >>= 1;
+                }
+                if (ndy < amy) {
+                    ndy >>= 1;
+                }
+                shl = shl > 128 ? 0 : 128 - shl;
+                svl = svl > 128 ? 0 : 128 - svl;
+                int ix = min(amx, 32), iy = min(amy, 32);
+                tt = ((sh * (32 - iy) + shl * iy) + 16) >> 5;
+                tt += ((sv * (32 - ix) + svl * ix) + 16) >> 5;
+                tt = (tt + 1) >> 1;
+                if (ndx < amy && ndy < amx) {
+                    tt = 0;
+                }
+            } else {
+                tt = (sh + sv + 1) >> 1;
+            }
+            tt = (tt * tndc + 4) >> 3;
+            tt = (min(tt, f.fthresh) * f.q) >> 12;
+            int addx = (min(ndy, f.fthresh) * f.q) >> 12;
+            int addy = (min(ndx, f.fthresh) * f.q) >> 12;
+            if (sh > 2 * sv || amy > 2 * amx) {
+                vfilter(dp, x, y, ev, tt + addy, tt);
+            } else if (sv > 2 * sh || amx > 2 * amy) {
+                hfilter(dp, x, y, eh, tt + addx, tt);
+            } else {
+                hfilter(dp, x, y, eh, tt + addx, tt);
+                vfilter(dp, x, y, ev, tt + addy, tt);
+            }
+        }
+    }
+    if (f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8) {
+        degrad(a, dp.stride);
+    }
+}
+
+__device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j)
+{
+    int bw = f.blk_w >> f.hshift, bh = f.blk_h >> f.vshift;
+    int x = i * bw, y = j * bh;
+    const DSV_MV *mv = &vecs[i + j * f.nbh];
+    uint32_t flags = mv->flags;
+    if (flags & (1u << DSV_MV_BIT_SKIP)) {
+        return;
+    }
+    int it = clampi((64 * f.q_raw) >> 12, 2, 32);
+    int tx = it, ty = it;
+    if (!(flags & (1u << DSV_MV_BIT_INTRA))) {
+        int ndx, ndy, amx = abs((int) mv->u.mv.x), amy = abs((int) mv->u.mv.y);
+        neighbordif2(vecs, f.nbh, i, j, ndx, ndy);
+        if (ndx < amy && ndy < amx) {
+            tx = ty = 0;
+        } else {
+            tx = (min(ndy, 64) * f.q_raw) >> 12;
+            ty = (min(ndx, 64) * f.q_raw) >> 12;
+        }
+    }
+    for (int z = 0; z < bh; z += 4) {
+        if (y + z + 4 < dp.h) {
+            hfilter(dp, x, y + z, false, tx, tx);
+        }
+    }
+    for (int z = 0; z < bw; z += 4) {
+        if (x + z + 4 < dp.w) {
+            vfilter(dp, x + z, y, false, ty, ty);
+        }
+    }
+}
+
+// wavefront sweep helper: front t holds the cells (i, j) with i + 2j == t
+template <class Body> __device__ __forceinline__ void sweep_fronts(int nx, int ny, Body body)
+{
+    int last = (nx - 1) + 2 * (ny - 1);
+    for (int t = 0; t <= last; t++) {
+        int jmax = min(ny - 1, t >> 1);
+        int jmin = max(0, (t - (nx - 1) + 1) >> 1);
+        for (int j = jmin + (int) threadIdx.x; j <= jmax; j += (int) blockDim.x) {
+            body(t - 2 * j, j);
+        }
+        __syncthreads(); // workgroup-scope release/acquire: the next front sees this front's pixels
+    }
+}
+
+// grid = 3 workgroups: luma filter, U chroma filter, V chroma filter
+__global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict__ vecs, FilterParams f, Planes3 pl)
+{
+    int c = blockIdx.x;
+    const DPlane dp = pl.p[c];
+    if (f.lossless) {
+        return;
+    }
+    if (c == 0) {
+        int nsbx = dp.w / 4, nsby = dp.h / 4;
+        sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(dp, f, vecs, i, j, nsbx, nsby); });
+    } else {
+        sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
+    }
+}
+
+__global__ __launch_bounds__(256) void k_intra_filter(const uint8_t *__restrict__ bd, FilterParams f, DPlane dp)
+{
+    int nsbx = dp.w / 4, nsby = dp.h / 4;
+    sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(dp, f, bd, i, j, nsbx, nsby); });
+}
+
+// ---- host drivers --------------------------------------------------------------------------
+
+static int host_lb2(unsigned n)
+{
+    unsigned i = 1;
+    int l = 0;
+    while (i < n) {
+        i <<= 1;
+        l++;
+    }
+    return l;
+}
+
+FilterParams make_filter_params(const MCParams &p, int q, int do_filter, int inter_sharpen)
+{
+    FilterParams f;
+    f.blk_w = p.blk_w;
+    f.blk_h = p.blk_h;
+    f.nbh = p.nbh;
+    f.nbv = p.nbv;
+    f.hshift = p.hshift;
+    f.vshift = p.vshift;
+    f.lossless = p.lossless;
+    f.do_filter = do_filter;
+    f.sharpen = inter_sharpen ? p.temporal_mc : 0; // bmc.c:470-474
+    f.q_raw = q;
+    // compute_filter_q (bmc.c:376) and fthresh (:408,:481)
+    int psyf = spatial_psy_factor_host(p.blk_w, p.blk_h, p.nbh, p.nbv, -1);
+    int fq = q > 1536 ? 1536 : q;
+    fq += fq * psyf >> 10;
+    if (fq < 1024) {
+        fq = 512 + fq / 2;
+    }
+    f.q = fq;
+    f.fthresh = 32 * (14 - host_lb2((unsigned) fq));
+    return f;
+}
+
+static Planes3 planes_of(const DFrame &f)
+{
+    Planes3 p;
+    for (int c = 0; c < 3; c++) {
+        p.p[c] = f.p[c];
+    }
+    return p;
+}
+
+void mc_sub_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DFrame &pred, const DFrame &resd, const DFrame &ref)
+{
+    hipLaunchKernelGGL((k_predict<MC_SUBTRACT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(pred),
+                       planes_of(resd));
+    HIPCHK(hipGetLastError());
+}
+
+void mc_add_res(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &pred, int do_filter,
+                int inter_sharpen)
+{
+    hipLaunchKernelGGL(k_reconstruct, dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(pred), planes_of(resd));
+    if (!p.lossless) {
+        hipLaunchKernelGGL(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
+                           planes_of(resd));
+    }
+    HIPCHK(hipGetLastError());
+}
+
+void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &out, const DFrame &ref,
+                 int do_filter, int inter_sharpen)
+{
+    hipLaunchKernelGGL((k_predict<MC_RECONSTRUCT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(out),
+                       planes_of(resd));
+    if (!p.lossless) {
+        hipLaunchKernelGGL(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
+                           planes_of(out));
+    }
+    HIPCHK(hipGetLastError());
+}
+
+void intra_filter_luma(hipStream_t s, const uint8_t *d_bd, const MCParams &p, int q, const DPlane &luma)
+{
+    if (p.lossless) {
+        return;
+    }
+    hipLaunchKernelGGL(k_intra_filter, dim3(1), dim3(256), 0, s, d_bd, make_filter_params(p, q, 1, 0), luma);
+    HIPCHK(hipGetLastError());
+}
+
+} // namespace dsv2
