@@ -13,6 +13,7 @@
 
 #include "dev.h"
 #include "bmc.h"
+#include "hme.h"
 #include "quant.h"
 
 using namespace dsv2;
@@ -380,6 +381,33 @@ void dsv_intra_filter(int q, DSV_PARAMS *p, DSV_FMETA *fm, int cpl, DSV_PLANE *d
     HIPCHK(hipMemcpy2DAsync(dp->data, dp->stride, g_pstage.p.data, g_pstage.p.stride, dp->w, dp->h, hipMemcpyDeviceToHost,
                             c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
+}
+
+DSV_MV *dsv_intra_analysis(DSV_FRAME *src, DSV_PARAMS *p)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    size_t nb = (size_t) p->nblocks_h * p->nblocks_v;
+    DFrame *d = c.get_frame(0, src->format, src->width, src->height);
+    dframe_upload(d, src, c.stream);
+    AnalysisParams ap;
+    ap.width = src->width;
+    ap.height = src->height;
+    ap.blk_w = p->blk_w;
+    ap.blk_h = p->blk_h;
+    ap.nbh = p->nblocks_h;
+    ap.nbv = p->nblocks_v;
+    ap.hshift = DSV_FORMAT_H_SHIFT(p->vidmeta->subsamp);
+    ap.vshift = DSV_FORMAT_V_SHIFT(p->vidmeta->subsamp);
+    ap.do_psy = p->do_psy;
+    ap.scale = 2 * spatial_psy_factor(p->blk_w, p->blk_h, p->nblocks_h, p->nblocks_v, -1);
+    DSV_MV *host = (DSV_MV *) dsv_alloc((int) (nb * sizeof(DSV_MV)));
+    c.put_mvs(host, nb); // sizes the device field (contents are overwritten by the kernel)
+    intra_analysis(c.stream, *d, ap, c.mvs);
+    HIPCHK(hipMemcpyAsync(host, c.mvs, nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return host;
 }
 
 DSV_FRAME *dsv_extend_frame(DSV_FRAME *frame)

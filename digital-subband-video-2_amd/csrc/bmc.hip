@@ -17,16 +17,13 @@
 //     with a workgroup barrier between them (the plane stays in L2 / the CU's L1).
 #include "dev.h"
 #include "bmc.h"
+#include "hme.h"
 
 namespace dsv2 {
 
 __device__ __forceinline__ int sar(int v, int s) { return v >> s; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t) (v > 255 ? 255 : (v < 0 ? 0 : v)); }
-
-struct Planes3 {
-    DPlane p[3];
-};
 
 // ---- prediction ---------------------------------------------------------------------
 

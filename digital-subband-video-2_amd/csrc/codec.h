@@ -1,0 +1,77 @@
+// codec.h -- device-resident state of one encoder / decoder instance and the stage drivers
+// shared by encoder.cpp and decoder.cpp.
+#pragma once
+
+#include <vector>
+
+#include "bmc.h"
+#include "dev.h"
+#include "hme.h"
+#include "quant.h"
+
+namespace dsv2 {
+
+// one picture and everything derived from it that a later frame may need as its reference
+struct PicSet {
+    DFrame src;                            // padded source picture
+    DFrame src_pyr[DSV_MAX_PYRAMID_LEVELS]; // luma decimation pyramid of the source
+    DFrame recon;                          // residual -> reconstruction (the "residual" frame of the reference)
+    DFrame recon_pyr[DSV_MAX_PYRAMID_LEVELS];
+    bool recon_pyr_valid = false;
+    DSV_MV *d_final_mvs = nullptr;         // motion field as finally transmitted (device)
+    bool has_final_mvs = false;
+};
+
+struct PlaneSyms { // host view of one plane's entropy input
+    int32_t LL;
+    const uint32_t *pos;
+    const int32_t *val;
+    int n;
+};
+
+// geometry + buffers that persist for the life of a codec instance
+struct CodecDev {
+    hipStream_t stream = nullptr;
+    int format = 0, w = 0, h = 0;
+    int blk_w = 0, blk_h = 0, nbh = 0, nbv = 0, pyr_levels = 0;
+    int cw[3], ch[3];
+    PicSet pics[2];
+    DFrame pred;
+    int32_t *coefs[3] = {nullptr, nullptr, nullptr};
+    int32_t *qv = nullptr; // dense quantised values of the 3 planes, concatenated
+    size_t qv_off[4] = {0, 0, 0, 0};
+    ScanGeom scan[3];
+    SbtScratch scratch;
+    Compactor comp;
+    uint8_t *d_blockdata = nullptr;
+    DSV_MV *d_mvs_stage = nullptr; // analysis output / upload staging
+    DSV_MV *d_mvf[DSV_MAX_PYRAMID_LEVELS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int *d_counters = nullptr;
+    int32_t *d_ll = nullptr;
+    // decoder-side symbol upload
+    uint32_t *d_sym_pos = nullptr;
+    int32_t *d_sym_val = nullptr;
+    size_t sym_cap = 0;
+    // pinned host staging
+    uint8_t *h_frame = nullptr; // one packed planar picture
+    size_t h_frame_bytes = 0;
+    DSV_MV *h_mvs = nullptr;
+    int *h_counters = nullptr;
+    int32_t *h_ll = nullptr;
+    uint8_t *h_small = nullptr; // coarsest pyramid level readback
+    uint32_t *h_pos = nullptr;
+    int32_t *h_val = nullptr;
+    size_t h_sym_cap = 0;
+
+    void init(int format, int w, int h, int blk_w, int blk_h, int pyr_levels, bool encoder);
+    void destroy();
+    void ensure_host_syms(size_t n);
+    void ensure_dev_syms(size_t n);
+    MCParams mc_params(int temporal_mc, int lossless) const;
+    QuantCfg quant_cfg(int plane, int isP, int lossless, int do_psy, const DSV_MV *d_mvs) const;
+    size_t nblocks() const { return (size_t) nbh * nbv; }
+};
+
+void block_geometry(int w, int h, int ovx, int ovy, int *blk_w, int *blk_h, int *nbh, int *nbv);
+
+} // namespace dsv2

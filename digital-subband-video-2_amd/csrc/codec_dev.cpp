@@ -1,0 +1,206 @@
+// codec_dev.cpp -- allocation of the device-resident state of a codec instance (codec.h).
+//
+// HBM footprint of one 1080p 4:2:0 encoder instance: 2 picture sets (source, source pyramid,
+// reconstruction, reconstruction pyramid: ~9 MB each), prediction 3.5 MB, coefficient planes
+// 12.4 MB, dense quantised array 12.4 MB, transform scratch 3 x 8.3 MB, symbol buffers 25 MB:
+// ~95 MB, so thousands of instances fit in 288 GB -- concurrency is bounded by CUs, not memory.
+#include "codec.h"
+
+namespace dsv2 {
+
+void block_geometry(int w, int h, int ovx, int ovy, int *blk_w, int *blk_h, int *nbh, int *nbv) // dsv_encoder.c:1203-1222
+{
+    int bw = w > 1280 ? DSV_MAX_BLOCK_SIZE : DSV_MIN_BLOCK_SIZE;
+    int bh = h > 1280 ? DSV_MAX_BLOCK_SIZE : DSV_MIN_BLOCK_SIZE;
+    int d = w > h ? w - h : h - w;
+    if (d < (w < h ? w : h)) { // mostly square picture: square blocks
+        bw = bh = bw < bh ? bw : bh;
+    }
+    if (ovx >= 0) {
+        bw = 16 << ovx;
+        bw = bw < 16 ? 16 : (bw > 32 ? 32 : bw);
+    }
+    if (ovy >= 0) {
+        bh = 16 << ovy;
+        bh = bh < 16 ? 16 : (bh > 32 ? 32 : bh);
+    }
+    *blk_w = bw;
+    *blk_h = bh;
+    *nbh = (w + bw - 1) / bw;
+    *nbv = (h + bh - 1) / bh;
+}
+
+void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr_levels_, bool encoder)
+{
+    ensure_device();
+    format = format_;
+    w = w_;
+    h = h_;
+    blk_w = blk_w_;
+    blk_h = blk_h_;
+    nbh = (w + blk_w - 1) / blk_w;
+    nbv = (h + blk_h - 1) / blk_h;
+    pyr_levels = pyr_levels_;
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    coef_dims(format, w, h, cw, ch);
+    size_t nb = nblocks();
+    for (int i = 0; i < 2; i++) {
+        dframe_alloc(&pics[i].recon, format, w, h);
+        HIPCHK(hipMalloc((void **) &pics[i].d_final_mvs, nb * sizeof(DSV_MV)));
+        HIPCHK(hipMemset(pics[i].d_final_mvs, 0, nb * sizeof(DSV_MV)));
+        if (encoder) {
+            dframe_alloc(&pics[i].src, format, w, h);
+            for (int l = 0; l < pyr_levels; l++) {
+                int lw = (w + (1 << (l + 1)) - 1) >> (l + 1), lh = (h + (1 << (l + 1)) - 1) >> (l + 1);
+                dframe_alloc(&pics[i].src_pyr[l], format, lw, lh);
+                dframe_alloc(&pics[i].recon_pyr[l], format, lw, lh);
+            }
+        }
+    }
+    dframe_alloc(&pred, format, w, h);
+    qv_off[0] = 0;
+    for (int c = 0; c < 3; c++) {
+        size_t n = (size_t) cw[c] * ch[c];
+        HIPCHK(hipMalloc((void **) &coefs[c], n * sizeof(int32_t)));
+        HIPCHK(hipMemset(coefs[c], 0, n * sizeof(int32_t)));
+        make_scan(&scan[c], cw[c], ch[c]);
+        qv_off[c + 1] = qv_off[c] + (size_t) scan[c].base[10];
+    }
+    HIPCHK(hipMalloc((void **) &qv, qv_off[3] * sizeof(int32_t)));
+    scratch.ensure((size_t) cw[0] * ch[0]);
+    if (encoder) {
+        comp.ensure(qv_off[3]);
+    }
+    HIPCHK(hipMalloc((void **) &d_blockdata, nb));
+    HIPCHK(hipMemset(d_blockdata, 0, nb));
+    HIPCHK(hipMalloc((void **) &d_mvs_stage, nb * sizeof(DSV_MV)));
+    HIPCHK(hipMemset(d_mvs_stage, 0, nb * sizeof(DSV_MV)));
+    for (int l = 0; l <= pyr_levels; l++) {
+        HIPCHK(hipMalloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
+    }
+    HIPCHK(hipMalloc((void **) &d_counters, 16 * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &d_ll, 4 * sizeof(int32_t)));
+    h_frame_bytes = 0;
+    for (int c = 0; c < 3; c++) {
+        h_frame_bytes += (size_t) pred.p[c].w * pred.p[c].h;
+    }
+    HIPCHK(hipHostMalloc((void **) &h_frame, h_frame_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h_mvs, nb * sizeof(DSV_MV), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h_counters, 16 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h_ll, 4 * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h_small, (size_t) 1 << 20, hipHostMallocDefault));
+}
+
+void CodecDev::ensure_host_syms(size_t n)
+{
+    if (n <= h_sym_cap) {
+        return;
+    }
+    if (h_pos) {
+        HIPCHK(hipHostFree(h_pos));
+        HIPCHK(hipHostFree(h_val));
+    }
+    size_t cap = n + n / 4 + 4096;
+    HIPCHK(hipHostMalloc((void **) &h_pos, cap * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h_val, cap * sizeof(int32_t), hipHostMallocDefault));
+    h_sym_cap = cap;
+}
+
+void CodecDev::ensure_dev_syms(size_t n)
+{
+    if (n <= sym_cap) {
+        return;
+    }
+    if (d_sym_pos) {
+        HIPCHK(hipFree(d_sym_pos));
+        HIPCHK(hipFree(d_sym_val));
+    }
+    size_t cap = n + n / 4 + 4096;
+    HIPCHK(hipMalloc((void **) &d_sym_pos, cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &d_sym_val, cap * sizeof(int32_t)));
+    sym_cap = cap;
+}
+
+void CodecDev::destroy()
+{
+    if (!stream) {
+        return;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    for (int i = 0; i < 2; i++) {
+        dframe_free(&pics[i].recon);
+        dframe_free(&pics[i].src);
+        for (int l = 0; l < DSV_MAX_PYRAMID_LEVELS; l++) {
+            dframe_free(&pics[i].src_pyr[l]);
+            dframe_free(&pics[i].recon_pyr[l]);
+        }
+        HIPCHK(hipFree(pics[i].d_final_mvs));
+    }
+    dframe_free(&pred);
+    for (int c = 0; c < 3; c++) {
+        HIPCHK(hipFree(coefs[c]));
+    }
+    HIPCHK(hipFree(qv));
+    scratch.release();
+    comp.release();
+    HIPCHK(hipFree(d_blockdata));
+    HIPCHK(hipFree(d_mvs_stage));
+    for (int l = 0; l <= DSV_MAX_PYRAMID_LEVELS; l++) {
+        if (d_mvf[l]) {
+            HIPCHK(hipFree(d_mvf[l]));
+        }
+    }
+    HIPCHK(hipFree(d_counters));
+    HIPCHK(hipFree(d_ll));
+    if (d_sym_pos) {
+        HIPCHK(hipFree(d_sym_pos));
+        HIPCHK(hipFree(d_sym_val));
+    }
+    HIPCHK(hipHostFree(h_frame));
+    HIPCHK(hipHostFree(h_mvs));
+    HIPCHK(hipHostFree(h_counters));
+    HIPCHK(hipHostFree(h_ll));
+    HIPCHK(hipHostFree(h_small));
+    if (h_pos) {
+        HIPCHK(hipHostFree(h_pos));
+        HIPCHK(hipHostFree(h_val));
+    }
+    HIPCHK(hipStreamDestroy(stream));
+    stream = nullptr;
+}
+
+MCParams CodecDev::mc_params(int temporal_mc, int lossless) const
+{
+    MCParams m;
+    m.blk_w = blk_w;
+    m.blk_h = blk_h;
+    m.nbh = nbh;
+    m.nbv = nbv;
+    m.hshift = DSV_FORMAT_H_SHIFT(format);
+    m.vshift = DSV_FORMAT_V_SHIFT(format);
+    m.temporal_mc = temporal_mc;
+    m.lossless = lossless;
+    return m;
+}
+
+QuantCfg CodecDev::quant_cfg(int plane, int isP, int lossless, int do_psy, const DSV_MV *d_mvs) const
+{
+    QuantCfg c;
+    c.w = cw[plane];
+    c.h = ch[plane];
+    c.plane = plane;
+    c.isP = isP;
+    c.lossless = lossless;
+    c.do_psy = do_psy;
+    c.hshift = DSV_FORMAT_H_SHIFT(format);
+    c.vshift = DSV_FORMAT_V_SHIFT(format);
+    c.blk_w = blk_w;
+    c.blk_h = blk_h;
+    c.nbh = nbh;
+    c.nbv = nbv;
+    c.bd = d_blockdata;
+    c.mvs = d_mvs;
+    return c;
+}
+
+} // namespace dsv2

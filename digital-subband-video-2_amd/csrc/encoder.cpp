@@ -1,0 +1,1222 @@
+// encoder.cpp -- host frame controller of the encoder (C ABI section 2 of include/dsv2_hip.h).
+//
+// Restates the serial control logic of reference src/dsv_encoder.c around the device pipeline:
+// GOP / I-P decision (encode_one_frame :1185), rate control (quality2quant :253, qual_to_qp :91),
+// scene-change detection (:546, avg_motion :130, scene_complexity :180), auto filter decision
+// (:519), per-block metadata coders (encode_stable_blocks :798, encode_motion :693,
+// encode_intra_meta :887, gather_stats :993), packet framing (:934-990, set_link_offsets :471)
+// and statistics (dsv_enc :1431).  Its outputs -- quantiser, flags, I/P decisions -- parameterise
+// every kernel, so it is restated exactly; the pixel work itself never runs on the host:
+//   upload -> extend / pyramid -> [P: HME] -> (host decisions) -> [P: predict+subtract]
+//   -> fwd SBT -> quantise + compact -> (host entropy packing) -> inv SBT -> [I: intra filter |
+//   P: reconstruct + in-loop filters] -> extend.
+#include <limits.h>
+#include <string.h>
+
+#include <vector>
+
+#include "codec.h"
+
+using namespace dsv2;
+
+namespace {
+
+struct EncImpl {
+    CodecDev dev;
+    bool ready = false;
+    int cur = 0;          // picture set receiving the current frame
+    bool have_ref = false; // pics[cur ^ 1] holds a usable reference
+    std::vector<DSV_MV> mvs; // host copy of the current motion field
+    std::vector<DSV_MV> intramv;
+};
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline int sar(int v, int s) { return v < 0 ? ~(~v >> s) : v >> s; }
+inline int sar_r(int v, int s) { return sar(v + (1 << (s - 1)), s); }
+inline int sqr(int x) { return x * x; }
+inline bool mvflag(const DSV_MV &m, int bit) { return (m.flags >> bit) & 1; }
+
+// ---- motion-vector helpers shared with the bitstream (dsv.c:324-447) ----------------------
+int mv_pred1(int left, int top, int topleft)
+{
+    int dif = left + top - topleft;
+    return abs(dif - left) < abs(dif - top) ? left : top;
+}
+
+void movec_pred(const DSV_MV *v, int nbh, int x, int y, int *px, int *py)
+{
+    int vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
+    if (x > 0) {
+        const DSV_MV *m = &v[y * nbh + x - 1];
+        vx[0] = m->u.mv.x;
+        vy[0] = m->u.mv.y;
+    }
+    if (y > 0) {
+        const DSV_MV *m = &v[(y - 1) * nbh + x];
+        vx[1] = m->u.mv.x;
+        vy[1] = m->u.mv.y;
+    }
+    if (x > 0 && y > 0) {
+        const DSV_MV *m = &v[(y - 1) * nbh + x - 1];
+        vx[2] = m->u.mv.x;
+        vy[2] = m->u.mv.y;
+    }
+    *px = mv_pred1(vx[0], vx[1], vx[2]);
+    *py = mv_pred1(vy[0], vy[1], vy[2]);
+}
+
+int seg_bits(int v)
+{
+    if (v < 0) {
+        v = -v;
+    }
+    v++;
+    int nb = 31 - __builtin_clz((unsigned) v);
+    return nb * 2 + 2;
+}
+
+int mv_cost(const DSV_MV *v, const DSV_PARAMS *p, int i, int j, int mx, int my, int q, int sqr_)
+{
+    int px, py;
+    movec_pred(v, p->nblocks_h, i, j, &px, &py);
+    int bits = seg_bits(mx - px) + seg_bits(my - py);
+    int b2sr = (256 * (q * q >> DSV_MAX_QP_BITS) * p->blk_w * p->blk_h) / (p->vidmeta->width * p->vidmeta->height);
+    bits += bits * b2sr >> 7;
+    return sqr_ ? bits * bits : bits;
+}
+
+void neighbordif2(const DSV_MV *v, int nbh, int x, int y, int *dx, int *dy)
+{
+    const DSV_MV *c = &v[x + y * nbh];
+    int cx = c->u.mv.x, cy = c->u.mv.y, lx = cx, ly = cy, tx = cx, ty = cy;
+    if (abs(cx) < 2 && abs(cy) < 2) {
+        *dx = *dy = 0;
+        return;
+    }
+    if (x > 0) {
+        const DSV_MV *m = c - 1;
+        if (m->u.all && !mvflag(*m, DSV_MV_BIT_SKIP)) {
+            lx = m->u.mv.x;
+            ly = m->u.mv.y;
+        }
+    }
+    if (y > 0) {
+        const DSV_MV *m = c - nbh;
+        if (m->u.all && !mvflag(*m, DSV_MV_BIT_SKIP)) {
+            tx = m->u.mv.x;
+            ty = m->u.mv.y;
+        }
+    }
+    *dx = abs(lx - cx) + abs(ly - cy);
+    *dy = abs(tx - cx) + abs(ty - cy);
+}
+
+int neighbordif(const DSV_MV *v, int nbh, int x, int y)
+{
+    int a, b;
+    neighbordif2(v, nbh, x, y, &a, &b);
+    return (a + b) / 3;
+}
+
+// ---- rate control ---------------------------------------------------------------------------
+int sample_point(int v) // dsv_encoder.c:72
+{
+    const int unit = 10 * DSV_RC_QUAL_SCALE;
+    v = 100 * DSV_RC_QUAL_SCALE - v;
+    int whole = v / unit, frac = v % unit;
+    int lo = 1 << whole, hi = 1 << (whole + 1);
+    int qp = ((unit - frac) * lo + frac * hi) / unit - 1;
+    return clampi(qp * 4, 0, DSV_MAX_QP);
+}
+
+int qual_to_qp(int v) // dsv_encoder.c:90
+{
+    int d_hi = 100 * DSV_RC_QUAL_SCALE - v;
+    if (d_hi < 60) {
+        return d_hi + 16;
+    }
+    v *= 2;
+    int actv = v / 3, frac = v % 3;
+    return (sample_point(actv) * (3 - frac) + frac * sample_point(actv + 1)) / 3;
+}
+
+#define RC_PCT(p) ((p) * DSV_RC_QUAL_SCALE)
+
+// mean luma of the coarsest source pyramid level, row means first (dsv_encoder.c:108)
+unsigned luma_avg_rows(const uint8_t *pix, int w, int h)
+{
+    unsigned avg = 0;
+    for (int j = 0; j < h; j++) {
+        unsigned r = 0;
+        for (int i = 0; i < w; i++) {
+            r += pix[j * w + i];
+        }
+        avg += r / (unsigned) w;
+    }
+    return avg / (unsigned) h;
+}
+
+struct FrameCtl { // per-frame control block (the reference's DSV_ENCDATA minus the pictures)
+    DSV_FNUM fnum;
+    DSV_PARAMS params;
+    int quant;
+    unsigned coarse_luma_avg;
+};
+
+void quality2quant(DSV_ENCODER *enc, FrameCtl *d, DSV_FNUM prev_I, int forced_intra) // dsv_encoder.c:252
+{
+    int q = (int) enc->rc_qual;
+    const DSV_META *vf = d->params.vidmeta;
+    bool isP = d->params.has_ref;
+
+    if (enc->rc_mode == DSV_RATE_CONTROL_CRF) {
+        int bound = RC_PCT(25);
+        int minq = isP ? enc->min_quality : enc->min_I_frame_quality;
+        int maxq = enc->max_quality;
+        int anchor = clampi(enc->quality, minq, maxq);
+        int fps = (vf->fps_num << 5) / vf->fps_den;
+        int gop = clampi(enc->gop, 1, (10 * fps >> 5));
+        int sqst = sqr(enc->motion_static) / 75;
+        if (sqst < enc->motion_static) {
+            sqst = enc->motion_static;
+        }
+        int plex;
+        if (!isP) {
+            plex = (forced_intra ? 2 : 1) * sqst - enc->motion_chaos;
+        } else {
+            int m = enc->avg_err < enc->motion_chaos / 3 ? enc->avg_err : enc->motion_chaos / 3;
+            plex = sqr(m) / 2 + sqst - 3 * enc->motion_chaos;
+        }
+        plex = (plex * gop * vf->fps_den) / (vf->fps_num << 4);
+        plex = clampi(plex, -bound / 4, bound / 4);
+        int clamped_avg = enc->rf_avg > enc->quality ? enc->rf_avg : enc->quality;
+        int target = (anchor + 3 * clamped_avg + 2) >> 2;
+        target = clampi(target, enc->quality - bound, enc->quality + bound);
+        if (enc->do_dark_intra_boost) {
+            unsigned la = d->coarse_luma_avg;
+            if (la < 80) {
+                int step = (int) (80 - la) / 5;
+                step = clampi(step, 5, 16) - 5;
+                plex += sqr(step) / 4;
+            }
+        }
+        q = target + plex;
+        if (!isP) {
+            int back = (DSV_RC_QUAL_MAX - q) / (1 + enc->motion_chaos / 4);
+            q += (back * gop * vf->fps_den) / (vf->fps_num << 4);
+        }
+        q = clampi(q, enc->quality - bound, enc->quality + bound);
+        q = clampi(q, minq, maxq);
+        enc->rc_qual = (unsigned) (q > 0 ? q : 0);
+    } else if (enc->rc_mode == DSV_RATE_CONTROL_ABR) {
+        int fps = (vf->fps_num << 5) / vf->fps_den;
+        if (fps == 0) {
+            fps = 1;
+        }
+        if (enc->prev_complexity < 0) {
+            enc->prev_complexity = enc->curr_complexity;
+        }
+        int target_rf = (int) (((enc->bitrate << 5) / (unsigned) fps) >> 3);
+        int rf = enc->rf_avg ? enc->rf_avg : target_rf;
+        int dir = (rf - target_rf) > 0 ? -1 : 1;
+        int delta;
+        enc->min_q_step = clampi(enc->min_q_step, 1, DSV_RC_QUAL_MAX);
+        enc->max_q_step = clampi(enc->max_q_step, 1, DSV_RC_QUAL_MAX);
+        if (!isP) {
+            unsigned dif = (unsigned) abs(rf - target_rf);
+            if (dif > 32768) {
+                dif = 32768;
+            }
+            delta = (int) ((dif * dif) / (unsigned) ((dir > 0 ? 32 : 64) * target_rf));
+            if (delta > RC_PCT(12)) {
+                delta -= RC_PCT(8);
+            } else if (delta > RC_PCT(8)) {
+                delta -= RC_PCT(4);
+            } else if (delta > RC_PCT(4)) {
+                delta -= RC_PCT(2);
+            }
+            delta = delta < RC_PCT(25) ? delta : RC_PCT(25);
+            q = (q > enc->avg_P_frame_q ? q : enc->avg_P_frame_q) + dir * delta;
+            if (enc->prev_complexity < 15) {
+                q += RC_PCT(2);
+            } else if (enc->prev_complexity < 30) {
+                q += RC_PCT(1);
+            } else if (enc->prev_complexity > 40) {
+                q -= RC_PCT(1);
+            } else if (enc->prev_complexity > 60) {
+                q -= RC_PCT(2);
+            }
+            enc->prev_I_frame_quality = q;
+        } else {
+            delta = (abs(rf - target_rf) * RC_PCT(100)) / target_rf;
+            if (dir < 0 && delta < enc->min_q_step) {
+                delta = 0;
+            }
+            int cap = enc->max_q_step * (dir > 0 ? 1 : 8);
+            delta = delta < cap ? delta : cap;
+            q += dir * delta;
+        }
+        int low_p = clampi(enc->avg_P_frame_q - RC_PCT(4), enc->min_quality, enc->max_quality);
+        int minq = isP ? low_p : enc->min_I_frame_quality;
+        if (enc->do_dark_intra_boost && !isP) {
+            unsigned la = d->coarse_luma_avg;
+            if (la < 80) {
+                q += clampi((int) (80 - la) / 5, 5, 16);
+            }
+        }
+        q = clampi(q, minq, enc->max_quality);
+        q = clampi(q, 0, DSV_RC_QUAL_MAX);
+        enc->rc_qual = (unsigned) q;
+        enc->prev_complexity = enc->curr_complexity;
+        if (enc->rc_pergop) {
+            q = clampi(enc->prev_I_frame_quality, enc->min_quality, enc->max_quality);
+        } else if (d->fnum > 0 && isP) {
+            int step = RC_PCT(8), closeness;
+            int gop = clampi(enc->gop, 1, 60);
+            int dist = abs((int) d->fnum - (int) prev_I);
+            if (dist >= enc->gop / 2) {
+                dist = abs((int) d->fnum - ((int) prev_I + gop / 2));
+                closeness = step - (step * dist / (gop / 2 > 1 ? gop / 2 : 1));
+            } else {
+                closeness = step * dist / (gop / 2 > 1 ? gop / 2 : 1);
+            }
+            q += clampi(closeness, 0, step) / 2;
+            q -= clampi((enc->avg_err * enc->avg_err) >> 1, 0, RC_PCT(16));
+            q = clampi(q, low_p, enc->max_quality);
+            if (enc->gop <= (2 * fps >> 5)) {
+                if (enc->prev_I_frame_quality < q) {
+                    q = enc->prev_I_frame_quality;
+                } else {
+                    q = (3 * q + enc->prev_I_frame_quality) >> 2;
+                }
+                q = clampi(q, enc->min_quality, enc->max_quality);
+            }
+        }
+    } else {
+        q = enc->quality;
+        enc->rc_qual = (unsigned) q;
+    }
+    d->quant = d->params.lossless ? 1 : qual_to_qp(q);
+    enc->prev_quant = d->quant;
+}
+
+// ---- scene statistics (dsv_encoder.c:129-250) ---------------------------------------------------
+int avg_motion(DSV_ENCODER *enc, const DSV_MV *v, const DSV_PARAMS *p)
+{
+    int ax = 0, ay = 0, chaos = 0, stat = 0;
+    int nblk = p->nblocks_h * p->nblocks_v;
+    for (int j = 0; j < p->nblocks_v; j++) {
+        for (int i = 0; i < p->nblocks_h; i++) {
+            const DSV_MV *mv = &v[i + j * p->nblocks_h];
+            if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                stat++;
+                continue;
+            }
+            ax += mv->u.mv.x;
+            ay += mv->u.mv.y;
+            int ndx, ndy;
+            neighbordif2(v, p->nblocks_h, i, j, &ndx, &ndy);
+            if (ndx > 4 || ndy > 4) {
+                chaos++;
+            } else {
+                stat++;
+            }
+        }
+    }
+    ax = (abs(ax) + abs(ay)) / (nblk * 2);
+    if (ax < 1) {
+        ax = 1;
+    }
+    enc->curr_avgmot = ax;
+    enc->motion_static = stat * 100 / nblk;
+    chaos = chaos * 100 / nblk;
+    if (enc->prev_chaos < 0) {
+        enc->motion_chaos = chaos;
+        enc->prev_chaos = chaos;
+    } else {
+        enc->prev_chaos = (enc->prev_chaos + enc->motion_chaos) / 2;
+        enc->motion_chaos = chaos;
+    }
+    return ax;
+}
+
+int scene_complexity(DSV_ENCODER *enc, const DSV_MV *v, const DSV_PARAMS *p)
+{
+    int complexity = 0, maxpot;
+    int nblk = p->nblocks_h * p->nblocks_v;
+    if (enc->rc_mode == DSV_RATE_CONTROL_ABR) {
+        maxpot = mv_cost(v, p, 0, 0, 64, 64, enc->prev_quant, 0) + 12 + 64;
+        maxpot = (maxpot * nblk + 1) >> 1;
+        for (int j = 0; j < p->nblocks_v; j++) {
+            for (int i = 0; i < p->nblocks_h; i++) {
+                const DSV_MV *mv = &v[i + j * p->nblocks_h];
+                if (!mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                    complexity += mv_cost(v, p, i, j, mv->u.mv.x, mv->u.mv.y, enc->prev_quant, 0);
+                    complexity += (int) mv->err - enc->avg_err;
+                }
+                if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
+                    complexity += mv->submask == DSV_MASK_ALL_INTRA ? 16 : 4;
+                }
+            }
+        }
+    } else if (enc->rc_mode == DSV_RATE_CONTROL_CRF) {
+        maxpot = 70 * nblk;
+        for (int j = 0; j < p->nblocks_v; j++) {
+            for (int i = 0; i < p->nblocks_h; i++) {
+                const DSV_MV *mv = &v[i + j * p->nblocks_h];
+                if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                    complexity -= 100;
+                } else {
+                    complexity += mv_cost(v, p, i, j, mv->u.mv.x, mv->u.mv.y, enc->prev_quant, 0);
+                }
+                if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
+                    complexity += mv->submask == DSV_MASK_ALL_INTRA ? 100 : 40;
+                }
+            }
+        }
+    } else {
+        return 0;
+    }
+    return complexity <= 0 ? 0 : complexity * 100 / maxpot;
+}
+
+void compute_auto_filter(DSV_ENCODER *enc, const FrameCtl *d) // dsv_encoder.c:518
+{
+    const DSV_PARAMS *p = &d->params;
+    int chaos = enc->motion_chaos;
+    int psy = spatial_psy_factor(p->blk_w, p->blk_h, p->nblocks_h, p->nblocks_v, -1);
+    int norm = sqr(d->quant) >> 15;
+    int relerr = (sqr(enc->curr_intra_pct) + enc->curr_scblocks + enc->avg_err * chaos) / (norm > 1 ? norm : 1);
+    relerr += relerr * psy >> 7;
+    int avg_chaos = (enc->prev_chaos + chaos + 1) >> 1;
+    int thresh = 8;
+    thresh += thresh * psy >> 5;
+    int ae = enc->avg_err / 2 > 1 ? enc->avg_err / 2 : 1;
+    thresh -= ((avg_chaos < 48 ? avg_chaos : 48) * psy * ae / (128 * (thresh - 2)));
+    enc->auto_filter = chaos <= 1 || relerr > thresh;
+}
+
+// returns 1 when the P frame must be re-coded as an I frame (dsv_encoder.c:545)
+int scene_change_detection(DSV_ENCODER *enc, FrameCtl *d, DSV_MV *mvs)
+{
+    DSV_PARAMS *p = &d->params;
+    int intra_pct = enc->curr_intra_pct, scblocks = enc->curr_scblocks;
+    int avgmot = avg_motion(enc, mvs, p);
+    int chaos = enc->motion_chaos;
+    int dchaos = abs(chaos - enc->prev_chaos);
+    int gopdiv = abs(enc->gop) * 3 / 4;
+    int closeness = (int) d->fnum - (int) enc->prev_gop;
+    int complexity = scene_complexity(enc, mvs, p);
+    int closefac = closeness / (gopdiv > 1 ? gopdiv : 1);
+    int shift;
+    if (complexity > 256 && chaos < 5) {
+        shift = 9;
+    } else if (complexity > chaos * 2) {
+        shift = 8;
+    } else if (complexity > chaos) {
+        shift = 7;
+    } else {
+        shift = 6;
+    }
+    int tipct = sqr(intra_pct) >> 5;
+    int likely_sc = (intra_pct * 3 / 2 > scblocks) + (tipct > scblocks);
+    int scp = enc->scene_change_pct > 1 ? enc->scene_change_pct : 1;
+    if (scblocks > enc->scene_change_pct && chaos < 34) {
+        scblocks = sqr(scblocks * 2) / scp;
+        likely_sc++;
+    } else {
+        scblocks = sqr(scblocks) / scp;
+    }
+    shift = shift - likely_sc > 5 ? shift - likely_sc : 5;
+    int a = dchaos / 16 + enc->avg_err / 8;
+    int blks = (a > 1 ? a : 1) * scblocks * (complexity > 1 ? complexity : 1) * (closefac > 1 ? closefac : 1) >> (shift + 1);
+    int pc = enc->prev_chaos - 10 > 30 ? enc->prev_chaos - 10 : 30;
+    bool sc = enc->do_scd && (blks > 120 || (blks > enc->scene_change_pct && avgmot < 20 && enc->motion_chaos <= pc));
+    bool high_intra = intra_pct > enc->intra_pct_thresh;
+    if (sc || high_intra) {
+        p->has_ref = 0;
+        return 1;
+    }
+    enc->curr_complexity = complexity;
+    int nintra = 0, skipn = 0;
+    int nblk = p->nblocks_h * p->nblocks_v;
+    for (int idx = 0; idx < nblk; idx++) {
+        const DSV_MV *mv = &mvs[idx];
+        enc->intra_map[idx] |= mvflag(*mv, DSV_MV_BIT_INTRA);
+        if (enc->intra_map[idx]) {
+            if (mvflag(*mv, DSV_MV_BIT_SKIP) || mv->u.all == 0) {
+                if (mvflag(*mv, DSV_MV_BIT_MAINTAIN)) {
+                    nintra += 3;
+                    skipn += 2;
+                } else {
+                    nintra += 1;
+                    skipn++;
+                }
+            } else if (mvflag(*mv, DSV_MV_BIT_NOXMITY) && mvflag(*mv, DSV_MV_BIT_MAINTAIN)) {
+                nintra++;
+            }
+        }
+        nintra += enc->intra_map[idx];
+    }
+    nintra = nintra * 100 / nblk;
+    skipn = skipn * 100 / nblk;
+    if (nintra > enc->intra_pct_thresh && enc->curr_avgmot < 10 &&
+        enc->motion_chaos <= clampi(enc->prev_chaos / 2 + skipn, 20, 40)) {
+        p->has_ref = 0;
+        return 1;
+    }
+    return 0;
+}
+
+// ---- packet framing -------------------------------------------------------------------------
+void put_packet_hdr(BitWriter &bw, int type) // dsv_encoder.c:934
+{
+    bw.put_bits(8, 'D');
+    bw.put_bits(8, 'S');
+    bw.put_bits(8, 'V');
+    bw.put_bits(8, '2');
+    bw.put_bits(8, 8); // DSV_VERSION_MINOR
+    bw.put_bits(8, (unsigned) type);
+    bw.put_bits(32, 0);
+    bw.put_bits(32, 0);
+}
+
+void put_be32(uint8_t *p, unsigned v)
+{
+    p[0] = (uint8_t) (v >> 24);
+    p[1] = (uint8_t) (v >> 16);
+    p[2] = (uint8_t) (v >> 8);
+    p[3] = (uint8_t) v;
+}
+
+void set_link_offsets(DSV_ENCODER *enc, DSV_BUF *buf, int is_eos) // dsv_encoder.c:470
+{
+    unsigned next = is_eos ? 0 : buf->len;
+    put_be32(buf->data + DSV_PACKET_PREV_OFFSET, (unsigned) enc->prev_link);
+    put_be32(buf->data + DSV_PACKET_NEXT_OFFSET, next);
+    enc->prev_link = (int) next;
+}
+
+void encode_metadata(DSV_ENCODER *enc, DSV_BUF *buf) // dsv_encoder.c:951
+{
+    const DSV_META *m = &enc->vidmeta;
+    dsv_mk_buf(buf, 64);
+    BitWriter bw{buf->data, 0};
+    put_packet_hdr(bw, DSV_PT_META);
+    bw.put_ueg((unsigned) m->width);
+    bw.put_ueg((unsigned) m->height);
+    bw.put_ueg((unsigned) m->subsamp);
+    bw.put_ueg((unsigned) m->fps_num);
+    bw.put_ueg((unsigned) m->fps_den);
+    bw.put_ueg((unsigned) m->aspect_num);
+    bw.put_ueg((unsigned) m->aspect_den);
+    bw.put_ueg((unsigned) m->inter_sharpen);
+    bw.put_bit(0);
+    bw.align();
+    unsigned len = bw.byte_pos();
+    put_be32(buf->data + DSV_PACKET_NEXT_OFFSET, len);
+    buf->len = len;
+}
+
+// ---- per-block metadata ---------------------------------------------------------------------
+enum { ST_STABLE = 0, ST_MAINTAIN, ST_RINGING, ST_MODE, ST_EPRM, ST_MAX };
+
+void gather_stats(DSV_ENCODER *enc, const FrameCtl *d, const DSV_MV *mvs, const DSV_MV *intramv, int *stats) // :992
+{
+    int nblk = d->params.nblocks_h * d->params.nblocks_v;
+    int avgdiv = (int) enc->refresh_ctr;
+    if (enc->refresh_ctr >= enc->stable_refresh) {
+        avgdiv = 0;
+    }
+    if (avgdiv <= 0) {
+        avgdiv = 1;
+    }
+    for (int i = 0; i < nblk; i++) {
+        int stable = 0;
+        if (d->params.has_ref) {
+            const DSV_MV *mv = &mvs[i];
+            stable = mvflag(*mv, DSV_MV_BIT_INTRA) ? 0 : mvflag(*mv, DSV_MV_BIT_SKIP);
+            if (!mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                stats[ST_MODE] += mvflag(*mv, DSV_MV_BIT_INTRA) ? 1 : -1;
+                stats[ST_EPRM] += mvflag(*mv, DSV_MV_BIT_EPRM) ? 1 : -1;
+            }
+        } else {
+            const DSV_MV *mv = &intramv[i];
+            if (d->fnum > 0 && enc->do_temporal_aq) {
+                stable = (enc->stability[i].x / avgdiv == 0) && (enc->stability[i].y / avgdiv == 0);
+            } else {
+                stable = mvflag(*mv, DSV_MV_BIT_SKIP);
+            }
+            stats[ST_MAINTAIN] += mvflag(*mv, DSV_MV_BIT_MAINTAIN) ? 1 : -1;
+            stats[ST_RINGING] += mvflag(*mv, DSV_MV_BIT_RINGING) ? 1 : -1;
+        }
+        stats[ST_STABLE] += (stable & 1) ? 1 : -1;
+    }
+}
+
+void append_sub(BitWriter &bs, const uint8_t *data, int bytes)
+{
+    bs.put_ueg((unsigned) bytes);
+    bs.align();
+    bs.concat(data, bytes);
+}
+
+void encode_stable_blocks(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DSV_MV *mvs, const DSV_MV *intramv,
+                          const int *stats) // dsv_encoder.c:797
+{
+    int nblk = d->params.nblocks_h * d->params.nblocks_v;
+    std::vector<uint8_t> buf((size_t) nblk * 32, 0);
+    RleWriter rle;
+    rle.bw = BitWriter{buf.data(), 0};
+    if (enc->refresh_ctr >= enc->stable_refresh) {
+        enc->refresh_ctr = 0;
+        memset(enc->stability, 0, sizeof(*enc->stability) * (size_t) nblk);
+    }
+    int avgdiv = (int) enc->refresh_ctr;
+    if (avgdiv <= 0) {
+        avgdiv = 1;
+    }
+    int fps = (d->params.vidmeta->fps_num + d->params.vidmeta->fps_den / 2) / d->params.vidmeta->fps_den;
+    int dsf = fps <= 24 ? 6 : (fps <= 30 ? 4 : (fps <= 60 ? 2 : 0));
+    for (int i = 0; i < nblk; i++) {
+        int stable = 0;
+        if (d->params.has_ref) {
+            DSV_MV *mv = &mvs[i];
+            enc->blockdata[i] = 0;
+            if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                mv->u.all = 0;
+            }
+            if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
+                enc->blockdata[i] |= DSV_IS_INTRA;
+            } else {
+                stable = mvflag(*mv, DSV_MV_BIT_SKIP);
+                if (!stable) {
+                    enc->stability[i].x += abs(mv->u.mv.x) >> dsf;
+                    enc->stability[i].y += abs(mv->u.mv.y) >> dsf;
+                } else {
+                    mv->u.all = 0;
+                }
+            }
+            enc->blockdata[i] |= (uint8_t) (stable << 2);                               /* DSV_SKIP_BIT */
+            enc->blockdata[i] |= (uint8_t) (mvflag(*mv, DSV_MV_BIT_SIMCMPLX) << 6);      /* DSV_SIMCMPLX_BIT */
+        } else {
+            const DSV_MV *mv = &intramv[i];
+            if (d->fnum > 0 && enc->do_temporal_aq) {
+                stable = (enc->stability[i].x / avgdiv == 0) && (enc->stability[i].y / avgdiv == 0);
+            }
+            stable |= mvflag(*mv, DSV_MV_BIT_SKIP);
+            enc->blockdata[i] = (uint8_t) (stable << 0); /* DSV_STABLE_BIT */
+        }
+        rle.put(stats[ST_STABLE] == 0 ? (stable & 1) : !(stable & 1));
+    }
+    bs.align();
+    int bytes = rle.finish();
+    append_sub(bs, buf.data(), bytes);
+}
+
+void encode_motion(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DSV_MV *mvs, const int *stats) // dsv_encoder.c:692
+{
+    const DSV_PARAMS *p = &d->params;
+    int nblk = p->nblocks_h * p->nblocks_v;
+    size_t ub = (size_t) nblk * 32;
+    std::vector<uint8_t> bufs[5];
+    for (auto &b : bufs) {
+        b.assign(ub, 0);
+    }
+    RleWriter mode_rle, eprm_rle;
+    mode_rle.bw = BitWriter{bufs[0].data(), 0};
+    eprm_rle.bw = BitWriter{bufs[4].data(), 0};
+    BitWriter mvx{bufs[1].data(), 0}, mvy{bufs[2].data(), 0}, sbim{bufs[3].data(), 0};
+
+    for (int j = 0; j < p->nblocks_v; j++) {
+        for (int i = 0; i < p->nblocks_h; i++) {
+            int idx = i + j * p->nblocks_h;
+            DSV_MV *mv = &mvs[idx];
+            enc->blockdata[idx] |= (uint8_t) (mvflag(*mv, DSV_MV_BIT_EPRM) << 5);
+            if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                enc->blockdata[idx] |= DSV_IS_STABLE;
+                continue;
+            }
+            int intra = mvflag(*mv, DSV_MV_BIT_INTRA);
+            int px, py, cvx, cvy;
+            movec_pred(mvs, p->nblocks_h, i, j, &px, &py);
+            if (intra) {
+                px = sar_r(px, 2);
+                py = sar_r(py, 2);
+                cvx = sar(mv->u.mv.x, 2);
+                cvy = sar(mv->u.mv.y, 2);
+                mv->u.mv.x = (int16_t) (cvx * 4);
+                mv->u.mv.y = (int16_t) (cvy * 4);
+                if (mv->submask == DSV_MASK_ALL_INTRA) {
+                    sbim.put_bit(1);
+                } else {
+                    sbim.put_bit(0);
+                    sbim.put_bits(4, mv->submask);
+                }
+                if (mv->dc & DSV_SRC_DC_PRED) {
+                    sbim.put_bit(1);
+                    sbim.put_bits(8, mv->dc & 0xff);
+                } else {
+                    sbim.put_bit(0);
+                }
+            } else {
+                cvx = mv->u.mv.x;
+                cvy = mv->u.mv.y;
+            }
+            mvx.put_seg(cvx - px);
+            mvy.put_seg(cvy - py);
+            if (neighbordif(mvs, p->nblocks_h, i, j) > 8) { /* DSV_NDIF_THRESH */
+                enc->blockdata[idx] |= DSV_IS_STABLE;
+            }
+            int eprm = mvflag(*mv, DSV_MV_BIT_EPRM);
+            mode_rle.put(stats[ST_MODE] == 0 ? intra : !intra);
+            eprm_rle.put(stats[ST_EPRM] == 0 ? eprm : !eprm);
+        }
+    }
+    for (int s = 0; s < 5; s++) {
+        int bytes;
+        bs.align();
+        if (s == 0) {
+            bytes = mode_rle.finish();
+        } else if (s == 4) {
+            bytes = eprm_rle.finish();
+        } else {
+            BitWriter &w = s == 1 ? mvx : (s == 2 ? mvy : sbim);
+            w.align();
+            bytes = (int) w.byte_pos();
+        }
+        append_sub(bs, bufs[s].data(), bytes);
+    }
+}
+
+void encode_intra_meta(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, const DSV_MV *intramv, const int *stats) // :886
+{
+    int nblk = d->params.nblocks_h * d->params.nblocks_v;
+    std::vector<uint8_t> br((size_t) nblk * 32, 0), bm((size_t) nblk * 32, 0);
+    RleWriter rr, rm;
+    rr.bw = BitWriter{br.data(), 0};
+    rm.bw = BitWriter{bm.data(), 0};
+    for (int i = 0; i < nblk; i++) {
+        int ring = mvflag(intramv[i], DSV_MV_BIT_RINGING), maintain = mvflag(intramv[i], DSV_MV_BIT_MAINTAIN);
+        enc->blockdata[i] |= (uint8_t) (ring << 3);
+        enc->blockdata[i] |= (uint8_t) (maintain << 1);
+        rr.put(stats[ST_RINGING] == 0 ? ring : !ring);
+        rm.put(stats[ST_MAINTAIN] == 0 ? maintain : !maintain);
+    }
+    bs.align();
+    int bytes = rr.finish();
+    append_sub(bs, br.data(), bytes);
+    bs.align();
+    bytes = rm.finish();
+    append_sub(bs, bm.data(), bytes);
+}
+
+// ---- device pipeline pieces -----------------------------------------------------------------
+void build_pyramid(CodecDev &dv, const DFrame &base, DFrame *pyr) // mk_pyramid, dsv_encoder.c:493
+{
+    const DFrame *prev = &base;
+    for (int l = 0; l < dv.pyr_levels; l++) {
+        ds2x_luma(dv.stream, prev->p[0], pyr[l].p[0]);
+        extend_plane(dv.stream, pyr[l].p[0]);
+        prev = &pyr[l];
+    }
+}
+
+AnalysisParams analysis_params(const CodecDev &dv, int do_psy)
+{
+    AnalysisParams a;
+    a.width = dv.w;
+    a.height = dv.h;
+    a.blk_w = dv.blk_w;
+    a.blk_h = dv.blk_h;
+    a.nbh = dv.nbh;
+    a.nbv = dv.nbv;
+    a.hshift = DSV_FORMAT_H_SHIFT(dv.format);
+    a.vshift = DSV_FORMAT_V_SHIFT(dv.format);
+    a.do_psy = do_psy;
+    a.scale = 2 * spatial_psy_factor(dv.blk_w, dv.blk_h, dv.nbh, dv.nbv, -1);
+    return a;
+}
+
+__global__ void k_grab_ll(const int32_t *c0, const int32_t *c1, const int32_t *c2, int32_t *out)
+{
+    out[0] = c0[0];
+    out[1] = c1[0];
+    out[2] = c2[0];
+}
+
+// dsv_encode_picture (dsv_encoder.c:1039): returns the picture packet in `out`
+void encode_picture(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
+{
+    CodecDev &dv = im->dev;
+    PicSet &cur = dv.pics[im->cur];
+    PicSet &ref = dv.pics[im->cur ^ 1];
+    const DSV_PARAMS *p = &d->params;
+    size_t nb = dv.nblocks();
+    bool isP = p->has_ref;
+    unsigned upper = (unsigned) (dv.w * dv.h);
+    switch (enc->vidmeta.subsamp) {
+        case DSV_SUBSAMP_444: upper *= 6; break;
+        case DSV_SUBSAMP_422:
+        case DSV_SUBSAMP_UYVY: upper *= 4; break;
+        default: upper *= 2; break;
+    }
+    dsv_mk_buf(out, (int) upper);
+    BitWriter bs{out->data, 0};
+    put_packet_hdr(bs, DSV_PT_PIC | (p->is_ref << 1) | p->has_ref);
+    bs.align();
+    bs.put_bits(32, d->fnum);
+
+    DSV_MV *intramv = nullptr;
+    if (!isP) {
+        intra_analysis(dv.stream, cur.src, analysis_params(dv, p->do_psy), dv.d_mvs_stage);
+        HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvs_stage, nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, dv.stream));
+        HIPCHK(hipStreamSynchronize(dv.stream));
+        im->intramv.assign(dv.h_mvs, dv.h_mvs + nb);
+        intramv = im->intramv.data();
+    }
+    int stats[ST_MAX] = {0, 0, 0, 0, 0};
+    if (enc->effort >= 7) {
+        gather_stats(enc, d, im->mvs.data(), intramv, stats);
+        for (int i = 0; i < ST_MAX; i++) {
+            stats[i] = stats[i] > 0 ? 1 : 0; // 1 = DSV_ZERO_MARKER
+        }
+    } else {
+        stats[ST_MAINTAIN] = stats[ST_RINGING] = 1;
+    }
+    bs.align();
+    bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_w) - 4));
+    bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_h) - 4));
+    bs.align();
+    bs.put_bit(stats[ST_STABLE]);
+    int inter_filter = 0;
+    if (isP) {
+        bs.put_bit(stats[ST_MODE]);
+        bs.put_bit(stats[ST_EPRM]);
+        inter_filter = enc->do_inter_filter == 1 || (enc->do_inter_filter == -1 && enc->auto_filter);
+        bs.put_bit(inter_filter);
+    } else {
+        bs.put_bit(stats[ST_MAINTAIN]);
+        bs.put_bit(stats[ST_RINGING]);
+        bs.put_bit(enc->do_intra_filter);
+    }
+    bs.put_bits(DSV_MAX_QP_BITS, (unsigned) d->quant);
+    bs.put_bit(0);
+    bs.align();
+
+    encode_stable_blocks(enc, d, bs, im->mvs.data(), intramv, stats);
+    MCParams mc = dv.mc_params(p->temporal_mc, p->lossless);
+    if (isP) {
+        // the motion field as transmitted: uploaded once, used by MC now and as the temporal
+        // candidate source of the next frame
+        HIPCHK(hipMemcpyAsync(cur.d_final_mvs, im->mvs.data(), nb * sizeof(DSV_MV), hipMemcpyHostToDevice, dv.stream));
+        mc_sub_pred(dv.stream, cur.d_final_mvs, mc, dv.pred, cur.recon, ref.recon);
+        bs.align();
+        encode_motion(enc, d, bs, im->mvs.data(), stats);
+    } else {
+        encode_intra_meta(enc, d, bs, intramv, stats);
+    }
+    HIPCHK(hipMemcpyAsync(dv.d_blockdata, enc->blockdata, nb, hipMemcpyHostToDevice, dv.stream));
+
+    BlockMap bm{dv.d_blockdata, dv.nbh, dv.nbv};
+    for (int c = 0; c < 3; c++) {
+        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
+        sbt_forward(dv.stream, cur.recon.p[c], co, dv.scratch, c, isP, p->lossless, bm);
+    }
+    hipLaunchKernelGGL(k_grab_ll, dim3(1), dim3(1), 0, dv.stream, dv.coefs[0], dv.coefs[1], dv.coefs[2], dv.d_ll);
+    for (int c = 0; c < 3; c++) {
+        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
+        quant_plane(dv.stream, co, dv.qv + dv.qv_off[c], dv.quant_cfg(c, isP, p->lossless, p->do_psy, cur.d_final_mvs), d->quant);
+    }
+    dv.comp.run(dv.stream, dv.qv, dv.qv_off[3]);
+    HIPCHK(hipMemcpyAsync(dv.h_ll, dv.d_ll, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, dv.stream));
+    // reconstruction continues on the device while the host packs bits
+    for (int c = 0; c < 3; c++) {
+        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
+        sbt_inverse(dv.stream, cur.recon.p[c], co, dv.scratch, d->quant, c, isP, p->lossless, bm);
+    }
+    if (!isP) {
+        if (enc->do_intra_filter) {
+            intra_filter_luma(dv.stream, dv.d_blockdata, mc, d->quant, cur.recon.p[0]);
+        }
+    } else {
+        mc_add_res(dv.stream, cur.d_final_mvs, mc, d->quant, cur.recon, dv.pred, inter_filter, enc->vidmeta.inter_sharpen);
+    }
+    HIPCHK(hipStreamSynchronize(dv.stream));
+    int nsym = *dv.comp.h_total;
+    dv.ensure_host_syms((size_t) nsym);
+    if (nsym) {
+        HIPCHK(hipMemcpyAsync(dv.h_pos, dv.comp.d_pos, (size_t) nsym * sizeof(uint32_t), hipMemcpyDeviceToHost, dv.stream));
+        HIPCHK(hipMemcpyAsync(dv.h_val, dv.comp.d_val, (size_t) nsym * sizeof(int32_t), hipMemcpyDeviceToHost, dv.stream));
+        HIPCHK(hipStreamSynchronize(dv.stream));
+    }
+    // split the concatenated symbol list at the plane boundaries and pack each plane
+    bs.align();
+    int at = 0;
+    for (int c = 0; c < 3; c++) {
+        uint32_t lo = (uint32_t) dv.qv_off[c], hi = (uint32_t) dv.qv_off[c + 1];
+        int begin = at;
+        while (at < nsym && dv.h_pos[at] < hi) {
+            dv.h_pos[at] -= lo;
+            at++;
+        }
+        entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
+    }
+    bs.align();
+    out->len = bs.byte_pos();
+}
+
+void fill_params(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d)
+{
+    DSV_PARAMS *p = &d->params;
+    memset(p, 0, sizeof(*p));
+    p->vidmeta = &enc->vidmeta;
+    p->effort = enc->effort;
+    p->do_psy = enc->do_psy;
+    p->temporal_mc = (int) (d->fnum % 2);
+    p->lossless = enc->quality == DSV_RC_QUAL_MAX;
+    p->blk_w = im->dev.blk_w;
+    p->blk_h = im->dev.blk_h;
+    p->nblocks_h = im->dev.nbh;
+    p->nblocks_v = im->dev.nbv;
+}
+
+// encode_one_frame (dsv_encoder.c:1184); returns 1 when a metadata packet must precede the picture
+int encode_one_frame(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
+{
+    CodecDev &dv = im->dev;
+    PicSet &cur = dv.pics[im->cur];
+    PicSet &ref = dv.pics[im->cur ^ 1];
+    DSV_PARAMS *p = &d->params;
+    size_t nb = dv.nblocks();
+    int gop_start = 0, forced_intra = 0;
+    DSV_FNUM prev_I = enc->prev_gop;
+
+    fill_params(enc, im, d);
+    build_pyramid(dv, cur.src, cur.src_pyr);
+    // mean luma of the coarsest level feeds the dark-scene quality boost (dsv_encoder.c:296,403)
+    {
+        const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
+        HIPCHK(hipMemcpy2DAsync(dv.h_small, cp.w, cp.data, cp.stride, cp.w, cp.h, hipMemcpyDeviceToHost, dv.stream));
+    }
+    if (enc->force_metadata || ((DSV_FNUM) (enc->prev_gop + (DSV_FNUM) enc->gop) <= d->fnum)) {
+        gop_start = 1;
+        enc->prev_gop = d->fnum;
+        enc->force_metadata = 0;
+    }
+    if (enc->gop == DSV_GOP_INTRA) {
+        p->is_ref = 0;
+        p->has_ref = 0;
+    } else {
+        p->is_ref = 1;
+        p->has_ref = gop_start ? 0 : 1;
+        if (p->has_ref && !im->have_ref) {
+            fatal("P frame requested without a reference picture", __FILE__, __LINE__);
+        }
+    }
+    enc->avg_err = 0;
+    cur.has_final_mvs = false;
+    if (!p->has_ref) {
+        if (!enc->intra_map) {
+            enc->intra_map = (uint8_t *) dsv_alloc((int) nb);
+        }
+    } else {
+        // motion_est (dsv_encoder.c:653)
+        if (!ref.recon_pyr_valid) {
+            build_pyramid(dv, ref.recon, ref.recon_pyr);
+            ref.recon_pyr_valid = true;
+        }
+        HmeParams hp;
+        hp.a = analysis_params(dv, p->do_psy);
+        hp.effort = p->effort;
+        hp.lossless = p->lossless;
+        hp.quant = enc->prev_quant;
+        hp.skip_block_thresh = enc->skip_block_thresh;
+        hp.pyr_levels = dv.pyr_levels;
+        hme_estimate(dv.stream, dv, cur, ref, hp);
+        HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, dv.stream));
+        HIPCHK(hipMemcpyAsync(dv.h_counters, dv.d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, dv.stream));
+        HIPCHK(hipStreamSynchronize(dv.stream));
+        im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
+        // hme.c:1825-1832, 2015
+        int nintra = dv.h_counters[0], ndiff = dv.h_counters[1], eligible = dv.h_counters[2];
+        unsigned total_err = (unsigned) dv.h_counters[3];
+        enc->curr_scblocks = ndiff * 100 / (eligible ? eligible : 1);
+        enc->avg_err = (int) (total_err / (unsigned) nb);
+        enc->curr_intra_pct = nintra * 100 / (int) nb;
+        // the HME result of a frame that is flipped to intra below still serves as the next
+        // frame's temporal candidates (dsv_encoder.c:680, hme.c:1651)
+        HIPCHK(hipMemcpyAsync(cur.d_final_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToDevice, dv.stream));
+        cur.has_final_mvs = true;
+        forced_intra = scene_change_detection(enc, d, im->mvs.data());
+    }
+    if (enc->variable_i_interval && forced_intra) {
+        enc->prev_gop = d->fnum;
+    }
+    if (!p->has_ref) {
+        memset(enc->intra_map, 0, nb);
+    }
+    HIPCHK(hipStreamSynchronize(dv.stream));
+    {
+        const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
+        d->coarse_luma_avg = luma_avg_rows(dv.h_small, cp.w, cp.h);
+    }
+    quality2quant(enc, d, prev_I, forced_intra);
+    compute_auto_filter(enc, d);
+
+    // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
+    copy_frame_full(dv.stream, cur.recon, cur.src);
+    cur.recon_pyr_valid = false;
+
+    encode_picture(enc, im, d, out);
+
+    bool keep = enc->frame_callback || (p->is_ref && enc->gop != DSV_GOP_INTRA);
+    if (keep) {
+        extend_frame(dv.stream, cur.recon, false);
+    }
+    if (enc->frame_callback) {
+        DSV_FRAME *orig = dsv_mk_frame(dv.format, dv.w, dv.h, 1), *rec = dsv_mk_frame(dv.format, dv.w, dv.h, 1);
+        dframe_download_full(&cur.src, orig, dv.stream);
+        dframe_download_full(&cur.recon, rec, dv.stream);
+        HIPCHK(hipStreamSynchronize(dv.stream));
+        enc->frame_callback(&enc->vidmeta, orig, rec);
+        dsv_frame_ref_dec(orig);
+        dsv_frame_ref_dec(rec);
+    }
+    if (p->is_ref && enc->gop != DSV_GOP_INTRA) {
+        im->cur ^= 1; // this picture set becomes the reference of the next frame
+        im->have_ref = true;
+    }
+    return gop_start;
+}
+
+void account(DSV_ENCODER *enc, EncImpl *im, const FrameCtl *d, unsigned len) // dsv_enc tail, dsv_encoder.c:1471-1570
+{
+    const DSV_PARAMS *p = &d->params;
+    struct DSV_STATS *st = &enc->stats;
+    if (p->has_ref) {
+        st->pnum++;
+        st->pfnum += !!enc->auto_filter;
+        st->psize += len;
+        st->pqual += enc->rc_qual;
+        st->pmaxq = enc->rc_qual > st->pmaxq ? enc->rc_qual : st->pmaxq;
+        st->pmaxs = len > st->pmaxs ? len : st->pmaxs;
+        st->pminq = enc->rc_qual < st->pminq ? enc->rc_qual : st->pminq;
+        st->pmins = len < st->pmins ? len : st->pmins;
+        int nblk = p->nblocks_h * p->nblocks_v;
+        for (int i = 0; i < nblk; i++) {
+            const DSV_MV *mv = &im->mvs[i];
+            if (mvflag(*mv, DSV_MV_BIT_EPRM)) {
+                st->eprm++;
+            }
+            if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
+                st->skip++;
+                continue;
+            }
+            if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
+                st->mbI++;
+                if (mv->dc & DSV_SRC_DC_PRED) {
+                    st->mbdc++;
+                }
+                if (mv->submask != DSV_MASK_ALL_INTRA) {
+                    st->mbsub++;
+                    for (int k = 0; k < 4; k++) {
+                        if (mv->submask & (1 << k)) {
+                            st->mbsubs[k]++;
+                        }
+                    }
+                }
+            } else {
+                st->mbP++;
+                int x = mv->u.mv.x, y = mv->u.mv.y;
+                if (x & 1) {
+                    st->qpx++;
+                } else if (x & 3) {
+                    st->hpx++;
+                } else {
+                    st->fpx++;
+                }
+                if (y & 1) {
+                    st->qpy++;
+                } else if (y & 3) {
+                    st->hpy++;
+                } else {
+                    st->fpy++;
+                }
+            }
+        }
+        st->mb += (unsigned) nblk;
+        enc->refresh_ctr++;
+    } else {
+        st->inum++;
+        st->ifnum += !!enc->do_intra_filter;
+        st->isize += len;
+        st->iqual += enc->rc_qual;
+        st->imaxq = enc->rc_qual > st->imaxq ? enc->rc_qual : st->imaxq;
+        st->imaxs = len > st->imaxs ? len : st->imaxs;
+        st->iminq = enc->rc_qual < st->iminq ? enc->rc_qual : st->iminq;
+        st->imins = len < st->imins ? len : st->imins;
+    }
+    if (enc->rc_mode != DSV_RATE_CONTROL_CQP) {
+        enc->rf_total += enc->rc_mode == DSV_RATE_CONTROL_CRF ? enc->rc_qual : len;
+        enc->rf_reset++;
+        if (p->has_ref) {
+            enc->total_P_frame_q += (int) enc->rc_qual;
+            enc->avg_P_frame_q = (int) ((unsigned) enc->total_P_frame_q / enc->rf_reset);
+        }
+        enc->rf_avg = (int) (enc->rf_total / enc->rf_reset);
+        if (enc->rf_reset >= 256) {
+            enc->rf_total = (unsigned) enc->rf_avg;
+            enc->total_P_frame_q = (int) ((unsigned) enc->total_P_frame_q / enc->rf_reset);
+            enc->rf_reset = 1;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+void dsv_enc_init(DSV_ENCODER *enc) // dsv_encoder.c:1319
+{
+    memset(enc, 0, sizeof(*enc));
+    enc->prev_gop = (DSV_FNUM) -1;
+    enc->quality = 80;
+    enc->gop = 48;
+    enc->effort = DSV_MAX_EFFORT;
+    enc->rc_mode = DSV_RATE_CONTROL_CRF;
+    enc->bitrate = INT_MAX;
+    enc->min_q_step = 4;
+    enc->max_q_step = 1;
+    enc->min_quality = enc->quality - DSV_USER_QUAL_TO_RC_QUAL(5);
+    enc->max_quality = DSV_RC_QUAL_MAX;
+    enc->min_I_frame_quality = enc->quality - DSV_USER_QUAL_TO_RC_QUAL(2);
+    enc->prev_chaos = -1;
+    enc->prev_complexity = -1;
+    enc->curr_complexity = -1;
+    enc->intra_pct_thresh = 90;
+    enc->stable_refresh = 24;
+    enc->scene_change_pct = 85;
+    enc->do_scd = 1;
+    enc->variable_i_interval = 1;
+    enc->block_size_override_x = -1;
+    enc->block_size_override_y = -1;
+    enc->do_temporal_aq = 1;
+    enc->do_psy = DSV_PSY_ALL;
+    enc->do_dark_intra_boost = 1;
+    enc->do_intra_filter = 1;
+    enc->do_inter_filter = -1;
+}
+
+void dsv_enc_start(DSV_ENCODER *enc) // dsv_encoder.c:1360
+{
+    enc->quality = clampi(enc->quality, 0, DSV_RC_QUAL_MAX);
+    switch (enc->rc_mode) {
+        case DSV_RATE_CONTROL_CRF:
+            enc->rc_qual = (unsigned) clampi(enc->quality + RC_PCT(5), enc->min_I_frame_quality, enc->max_quality);
+            enc->rf_avg = (int) enc->rc_qual;
+            enc->avg_P_frame_q = enc->quality;
+            break;
+        case DSV_RATE_CONTROL_ABR:
+            enc->rc_qual = (unsigned) enc->quality;
+            enc->avg_P_frame_q = enc->quality * 4 / 5;
+            break;
+        default:
+            break;
+    }
+    enc->stats.iminq = enc->stats.pminq = enc->stats.imins = enc->stats.pmins = INT_MAX;
+    enc->force_metadata = 1;
+}
+
+void dsv_enc_free(DSV_ENCODER *enc)
+{
+    if (enc->ref) {
+        EncImpl *im = (EncImpl *) enc->ref;
+        if (im->ready) {
+            im->dev.destroy();
+        }
+        delete im;
+        enc->ref = NULL;
+    }
+    if (enc->stability) {
+        dsv_free(enc->stability);
+        enc->stability = NULL;
+    }
+    if (enc->blockdata) {
+        dsv_free(enc->blockdata);
+        enc->blockdata = NULL;
+    }
+    if (enc->intra_map) {
+        dsv_free(enc->intra_map);
+        enc->intra_map = NULL;
+    }
+}
+
+void dsv_enc_set_metadata(DSV_ENCODER *enc, DSV_META *md) { memcpy(&enc->vidmeta, md, sizeof(DSV_META)); }
+void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
+
+void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs) // dsv_encoder.c:1416
+{
+    dsv_mk_buf(&bufs[0], DSV_PACKET_HDR_SIZE);
+    BitWriter bw{bufs[0].data, 0};
+    put_packet_hdr(bw, DSV_PT_EOS);
+    set_link_offsets(enc, &bufs[0], 1);
+}
+
+int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:1430
+{
+    if (frame == NULL || bufs == NULL) {
+        return 0;
+    }
+    EncImpl *im = (EncImpl *) enc->ref;
+    if (!im) {
+        im = new EncImpl();
+        enc->ref = im;
+    }
+    int w = enc->vidmeta.width, h = enc->vidmeta.height;
+    if (!im->ready) {
+        if ((w & 1) || (h & 1) || w < 16 || h < 16) {
+            fatal("DSV2 needs even picture dimensions of at least 16x16 (dsv_main.c:621, sbt.c:384-388)", __FILE__, __LINE__);
+        }
+        int bw, bh, nbh, nbv;
+        block_geometry(w, h, enc->block_size_override_x, enc->block_size_override_y, &bw, &bh, &nbh, &nbv);
+        if (enc->pyramid_levels == 0) { // dsv_encoder.c:1229-1241
+            int lvls = dsv_lb2((unsigned) (w < h ? w : h));
+            int maxdim = nbh > nbv ? nbh : nbv;
+            while ((1 << lvls) > maxdim) {
+                lvls--;
+            }
+            enc->pyramid_levels = clampi(lvls, 3, DSV_MAX_PYRAMID_LEVELS);
+        }
+        im->dev.init(enc->vidmeta.subsamp, w, h, bw, bh, enc->pyramid_levels, true);
+        im->ready = true;
+        im->mvs.assign((size_t) nbh * nbv, DSV_MV{});
+        enc->stability = (struct DSV_STAB_ACC *) dsv_alloc((int) (sizeof(struct DSV_STAB_ACC) * (size_t) nbh * nbv));
+        enc->blockdata = (uint8_t *) dsv_alloc(nbh * nbv);
+    }
+    CodecDev &dv = im->dev;
+    PicSet &cur = dv.pics[im->cur];
+    // ingest: the picture goes to HBM once; the border is synthesised there (dsv_encoder.c:1455-1456)
+    dframe_upload(&cur.src, frame, dv.stream);
+    extend_frame(dv.stream, cur.src, false);
+    HIPCHK(hipStreamSynchronize(dv.stream)); // the caller's pixels may be released below
+    dsv_frame_ref_dec(frame);
+
+    FrameCtl d;
+    memset(&d, 0, sizeof(d));
+    d.fnum = enc->next_fnum++;
+    int nbuf = 0;
+    DSV_BUF outbuf;
+    if (encode_one_frame(enc, im, &d, &outbuf)) {
+        DSV_BUF metabuf;
+        encode_metadata(enc, &metabuf);
+        bufs[nbuf++] = metabuf;
+        set_link_offsets(enc, &bufs[nbuf - 1], 0);
+    }
+    bufs[nbuf++] = outbuf;
+    set_link_offsets(enc, &bufs[nbuf - 1], 0);
+    account(enc, im, &d, outbuf.len);
+    return nbuf;
+}
+
+} // extern "C"

@@ -33,3 +33,23 @@ def oframe(hf):
         f.stride[c] = hf.strides[c]
         f.w[c], f.h[c] = hf.dims[c]
     return f
+
+
+class HPlane(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("stride", C.c_int), ("w", C.c_int), ("h", C.c_int)]
+
+
+class HmeCtx(C.Structure):
+    _fields_ = [("p", OrcParams), ("quant", C.c_int), ("skip_block_thresh", C.c_int), ("pyr_levels", C.c_int),
+                ("src", HPlane * 6), ("ref", HPlane * 6), ("ogr", HPlane * 6),
+                ("srcc", HPlane * 2), ("refc", HPlane * 2),
+                ("mvf", C.c_void_p * 6), ("ref_mvf", C.c_void_p),
+                ("nintra", C.c_int), ("ndiff", C.c_int), ("eligible", C.c_int), ("total_err", C.c_uint)]
+
+
+def hplane(hf, c):
+    p = HPlane()
+    p.data = hf.c.planes[c].data
+    p.stride = hf.strides[c]
+    p.w, p.h = hf.dims[c]
+    return p

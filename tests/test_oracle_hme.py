@@ -1,0 +1,27 @@
+"""oracle/orc_hme.c (anti-diagonal, per-block restatement) vs the reference's dsv_hme."""
+import os
+
+import pytest
+
+import dsvabi as A
+from hme_common import Scene, assert_fields_equal
+
+pytestmark = pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")
+
+
+@pytest.mark.parametrize("w,h,subsamp,seed,quant,effort,prev", [
+    (352, 288, A.SUBSAMP_420, 1, 172, 10, True),
+    (352, 288, A.SUBSAMP_420, 2, 900, 10, False),
+    (354, 290, A.SUBSAMP_420, 3, 61, 10, True),
+    (640, 360, A.SUBSAMP_444, 4, 300, 7, True),
+    (640, 360, A.SUBSAMP_420, 5, 172, 3, True),
+    (1280, 720, A.SUBSAMP_420, 6, 172, 10, True),
+])
+def test_hme_matches_reference(w, h, subsamp, seed, quant, effort, prev):
+    ref, orc = A.load_ref(), A.load_oracle()
+    sc = Scene(ref, w, h, subsamp, seed, with_prev_mvs=prev)
+    want, ipct_r, scb_r, err_r = sc.run_reference(ref, quant, effort)
+    got, ipct_o, scb_o, err_o = sc.run_oracle(orc, quant, effort)
+    for l in range(sc.levels, -1, -1):
+        assert_fields_equal(want[l], got[l], "level %d" % l)
+    assert (ipct_r, scb_r, err_r) == (ipct_o, scb_o, err_o)
