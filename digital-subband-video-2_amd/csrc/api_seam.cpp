@@ -410,6 +410,74 @@ DSV_MV *dsv_intra_analysis(DSV_FRAME *src, DSV_PARAMS *p)
     return host;
 }
 
+int dsv_hme(DSV_HME *hme, int *scene_change_blocks, int *avg_err) // hme.c:2001
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    DSV_PARAMS *p = hme->params;
+    int levels = hme->enc->pyramid_levels;
+    size_t nb = (size_t) p->nblocks_h * p->nblocks_v;
+    // upload every pyramid level exactly as handed over (bordered host frames)
+    std::vector<DFrame> dsrc((size_t) levels + 1), dref((size_t) levels + 1), dogr((size_t) levels + 1);
+    HmeFrames f;
+    for (int l = 0; l <= levels; l++) {
+        DSV_FRAME *hs = hme->src[l], *hr = hme->ref[l], *ho = hme->ogr[l];
+        dframe_alloc(&dsrc[(size_t) l], hs->format, hs->width, hs->height);
+        dframe_alloc(&dref[(size_t) l], hr->format, hr->width, hr->height);
+        dframe_alloc(&dogr[(size_t) l], ho->format, ho->width, ho->height);
+        dframe_upload_full(&dsrc[(size_t) l], hs, c.stream);
+        dframe_upload_full(&dref[(size_t) l], hr, c.stream);
+        dframe_upload_full(&dogr[(size_t) l], ho, c.stream);
+        f.src[l] = dsrc[(size_t) l].p[0];
+        f.ref[l] = dref[(size_t) l].p[0];
+        f.ogr[l] = dogr[(size_t) l].p[0];
+        HIPCHK(hipMalloc((void **) &f.mvf[l], nb * sizeof(DSV_MV)));
+    }
+    for (int k = 0; k < 2; k++) {
+        f.srcc[k] = dsrc[0].p[k + 1];
+        f.refc[k] = dref[0].p[k + 1];
+    }
+    f.ref_mvf = c.put_mvs(hme->ref_mvf, nb);
+    int *d_counters;
+    HIPCHK(hipMalloc((void **) &d_counters, 16 * sizeof(int)));
+    f.counters = d_counters;
+    HmeParams hp;
+    hp.a.width = p->vidmeta->width;
+    hp.a.height = p->vidmeta->height;
+    hp.a.blk_w = p->blk_w;
+    hp.a.blk_h = p->blk_h;
+    hp.a.nbh = p->nblocks_h;
+    hp.a.nbv = p->nblocks_v;
+    hp.a.hshift = DSV_FORMAT_H_SHIFT(p->vidmeta->subsamp);
+    hp.a.vshift = DSV_FORMAT_V_SHIFT(p->vidmeta->subsamp);
+    hp.a.do_psy = p->do_psy;
+    hp.a.scale = 0;
+    hp.effort = p->effort;
+    hp.lossless = p->lossless;
+    hp.quant = hme->quant;
+    hp.skip_block_thresh = hme->enc->skip_block_thresh;
+    hp.pyr_levels = levels;
+    hme_run(c.stream, f, hp);
+    int counters[16];
+    HIPCHK(hipMemcpyAsync(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost, c.stream));
+    for (int l = 0; l <= levels; l++) {
+        hme->mvf[l] = (DSV_MV *) dsv_alloc((int) (nb * sizeof(DSV_MV)));
+        HIPCHK(hipMemcpyAsync(hme->mvf[l], f.mvf[l], nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, c.stream));
+    }
+    HIPCHK(hipStreamSynchronize(c.stream));
+    for (int l = 0; l <= levels; l++) {
+        dframe_free(&dsrc[(size_t) l]);
+        dframe_free(&dref[(size_t) l]);
+        dframe_free(&dogr[(size_t) l]);
+        HIPCHK(hipFree(f.mvf[l]));
+    }
+    HIPCHK(hipFree(d_counters));
+    *scene_change_blocks = counters[1] * 100 / (counters[2] ? counters[2] : 1); // hme.c:1825-1832
+    *avg_err = (int) ((unsigned) counters[3] / (unsigned) nb);
+    return counters[0] * 100 / (int) nb;
+}
+
 DSV_FRAME *dsv_extend_frame(DSV_FRAME *frame)
 {
     if (!frame->border) {

@@ -19,4 +19,29 @@ struct AnalysisParams {
 // dsv_intra_analysis (hme.c:1836): flags-only DSV_MV field for an I frame
 void intra_analysis(hipStream_t s, const DFrame &src, const AnalysisParams &p, DSV_MV *d_out);
 
+struct HmeParams {
+    AnalysisParams a;
+    int effort, lossless;
+    int quant; // quantiser of the previous frame (dsv_encoder.c:665)
+    int skip_block_thresh;
+    int pyr_levels;
+};
+
+// device operands of one motion search: luma of every pyramid level (0 = full size) for the
+// source, the reconstructed reference and the original reference; chroma of level 0
+struct HmeFrames {
+    DPlane src[6], ref[6], ogr[6];
+    DPlane srcc[2], refc[2];
+    DSV_MV *mvf[6];        // out: one field per level, nblocks entries each
+    const DSV_MV *ref_mvf; // previous frame's transmitted field or null
+    int *counters;         // out: [0] nintra [1] ndiff [2] eligible [3] total_err ([4],[5] scratch)
+};
+
+// dsv_hme (hme.c:2001): all levels coarse to fine, asynchronous on `s`
+void hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp);
+
+struct CodecDev;
+struct PicSet;
+void hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp);
+
 } // namespace dsv2

@@ -1,0 +1,1019 @@
+// hme.hip -- hierarchical block motion estimation and P-frame mode decision on gfx950.
+//
+// Replaces reference src/hme.c: dsv_hme (:2001), refine_level (:1373), refine_best_fpel_cand
+// (:1301), subpixel_ME (:1052) with hpel/qpel/qpsad (:788/:816/:245), the block metrics
+// METR_BODY (:136) / SSE_BODY (:198), the mode decision (:1636-1821: skip / no-transmit /
+// EPRM / sub-block intra tests :892/:988, calc_EPRM :453, yuv_max_subblock_err :370) and
+// global_motion (:1974).  CPU proof of the decomposition: oracle/orc_hme.c.
+//
+// Mapping to the machine:
+//   * one 64-lane wavefront (= one workgroup) per block.  The block's control flow is
+//     wave-uniform scalar code; every pixel-touching primitive (psy metric, SSE, block
+//     statistics, half-pel interpolation, clip tests) is evaluated cooperatively: a 16x16
+//     block is exactly 64 2x2 quads = one quad per lane, partial sums are combined with a
+//     6-step cross-lane butterfly (__shfl_xor) and broadcast to all lanes;
+//   * a block reads the final vectors of its left / top / top-left neighbours of the same
+//     level, so blocks on one anti-diagonal (i/step + j/step = t) are independent: each
+//     front is one kernel launch (grid = blocks on the front), launch order gives the
+//     inter-front ordering with no in-kernel spinning;
+//   * the 68x68 quarter-pel image of the reference is never materialised: the 34x34
+//     half-pel image lives in LDS and quarter-pel samples are averaged on the fly.
+#include "blockstat.h"
+#include "codec.h"
+#include "hme.h"
+
+namespace dsv2 {
+
+struct HmeDev {
+    AnalysisParams a;
+    int effort, lossless, quant, skip_block_thresh, pyr_levels, psyscale;
+    DPlane src[6], ref[6], ogr[6];
+    DPlane srcc[2], refc[2];
+    DSV_MV *mvf[6];
+    const DSV_MV *ref_mvf;
+    int *counters; // [0] nintra [1] ndiff [2] eligible [3] total_err [4] gx [5] gy
+};
+
+struct Psy {
+    int err_weight, tex_weight, avg_weight;
+};
+
+#define UAVG4(a, b, c, d) ((unsigned) ((a) + (b) + (c) + (d) + 2) >> 2)
+#define AVG2(a, b) (((a) + (b) + 1) >> 1)
+#define SQR(x) ((x) * (x))
+
+__device__ __forceinline__ int sarx(int v, int s) { return v >> s; }
+
+__device__ __forceinline__ unsigned quad_metric(int a1, int a2, int a3, int a4, int b1, int b2, int b3, int b4, const Psy &psy)
+{
+    int s0 = (int) UAVG4(a1, a2, a3, a4), s1 = (int) UAVG4(b1, b2, b3, b4);
+    int se = (int) UAVG4(abs(a1 - b1), abs(a2 - b2), abs(a3 - b3), abs(a4 - b4));
+    int ta = (int) UAVG4(abs(a1 - a2), abs(a2 - a3), abs(a3 - a4), abs(a4 - a1));
+    int tb = (int) UAVG4(abs(b1 - b2), abs(b2 - b3), abs(b3 - b4), abs(b4 - b1));
+    return (unsigned) (SQR(se) << psy.err_weight) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
+           (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+}
+
+// ---- wave-cooperative block primitives (all 64 lanes call with identical arguments) ----------
+
+__device__ __forceinline__ unsigned ws_umetr(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h, const Psy &psy)
+{
+    int lane = threadIdx.x & 63, qw = w / 2, qh = h / 2;
+    unsigned acc = 0;
+    for (int q = lane; q < qw * qh; q += 64) {
+        int i = q % qw, j = q / qw;
+        const uint8_t *p = a + (ptrdiff_t) (2 * j) * as + 2 * i, *r = b + (ptrdiff_t) (2 * j) * bs + 2 * i;
+        acc += quad_metric(p[0], p[1], p[as], p[as + 1], r[0], r[1], r[bs], r[bs + 1], psy);
+    }
+    return wave_sum(acc);
+}
+
+__device__ __forceinline__ unsigned metric_return(unsigned acc, int w, int h)
+{
+    return isqrt_u32(acc) * (unsigned) w * (unsigned) h / (unsigned) AVG2(w, h);
+}
+
+__device__ __forceinline__ unsigned ws_metr(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h, const Psy &psy)
+{
+    if (w == 0 || h == 0) {
+        return 0x7fffffffu;
+    }
+    return metric_return(ws_umetr(a, as, b, bs, w, h, psy), w, h);
+}
+
+__device__ __forceinline__ unsigned ws_sse(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h)
+{
+    if (w == 0 || h == 0) {
+        return 0x7fffffffu;
+    }
+    int lane = threadIdx.x & 63;
+    unsigned acc = 0;
+    for (int idx = lane; idx < w * h; idx += 64) {
+        int x = idx % w, y = idx / w;
+        int d = (int) a[(ptrdiff_t) y * as + x] - (int) b[(ptrdiff_t) y * bs + x];
+        acc += (unsigned) (d * d);
+    }
+    return wave_sum(acc);
+}
+
+__device__ __forceinline__ unsigned ws_hier_metr(int level, const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h,
+                                                 const Psy &psy)
+{
+    return level > 1 ? ws_sse(a, as, b, bs, w, h) : ws_metr(a, as, b, bs, w, h, psy);
+}
+
+__device__ __forceinline__ const uint8_t *at(const DPlane &p, int x, int y) { return p.data + (ptrdiff_t) y * p.stride + x; }
+
+__device__ __forceinline__ bool invalid_block(const DPlane &f, int bx, int by, int bw, int bh, int pad)
+{
+    return (bx - pad) < -kBorder || (by - pad) < -kBorder || (bx + bw + pad) >= (f.w + kBorder) || (by + bh + pad) >= (f.h + kBorder);
+}
+
+// ---- motion vector cost ---------------------------------------------------------------------
+__device__ __forceinline__ int pred1(int left, int top, int topleft)
+{
+    int dif = left + top - topleft;
+    return abs(dif - left) < abs(dif - top) ? left : top;
+}
+
+__device__ __forceinline__ void movec_pred(const DSV_MV *v, int nbh, int x, int y, int &px, int &py)
+{
+    int vx0 = 0, vx1 = 0, vx2 = 0, vy0 = 0, vy1 = 0, vy2 = 0;
+    if (x > 0) {
+        vx0 = v[y * nbh + x - 1].u.mv.x;
+        vy0 = v[y * nbh + x - 1].u.mv.y;
+    }
+    if (y > 0) {
+        vx1 = v[(y - 1) * nbh + x].u.mv.x;
+        vy1 = v[(y - 1) * nbh + x].u.mv.y;
+    }
+    if (x > 0 && y > 0) {
+        vx2 = v[(y - 1) * nbh + x - 1].u.mv.x;
+        vy2 = v[(y - 1) * nbh + x - 1].u.mv.y;
+    }
+    px = pred1(vx0, vx1, vx2);
+    py = pred1(vy0, vy1, vy2);
+}
+
+__device__ __forceinline__ int seg_bits(int v)
+{
+    v = abs(v) + 1;
+    return (31 - __clz(v)) * 2 + 2;
+}
+
+struct CostCtx { // the per-block constant part of mv_cost (hme.c:354, dsv.c:357)
+    int px, py, b2sr, q;
+};
+
+__device__ __forceinline__ int mv_cost(const CostCtx &c, int mx, int my, int level)
+{
+    int bits = seg_bits(mx - c.px) + seg_bits(my - c.py);
+    bool sqr = level > 1;
+    bits += bits * c.b2sr >> 7;
+    if (sqr) {
+        bits *= bits;
+    }
+    int cost = min(bits, 1 << 19);
+    if (sqr) {
+        return (int) ((unsigned) cost * (unsigned) (c.q * c.q >> 12)) >> 10;
+    }
+    return 3 * cost * c.q >> 12;
+}
+
+// neighbour difference of the current block (vector cx,cy not yet stored) -- dsv.c:403
+__device__ __forceinline__ void neighbordif2_cur(const DSV_MV *v, int nbh, int x, int y, int cx, int cy, int &dx, int &dy)
+{
+    int lx = cx, ly = cy, tx = cx, ty = cy;
+    if (abs(cx) < 2 && abs(cy) < 2) {
+        dx = dy = 0;
+        return;
+    }
+    if (x > 0) {
+        const DSV_MV *m = &v[x - 1 + y * nbh];
+        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
+            lx = m->u.mv.x;
+            ly = m->u.mv.y;
+        }
+    }
+    if (y > 0) {
+        const DSV_MV *m = &v[x + (y - 1) * nbh];
+        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
+            tx = m->u.mv.x;
+            ty = m->u.mv.y;
+        }
+    }
+    dx = abs(lx - cx) + abs(ly - cy);
+    dy = abs(tx - cx) + abs(ty - cy);
+}
+
+__device__ __forceinline__ int qp2fp(int v) { return (v + 2) >> 2; } // DSV_SAR_R(v, 2)
+
+struct Vec2 {
+    int x, y;
+};
+
+__device__ int find_inliers(const Vec2 *list, Vec2 *out, int n, int &ax, int &ay) // hme.c:1260
+{
+    int dist[16], avgd = 0, ssd = 0, nin = 0, sx = 0, sy = 0;
+    if (n == 0) {
+        return 0;
+    }
+    for (int i = 0; i < n; i++) {
+        dist[i] = SQR(list[i].x - ax) + SQR(list[i].y - ay);
+        avgd += dist[i];
+    }
+    avgd /= n;
+    for (int i = 0; i < n; i++) {
+        ssd += SQR(dist[i] - avgd);
+    }
+    int thresh = avgd + (int) isqrt_u32((unsigned) (ssd / n));
+    for (int i = 0; i < n; i++) {
+        if (dist[i] <= thresh) {
+            sx += list[i].x;
+            sy += list[i].y;
+            out[nin++] = list[i];
+        }
+    }
+    if (nin == 0) {
+        return 0;
+    }
+    ax = sx / nin;
+    ay = sy / nin;
+    return nin;
+}
+
+// ---- half / quarter-pel refinement ---------------------------------------------------------------
+#define HPF_ME(a, b, c, d) ((5 * ((b) + (c))) - ((a) + (d)))
+__device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t) (v > 255 ? 255 : (v < 0 ? 0 : v)); }
+
+struct SubpelLds {
+    uint8_t win[20 * 20]; // reference window rows/cols -1..18 around the 17x17 area
+    uint8_t h[34 * 34];   // half-pel image
+};
+
+// cooperative construction of the 34x34 half-pel image (hme.c:787); r = top-left full-pel sample
+__device__ void build_hpel(SubpelLds &s, const uint8_t *r, int rs)
+{
+    int lane = threadIdx.x & 63;
+    for (int idx = lane; idx < 400; idx += 64) {
+        int x = idx % 20, y = idx / 20;
+        s.win[idx] = r[(ptrdiff_t) (y - 1) * rs + (x - 1)];
+    }
+    __syncthreads();
+    for (int idx = lane; idx < 289; idx += 64) {
+        int i = idx % 17, j = idx / 17;
+        const uint8_t *p = &s.win[(j + 1) * 20 + (i + 1)];
+        int hz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *q = p + (k - 1) * 20;
+            hz[k] = HPF_ME(q[-1], q[0], q[1], q[2]);
+        }
+        int c = HPF_ME(hz[0], hz[1], hz[2], hz[3]);
+        uint8_t *o = &s.h[(2 * j) * 34 + 2 * i];
+        o[0] = p[0];
+        o[1] = clamp_u8((hz[1] + 4) >> 3);
+        o[34] = clamp_u8((HPF_ME(p[-20], p[0], p[20], p[40]) + 4) >> 3);
+        o[35] = clamp_u8((c + 32) >> 6);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int qsample(const uint8_t *h, int X, int Y) // hme.c:815
+{
+    const uint8_t *p = h + (Y >> 1) * 34 + (X >> 1);
+    switch ((X & 1) | ((Y & 1) << 1)) {
+        case 0: return p[0];
+        case 1: return AVG2(p[0], p[1]);
+        case 2: return AVG2(p[0], p[34]);
+        default: return (p[0] + p[1] + p[34] + p[35] + 2) >> 2;
+    }
+}
+
+// one quad per lane: the 16x16 source window against the block sampled at quarter-pel offset (tx, ty) (hme.c:244)
+__device__ __forceinline__ unsigned ws_qpsad(const uint8_t *a, int as, const uint8_t *h, int tx, int ty, const Psy &psy)
+{
+    int lane = threadIdx.x & 63;
+    int i = lane & 7, j = lane >> 3;
+    const uint8_t *p = a + (ptrdiff_t) (2 * j) * as + 2 * i;
+    int X = 4 + 8 * i + tx, Y = 4 + 8 * j + ty;
+    unsigned acc = quad_metric(p[0], p[1], p[as], p[as + 1], qsample(h, X, Y), qsample(h, X + 4, Y), qsample(h, X, Y + 4),
+                               qsample(h, X + 4, Y + 4), psy);
+    return metric_return(wave_sum(acc), 16, 16);
+}
+
+__device__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely,
+                                unsigned best, int bx, int by, int bw, int bh, const Psy &psy) // hme.c:1051
+{
+    const DPlane &src = c.src[0], &ref = c.ref[0];
+    sub_x = sub_y = 0;
+    if (best == 0) {
+        return best;
+    }
+    unsigned yarea = (unsigned) (bw * bh);
+    unsigned quad[4];
+    const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        quad[n] = ws_sse(at(src, bx, by), src.stride, at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, bw, bh);
+    }
+    int area_ratio = (int) (8 * 256 / yarea), iarea_ratio = (int) (8 * yarea / 256);
+    best = best * (unsigned) area_ratio >> 3;
+    int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
+    const uint8_t *srcw = at(src, xx, yy);
+    build_hpel(lds, at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
+
+    int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
+    unsigned ms1 = quad[1], ms2 = quad[3];
+    if (quad[3] >= quad[2]) {
+        pri1 = 1;
+        ms2 = quad[2];
+    }
+    if (quad[1] >= quad[0]) {
+        sec0 = 1;
+        ms1 = quad[0];
+    }
+    if (ms2 > ms1) {
+        int t0 = sec0, t1 = sec1;
+        sec0 = pri0, sec1 = pri1;
+        pri0 = t0, pri1 = t1;
+    }
+    int diag0 = pri0 + sec0, diag1 = pri1 + sec1;
+    int bestv0 = 0, bestv1 = 0;
+    for (int n = 0; n <= 6; n++) {
+        int t0, t1;
+        if (n == 6) {
+            t0 = pri0 + diag0;
+            t1 = pri1 + diag1;
+        } else {
+            int v0 = (n >> 1) == 0 ? pri0 : ((n >> 1) == 1 ? sec0 : diag0);
+            int v1 = (n >> 1) == 0 ? pri1 : ((n >> 1) == 1 ? sec1 : diag1);
+            int hp = !(n & 1);
+            t0 = v0 * (1 << hp);
+            t1 = v1 * (1 << hp);
+        }
+        if (((t0 | t1) & 1) && c.effort < 8) {
+            continue;
+        }
+        unsigned score = ws_qpsad(srcw, src.stride, lds.h, t0, t1, psy);
+        score += (unsigned) mv_cost(cc, fpelx * 4 + t0, fpely * 4 + t1, 0);
+        if (best > score) {
+            best = score;
+            bestv0 = t0;
+            bestv1 = t1;
+        }
+    }
+    sub_x = bestv0;
+    sub_y = bestv1;
+    __syncthreads(); // the LDS image may be rebuilt by a second call
+    return best * (unsigned) iarea_ratio >> 3;
+}
+
+// ---- mode decision helpers -----------------------------------------------------------------------
+__device__ void ws_yuv_max_subblock_err(unsigned out[3], const HmeDev &c, int bx, int by, int brx, int bry, int bw, int bh, int cbx,
+                                        int cby, int cbrx, int cbry, int cbw, int cbh, const Psy &psy) // hme.c:369
+{
+    for (int z = 0; z < 3; z++) {
+        const uint8_t *sp, *rp;
+        int ss, rs, w, h;
+        if (z == 0) {
+            sp = at(c.src[0], bx, by);
+            ss = c.src[0].stride;
+            rp = at(c.ref[0], brx, bry);
+            rs = c.ref[0].stride;
+            w = bw / 2;
+            h = bh / 2;
+        } else {
+            sp = at(c.srcc[z - 1], cbx, cby);
+            ss = c.srcc[z - 1].stride;
+            rp = at(c.refc[z - 1], cbrx, cbry);
+            rs = c.refc[z - 1].stride;
+            w = cbw / 2;
+            h = cbh / 2;
+        }
+        unsigned mx = 0;
+        for (int k = 0; k < 4; k++) {
+            int f = (k & 1) ? w : 0, g = (k & 2) ? h : 0;
+            unsigned e = ws_umetr(sp + f + (ptrdiff_t) g * ss, ss, rp + f + (ptrdiff_t) g * rs, rs, w, h, psy);
+            mx = max(mx, e);
+        }
+        out[z] = mx;
+    }
+}
+
+__device__ void ws_calc_eprm(const uint8_t *src, int ss, const uint8_t *mvr, int rs, int avg_src, int avg_ref, int w, int h, int &eprmi,
+                             int &eprmd, int &eprmr) // hme.c:452
+{
+    int lane = threadIdx.x & 63;
+    int ci = 0, cd = 0, cr = 0;
+    avg_src -= 128;
+    avg_ref -= 128;
+    for (int idx = lane; idx < w * h; idx += 64) {
+        int x = idx % w, y = idx / w;
+        int s = src[(ptrdiff_t) y * ss + x];
+        cr |= ((s - (int) mvr[(ptrdiff_t) y * rs + x]) + 128) & ~0xff;
+        ci |= (s - avg_ref) & ~0xff;
+        cd |= (s - avg_src) & ~0xff;
+    }
+    eprmi = __any(ci != 0) ? 1 : 0;
+    eprmd = __any(cd != 0) ? 1 : 0;
+    eprmr = __any(cr != 0) ? 1 : 0;
+}
+
+__device__ void ws_err_intra(const uint8_t *a, int as, const uint8_t *b, int bs, int avg_sb, int avg_src, int w, int h,
+                             unsigned &intra_err, unsigned &intrasrc_err, unsigned &inter_err, const Psy &psy, int ratio) // hme.c:839
+{
+    int lane = threadIdx.x & 63, qw = w / 2, qh = h / 2;
+    unsigned isb = 0, isrc = 0, inter = 0;
+    for (int q = lane; q < qw * qh; q += 64) {
+        int i = q % qw, j = q / qw;
+        const uint8_t *p = a + (ptrdiff_t) (2 * j) * as + 2 * i, *r = b + (ptrdiff_t) (2 * j) * bs + 2 * i;
+        int a1 = p[0], a2 = p[1], a3 = p[as], a4 = p[as + 1];
+        int b1 = r[0], b2 = r[1], b3 = r[bs], b4 = r[bs + 1];
+        int s0 = (int) UAVG4(a1, a2, a3, a4), s1 = (int) UAVG4(b1, b2, b3, b4);
+        int ae = (int) UAVG4(abs(a1 - b1), abs(a2 - b2), abs(a3 - b3), abs(a4 - b4));
+        int ta = (int) UAVG4(abs(a1 - a2), abs(a2 - a3), abs(a3 - a4), abs(a4 - a1));
+        int tb = (int) UAVG4(abs(b1 - b2), abs(b2 - b3), abs(b3 - b4), abs(b4 - b1));
+        inter += (unsigned) (SQR(ae) * ratio >> (5 - psy.err_weight));
+        inter += (unsigned) (SQR(ta - tb) << psy.tex_weight);
+        inter += (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+        ae = (int) UAVG4(abs(a1 - avg_sb), abs(a2 - avg_sb), abs(a3 - avg_sb), abs(a4 - avg_sb));
+        isb += (unsigned) (SQR(ae) << psy.err_weight);
+        isb += (unsigned) (SQR(ta) << psy.tex_weight);
+        isb += (unsigned) (SQR(s0 - avg_sb) << (psy.avg_weight + 1));
+        ae = (int) UAVG4(abs(a1 - avg_src), abs(a2 - avg_src), abs(a3 - avg_src), abs(a4 - avg_src));
+        isrc += (unsigned) (SQR(ae) << psy.err_weight);
+        isrc += (unsigned) (SQR(ta) << psy.tex_weight);
+        isrc += (unsigned) (SQR(s0 - avg_src) << (psy.avg_weight + 1));
+    }
+    intra_err = wave_sum(isb);
+    intrasrc_err = wave_sum(isrc);
+    inter_err = wave_sum(inter) * (unsigned) ratio >> 5;
+}
+
+__device__ __forceinline__ int ws_plane_avg(const DPlane &p, int x, int y, int w, int h) { return ws_block_avg(at(p, x, y), p.stride, w, h); }
+
+__device__ void test_subblock_intra_y(const HmeDev &c, const DSV_MV *refmv, DSV_MV &mv, const uint8_t *srcd, int ss, const uint8_t *refd,
+                                      int rs, int detail_src, int avg_src, int neidif, unsigned ratio, int bw, int bh) // hme.c:891
+{
+    int sbw = bw / 2, sbh = bh / 2, nsub = 0;
+    unsigned avg_tot = 0, err_sub = 0, err_src = 0;
+    Psy psy = {0, 1, 2};
+    int rx = refmv ? refmv->u.mv.x : mv.u.mv.x, ry = refmv ? refmv->u.mv.y : mv.u.mv.y;
+    if (mv.u.all && neidif < 3 && abs(rx - mv.u.mv.x) < 3 && abs(ry - mv.u.mv.y) < 3) {
+        return;
+    }
+    if (sbw == 0 || sbh == 0) {
+        return;
+    }
+    detail_src += detail_src / max(neidif, 1);
+    for (int k = 0; k < 4; k++) {
+        int f = (k & 1) ? sbw : 0, g = (k & 2) ? sbh : 0;
+        const uint8_t *sd = srcd + f + (ptrdiff_t) g * ss, *md = refd + f + (ptrdiff_t) g * rs;
+        if (mv.submask & (1 << k)) {
+            continue;
+        }
+        unsigned avg_local;
+        unsigned avg_sub = (unsigned) ws_block_avg(md, rs, sbw, sbh);
+        unsigned local_detail = (unsigned) ws_block_detail(sd, ss, sbw, sbh, avg_local);
+        unsigned dcd = (unsigned) abs((int) avg_local - (int) avg_sub) + 2;
+        if (local_detail > (unsigned) (SQR(dcd) * (unsigned) bw * (unsigned) bh * ratio >> 5)) {
+            continue;
+        }
+        int dc = (int) (avg_local + (unsigned) avg_src * 3 + 2) >> 2;
+        unsigned sub_err, src_err, inter_err;
+        ws_err_intra(sd, ss, md, rs, (int) avg_sub, dc, sbw, sbh, sub_err, src_err, inter_err, psy, (int) ratio);
+        int lo = AVG2(detail_src, (int) local_detail), hi = detail_src;
+        int lerp = (lo * (32 - c.psyscale) + hi * c.psyscale) >> 5;
+        local_detail = (unsigned) max(lerp, lo);
+        if ((sub_err + local_detail) < inter_err || (src_err + local_detail) < inter_err) {
+            mv.submask |= (uint8_t) (1 << k);
+            err_src += src_err;
+            err_sub += sub_err;
+            avg_tot += sub_err < src_err ? avg_sub : (unsigned) dc;
+            nsub++;
+            detail_src = detail_src * 4 / 5;
+        }
+    }
+    if (mv.submask) {
+        mv.flags |= 1u << DSV_MV_BIT_INTRA;
+        mv.dc = err_src < err_sub ? (uint16_t) ((avg_tot / (unsigned) nsub) | DSV_SRC_DC_PRED) : 0;
+    }
+}
+
+__device__ void test_subblock_intra_c(const HmeDev &c, DSV_MV &mv, unsigned mad, unsigned detail_src, unsigned avg_src, int cbx, int cby,
+                                      int cbmx, int cbmy, int cbw, int cbh) // hme.c:987
+{
+    int sbw = cbw / 2, sbh = cbh / 2;
+    if (c.effort < 6) {
+        return;
+    }
+    unsigned thr = (mv.flags & (1u << DSV_MV_BIT_INTRA)) ? detail_src : SQR(detail_src);
+    if (sbw == 0 || sbh == 0 || mad <= thr || thr > 64 || (abs((int) mv.u.mv.x) < 4 && abs((int) mv.u.mv.y) < 4)) {
+        return;
+    }
+    unsigned avg_ramp = avg_src * avg_src >> 8;
+    for (int k = 0; k < 4; k++) {
+        int f = (k & 1) ? sbw : 0, g = (k & 2) ? sbh : 0;
+        if (mv.submask & (1 << k)) {
+            continue;
+        }
+        int us = ws_plane_avg(c.srcc[0], cbx + f, cby + g, sbw, sbh);
+        int vs = ws_plane_avg(c.srcc[1], cbx + f, cby + g, sbw, sbh);
+        int um = ws_plane_avg(c.refc[0], cbmx + f, cbmy + g, sbw, sbh);
+        int vm = ws_plane_avg(c.refc[1], cbmx + f, cbmy + g, sbw, sbh);
+        unsigned dif = (unsigned) (SQR(us - um) + SQR(vs - vm)) * avg_ramp >> 8;
+        if (dif > thr) {
+            mv.submask |= (uint8_t) (1 << k);
+        }
+    }
+    if (mv.submask) {
+        mv.flags |= 1u << DSV_MV_BIT_INTRA;
+    }
+}
+
+// ---- one block (wave-uniform control flow) --------------------------------------------------------
+#define MAXC 40
+
+__device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int gy, int *hist, SubpelLds &lds)
+{
+    const int rectx[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1};
+    const int recty[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};
+    int lane = threadIdx.x & 63;
+    int nxb = c.a.nbh, nyb = c.a.nbv, y_w = c.a.blk_w, y_h = c.a.blk_h;
+    int step = 1 << level;
+    const DPlane &src = c.src[level], &ref = c.ref[level], &ogr = c.ogr[level];
+    DSV_MV *mvf = c.mvf[level];
+    const DSV_MV *parent = level < c.pyr_levels ? c.mvf[level + 1] : nullptr;
+    DSV_MV *out = &mvf[i + j * nxb];
+    DSV_MV mv = {};
+    Vec2 cands[MAXC];
+    int n = 0;
+
+    int bx = (i * y_w) >> level, by = (j * y_h) >> level;
+    if (bx >= src.w || by >= src.h) {
+        if (lane == 0) {
+            *out = mv;
+        }
+        return;
+    }
+    int bw = min(src.w - bx, y_w), bh = min(src.h - by, y_h);
+    const uint8_t *sblk = at(src, bx, by);
+    cands[n++] = Vec2{0, 0};
+    int motion_bias = y_w * y_h;
+    unsigned var_src = 0, avg_src = 0;
+    Psy psy = {2, 1, 0};
+    int lax = 0, lay = 0;
+    if (level <= 1) {
+        var_src = (unsigned) ws_block_detail(sblk, src.stride, bw, bh, avg_src);
+        int tvar = (int) (var_src + SQR(var_src >> 10));
+        tvar = (8 * tvar * c.quant >> 9) / (bw * bh);
+        if (tvar) {
+            int hvar = (int) ws_hist_var(sblk, src.stride, bw, bh, hist);
+            int qtex = ws_quant_tex(sblk, src.stride, bw, bh);
+            int npeaks = ws_peaks(sblk, src.stride, bw, bh, (int) avg_src, hist);
+            motion_bias += tvar * (hvar - qtex) * npeaks;
+        }
+        motion_bias = max(motion_bias, 0) / (2 + (abs(gx) + abs(gy)));
+        if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
+            psy = Psy{2, 1, 2};
+            motion_bias = 0;
+        } else {
+            psy = Psy{1, 2, 1};
+        }
+        if (var_src > (unsigned) (24 * bw * bh)) {
+            psy.avg_weight = 0;
+        }
+    }
+    if (parent != nullptr) {
+        const int pt[18] = {0, 0, -2, 0, 2, 0, 0, -2, 0, 2, -2, -2, 2, 2, 2, -2, -2, 2};
+        unsigned parent_mask = ~(((unsigned) step << 1) - 1);
+        int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
+        int sumx = 0, sumy = 0, npar = 0;
+        Vec2 lc[16], inl[16];
+        for (int m = 0; m < 9; m++) {
+            int x = pi + pt[2 * m] * step, y = pj + pt[2 * m + 1] * step;
+            if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
+                const DSV_MV *pm = &parent[x + y * nxb];
+                int vx = pm->u.mv.x, vy = pm->u.mv.y;
+                sumx += vx;
+                sumy += vy;
+                lc[npar++] = Vec2{vx, vy};
+            }
+        }
+        if (npar) {
+            lax = sumx / npar;
+            lay = sumy / npar;
+            int nl = find_inliers(lc, inl, npar, lax, lay);
+            cands[n++] = Vec2{lax, lay};
+            if (level == 0) {
+                int px, py;
+                movec_pred(mvf, nxb, i, j, px, py);
+                cands[n++] = Vec2{qp2fp(px), qp2fp(py)};
+            }
+            if (i > 0) {
+                const DSV_MV *m = &mvf[(i - step) + j * nxb];
+                cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+            }
+            if (j > 0) {
+                const DSV_MV *m = &mvf[i + (j - step) * nxb];
+                cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+            }
+            if (i > 0 && j > 0) {
+                const DSV_MV *m = &mvf[(i - step) + (j - step) * nxb];
+                cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+            }
+            if (c.ref_mvf != nullptr) {
+                for (int k = 0; k < 9; k++) {
+                    int rx = i + rectx[k] * step, ry = j + recty[k] * step;
+                    if (rx < 0 || ry < 0 || rx >= nxb || ry >= nyb) {
+                        continue;
+                    }
+                    const DSV_MV *m = &c.ref_mvf[rx + ry * nxb];
+                    cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+                }
+            }
+            cands[n++] = Vec2{gx, gy};
+            for (int m = 0; m < nl; m++) {
+                cands[n++] = inl[m];
+            }
+        }
+    }
+    for (int k = 0; k < n; k++) {
+        cands[k].x = (int) (int16_t) ((int) (int16_t) cands[k].x >> level);
+        cands[k].y = (int) (int16_t) ((int) (int16_t) cands[k].y >> level);
+    }
+    {
+        int newn = 1;
+        for (int k = 1; k < n; k++) {
+            int m;
+            for (m = 0; m < newn; m++) {
+                if (cands[k].x == cands[m].x && cands[k].y == cands[m].y) {
+                    break;
+                }
+            }
+            if (m == newn) {
+                cands[newn++] = cands[k];
+            }
+        }
+        n = newn;
+    }
+    CostCtx cc;
+    movec_pred(mvf, nxb, i, j, cc.px, cc.py);
+    cc.q = c.quant;
+    cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
+
+    int best_k = 0, dx, dy;
+    unsigned best_score = 0xffffffffu, score_zero = 0xffffffffu, score;
+    for (int k = 0; k < n; k++) {
+        dx = cands[k].x;
+        dy = cands[k].y;
+        if (invalid_block(ref, bx + dx, by + dy, bw, bh, 0)) {
+            continue;
+        }
+        score = ws_hier_metr(level, sblk, src.stride, at(ref, bx + dx, by + dy), ref.stride, bw, bh, psy);
+        if (dx == 0 && dy == 0) {
+            score_zero = score;
+        }
+        score += (unsigned) mv_cost(cc, dx * step * 4, dy * step * 4, level);
+        if (dx == lax && dy == lay) {
+            score = (unsigned) max((int) score - (motion_bias >> level), 0);
+        }
+        if (best_score > score) {
+            best_score = score;
+            best_k = k;
+        }
+    }
+    dx = cands[best_k].x;
+    dy = cands[best_k].y;
+    unsigned best = best_score;
+    unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
+    bool good_enough = false;
+    {
+        unsigned zoscore = ws_metr(sblk, src.stride, at(ogr, bx, by), ogr.stride, bw, bh, psy);
+        if (abs(dx) <= 1 && abs(dy) <= 1) {
+            qthresh *= 2;
+        }
+        if (zoscore < qthresh) {
+            best = level == 0 ? score_zero : 0;
+            dx = dy = 0;
+            good_enough = true;
+        }
+    }
+    if (!good_enough) { // refine_best_fpel_cand, hme.c:1300
+        unsigned metr[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        bool again = true;
+        while (again && !good_enough) {
+            int tvx, tvy;
+            again = false;
+            for (int k = 0; k < 5; k++) {
+                tvx = dx + rectx[k];
+                tvy = dy + recty[k];
+                if (invalid_block(ref, bx + tvx, by + tvy, bw, bh, 0)) {
+                    continue;
+                }
+                score = ws_hier_metr(level, sblk, src.stride, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh, psy);
+                if (k >= 1) {
+                    metr[k - 1] = score;
+                }
+                if (level == 0 && !tvx && !tvy && score <= qthresh) {
+                    dx = tvx;
+                    dy = tvy;
+                    best = score;
+                    good_enough = true;
+                    break;
+                }
+                score += (unsigned) mv_cost(cc, tvx * step * 4, tvy * step * 4, level);
+                if (best > score) {
+                    best = score;
+                    dx = tvx;
+                    dy = tvy;
+                    again = true;
+                    break;
+                }
+            }
+            if (again || good_enough) {
+                continue;
+            }
+            tvx = dx + (metr[0] <= metr[1] ? 1 : -1);
+            tvy = dy + (metr[2] <= metr[3] ? 1 : -1);
+            if (invalid_block(ref, bx + tvx, by + tvy, bw, bh, 0)) {
+                break;
+            }
+            score = ws_hier_metr(level, sblk, src.stride, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh, psy);
+            score += (unsigned) mv_cost(cc, tvx * step * 4, tvy * step * 4, level);
+            if (best > score) {
+                best = score;
+                dx = tvx;
+                dy = tvy;
+                again = true;
+            }
+        }
+    }
+    mv.u.mv.x = (int16_t) (dx * step);
+    mv.u.mv.y = (int16_t) (dy * step);
+    if (level != 0) {
+        if (lane == 0) {
+            *out = mv;
+        }
+        return;
+    }
+
+    // ---- sub-pel refinement + mode decision (hme.c:1598-1821) ----
+    int fpelx = mv.u.mv.x, fpely = mv.u.mv.y, sx = 0, sy = 0;
+    bool found_sub = false;
+    unsigned yarea = (unsigned) (bw * bh);
+    const DPlane &ref0 = c.ref[0];
+    if (fpelx == lax && fpely == lay) {
+        best += (unsigned) motion_bias;
+    }
+    unsigned best_fp = best;
+    if (c.effort >= 4) {
+        if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
+            best = subpixel_me(c, lds, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, psy);
+            if (sx || sy) {
+                fpelx = lax;
+                fpely = lay;
+                found_sub = true;
+            }
+        }
+        if (!found_sub && !good_enough && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
+            best = subpixel_me(c, lds, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, psy);
+        }
+    }
+    mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
+    mv.u.mv.y = (int16_t) (fpely * 4 + sy);
+
+    unsigned ratio = 32;
+    if ((mv.u.mv.x | mv.u.mv.y) & 3) {
+        ratio = (best << 5) / (best_fp + !best_fp);
+    }
+    const uint8_t *ogrd = at(c.ogr[0], bx + fpelx, by + fpely);
+    const uint8_t *refd = at(ref0, bx + fpelx, by + fpely);
+    unsigned ogrerr = ws_metr(sblk, src.stride, ogrd, c.ogr[0].stride, bw, bh, psy);
+    unsigned ogrmad = (ogrerr + yarea / 2) / yarea;
+    ogrmad = ogrmad * ratio >> 5;
+    unsigned mad = (best + yarea / 2) / yarea;
+    unsigned avg_ref;
+    unsigned var_ref = (unsigned) ws_block_detail(refd, ref0.stride, bw, bh, avg_ref);
+    int dv = (int) min(ratio, 32u);
+    int ipolvar = (int) ((var_src * (unsigned) dv + var_ref * (unsigned) (32 - dv)) >> 5);
+    dv = abs((int) var_src - ipolvar);
+    if (var_src > 16 * yarea && var_src < 32 * yarea) {
+        mv.flags |= 1u << DSV_MV_BIT_MAINTAIN;
+    }
+    int hs = c.a.hshift, vs = c.a.vshift;
+    int cbx = i * (y_w >> hs), cby = j * (y_h >> vs);
+    int cbmx = cbx + sarx(fpelx, hs), cbmy = cby + sarx(fpely, vs);
+    int cbw = bw >> hs, cbh = bh >> vs;
+    unsigned chroma_ratio = (unsigned) ((cbw * cbh) << 4) / yarea;
+    int uavg_src = ws_plane_avg(c.srcc[0], cbx, cby, cbw, cbh), vavg_src = ws_plane_avg(c.srcc[1], cbx, cby, cbw, cbh);
+    int uavg_ref = ws_plane_avg(c.refc[0], cbmx, cbmy, cbw, cbh), vavg_ref = ws_plane_avg(c.refc[1], cbmx, cbmy, cbw, cbh);
+    ChromaPsy cpsy = chroma_analysis((int) avg_src, uavg_src, vavg_src);
+    unsigned avg_y_dif = (unsigned) abs((int) avg_src - (int) avg_ref);
+    unsigned avg_c_dif = (unsigned) AVG2(abs(uavg_src - uavg_ref), abs(vavg_src - vavg_ref));
+    int eprmi, eprmd, eprmr;
+    ws_calc_eprm(sblk, src.stride, refd, ref0.stride, (int) avg_src, (int) avg_ref, bw, bh, eprmi, eprmd, eprmr);
+    bool oob;
+    {
+        int px = i * y_w + sarx(mv.u.mv.x, 2), py = j * y_h + sarx(mv.u.mv.y, 2);
+        oob = px < 0 || py < 0 || px >= ((nxb - 1) * y_w) - 1 || py >= ((nyb - 1) * y_h) - 1;
+    }
+    int neidif;
+    {
+        int a, b;
+        neighbordif2_cur(mvf, nxb, i, j, mv.u.mv.x, mv.u.mv.y, a, b);
+        neidif = (a + b) / 3;
+    }
+    unsigned skipt = ((unsigned) c.quant * (unsigned) c.quant) >> 19;
+    bool skipped = false;
+    if ((good_enough || mv.u.all == 0) && c.skip_block_thresh >= 0 && !c.lossless) {
+        unsigned sth = skipt * yarea, zsub[3];
+        sth += 4 * var_src;
+        sth += yarea * (unsigned) c.skip_block_thresh;
+        if (c.quant < (1 << 10)) {
+            sth = sth * (unsigned) c.quant >> 10;
+        }
+        if (avg_y_dif <= 2) {
+            sth = max(sth, 3 * (yarea + var_src));
+        }
+        sth = max(sth, yarea);
+        if (good_enough) {
+            sth *= 2;
+        }
+        ws_yuv_max_subblock_err(zsub, c, bx, by, bx, by, bw, bh, cbx, cby, cbx, cby, cbw, cbh, psy);
+        unsigned cth = chroma_ratio * sth * max(skipt, 1u) >> 5;
+        zsub[0] = zsub[0] * ratio >> 5;
+        zsub[1] = zsub[1] * ratio >> 5;
+        zsub[2] = zsub[2] * ratio >> 5;
+        zsub[0] += (unsigned) SQR((int) avg_src - (int) avg_ref) * yarea;
+        if (zsub[0] <= sth && zsub[1] <= cth && zsub[2] <= cth) {
+            mv.flags |= 1u << DSV_MV_BIT_SKIP;
+            mv.u.all = 0;
+            mv.err = 0;
+            skipped = true;
+        }
+    }
+    int add_err = 0, add_ndiff = 0;
+    if (!skipped) {
+        if (!oob && !c.lossless) {
+            bool y_prereq = avg_y_dif <= 2, c_prereq = !cpsy.greyish && avg_c_dif <= 2;
+            if (y_prereq || c_prereq) {
+                unsigned bsub[3], xth = skipt * yarea;
+                int carea = 4 * cbw * cbh;
+                ws_yuv_max_subblock_err(bsub, c, bx, by, bx + fpelx, by + fpely, bw, bh, cbx, cby, cbmx, cbmy, cbw, cbh, psy);
+                xth += (unsigned) ipolvar;
+                xth = (unsigned) max((int) xth - ((int) yarea * neidif * 2), 0);
+                xth = xth * (unsigned) c.quant >> 12;
+                xth = min(max(xth, 32u), yarea * 4);
+                bsub[0] = bsub[0] * ratio >> 5;
+                bsub[1] = bsub[1] * ratio >> 5;
+                bsub[2] = bsub[2] * ratio >> 5;
+                if (y_prereq && bsub[0] < 4 * xth) {
+                    mv.flags |= 1u << DSV_MV_BIT_NOXMITY;
+                }
+                int utex = (int) ws_block_tex(at(c.srcc[0], cbx, cby), c.srcc[0].stride, cbw, cbh);
+                int vtex = (int) ws_block_tex(at(c.srcc[1], cbx, cby), c.srcc[1].stride, cbw, cbh);
+                c_prereq = c_prereq && (utex > carea || vtex > carea);
+                xth = chroma_ratio * xth >> 4;
+                if (c_prereq && bsub[1] < xth && bsub[2] < xth) {
+                    mv.flags |= 1u << DSV_MV_BIT_NOXMITC;
+                }
+            }
+            if ((unsigned) dv < var_src / 4) {
+                mv.flags |= 1u << DSV_MV_BIT_SIMCMPLX;
+            }
+        }
+        const DSV_MV *refmv = c.ref_mvf ? &c.ref_mvf[i + j * nxb] : nullptr;
+        test_subblock_intra_y(c, refmv, mv, sblk, src.stride, refd, ref0.stride, ipolvar, (int) avg_src, neidif, ratio, bw, bh);
+        test_subblock_intra_c(c, mv, mad, (unsigned) (ipolvar / (bw * bh)), avg_src, cbx, cby, cbmx, cbmy, cbw, cbh);
+        if (!(mv.flags & (1u << DSV_MV_BIT_NOXMITY))) {
+            mv.err = (uint16_t) mad;
+            add_err = (int) mad;
+        }
+        add_ndiff = (ogrmad > 11) + (avg_c_dif >= 32);
+    }
+    int is_intra = 0;
+    if (mv.flags & (1u << DSV_MV_BIT_INTRA)) {
+        int merged = (mv.dc & DSV_SRC_DC_PRED) ? eprmd : eprmi;
+        if (mv.submask != DSV_MASK_ALL_INTRA) {
+            merged |= eprmr;
+        }
+        mv.flags = (mv.flags & ~(1u << DSV_MV_BIT_EPRM)) | (merged ? (1u << DSV_MV_BIT_EPRM) : 0u);
+        is_intra = 1;
+        mv.u.mv.x = (int16_t) (fpelx * 4);
+        mv.u.mv.y = (int16_t) (fpely * 4);
+    } else {
+        int merged = eprmr;
+        if (mv.submask) {
+            merged |= eprmi;
+        }
+        mv.flags = (mv.flags & ~(1u << DSV_MV_BIT_EPRM)) | (merged ? (1u << DSV_MV_BIT_EPRM) : 0u);
+    }
+    if (mv.flags & ((1u << DSV_MV_BIT_INTRA) | (1u << DSV_MV_BIT_EPRM))) {
+        mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
+    }
+    if (lane == 0) {
+        *out = mv;
+        if (is_intra) {
+            atomicAdd(&c.counters[0], 1);
+        }
+        if (add_ndiff) {
+            atomicAdd(&c.counters[1], add_ndiff);
+        }
+        if (best > 0) {
+            atomicAdd(&c.counters[2], 1);
+        }
+        if (add_err) {
+            atomicAdd(&c.counters[3], add_err);
+        }
+    }
+}
+
+// one anti-diagonal front of one level: blockIdx.x enumerates the blocks on the front
+__global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, int nbx, int nby)
+{
+    __shared__ int hist[16];
+    __shared__ SubpelLds lds;
+    int bj_hi = min(nby - 1, t);
+    int bj = bj_hi - (int) blockIdx.x;
+    int bi = t - bj;
+    if (bj < 0 || bi >= nbx) {
+        return;
+    }
+    int gx = c.counters[4], gy = c.counters[5];
+    hme_block(c, level, bi << level, bj << level, gx, gy, hist, lds);
+}
+
+// global_motion (hme.c:1973): mean vector of the level just finished, scaled up for the next one
+__global__ __launch_bounds__(256) void k_global_motion(HmeDev c, int level)
+{
+    __shared__ int sx[4], sy[4];
+    int step = 1 << level;
+    int nbx = (c.a.nbh + step - 1) / step, nby = (c.a.nbv + step - 1) / step;
+    int ax = 0, ay = 0;
+    for (int idx = threadIdx.x; idx < nbx * nby; idx += 256) {
+        int i = (idx % nbx) * step, j = (idx / nbx) * step;
+        const DSV_MV *m = &c.mvf[level][i + j * c.a.nbh];
+        ax += m->u.mv.x;
+        ay += m->u.mv.y;
+    }
+    ax = wave_sum(ax);
+    ay = wave_sum(ay);
+    if ((threadIdx.x & 63) == 0) {
+        sx[threadIdx.x >> 6] = ax;
+        sy[threadIdx.x >> 6] = ay;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nblk = nbx * nby;
+        int tx = sx[0] + sx[1] + sx[2] + sx[3], ty = sy[0] + sy[1] + sy[2] + sy[3];
+        c.counters[4] = nblk ? tx * 2 / nblk : 0;
+        c.counters[5] = nblk ? ty * 2 / nblk : 0;
+    }
+}
+
+void hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp)
+{
+    HmeFrames f;
+    f.src[0] = cur.src.p[0];
+    f.ref[0] = ref.recon.p[0];
+    f.ogr[0] = ref.src.p[0];
+    for (int l = 0; l < hp.pyr_levels; l++) {
+        f.src[l + 1] = cur.src_pyr[l].p[0];
+        f.ref[l + 1] = ref.recon_pyr[l].p[0];
+        f.ogr[l + 1] = ref.src_pyr[l].p[0];
+    }
+    for (int k = 0; k < 2; k++) {
+        f.srcc[k] = cur.src.p[k + 1];
+        f.refc[k] = ref.recon.p[k + 1];
+    }
+    for (int l = 0; l <= hp.pyr_levels; l++) {
+        f.mvf[l] = dv.d_mvf[l];
+    }
+    f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
+    f.counters = dv.d_counters;
+    hme_run(s, f, hp);
+}
+
+void hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
+{
+    HmeDev c;
+    c.a = hp.a;
+    c.effort = hp.effort;
+    c.lossless = hp.lossless;
+    c.quant = hp.quant;
+    c.skip_block_thresh = hp.skip_block_thresh;
+    c.pyr_levels = hp.pyr_levels;
+    c.psyscale = spatial_psy_factor(hp.a.blk_w, hp.a.blk_h, hp.a.nbh, hp.a.nbv, -1);
+    for (int l = 0; l <= hp.pyr_levels; l++) {
+        c.src[l] = f.src[l];
+        c.ref[l] = f.ref[l];
+        c.ogr[l] = f.ogr[l];
+        c.mvf[l] = f.mvf[l];
+    }
+    for (int k = 0; k < 2; k++) {
+        c.srcc[k] = f.srcc[k];
+        c.refc[k] = f.refc[k];
+    }
+    c.ref_mvf = f.ref_mvf;
+    c.counters = f.counters;
+    size_t nb = (size_t) hp.a.nbh * hp.a.nbv;
+    HIPCHK(hipMemsetAsync(f.counters, 0, 16 * sizeof(int), s));
+    for (int level = hp.pyr_levels; level >= 0; level--) {
+        int step = 1 << level;
+        int nbx = (hp.a.nbh + step - 1) / step, nby = (hp.a.nbv + step - 1) / step;
+        HIPCHK(hipMemsetAsync(f.mvf[level], 0, nb * sizeof(DSV_MV), s));
+        for (int t = 0; t <= nbx + nby - 2; t++) {
+            int jhi = nby - 1 < t ? nby - 1 : t;
+            int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
+            hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby);
+        }
+        if (level != 0) {
+            hipLaunchKernelGGL(k_global_motion, dim3(1), dim3(256), 0, s, c, level);
+        }
+    }
+    HIPCHK(hipGetLastError());
+}
+
+} // namespace dsv2

@@ -1,0 +1,35 @@
+"""HIP hierarchical motion estimation (wavefront-per-block kernels) vs the real reference's dsv_hme."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import dsvabi as A
+from hme_common import HME, Scene, assert_fields_equal
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+
+
+def run_lib(lib, sc, quant, effort, skip_thresh=0):
+    return sc.run_reference(lib, quant, effort, skip_thresh)
+
+
+@pytest.mark.parametrize("w,h,subsamp,seed,quant,effort,prev", [
+    (352, 288, A.SUBSAMP_420, 1, 172, 10, True),
+    (352, 288, A.SUBSAMP_420, 2, 900, 10, False),
+    (354, 290, A.SUBSAMP_420, 3, 61, 10, True),
+    (640, 360, A.SUBSAMP_444, 4, 300, 7, True),
+    (640, 360, A.SUBSAMP_420, 5, 172, 3, True),
+    (1280, 720, A.SUBSAMP_420, 6, 172, 10, True),
+    (1920, 1080, A.SUBSAMP_420, 7, 172, 10, True),
+])
+def test_hme_matches_reference(w, h, subsamp, seed, quant, effort, prev):
+    ref, hip = A.load_ref(), A.load_hip()
+    sc = Scene(ref, w, h, subsamp, seed, with_prev_mvs=prev)
+    want, ipct_r, scb_r, err_r = run_lib(ref, sc, quant, effort)
+    got, ipct_h, scb_h, err_h = run_lib(hip, sc, quant, effort)
+    for l in range(sc.levels, -1, -1):
+        assert_fields_equal(want[l], got[l], "level %d" % l)
+    assert (ipct_r, scb_r, err_r) == (ipct_h, scb_h, err_h)
