@@ -383,6 +383,18 @@ void dsv_intra_filter(int q, DSV_PARAMS *p, DSV_FMETA *fm, int cpl, DSV_PLANE *d
     HIPCHK(hipStreamSynchronize(c.stream));
 }
 
+void dsv_post_process(DSV_PLANE *dp)
+{
+    SeamCtx &c = g_seam;
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.init();
+    stage_plane_in(c, dp, true);
+    post_process_plane(c.stream, g_pstage.p);
+    HIPCHK(hipMemcpy2DAsync(dp->data, dp->stride, g_pstage.p.data, g_pstage.p.stride, dp->w, dp->h, hipMemcpyDeviceToHost,
+                            c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+}
+
 DSV_MV *dsv_intra_analysis(DSV_FRAME *src, DSV_PARAMS *p)
 {
     SeamCtx &c = g_seam;

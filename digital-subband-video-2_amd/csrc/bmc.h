@@ -35,4 +35,7 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
 // dsv_intra_filter (bmc.c:391), luma plane only
 void intra_filter_luma(hipStream_t s, const uint8_t *d_bd, const MCParams &p, int q, const DPlane &luma);
 
+// dsv_post_process (bmc.c:340): de-gradient sharpen of every interior 4x4 cell
+void post_process_plane(hipStream_t s, const DPlane &dp);
+
 } // namespace dsv2

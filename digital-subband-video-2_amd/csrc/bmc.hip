@@ -586,6 +586,23 @@ __global__ __launch_bounds__(256) void k_intra_filter(const uint8_t *__restrict_
     sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(dp, f, bd, i, j, nsbx, nsby); });
 }
 
+// decoder-side sharpening (dsv_post_process, bmc.c:340): every 4x4 cell is independent
+__global__ __launch_bounds__(256) void k_post_process(DPlane dp)
+{
+    int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    int x = i * 4, y = j * 4;
+    if (i >= dp.w / 4 || j >= dp.h / 4 || x + 4 >= dp.w || y + 4 >= dp.h) {
+        return;
+    }
+    degrad(dp.data + (ptrdiff_t) y * dp.stride + x, dp.stride);
+}
+
+void post_process_plane(hipStream_t s, const DPlane &dp)
+{
+    hipLaunchKernelGGL(k_post_process, dim3((dp.w / 4 + 63) / 64, (dp.h / 4 + 3) / 4), dim3(64, 4), 0, s, dp);
+    HIPCHK(hipGetLastError());
+}
+
 // ---- host drivers --------------------------------------------------------------------------
 
 static int host_lb2(unsigned n)
