@@ -42,7 +42,7 @@ struct SeamCtx {
 
     void init()
     {
-        ensure_device();
+        bind_device();
         if (!stream) {
             HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         }
@@ -181,7 +181,11 @@ const char *dsv2hip_version(void) { return "dsv2hip 0.1 (DSV2 v2.8 bitstream, en
 int dsv2hip_set_device(int ordinal)
 {
     ensure_device();
-    return hipSetDevice(ordinal) == hipSuccess ? 0 : -1;
+    if (hipSetDevice(ordinal) != hipSuccess) {
+        return -1;
+    }
+    set_default_device(ordinal);
+    return 0;
 }
 
 void dsv_fwd_sbt(DSV_PLANE *src, DSV_COEFS *dst, DSV_FMETA *fm)

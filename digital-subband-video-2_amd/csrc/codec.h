@@ -29,6 +29,22 @@ struct PlaneSyms { // host view of one plane's entropy input
     int n;
 };
 
+// ---- optional stage timing with HIP events on the codec's own stream (bench.py roofline) ----
+enum Stage { ST_INGEST = 0, ST_HME, ST_PREDICT, ST_FWD_SBT, ST_QUANT, ST_INV_SBT, ST_RECON_FILTER, ST_EXTEND, ST_COUNT };
+
+struct StageProf {
+    bool on = false;
+    hipEvent_t ev[ST_COUNT][2];
+    bool used[ST_COUNT];
+    long long launches[ST_COUNT];
+    void init();
+    void destroy();
+    void begin(hipStream_t s, int st);
+    void end(hipStream_t s, int st, int nlaunch);
+    void collect(); // after a stream synchronise: fold the frame's event pairs into the global totals
+};
+bool prof_enabled();
+
 // geometry + buffers that persist for the life of a codec instance
 struct CodecDev {
     hipStream_t stream = nullptr;
@@ -52,6 +68,7 @@ struct CodecDev {
     uint32_t *d_sym_pos = nullptr;
     int32_t *d_sym_val = nullptr;
     size_t sym_cap = 0;
+    StageProf prof;
     // pinned host staging
     uint8_t *h_frame = nullptr; // one packed planar picture
     size_t h_frame_bytes = 0;
@@ -73,5 +90,7 @@ struct CodecDev {
 };
 
 void block_geometry(int w, int h, int ovx, int ovy, int *blk_w, int *blk_h, int *nbh, int *nbv);
+
+
 
 } // namespace dsv2

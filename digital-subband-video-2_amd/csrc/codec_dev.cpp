@@ -6,7 +6,101 @@
 // ~95 MB, so thousands of instances fit in 288 GB -- concurrency is bounded by CUs, not memory.
 #include "codec.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace dsv2 {
+
+static std::atomic<int> g_prof_on{0};
+static std::mutex g_prof_mu;
+static double g_prof_ms[ST_COUNT];
+static long long g_prof_launches[ST_COUNT];
+static long long g_prof_frames;
+
+bool prof_enabled() { return g_prof_on.load() != 0; }
+
+void StageProf::init()
+{
+    on = prof_enabled();
+    if (!on) {
+        return;
+    }
+    for (int i = 0; i < ST_COUNT; i++) {
+        HIPCHK(hipEventCreate(&ev[i][0]));
+        HIPCHK(hipEventCreate(&ev[i][1]));
+        used[i] = false;
+        launches[i] = 0;
+    }
+}
+
+void StageProf::destroy()
+{
+    if (!on) {
+        return;
+    }
+    for (int i = 0; i < ST_COUNT; i++) {
+        HIPCHK(hipEventDestroy(ev[i][0]));
+        HIPCHK(hipEventDestroy(ev[i][1]));
+    }
+    on = false;
+}
+
+void StageProf::begin(hipStream_t s, int st)
+{
+    if (on && !used[st]) {
+        HIPCHK(hipEventRecord(ev[st][0], s));
+    }
+}
+
+void StageProf::end(hipStream_t s, int st, int nlaunch)
+{
+    if (on) {
+        HIPCHK(hipEventRecord(ev[st][1], s)); // the last end() of a frame closes the stage's span
+        used[st] = true;
+        launches[st] += nlaunch;
+    }
+}
+
+void StageProf::collect()
+{
+    if (!on) {
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (used[i]) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1]));
+            g_prof_ms[i] += ms;
+            g_prof_launches[i] += launches[i];
+            used[i] = false;
+            launches[i] = 0;
+        }
+    }
+    g_prof_frames++;
+}
+
+extern "C" void dsv2hip_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on;
+    for (int i = 0; i < ST_COUNT; i++) {
+        g_prof_ms[i] = 0;
+        g_prof_launches[i] = 0;
+    }
+    g_prof_frames = 0;
+}
+
+extern "C" int dsv2hip_prof_read(double *ms, long long *launches, long long *frames)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < ST_COUNT; i++) {
+        ms[i] = g_prof_ms[i];
+        launches[i] = g_prof_launches[i];
+    }
+    *frames = g_prof_frames;
+    return ST_COUNT;
+}
 
 void block_geometry(int w, int h, int ovx, int ovy, int *blk_w, int *blk_h, int *nbh, int *nbv) // dsv_encoder.c:1203-1222
 {
@@ -42,6 +136,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     nbv = (h + blk_h - 1) / blk_h;
     pyr_levels = pyr_levels_;
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    prof.init();
     coef_dims(format, w, h, cw, ch);
     size_t nb = nblocks();
     for (int i = 0; i < 2; i++) {
@@ -127,6 +222,7 @@ void CodecDev::destroy()
         return;
     }
     HIPCHK(hipStreamSynchronize(stream));
+    prof.destroy();
     for (int i = 0; i < 2; i++) {
         dframe_free(&pics[i].recon);
         dframe_free(&pics[i].src);

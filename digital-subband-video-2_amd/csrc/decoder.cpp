@@ -259,6 +259,7 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn) // d
         dsv_buf_free(buffer);
         return DSV_DEC_ERROR;
     }
+    bind_device();
     DecImpl *im = (DecImpl *) d->ref;
     if (!im) {
         im = new DecImpl();

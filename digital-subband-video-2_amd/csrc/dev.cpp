@@ -40,6 +40,15 @@ void ensure_device()
     }
 }
 
+static int g_device_ordinal = 0;
+void set_default_device(int ordinal) { g_device_ordinal = ordinal; }
+// HIP's current device is per host thread: every entry point that may run on a new thread binds it
+void bind_device()
+{
+    ensure_device();
+    HIPCHK(hipSetDevice(g_device_ordinal));
+}
+
 void coef_dims(int format, int w, int h, int cw[3], int ch[3]) // frame.c:30-60
 {
     int hs = DSV_FORMAT_H_SHIFT(format), vs = DSV_FORMAT_V_SHIFT(format);

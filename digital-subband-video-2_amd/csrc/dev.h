@@ -92,6 +92,8 @@ void copy_frame_pixels(hipStream_t s, const DFrame &dst, const DFrame &src);
 void copy_frame_full(hipStream_t s, const DFrame &dst, const DFrame &src);
 
 void ensure_device();
+void set_default_device(int ordinal);
+void bind_device(); // ensure_device + hipSetDevice(default ordinal) for the calling thread
 int device_status(); // 0 = usable HIP device present
 
 } // namespace dsv2

@@ -810,7 +810,9 @@ void encode_picture(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
         // the motion field as transmitted: uploaded once, used by MC now and as the temporal
         // candidate source of the next frame
         HIPCHK(hipMemcpyAsync(cur.d_final_mvs, im->mvs.data(), nb * sizeof(DSV_MV), hipMemcpyHostToDevice, dv.stream));
+        dv.prof.begin(dv.stream, ST_PREDICT);
         mc_sub_pred(dv.stream, cur.d_final_mvs, mc, dv.pred, cur.recon, ref.recon);
+        dv.prof.end(dv.stream, ST_PREDICT, 1);
         bs.align();
         encode_motion(enc, d, bs, im->mvs.data(), stats);
     } else {
@@ -819,22 +821,29 @@ void encode_picture(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
     HIPCHK(hipMemcpyAsync(dv.d_blockdata, enc->blockdata, nb, hipMemcpyHostToDevice, dv.stream));
 
     BlockMap bm{dv.d_blockdata, dv.nbh, dv.nbv};
+    dv.prof.begin(dv.stream, ST_FWD_SBT);
     for (int c = 0; c < 3; c++) {
         DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
         sbt_forward(dv.stream, cur.recon.p[c], co, dv.scratch, c, isP, p->lossless, bm);
     }
+    dv.prof.end(dv.stream, ST_FWD_SBT, 3);
+    dv.prof.begin(dv.stream, ST_QUANT);
     hipLaunchKernelGGL(k_grab_ll, dim3(1), dim3(1), 0, dv.stream, dv.coefs[0], dv.coefs[1], dv.coefs[2], dv.d_ll);
     for (int c = 0; c < 3; c++) {
         DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
         quant_plane(dv.stream, co, dv.qv + dv.qv_off[c], dv.quant_cfg(c, isP, p->lossless, p->do_psy, cur.d_final_mvs), d->quant);
     }
     dv.comp.run(dv.stream, dv.qv, dv.qv_off[3]);
+    dv.prof.end(dv.stream, ST_QUANT, 3);
     HIPCHK(hipMemcpyAsync(dv.h_ll, dv.d_ll, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, dv.stream));
+    dv.prof.begin(dv.stream, ST_INV_SBT);
     // reconstruction continues on the device while the host packs bits
     for (int c = 0; c < 3; c++) {
         DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
         sbt_inverse(dv.stream, cur.recon.p[c], co, dv.scratch, d->quant, c, isP, p->lossless, bm);
     }
+    dv.prof.end(dv.stream, ST_INV_SBT, 3);
+    dv.prof.begin(dv.stream, ST_RECON_FILTER);
     if (!isP) {
         if (enc->do_intra_filter) {
             intra_filter_luma(dv.stream, dv.d_blockdata, mc, d->quant, cur.recon.p[0]);
@@ -842,6 +851,7 @@ void encode_picture(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
     } else {
         mc_add_res(dv.stream, cur.d_final_mvs, mc, d->quant, cur.recon, dv.pred, inter_filter, enc->vidmeta.inter_sharpen);
     }
+    dv.prof.end(dv.stream, ST_RECON_FILTER, 2);
     HIPCHK(hipStreamSynchronize(dv.stream));
     int nsym = *dv.comp.h_total;
     dv.ensure_host_syms((size_t) nsym);
@@ -894,6 +904,7 @@ int encode_one_frame(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
 
     fill_params(enc, im, d);
     build_pyramid(dv, cur.src, cur.src_pyr);
+    dv.prof.end(dv.stream, ST_INGEST, 2 * dv.pyr_levels + 3);
     // mean luma of the coarsest level feeds the dark-scene quality boost (dsv_encoder.c:296,403)
     {
         const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
@@ -933,7 +944,9 @@ int encode_one_frame(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
         hp.quant = enc->prev_quant;
         hp.skip_block_thresh = enc->skip_block_thresh;
         hp.pyr_levels = dv.pyr_levels;
-        hme_estimate(dv.stream, dv, cur, ref, hp);
+        dv.prof.begin(dv.stream, ST_HME);
+        int nfronts = hme_estimate(dv.stream, dv, cur, ref, hp);
+        dv.prof.end(dv.stream, ST_HME, nfronts);
         HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, dv.stream));
         HIPCHK(hipMemcpyAsync(dv.h_counters, dv.d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, dv.stream));
         HIPCHK(hipStreamSynchronize(dv.stream));
@@ -972,8 +985,14 @@ int encode_one_frame(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
 
     bool keep = enc->frame_callback || (p->is_ref && enc->gop != DSV_GOP_INTRA);
     if (keep) {
+        dv.prof.begin(dv.stream, ST_EXTEND);
         extend_frame(dv.stream, cur.recon, false);
+        dv.prof.end(dv.stream, ST_EXTEND, 3);
+        if (dv.prof.on) {
+            HIPCHK(hipStreamSynchronize(dv.stream));
+        }
     }
+    dv.prof.collect();
     if (enc->frame_callback) {
         DSV_FRAME *orig = dsv_mk_frame(dv.format, dv.w, dv.h, 1), *rec = dsv_mk_frame(dv.format, dv.w, dv.h, 1);
         dframe_download_full(&cur.src, orig, dv.stream);
@@ -1163,11 +1182,9 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs) // dsv_encoder.c:141
     set_link_offsets(enc, &bufs[0], 1);
 }
 
-int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:1430
+static int enc_common(DSV_ENCODER *enc, DSV_FRAME *frame, const uint8_t *dev_planar, DSV_BUF *bufs)
 {
-    if (frame == NULL || bufs == NULL) {
-        return 0;
-    }
+    bind_device();
     EncImpl *im = (EncImpl *) enc->ref;
     if (!im) {
         im = new EncImpl();
@@ -1197,10 +1214,21 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
     CodecDev &dv = im->dev;
     PicSet &cur = dv.pics[im->cur];
     // ingest: the picture goes to HBM once; the border is synthesised there (dsv_encoder.c:1455-1456)
-    dframe_upload(&cur.src, frame, dv.stream);
-    extend_frame(dv.stream, cur.src, false);
-    HIPCHK(hipStreamSynchronize(dv.stream)); // the caller's pixels may be released below
-    dsv_frame_ref_dec(frame);
+    dv.prof.begin(dv.stream, ST_INGEST);
+    if (frame) {
+        dframe_upload(&cur.src, frame, dv.stream);
+        extend_frame(dv.stream, cur.src, false);
+        HIPCHK(hipStreamSynchronize(dv.stream)); // the caller's pixels may be released below
+        dsv_frame_ref_dec(frame);
+    } else { // packed planar picture already resident in HBM
+        const uint8_t *sp = dev_planar;
+        for (int c = 0; c < 3; c++) {
+            const DPlane &pl = cur.src.p[c];
+            HIPCHK(hipMemcpy2DAsync(pl.data, pl.stride, sp, pl.w, pl.w, pl.h, hipMemcpyDeviceToDevice, dv.stream));
+            sp += (size_t) pl.w * pl.h;
+        }
+        extend_frame(dv.stream, cur.src, false);
+    }
 
     FrameCtl d;
     memset(&d, 0, sizeof(d));
@@ -1217,6 +1245,24 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
     set_link_offsets(enc, &bufs[nbuf - 1], 0);
     account(enc, im, &d, outbuf.len);
     return nbuf;
+}
+
+int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:1430
+{
+    if (frame == NULL || bufs == NULL) {
+        return 0;
+    }
+    return enc_common(enc, frame, NULL, bufs);
+}
+
+/* same as dsv_enc for a packed planar 8-bit picture (Y, then U, then V, no padding) that is
+ * already resident in device memory: no host->device copy is made */
+int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *bufs)
+{
+    if (dev_planar == NULL || bufs == NULL) {
+        return 0;
+    }
+    return enc_common(enc, NULL, (const uint8_t *) dev_planar, bufs);
 }
 
 } // extern "C"

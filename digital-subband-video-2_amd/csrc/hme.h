@@ -38,10 +38,10 @@ struct HmeFrames {
 };
 
 // dsv_hme (hme.c:2001): all levels coarse to fine, asynchronous on `s`
-void hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp);
+int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns the number of front launches
 
 struct CodecDev;
 struct PicSet;
-void hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp);
+int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp);
 
 } // namespace dsv2

@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void k_global_motion(HmeDev c, int level)
     }
 }
 
-void hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp)
+int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp)
 {
     HmeFrames f;
     f.src[0] = cur.src.p[0];
@@ -973,11 +973,12 @@ void hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &
     }
     f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
     f.counters = dv.d_counters;
-    hme_run(s, f, hp);
+    return hme_run(s, f, hp);
 }
 
-void hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
+int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
 {
+    int nlaunch = 0;
     HmeDev c;
     c.a = hp.a;
     c.effort = hp.effort;
@@ -1008,12 +1009,14 @@ void hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
             int jhi = nby - 1 < t ? nby - 1 : t;
             int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
             hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby);
+            nlaunch++;
         }
         if (level != 0) {
             hipLaunchKernelGGL(k_global_motion, dim3(1), dim3(256), 0, s, c, level);
         }
     }
     HIPCHK(hipGetLastError());
+    return nlaunch;
 }
 
 } // namespace dsv2

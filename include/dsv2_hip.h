@@ -364,6 +364,16 @@ const char *dsv2hip_version(void);
 /* select the HIP device used by contexts created afterwards on this thread (one process per GPU: LOCAL_RANK) */
 int dsv2hip_set_device(int ordinal);
 
+/* dsv_enc for a packed planar 8-bit picture (Y, U, V back to back, no padding) that already
+ * lives in device memory: the picture is not copied from the host.  Used by bench.py so that
+ * the timed region starts with inputs resident in HBM. */
+int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *bufs);
+/* stage timing with HIP events on each codec instance's own stream.  Enable before creating
+ * encoders; dsv2hip_prof_read fills 8 entries (ingest+pyramid, HME, predict, fwd SBT,
+ * quant+compact, inv SBT, reconstruct+filters, extend): milliseconds and kernel launches. */
+void dsv2hip_prof_enable(int on);
+int dsv2hip_prof_read(double *ms, long long *launches, long long *frames);
+
 /* Device-resident transform benchmark/ops handle: a plane set kept in HBM. */
 typedef struct dsv2hip_planeset dsv2hip_planeset;
 /* allocate device buffers for one picture (format, width, height) and its coefficient planes */
