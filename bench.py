@@ -168,16 +168,10 @@ def main():
     t_max = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        lens = torch.tensor([seg_bytes], device="cuda", dtype=torch.int64)
-        all_lens = [torch.zeros_like(lens) for _ in range(world)]
-        dist.all_gather(all_lens, lens)
-        cap = int(max(int(x.item()) for x in all_lens))
-        payload = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-        mine = torch.frombuffer(bytearray(b"".join(b for s in range(S) for b in out_bytes[s])), dtype=torch.uint8)
-        payload[:seg_bytes] = mine.cuda()
-        gathered = [torch.zeros_like(payload) for _ in range(world)] if rank == 0 else None
-        dist.gather(payload, gathered, dst=0)
-        total_bytes = int(sum(int(x.item()) for x in all_lens))
+        # segment id = global stream index: rank-major, so the gathered file is the ordered concatenation
+        segs = {rank * S + s: b"".join(out_bytes[s]) for s in range(S)}
+        whole = pkg.sharding.gather_segments(dist, rank, world, segs, device="cuda")
+        total_bytes = len(whole) if rank == 0 else 0
     else:
         total_bytes = seg_bytes
     elapsed = float(t_max.item())

@@ -5,4 +5,4 @@ a C++ host controller, drop-in for the reference's dsv_encoder.h / dsv_decoder.h
 API).  This Python package only holds the thin ctypes host binding used by the
 tests and bench, and the deterministic synthetic-video generator.
 """
-from . import synth  # noqa: F401
+from . import sharding, synth  # noqa: F401

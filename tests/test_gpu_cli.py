@@ -37,7 +37,7 @@ def test_cli_streams_identical(tmp_path, w, h, n, flags):
     outs = {}
     for name, exe in (("ref", A.REF_CLI), ("hip", DROPIN)):
         dsv = str(tmp_path / (name + ".dsv"))
-        run([exe, "e", "-inp=" + y4m, "-out=" + dsv, "-y4m=1", "-y"] + flags)
+        run([exe, "e", "-inp=" + y4m, "-out=" + dsv, "-y4m=1", "-y", "-nfr=%d" % n] + flags)
         outs[name] = dsv
     assert md5(outs["ref"]) == md5(outs["hip"]), "encoded streams differ"
     # decode the GPU-made stream with: the reference decoder, the GPU decoder, the single-header decoder

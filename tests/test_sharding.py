@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo run of the segment sharding + ordered gather.  The per-segment encoder
+is the reference library here (the product encoder needs a GPU): what is checked is the partition, the
+fresh-state-per-segment rule and the gather order, against the reference invoked per segment and concatenated
+(parallel_encode_yuv.sh:36-50)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import dsvabi as A  # noqa: E402
+from conftest import load_pkg  # noqa: E402
+
+W, H, GOP, NFRAMES = 176, 144, 4, 14
+
+
+def encode_segment(seg):
+    from codec_run import encode_stream
+    pkg = load_pkg()
+    v = pkg.synth.SynthVideo(W, H, "420", seed=9)
+    a, b = pkg.sharding.frame_range(seg, GOP, NFRAMES)
+    frames = [v.frame_bytes(t) for t in range(a, b)]
+    packets, _ = encode_stream(A.load_ref(), frames, W, H, A.SUBSAMP_420, eos=False, qp=70, gop=GOP)
+    return b"".join(packets)
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    nseg = (NFRAMES + GOP - 1) // GOP
+    mine = pkg.sharding.assign_segments(nseg, world)[rank]
+    segs = {s: encode_segment(s) for s in mine}
+    out = pkg.sharding.gather_segments(dist, rank, world, segs)
+    if rank == 0:
+        open(os.path.join(outdir, "gathered.dsv"), "wb").write(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")
+def test_two_rank_gather_equals_sequential_per_segment(tmp_path):
+    from codec_run import decode_stream
+    world = 2
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = open(tmp_path / "gathered.dsv", "rb").read()
+    nseg = (NFRAMES + GOP - 1) // GOP
+    want = b"".join(encode_segment(s) for s in range(nseg))
+    assert got == want
+    # the concatenation is a valid stream: split at packet links and decode every frame
+    packets, off = [], 0
+    while off < len(got):
+        nxt = int.from_bytes(got[off + 10:off + 14], "big")
+        packets.append(got[off:off + nxt])
+        off += nxt
+    frames = decode_stream(A.load_ref(), packets)
+    assert len(frames) == NFRAMES
+
+
+def test_assignment_is_a_partition():
+    pkg = load_pkg()
+    for nseg in (1, 5, 8, 17):
+        for world in (1, 2, 4, 8):
+            parts = pkg.sharding.assign_segments(nseg, world)
+            flat = sorted(s for p in parts for s in p)
+            assert flat == list(range(nseg))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
