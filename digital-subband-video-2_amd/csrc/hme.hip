@@ -910,11 +910,30 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     }
 }
 
-// one anti-diagonal front of one level: blockIdx.x enumerates the blocks on the front
-__global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, int nbx, int nby)
+#include "hme_fast.h"
+
+// true when hme_block_fast() handles this block (see hme_fast.h preconditions)
+__device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, int j)
 {
-    __shared__ int hist[16];
-    __shared__ SubpelLds lds;
+    if (c.a.blk_w != 16 || c.a.blk_h != 16 || c.a.hshift != 1 || c.a.vshift != 1) {
+        return false;
+    }
+    const DPlane &src = c.src[level];
+    int bx = (i * 16) >> level, by = (j * 16) >> level;
+    if (bx >= src.w || by >= src.h) {
+        return false;
+    }
+    int bw = min(src.w - bx, 16), bh = min(src.h - by, 16);
+    if (level == 0) {
+        return (bw & 7) == 0 && (bh & 7) == 0;
+    }
+    return !(bw & 1) && !(bh & 1);
+}
+
+// one anti-diagonal front of one level: blockIdx.x enumerates the blocks on the front
+__global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, int nbx, int nby, int allow_fast)
+{
+    __shared__ FastLds S;
     int bj_hi = min(nby - 1, t);
     int bj = bj_hi - (int) blockIdx.x;
     int bi = t - bj;
@@ -922,7 +941,12 @@ __global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, in
         return;
     }
     int gx = c.counters[4], gy = c.counters[5];
-    hme_block(c, level, bi << level, bj << level, gx, gy, hist, lds);
+    int i = bi << level, j = bj << level;
+    if (allow_fast && fast_path_ok(c, level, i, j)) {
+        hme_block_fast(c, level, i, j, gx, gy, S);
+    } else {
+        hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
+    }
 }
 
 // global_motion (hme.c:1973): mean vector of the level just finished, scaled up for the next one
@@ -976,6 +1000,9 @@ int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &r
     return hme_run(s, f, hp);
 }
 
+// DSV2_HME_FAST=0 forces the generic per-block routine (A/B checks); default: fast path on
+static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
+
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
 {
     int nlaunch = 0;
@@ -1008,7 +1035,7 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
         for (int t = 0; t <= nbx + nby - 2; t++) {
             int jhi = nby - 1 < t ? nby - 1 : t;
             int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-            hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby);
+            hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby, g_hme_fast);
             nlaunch++;
         }
         if (level != 0) {

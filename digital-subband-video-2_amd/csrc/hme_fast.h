@@ -1,0 +1,1006 @@
+// hme_fast.h -- latency-optimised evaluation of one motion-estimation block by one wavefront.
+// Included by hme.hip (uses its primitives).  Same results as hme_block(); what changes is how the
+// work is laid out on the 64 lanes:
+//   * the block's 2x2 quads are register-resident (lane = 8*qj + qi owns quad (qi,qj) of the
+//     source block, of each reference candidate, of the chroma blocks ...), so a metric needs
+//     four byte loads per lane and no loop;
+//   * independent sums are reduced TOGETHER: reduceN<16> folds 16 per-lane partial sums across
+//     the wave with 17 cross-lane exchanges (a transpose-style butterfly: each step halves the
+//     number of live values per lane) instead of 16 x 6 -- candidates are scored 16 at a time, a
+//     refinement round scores the whole 3x3 neighbourhood at once, and the mode decision gathers
+//     its ~60 block / sub-block sums into six such rounds;
+//   * candidate bookkeeping (gather, qpel->fpel rounding, level scaling, first-occurrence
+//     de-duplication, cost, arg-min with first-wins ties) is lane-parallel: lane k owns candidate
+//     k; order-preserving compaction uses ballots.
+// Preconditions (else hme_block() is used): 16x16 blocks, 4:2:0, even clipped block size; at
+// level 0 additionally block width/height multiples of 8.
+#pragma once
+
+struct Quad {
+    int p1, p2, p3, p4;
+};
+
+__device__ __forceinline__ Quad ldq(const uint8_t *blk, int stride, int qi, int qj, bool act)
+{
+    Quad q = {0, 0, 0, 0};
+    if (act) {
+        const uint8_t *p = blk + (ptrdiff_t) (2 * qj) * stride + 2 * qi;
+        q.p1 = p[0];
+        q.p2 = p[1];
+        q.p3 = p[stride];
+        q.p4 = p[stride + 1];
+    }
+    return q;
+}
+
+__device__ __forceinline__ unsigned qmetric(const Quad &a, const Quad &b, const Psy &psy)
+{
+    return quad_metric(a.p1, a.p2, a.p3, a.p4, b.p1, b.p2, b.p3, b.p4, psy);
+}
+
+__device__ __forceinline__ unsigned qsse(const Quad &a, const Quad &b)
+{
+    int d1 = a.p1 - b.p1, d2 = a.p2 - b.p2, d3 = a.p3 - b.p3, d4 = a.p4 - b.p4;
+    return (unsigned) (d1 * d1 + d2 * d2 + d3 * d3 + d4 * d4);
+}
+
+// Folds N (power of two <= 16) per-lane partial sums across the wavefront.  On return lane L
+// holds the total of entry (L >> (6 - log2 N)); fetch entry e with bcastN<N>(r, e).
+template <int N> __device__ __forceinline__ int reduceN(int (&v)[N])
+{
+    int lane = threadIdx.x & 63;
+    int bit = 32;
+#pragma unroll
+    for (int n = N; n > 1; n >>= 1) {
+        int half = n >> 1;
+        bool sel = (lane & bit) != 0;
+#pragma unroll
+        for (int t = 0; t < half; t++) {
+            int a = v[t], b = v[t + half];
+            int mine = sel ? b : a, other = sel ? a : b;
+            v[t] = mine + __shfl_xor(other, bit, 64);
+        }
+        bit >>= 1;
+    }
+    int r = v[0];
+#pragma unroll
+    for (; bit >= 1; bit >>= 1) {
+        r += __shfl_xor(r, bit, 64);
+    }
+    return r;
+}
+
+template <int N> __device__ __forceinline__ int bcastN(int r, int e)
+{
+    constexpr int sh = N == 16 ? 2 : (N == 8 ? 3 : (N == 4 ? 4 : (N == 2 ? 5 : 6)));
+    return __shfl(r, e << sh, 64);
+}
+
+__device__ __forceinline__ unsigned wave_min_u(unsigned v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        v = min(v, (unsigned) __shfl_xor((int) v, m, 64));
+    }
+    return v;
+}
+
+struct FastLds {
+    int hist[16];
+    int cx[64], cy[64];
+    SubpelLds sp;
+};
+
+// sums needed by block_detail (hme.c:546) from a register-resident block: pixel sum and the
+// horizontal / vertical first-difference sums; partials only, the caller reduces them
+__device__ __forceinline__ void quad_grad_partials(const Quad &q, bool act, int qi, int qj, int qi0, int qj0, int &sum, int &sh, int &sv)
+{
+    // (qi0, qj0): first quad column / row of the (sub-)block this lane's quad belongs to
+    int l2 = __shfl_up(q.p2, 1, 64), l4 = __shfl_up(q.p4, 1, 64);
+    int u3 = __shfl_up(q.p3, 8, 64), u4 = __shfl_up(q.p4, 8, 64);
+    sum = sh = sv = 0;
+    if (act) {
+        sum = q.p1 + q.p2 + q.p3 + q.p4;
+        sh = abs(q.p2 - q.p1) + abs(q.p4 - q.p3);
+        sv = abs(q.p3 - q.p1) + abs(q.p4 - q.p2);
+        if (qi > qi0) {
+            sh += abs(q.p1 - l2) + abs(q.p3 - l4);
+        }
+        if (qj > qj0) {
+            sv += abs(q.p1 - u3) + abs(q.p2 - u4);
+        }
+    }
+}
+
+__device__ __forceinline__ int quad_absdev(const Quad &q, bool act, int mean)
+{
+    return act ? abs(q.p1 - mean) + abs(q.p2 - mean) + abs(q.p3 - mean) + abs(q.p4 - mean) : 0;
+}
+
+// hist_var / quant_tex / peaks of the source block from its register-resident quads (hme.c:586-749)
+__device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int *hist)
+{
+    int lane = threadIdx.x & 63;
+    unsigned avg = (unsigned) (sum / (w * h));
+    if (avg == 0) {
+        avg = 1;
+    }
+    unsigned q16 = (8u << 16) / avg;
+    if (lane < 16) {
+        hist[lane] = 0;
+    }
+    __syncthreads();
+    if (act) {
+        atomicAdd(&hist[min((int) ((unsigned) q.p1 * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p2 * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p3 * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p4 * q16 >> 16), 15)], 1);
+    }
+    __syncthreads();
+    avg = (unsigned) (w * h) / 16;
+    unsigned var = 0;
+    if (lane < 16) {
+        unsigned d = (unsigned) hist[lane] - avg;
+        var = d * d;
+    }
+    var = wave_sum(var);
+    __syncthreads();
+    return (int) ((var * 16 * 16) / (16u * (unsigned) (w * h * w * h)));
+}
+
+__device__ int src_quant_tex(const Quad &q, bool act, int qi, int qj, int qw, int w, int h)
+{
+    int a1 = q.p1 >> 4, a2 = q.p2 >> 4, a3 = q.p3 >> 4, a4 = q.p4 >> 4;
+    int r1 = __shfl_down(a1, 1, 64), r3 = __shfl_down(a3, 1, 64); // right neighbour quad's left column
+    int u3 = __shfl_up(a3, 8, 64), u4 = __shfl_up(a4, 8, 64);     // upper neighbour quad's bottom row
+    unsigned sh = 0, sv = 0;
+    if (act) {
+        int e2 = (qi + 1 < qw) ? r1 : a2, e4 = (qi + 1 < qw) ? r3 : a4; // past the last column: the pixel itself
+        sh = (unsigned) ((a1 - a2) * (a1 - a2) + (a2 - e2) * (a2 - e2) + (a3 - a4) * (a3 - a4) + (a4 - e4) * (a4 - e4));
+        int t1 = qj > 0 ? u3 : a1, t2 = qj > 0 ? u4 : a2;
+        sv = (unsigned) ((a1 - t1) * (a1 - t1) + (a2 - t2) * (a2 - t2) + (a3 - a1) * (a3 - a1) + (a4 - a2) * (a4 - a2));
+    }
+    sh = wave_sum(sh);
+    sv = wave_sum(sv);
+    return (int) (isqrt_u32(max(sh, sv)) / (unsigned) ((w + h + 1) >> 1));
+}
+
+__device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
+{
+    int lane = threadIdx.x & 63;
+    int avg = bavg ? bavg : 1;
+    int q16 = (8 << 16) / avg;
+    if (lane < 16) {
+        hist[lane] = 0;
+    }
+    __syncthreads();
+    if (act) {
+        int ds = (int) ((unsigned) (q.p1 + q.p2 + q.p3 + q.p4 + 2) >> 2);
+        atomicAdd(&hist[min(ds * q16 >> 16, 15)], 1);
+    }
+    __syncthreads();
+    int c = lane < 16 ? hist[lane] : 0;
+    int total = wave_sum(c);
+    int maxv = c;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        maxv = max(maxv, __shfl_xor(maxv, m, 64));
+    }
+    maxv = __shfl(maxv, 0, 64) >> 2;
+    int left = __shfl_up(c, 1, 64), right = __shfl_down(c, 1, 64);
+    int pk = 0;
+    if (lane < 16) {
+        pk = 1;
+        if (lane > 0) {
+            pk &= c > left;
+        }
+        if (lane < 15) {
+            pk &= c > right;
+        }
+        pk &= (c > maxv) || (c > total / 16);
+    }
+    int np = wave_sum(pk);
+    __syncthreads();
+    return np;
+}
+
+// scores up to 16 displacement vectors held in LDS (s.cx/cy[first .. first+cnt)) against the
+// register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
+// first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
+__device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
+                                            const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
+{
+    int v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        int dx = s.cx[first + t], dy = s.cy[first + t];
+        bool ok = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
+        Quad b = ldq(at(ref, bx + dx, by + dy), ref.stride, qi, qj, act && ok);
+        v[t] = (act && ok) ? (int) (level > 1 ? qsse(a, b) : qmetric(a, b, psy)) : 0;
+    }
+    int r = reduceN<16>(v);
+    return (unsigned) bcastN<16>(r, threadIdx.x & 15);
+}
+
+// psy accumulator of one 2x2 quad pair for the three predictions compared by err_intra (hme.c:839)
+__device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int avg_sb, int dc, int ratio, unsigned &inter, unsigned &isb,
+                                               unsigned &isrc)
+{
+    const Psy psy = {0, 1, 2};
+    int s0 = (int) UAVG4(a.p1, a.p2, a.p3, a.p4), s1 = (int) UAVG4(b.p1, b.p2, b.p3, b.p4);
+    int ae = (int) UAVG4(abs(a.p1 - b.p1), abs(a.p2 - b.p2), abs(a.p3 - b.p3), abs(a.p4 - b.p4));
+    int ta = (int) UAVG4(abs(a.p1 - a.p2), abs(a.p2 - a.p3), abs(a.p3 - a.p4), abs(a.p4 - a.p1));
+    int tb = (int) UAVG4(abs(b.p1 - b.p2), abs(b.p2 - b.p3), abs(b.p3 - b.p4), abs(b.p4 - b.p1));
+    inter = (unsigned) (SQR(ae) * ratio >> (5 - psy.err_weight)) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
+            (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+    ae = (int) UAVG4(abs(a.p1 - avg_sb), abs(a.p2 - avg_sb), abs(a.p3 - avg_sb), abs(a.p4 - avg_sb));
+    isb = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - avg_sb) << (psy.avg_weight + 1));
+    ae = (int) UAVG4(abs(a.p1 - dc), abs(a.p2 - dc), abs(a.p3 - dc), abs(a.p4 - dc));
+    isrc = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - dc) << (psy.avg_weight + 1));
+}
+
+// sub-pel search around full-pel vector (fpelx, fpely): hme.c:1051
+__device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
+                                     int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy)
+{
+    const DPlane &src = c.src[0], &ref = c.ref[0];
+    const int lane = threadIdx.x & 63;
+    sub_x = sub_y = 0;
+    if (best == 0) {
+        return best;
+    }
+    unsigned yarea = (unsigned) (bw * bh);
+    const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
+    int v4[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        Quad b = ldq(at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, qi, qj, act);
+        v4[n] = act ? (int) qsse(a, b) : 0;
+    }
+    int r4 = reduceN<4>(v4);
+    unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
+             quad3 = (unsigned) bcastN<4>(r4, 3);
+    int area_ratio = (int) (8 * 256 / yarea), iarea_ratio = (int) (8 * yarea / 256);
+    best = best * (unsigned) area_ratio >> 3;
+    int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
+    Quad aw = ldq(at(src, xx, yy), src.stride, qi, qj, true); // the centred 16x16 source window
+    build_hpel(S.sp, at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
+
+    int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
+    unsigned ms1 = quad1, ms2 = quad3;
+    if (quad3 >= quad2) {
+        pri1 = 1;
+        ms2 = quad2;
+    }
+    if (quad1 >= quad0) {
+        sec0 = 1;
+        ms1 = quad0;
+    }
+    if (ms2 > ms1) {
+        int t0 = sec0, t1 = sec1;
+        sec0 = pri0, sec1 = pri1;
+        pri0 = t0, pri1 = t1;
+    }
+    int diag0 = pri0 + sec0, diag1 = pri1 + sec1;
+    int tx[8], ty[8], v8[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        int t0 = 0, t1 = 0;
+        if (n == 6) {
+            t0 = pri0 + diag0;
+            t1 = pri1 + diag1;
+        } else if (n < 6) {
+            int v0 = (n >> 1) == 0 ? pri0 : ((n >> 1) == 1 ? sec0 : diag0);
+            int v1 = (n >> 1) == 0 ? pri1 : ((n >> 1) == 1 ? sec1 : diag1);
+            int hp = !(n & 1);
+            t0 = v0 * (1 << hp);
+            t1 = v1 * (1 << hp);
+        }
+        tx[n] = t0;
+        ty[n] = t1;
+        int X = 4 + 8 * qi + t0, Y = 4 + 8 * qj + t1;
+        v8[n] = n < 7 ? (int) quad_metric(aw.p1, aw.p2, aw.p3, aw.p4, qsample(S.sp.h, X, Y), qsample(S.sp.h, X + 4, Y),
+                                          qsample(S.sp.h, X, Y + 4), qsample(S.sp.h, X + 4, Y + 4), psy)
+                      : 0;
+    }
+    int r8 = reduceN<8>(v8);
+    // lane n finishes probe n: metric_return + vector cost
+    unsigned acc = (unsigned) bcastN<8>(r8, lane & 7);
+    int mtx = 0, mty = 0;
+#pragma unroll
+    for (int n = 0; n < 7; n++) {
+        if ((lane & 7) == n) {
+            mtx = tx[n];
+            mty = ty[n];
+        }
+    }
+    unsigned sc = metric_return(acc, 16, 16) + (unsigned) mv_cost(cc, fpelx * 4 + mtx, fpely * 4 + mty, 0);
+    int b0 = 0, b1 = 0;
+    for (int n = 0; n <= 6; n++) {
+        int t0 = __shfl(mtx, n, 64), t1 = __shfl(mty, n, 64);
+        if (((t0 | t1) & 1) && c.effort < 8) {
+            continue;
+        }
+        unsigned s = (unsigned) __shfl((int) sc, n, 64);
+        if (best > s) {
+            best = s;
+            b0 = t0;
+            b1 = t1;
+        }
+    }
+    sub_x = b0;
+    sub_y = b1;
+    __syncthreads();
+    return best * (unsigned) iarea_ratio >> 3;
+}
+
+// level-0 tail of hme_block_fast: sub-pel refinement + mode decision (hme.c:1598-1821)
+__device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
+                                  bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
+                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy)
+{
+    const int lane = threadIdx.x & 63;
+    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
+    const DPlane &src = c.src[0], &ref0 = c.ref[0];
+    const int qw = bw >> 1, qh = bh >> 1;
+    int fpelx = mv.u.mv.x, fpely = mv.u.mv.y, sx = 0, sy = 0;
+    bool found_sub = false;
+    unsigned yarea = (unsigned) (bw * bh);
+    if (fpelx == lax && fpely == lay) {
+        best += (unsigned) motion_bias;
+    }
+    unsigned best_fp = best;
+    if (c.effort >= 4) {
+        if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
+            best = subpixel_me_fast(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+            if (sx || sy) {
+                fpelx = lax;
+                fpely = lay;
+                found_sub = true;
+            }
+        }
+        if (!found_sub && !good_enough && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
+            best = subpixel_me_fast(c, S, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+        }
+    }
+    mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
+    mv.u.mv.y = (int16_t) (fpely * 4 + sy);
+    unsigned ratio = 32;
+    if ((mv.u.mv.x | mv.u.mv.y) & 3) {
+        ratio = (best << 5) / (best_fp + !best_fp);
+    }
+
+    // ---- operands of the mode decision, one load round ----
+    const int cbx = i * 8, cby = j * 8;                     // 4:2:0, 16x16 blocks
+    const int cbmx = cbx + sarx(fpelx, 1), cbmy = cby + sarx(fpely, 1);
+    const int cbw = bw >> 1, cbh = bh >> 1;
+    const int cxp = lane & 7, cyp = lane >> 3;              // chroma pixel owned by this lane
+    const bool actc = cxp < cbw && cyp < cbh;
+    const Quad r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
+    const Quad o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
+    const Quad rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
+    int us = 0, vs = 0, um = 0, vm = 0;
+    if (actc) {
+        us = *at(c.srcc[0], cbx + cxp, cby + cyp);
+        vs = *at(c.srcc[1], cbx + cxp, cby + cyp);
+        um = *at(c.refc[0], cbmx + cxp, cbmy + cyp);
+        vm = *at(c.refc[1], cbmx + cxp, cbmy + cyp);
+    }
+    // chroma quads for the sub-block metrics: lanes 0..15 U, 16..31 V
+    const int cpl = (lane >> 4) & 1, cqi = lane & 3, cqj = (lane >> 2) & 3;
+    const bool actq = lane < 32 && cqi < (cbw >> 1) && cqj < (cbh >> 1);
+    const Quad cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
+    const Quad cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
+    const Quad cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
+    const int kq = (qi >= (qw >> 1) ? 1 : 0) | (qj >= (qh >> 1) ? 2 : 0);         // luma quadrant of this lane's quad
+    const int kc = (cqi >= (cbw >> 2) ? 1 : 0) | (cqj >= (cbh >> 2) ? 2 : 0);      // chroma quadrant of this lane's chroma quad
+    const int kp = (cxp >= (cbw >> 1) ? 1 : 0) | (cyp >= (cbh >> 1) ? 2 : 0);      // chroma quadrant of this lane's chroma pixel
+
+    // round 1: block sums
+    int v[16];
+    {
+        int rs, rh, rv;
+        quad_grad_partials(r, act, qi, qj, 0, 0, rs, rh, rv);
+        int ul = __shfl_up(us, 1, 64), uu = __shfl_up(us, 8, 64), vl = __shfl_up(vs, 1, 64), vu = __shfl_up(vs, 8, 64);
+        v[0] = act ? (int) qmetric(a, o, psy) : 0;
+        v[1] = rs;
+        v[2] = rh;
+        v[3] = rv;
+        v[4] = us;
+        v[5] = vs;
+        v[6] = um;
+        v[7] = vm;
+        v[8] = (actc && cxp > 0) ? abs(us - ul) : 0;
+        v[9] = (actc && cyp > 0) ? abs(us - uu) : 0;
+        v[10] = (actc && cxp > 0) ? abs(vs - vl) : 0;
+        v[11] = (actc && cyp > 0) ? abs(vs - vu) : 0;
+        v[12] = v[13] = v[14] = v[15] = 0;
+    }
+    int R = reduceN<16>(v);
+    unsigned ogrerr = metric_return((unsigned) bcastN<16>(R, 0), bw, bh);
+    int ref_sum = bcastN<16>(R, 1);
+    unsigned ref_sh = (unsigned) bcastN<16>(R, 2), ref_sv = (unsigned) bcastN<16>(R, 3);
+    int uavg_src = bcastN<16>(R, 4) / (cbw * cbh), vavg_src = bcastN<16>(R, 5) / (cbw * cbh);
+    int uavg_ref = bcastN<16>(R, 6) / (cbw * cbh), vavg_ref = bcastN<16>(R, 7) / (cbw * cbh);
+    int utex = (int) max((unsigned) bcastN<16>(R, 8), (unsigned) bcastN<16>(R, 9));
+    int vtex = (int) max((unsigned) bcastN<16>(R, 10), (unsigned) bcastN<16>(R, 11));
+    unsigned avg_ref = (unsigned) (ref_sum / (bw * bh));
+
+    // round 2: reference deviation + zero-motion sub-block metrics (skip test operands)
+    {
+        v[0] = quad_absdev(r, act, (int) avg_ref);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[1 + k] = (act && kq == k) ? (int) qmetric(a, rz, psy) : 0;
+            v[5 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
+            v[9 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
+        }
+        v[13] = v[14] = v[15] = 0;
+    }
+    R = reduceN<16>(v);
+    int ref_dev = bcastN<16>(R, 0) >> 1;
+    unsigned zsub[3];
+#pragma unroll
+    for (int z = 0; z < 3; z++) {
+        unsigned m0 = (unsigned) bcastN<16>(R, 1 + 4 * z), m1 = (unsigned) bcastN<16>(R, 2 + 4 * z);
+        unsigned m2 = (unsigned) bcastN<16>(R, 3 + 4 * z), m3 = (unsigned) bcastN<16>(R, 4 + 4 * z);
+        zsub[z] = max(max(m0, m1), max(m2, m3));
+    }
+    int tex_ref = (int) (max(ref_sh, ref_sv) - (unsigned) ref_dev);
+    unsigned var_ref = (unsigned) (ref_dev + max(tex_ref, 0));
+
+    unsigned ogrmad = (ogrerr + yarea / 2) / yarea;
+    ogrmad = ogrmad * ratio >> 5;
+    unsigned mad = (best + yarea / 2) / yarea;
+    int dv = (int) min(ratio, 32u);
+    int ipolvar = (int) ((var_src * (unsigned) dv + var_ref * (unsigned) (32 - dv)) >> 5);
+    dv = abs((int) var_src - ipolvar);
+    if (var_src > 16 * yarea && var_src < 32 * yarea) {
+        mv.flags |= 1u << DSV_MV_BIT_MAINTAIN;
+    }
+    unsigned chroma_ratio = (unsigned) ((cbw * cbh) << 4) / yarea;
+    ChromaPsy cpsy = chroma_analysis((int) avg_src, uavg_src, vavg_src);
+    unsigned avg_y_dif = (unsigned) abs((int) avg_src - (int) avg_ref);
+    unsigned avg_c_dif = (unsigned) AVG2(abs(uavg_src - uavg_ref), abs(vavg_src - vavg_ref));
+    int eprmi, eprmd, eprmr;
+    {
+        int as128 = (int) avg_src - 128, ar128 = (int) avg_ref - 128;
+        int ci = 0, cd = 0, cr = 0;
+        if (act) {
+            cr = (((a.p1 - r.p1) + 128) | ((a.p2 - r.p2) + 128) | ((a.p3 - r.p3) + 128) | ((a.p4 - r.p4) + 128)) & ~0xff;
+            ci = ((a.p1 - ar128) | (a.p2 - ar128) | (a.p3 - ar128) | (a.p4 - ar128)) & ~0xff;
+            cd = ((a.p1 - as128) | (a.p2 - as128) | (a.p3 - as128) | (a.p4 - as128)) & ~0xff;
+        }
+        eprmi = __any(ci != 0) ? 1 : 0;
+        eprmd = __any(cd != 0) ? 1 : 0;
+        eprmr = __any(cr != 0) ? 1 : 0;
+    }
+    bool oob;
+    {
+        int px = i * y_w + sarx(mv.u.mv.x, 2), py = j * y_h + sarx(mv.u.mv.y, 2);
+        oob = px < 0 || py < 0 || px >= ((nxb - 1) * y_w) - 1 || py >= ((nyb - 1) * y_h) - 1;
+    }
+    int neidif;
+    {
+        int na, nb_;
+        neighbordif2_cur(mvf, nxb, i, j, mv.u.mv.x, mv.u.mv.y, na, nb_);
+        neidif = (na + nb_) / 3;
+    }
+    unsigned skipt = ((unsigned) c.quant * (unsigned) c.quant) >> 19;
+    bool skipped = false;
+    if ((good_enough || mv.u.all == 0) && c.skip_block_thresh >= 0 && !c.lossless) {
+        unsigned sth = skipt * yarea;
+        sth += 4 * var_src;
+        sth += yarea * (unsigned) c.skip_block_thresh;
+        if (c.quant < (1 << 10)) {
+            sth = sth * (unsigned) c.quant >> 10;
+        }
+        if (avg_y_dif <= 2) {
+            sth = max(sth, 3 * (yarea + var_src));
+        }
+        sth = max(sth, yarea);
+        if (good_enough) {
+            sth *= 2;
+        }
+        unsigned cth = chroma_ratio * sth * max(skipt, 1u) >> 5;
+        unsigned z0 = zsub[0] * ratio >> 5, z1 = zsub[1] * ratio >> 5, z2 = zsub[2] * ratio >> 5;
+        z0 += (unsigned) SQR((int) avg_src - (int) avg_ref) * yarea;
+        if (z0 <= sth && z1 <= cth && z2 <= cth) {
+            mv.flags |= 1u << DSV_MV_BIT_SKIP;
+            mv.u.all = 0;
+            mv.err = 0;
+            skipped = true;
+        }
+    }
+    int add_err = 0, add_ndiff = 0;
+    if (!skipped) {
+        if (!oob && !c.lossless) {
+            bool y_prereq = avg_y_dif <= 2, c_prereq = !cpsy.greyish && avg_c_dif <= 2;
+            if (y_prereq || c_prereq) {
+                // round 3: sub-block metrics at the chosen full-pel motion (hme.c:1741)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    v[k] = (act && kq == k) ? (int) qmetric(a, r, psy) : 0;
+                    v[4 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
+                    v[8 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
+                    v[12 + k] = 0;
+                }
+                R = reduceN<16>(v);
+                unsigned bsub[3];
+#pragma unroll
+                for (int z = 0; z < 3; z++) {
+                    unsigned m0 = (unsigned) bcastN<16>(R, 4 * z), m1 = (unsigned) bcastN<16>(R, 4 * z + 1);
+                    unsigned m2 = (unsigned) bcastN<16>(R, 4 * z + 2), m3 = (unsigned) bcastN<16>(R, 4 * z + 3);
+                    bsub[z] = max(max(m0, m1), max(m2, m3)) * ratio >> 5;
+                }
+                unsigned xth = skipt * yarea;
+                int carea = 4 * cbw * cbh;
+                xth += (unsigned) ipolvar;
+                xth = (unsigned) max((int) xth - ((int) yarea * neidif * 2), 0);
+                xth = xth * (unsigned) c.quant >> 12;
+                xth = min(max(xth, 32u), yarea * 4);
+                if (y_prereq && bsub[0] < 4 * xth) {
+                    mv.flags |= 1u << DSV_MV_BIT_NOXMITY;
+                }
+                c_prereq = c_prereq && (utex > carea || vtex > carea);
+                xth = chroma_ratio * xth >> 4;
+                if (c_prereq && bsub[1] < xth && bsub[2] < xth) {
+                    mv.flags |= 1u << DSV_MV_BIT_NOXMITC;
+                }
+            }
+            if ((unsigned) dv < var_src / 4) {
+                mv.flags |= 1u << DSV_MV_BIT_SIMCMPLX;
+            }
+        }
+        // ---- test_subblock_intra_y (hme.c:891), all four sub-blocks evaluated together ----
+        {
+            const DSV_MV *refmv = c.ref_mvf ? &c.ref_mvf[i + j * nxb] : nullptr;
+            int rx = refmv ? refmv->u.mv.x : mv.u.mv.x, ry = refmv ? refmv->u.mv.y : mv.u.mv.y;
+            int sbw = bw / 2, sbh = bh / 2;
+            bool run = !(mv.u.all && neidif < 3 && abs(rx - mv.u.mv.x) < 3 && abs(ry - mv.u.mv.y) < 3) && sbw != 0 && sbh != 0;
+            if (run) {
+                int ss, sh, sv2;
+                quad_grad_partials(a, act, qi, qj, (kq & 1) ? (qw >> 1) : 0, (kq & 2) ? (qh >> 1) : 0, ss, sh, sv2);
+                int rsum = act ? r.p1 + r.p2 + r.p3 + r.p4 : 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bool in = act && kq == k;
+                    v[4 * k + 0] = in ? ss : 0;
+                    v[4 * k + 1] = in ? rsum : 0;
+                    v[4 * k + 2] = in ? sh : 0;
+                    v[4 * k + 3] = in ? sv2 : 0;
+                }
+                R = reduceN<16>(v);
+                int my_avg_local = bcastN<16>(R, 4 * kq + 0) / (sbw * sbh);
+                int my_avg_sub = bcastN<16>(R, 4 * kq + 1) / (sbw * sbh);
+                int my_dc = (int) ((unsigned) my_avg_local + (unsigned) avg_src * 3 + 2) >> 2;
+                unsigned e_inter = 0, e_sb = 0, e_src = 0;
+                if (act) {
+                    quad_err_intra(a, r, my_avg_sub, my_dc, (int) ratio, e_inter, e_sb, e_src);
+                }
+                int w16[16];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bool in = act && kq == k;
+                    w16[k] = in ? quad_absdev(a, true, my_avg_local) : 0;
+                    w16[4 + 3 * k + 0] = in ? (int) e_inter : 0;
+                    w16[4 + 3 * k + 1] = in ? (int) e_sb : 0;
+                    w16[4 + 3 * k + 2] = in ? (int) e_src : 0;
+                }
+                int R2 = reduceN<16>(w16);
+                int detail_src = ipolvar, nsub = 0;
+                unsigned avg_tot = 0, err_sub = 0, err_src = 0;
+                detail_src += detail_src / max(neidif, 1);
+                for (int k = 0; k < 4; k++) {
+                    if (mv.submask & (1 << k)) {
+                        continue;
+                    }
+                    unsigned avg_local = (unsigned) (bcastN<16>(R, 4 * k + 0) / (sbw * sbh));
+                    unsigned avg_sub = (unsigned) (bcastN<16>(R, 4 * k + 1) / (sbw * sbh));
+                    unsigned g_sh = (unsigned) bcastN<16>(R, 4 * k + 2), g_sv = (unsigned) bcastN<16>(R, 4 * k + 3);
+                    int var = bcastN<16>(R2, k) >> 1;
+                    int tex = (int) (max(g_sh, g_sv) - (unsigned) var);
+                    unsigned local_detail = (unsigned) (var + max(tex, 0));
+                    unsigned dcd = (unsigned) abs((int) avg_local - (int) avg_sub) + 2;
+                    if (local_detail > (unsigned) (SQR(dcd) * (unsigned) bw * (unsigned) bh * ratio >> 5)) {
+                        continue;
+                    }
+                    int dc = (int) (avg_local + (unsigned) avg_src * 3 + 2) >> 2;
+                    unsigned inter_err = (unsigned) bcastN<16>(R2, 4 + 3 * k + 0) * ratio >> 5;
+                    unsigned sub_err = (unsigned) bcastN<16>(R2, 4 + 3 * k + 1), src_err = (unsigned) bcastN<16>(R2, 4 + 3 * k + 2);
+                    int lo = AVG2(detail_src, (int) local_detail), hi = detail_src;
+                    int lerp = (lo * (32 - c.psyscale) + hi * c.psyscale) >> 5;
+                    local_detail = (unsigned) max(lerp, lo);
+                    if ((sub_err + local_detail) < inter_err || (src_err + local_detail) < inter_err) {
+                        mv.submask |= (uint8_t) (1 << k);
+                        err_src += src_err;
+                        err_sub += sub_err;
+                        avg_tot += sub_err < src_err ? avg_sub : (unsigned) dc;
+                        nsub++;
+                        detail_src = detail_src * 4 / 5;
+                    }
+                }
+                if (mv.submask) {
+                    mv.flags |= 1u << DSV_MV_BIT_INTRA;
+                    mv.dc = err_src < err_sub ? (uint16_t) ((avg_tot / (unsigned) nsub) | DSV_SRC_DC_PRED) : 0;
+                }
+            }
+        }
+        // ---- test_subblock_intra_c (hme.c:987) ----
+        if (c.effort >= 6) {
+            unsigned detail_c = (unsigned) (ipolvar / (bw * bh));
+            unsigned thr = (mv.flags & (1u << DSV_MV_BIT_INTRA)) ? detail_c : SQR(detail_c);
+            int sbw = cbw / 2, sbh = cbh / 2;
+            if (!(sbw == 0 || sbh == 0 || mad <= thr || thr > 64 || (abs((int) mv.u.mv.x) < 4 && abs((int) mv.u.mv.y) < 4))) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bool in = actc && kp == k;
+                    v[4 * k + 0] = in ? us : 0;
+                    v[4 * k + 1] = in ? vs : 0;
+                    v[4 * k + 2] = in ? um : 0;
+                    v[4 * k + 3] = in ? vm : 0;
+                }
+                R = reduceN<16>(v);
+                unsigned avg_ramp = avg_src * avg_src >> 8;
+                for (int k = 0; k < 4; k++) {
+                    if (mv.submask & (1 << k)) {
+                        continue;
+                    }
+                    int a_us = bcastN<16>(R, 4 * k + 0) / (sbw * sbh), a_vs = bcastN<16>(R, 4 * k + 1) / (sbw * sbh);
+                    int a_um = bcastN<16>(R, 4 * k + 2) / (sbw * sbh), a_vm = bcastN<16>(R, 4 * k + 3) / (sbw * sbh);
+                    unsigned dif = (unsigned) (SQR(a_us - a_um) + SQR(a_vs - a_vm)) * avg_ramp >> 8;
+                    if (dif > thr) {
+                        mv.submask |= (uint8_t) (1 << k);
+                    }
+                }
+                if (mv.submask) {
+                    mv.flags |= 1u << DSV_MV_BIT_INTRA;
+                }
+            }
+        }
+        if (!(mv.flags & (1u << DSV_MV_BIT_NOXMITY))) {
+            mv.err = (uint16_t) mad;
+            add_err = (int) mad;
+        }
+        add_ndiff = (ogrmad > 11) + (avg_c_dif >= 32);
+    }
+    int is_intra = 0;
+    if (mv.flags & (1u << DSV_MV_BIT_INTRA)) {
+        int merged = (mv.dc & DSV_SRC_DC_PRED) ? eprmd : eprmi;
+        if (mv.submask != DSV_MASK_ALL_INTRA) {
+            merged |= eprmr;
+        }
+        mv.flags = (mv.flags & ~(1u << DSV_MV_BIT_EPRM)) | (merged ? (1u << DSV_MV_BIT_EPRM) : 0u);
+        is_intra = 1;
+        mv.u.mv.x = (int16_t) (fpelx * 4);
+        mv.u.mv.y = (int16_t) (fpely * 4);
+    } else {
+        int merged = eprmr;
+        if (mv.submask) {
+            merged |= eprmi;
+        }
+        mv.flags = (mv.flags & ~(1u << DSV_MV_BIT_EPRM)) | (merged ? (1u << DSV_MV_BIT_EPRM) : 0u);
+    }
+    if (mv.flags & ((1u << DSV_MV_BIT_INTRA) | (1u << DSV_MV_BIT_EPRM))) {
+        mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
+    }
+    if (lane == 0) {
+        *out = mv;
+        if (is_intra) {
+            atomicAdd(&c.counters[0], 1);
+        }
+        if (add_ndiff) {
+            atomicAdd(&c.counters[1], add_ndiff);
+        }
+        if (best > 0) {
+            atomicAdd(&c.counters[2], 1);
+        }
+        if (add_err) {
+            atomicAdd(&c.counters[3], add_err);
+        }
+    }
+}
+
+__device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx, int gy, FastLds &S)
+{
+    const int rectx[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1};
+    const int recty[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};
+    const int lane = threadIdx.x & 63;
+    const int qi = lane & 7, qj = lane >> 3;
+    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
+    const int step = 1 << level;
+    const DPlane &src = c.src[level], &ref = c.ref[level], &ogr = c.ogr[level];
+    DSV_MV *mvf = c.mvf[level];
+    const DSV_MV *parent = level < c.pyr_levels ? c.mvf[level + 1] : nullptr;
+    DSV_MV *out = &mvf[i + j * nxb];
+    DSV_MV mv = {};
+
+    const int bx = (i * y_w) >> level, by = (j * y_h) >> level;
+    const int bw = min(src.w - bx, y_w), bh = min(src.h - by, y_h);
+    const int qw = bw >> 1, qh = bh >> 1;
+    const bool act = qi < qw && qj < qh;
+    const uint8_t *sblk = at(src, bx, by);
+    const Quad a = ldq(sblk, src.stride, qi, qj, act);
+
+    int motion_bias = y_w * y_h;
+    unsigned var_src = 0, avg_src = 0;
+    Psy psy = {2, 1, 0};
+    if (level <= 1) {
+        int ps, ph, pv;
+        quad_grad_partials(a, act, qi, qj, 0, 0, ps, ph, pv);
+        int v4[4] = {ps, ph, pv, 0};
+        int r = reduceN<4>(v4);
+        int sum = bcastN<4>(r, 0);
+        unsigned sh = (unsigned) bcastN<4>(r, 1), sv = (unsigned) bcastN<4>(r, 2);
+        int mean = sum / (bw * bh);
+        avg_src = (unsigned) mean;
+        int var = wave_sum(quad_absdev(a, act, mean)) >> 1;
+        int tex = (int) (max(sh, sv) - (unsigned) var);
+        var_src = (unsigned) (var + max(tex, 0));
+        int tvar = (int) (var_src + SQR(var_src >> 10));
+        tvar = (8 * tvar * c.quant >> 9) / (bw * bh);
+        if (tvar) {
+            int hvar = src_hist_var(a, act, sum, bw, bh, S.hist);
+            int qtex = src_quant_tex(a, act, qi, qj, qw, bw, bh);
+            int npeaks = src_peaks(a, act, (int) avg_src, S.hist);
+            motion_bias += tvar * (hvar - qtex) * npeaks;
+        }
+        motion_bias = max(motion_bias, 0) / (2 + (abs(gx) + abs(gy)));
+        if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
+            psy = Psy{2, 1, 2};
+            motion_bias = 0;
+        } else {
+            psy = Psy{1, 2, 1};
+        }
+        if (var_src > (unsigned) (24 * bw * bh)) {
+            psy.avg_weight = 0;
+        }
+    }
+
+    // ---- candidate gathering: lane p owns canonical list position p (hme.c:1443-1528) ----
+    //  0 zero | 1 parent inlier average | 2 predictor (level 0) | 3 left 4 top 5 top-left |
+    //  6..14 temporal | 15 global | 16..24 parent inliers
+    int lax = 0, lay = 0;
+    bool exist = lane == 0;
+    int cxv = 0, cyv = 0;
+    if (parent != nullptr) {
+        const int ptx[9] = {0, -2, 2, 0, 0, -2, 2, 2, -2}, pty[9] = {0, 0, 0, -2, 2, -2, 2, -2, 2};
+        unsigned parent_mask = ~(((unsigned) step << 1) - 1);
+        int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
+        bool pvalid = false;
+        int pvx = 0, pvy = 0;
+        if (lane >= 16 && lane < 25) {
+            int m = lane - 16;
+            int x = pi + ptx[m] * step, y = pj + pty[m] * step;
+            if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
+                const DSV_MV *pm = &parent[x + y * nxb];
+                pvx = pm->u.mv.x;
+                pvy = pm->u.mv.y;
+                pvalid = true;
+            }
+        }
+        int npar = __popcll(__ballot(pvalid));
+        if (npar) {
+            int v2[2] = {pvx, pvy};
+            int r = reduceN<2>(v2);
+            lax = bcastN<2>(r, 0) / npar;
+            lay = bcastN<2>(r, 1) / npar;
+            // find_inliers (hme.c:1260)
+            int dist = pvalid ? SQR(pvx - lax) + SQR(pvy - lay) : 0;
+            int avgd = wave_sum(dist) / npar;
+            int ssd = wave_sum(pvalid ? SQR(dist - avgd) : 0);
+            int thresh = avgd + (int) isqrt_u32((unsigned) (ssd / npar));
+            bool inl = pvalid && dist <= thresh;
+            int nin = __popcll(__ballot(inl));
+            if (nin) {
+                int w2[2] = {inl ? pvx : 0, inl ? pvy : 0};
+                int r2 = reduceN<2>(w2);
+                lax = bcastN<2>(r2, 0) / nin;
+                lay = bcastN<2>(r2, 1) / nin;
+            }
+            // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)
+            if (lane == 1) {
+                exist = true;
+                cxv = qp2fp((int16_t) (lax * 4));
+                cyv = qp2fp((int16_t) (lay * 4));
+            } else if (lane == 2 && level == 0) {
+                int px, py;
+                movec_pred(mvf, nxb, i, j, px, py);
+                exist = true;
+                cxv = qp2fp((int16_t) px);
+                cyv = qp2fp((int16_t) py);
+            } else if (lane >= 3 && lane <= 5) {
+                bool need_i = lane != 4, need_j = lane != 3;
+                if ((!need_i || i > 0) && (!need_j || j > 0)) {
+                    const DSV_MV *m = &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb];
+                    exist = true;
+                    cxv = qp2fp(m->u.mv.x);
+                    cyv = qp2fp(m->u.mv.y);
+                }
+            } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
+                int k = lane - 6;
+                int rx = i + rectx[k] * step, ry = j + recty[k] * step;
+                if (rx >= 0 && ry >= 0 && rx < nxb && ry < nyb) {
+                    const DSV_MV *m = &c.ref_mvf[rx + ry * nxb];
+                    exist = true;
+                    cxv = qp2fp(m->u.mv.x);
+                    cyv = qp2fp(m->u.mv.y);
+                }
+            } else if (lane == 15) {
+                exist = true;
+                cxv = qp2fp((int16_t) (gx * 4));
+                cyv = qp2fp((int16_t) (gy * 4));
+            } else if (lane >= 16 && lane < 25 && nin && inl) {
+                exist = true;
+                cxv = qp2fp((int16_t) (pvx * 4));
+                cyv = qp2fp((int16_t) (pvy * 4));
+            }
+        }
+    }
+    cxv = (int) (int16_t) ((int) (int16_t) cxv >> level);
+    cyv = (int) (int16_t) ((int) (int16_t) cyv >> level);
+    // order-preserving compaction, then first-occurrence de-duplication (hme.c:1166)
+    int n;
+    {
+        unsigned long long em = __ballot(exist);
+        int idx = __popcll(em & ((1ull << lane) - 1));
+        if (exist) {
+            S.cx[idx] = cxv;
+            S.cy[idx] = cyv;
+        }
+        n = __popcll(em);
+        __syncthreads();
+        int mx = lane < n ? S.cx[lane] : 0, my = lane < n ? S.cy[lane] : 0;
+        bool dup = false;
+        for (int m = 0; m < n; m++) {
+            int ox = S.cx[m], oy = S.cy[m];
+            dup = dup || (m < lane && ox == mx && oy == my);
+        }
+        __syncthreads();
+        bool keep = lane < n && !dup;
+        unsigned long long km = __ballot(keep);
+        int nidx = __popcll(km & ((1ull << lane) - 1));
+        if (keep) {
+            S.cx[nidx] = mx;
+            S.cy[nidx] = my;
+        }
+        n = __popcll(km);
+        if (lane >= n) { // pad: unused slots hold the zero vector (never selected: masked below)
+            S.cx[lane] = 0;
+            S.cy[lane] = 0;
+        }
+        __syncthreads();
+    }
+    CostCtx cc;
+    movec_pred(mvf, nxb, i, j, cc.px, cc.py);
+    cc.q = c.quant;
+    cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
+
+    // ---- best candidate (hme.c:1530-1557): lane k scores candidate k ----
+    int dx, dy;
+    unsigned best, score_zero;
+    {
+        unsigned raw = 0;
+        for (int first = 0; first < n; first += 16) {
+            unsigned r = score16(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            if (lane >= first && lane < first + 16) {
+                raw = r;
+            }
+        }
+        int mx = S.cx[lane], my = S.cy[lane];
+        bool valid = lane < n && !invalid_block(ref, bx + mx, by + my, bw, bh, 0);
+        if (level <= 1) {
+            raw = metric_return(raw, bw, bh);
+        }
+        unsigned sc = raw + (unsigned) mv_cost(cc, mx * step * 4, my * step * 4, level);
+        if (mx == lax && my == lay) {
+            sc = (unsigned) max((int) sc - (motion_bias >> level), 0);
+        }
+        if (!valid) {
+            sc = 0xffffffffu;
+        }
+        unsigned mn = wave_min_u(sc);
+        unsigned long long hit = __ballot(valid && sc == mn);
+        int best_k = (mn != 0xffffffffu && hit) ? (int) __ffsll((long long) hit) - 1 : 0;
+        best = mn;
+        bool z_valid = __shfl((int) valid, 0, 64) != 0;
+        unsigned z_raw = (unsigned) __shfl((int) raw, 0, 64);
+        score_zero = z_valid ? z_raw : 0xffffffffu;
+        dx = S.cx[best_k];
+        dy = S.cy[best_k];
+    }
+    unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
+    bool good_enough = false;
+    {
+        Quad o = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
+        unsigned zoscore = metric_return(wave_sum(act ? qmetric(a, o, psy) : 0u), bw, bh);
+        if (abs(dx) <= 1 && abs(dy) <= 1) {
+            qthresh *= 2;
+        }
+        if (zoscore < qthresh) {
+            best = level == 0 ? score_zero : 0;
+            dx = dy = 0;
+            good_enough = true;
+        }
+    }
+    // ---- refinement (hme.c:1300): each round scores the full 3x3 neighbourhood at once ----
+    if (!good_enough) {
+        unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
+        bool again = true;
+        while (again && !good_enough) {
+            again = false;
+            __syncthreads();
+            if (lane < 16) {
+                S.cx[lane] = dx + (lane < 9 ? rectx[lane] : 0);
+                S.cy[lane] = dy + (lane < 9 ? recty[lane] : 0);
+            }
+            __syncthreads();
+            unsigned raw = score16(S, 0, 9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            int tx = dx + rectx[lane < 9 ? lane : 0], ty = dy + recty[lane < 9 ? lane : 0];
+            bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
+            if (level <= 1) {
+                raw = metric_return(raw, bw, bh);
+            }
+            unsigned full = raw + (unsigned) mv_cost(cc, tx * step * 4, ty * step * 4, level);
+            int cdx = dx, cdy = dy;
+            for (int k = 0; k < 5; k++) {
+                bool vk = __shfl((int) valid, k, 64) != 0;
+                if (!vk) {
+                    continue;
+                }
+                unsigned sk = (unsigned) __shfl((int) raw, k, 64);
+                int tvx = cdx + rectx[k], tvy = cdy + recty[k];
+                if (k == 1) {
+                    metr0 = sk;
+                } else if (k == 2) {
+                    metr1 = sk;
+                } else if (k == 3) {
+                    metr2 = sk;
+                } else if (k == 4) {
+                    metr3 = sk;
+                }
+                if (level == 0 && !tvx && !tvy && sk <= qthresh) {
+                    dx = tvx;
+                    dy = tvy;
+                    best = sk;
+                    good_enough = true;
+                    break;
+                }
+                unsigned fk = (unsigned) __shfl((int) full, k, 64);
+                if (best > fk) {
+                    best = fk;
+                    dx = tvx;
+                    dy = tvy;
+                    again = true;
+                    break;
+                }
+            }
+            if (again || good_enough) {
+                continue;
+            }
+            int sxs = metr0 <= metr1 ? 1 : -1, sys = metr2 <= metr3 ? 1 : -1;
+            int kd = sys < 0 ? (sxs < 0 ? 5 : 6) : (sxs < 0 ? 7 : 8); // index of (sxs, sys) in rect[]
+            bool vd = __shfl((int) valid, kd, 64) != 0;
+            if (!vd) {
+                break;
+            }
+            unsigned fd = (unsigned) __shfl((int) full, kd, 64);
+            if (best > fd) {
+                best = fd;
+                dx = cdx + sxs;
+                dy = cdy + sys;
+                again = true;
+            }
+        }
+    }
+    mv.u.mv.x = (int16_t) (dx * step);
+    mv.u.mv.y = (int16_t) (dy * step);
+    if (level != 0) {
+        if (lane == 0) {
+            *out = mv;
+        }
+        return;
+    }
+    hme_block_fast_l0(c, i, j, S, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
+                      avg_src, psy);
+}
