@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["batch", "threads"], default=os.environ.get("DSV2_BENCH_MODE", "batch"),
+                    help="batch: lockstep dsv2hip_enc_batch over all streams; threads: one host thread + HIP stream per stream")
     return ap.parse_args()
 
 
@@ -122,7 +124,33 @@ def main():
                 hip.dsv_buf_free(C.byref(bufs[i]))
         barrier.wait()
 
+    hip.dsv2hip_enc_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(A.BUF), C.POINTER(C.c_int)]
+    hip.dsv2hip_enc_batch.restype = C.c_int
+    encp = (C.POINTER(A.ENCODER) * S)(*[C.pointer(e) for e in encs])
+    bbufs = (A.BUF * (4 * S))()
+    bn = (C.c_int * S)()
+
+    def run_phase_batch(t0, t1):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for t in range(t0, t1):
+            ptrs = (C.c_void_p * S)(*[dev_frames[s][frame_index(t)].data_ptr() for s in range(S)])
+            hip.dsv2hip_enc_batch(S, encp, ptrs, bbufs, bn)
+            for s in range(S):
+                for i in range(bn[s]):
+                    b = bbufs[4 * s + i]
+                    out_bytes[s].append(C.string_at(b.data, b.len))
+                    hip.dsv_buf_free(C.byref(b))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t_start
+
     def run_phase(t0, t1):
+        if args.mode == "batch":
+            return run_phase_batch(t0, t1)
         ths = [threading.Thread(target=worker, args=(s, t0, t1, False)) for s in range(S)]
         for th in ths:
             th.start()
@@ -200,7 +228,7 @@ def main():
         "dtype": "u8/int32",
         "data": "synthetic",
         "config": {"workload": "1920x1080 4:2:0 -qp=60 -gop=48 effort=10 CRF, %d closed-GOP streams per GPU" % S,
-                   "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mpix_per_s": round(fps * N_PIX / 1e6, 1),
+                   "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mode": args.mode, "mpix_per_s": round(fps * N_PIX / 1e6, 1),
                    "stream_bytes_total": total_bytes, "host_cpus": ncpu},
     }
     if stage_ms is not None and prof_frames:

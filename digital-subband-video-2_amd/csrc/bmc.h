@@ -20,6 +20,19 @@ struct FilterParams {
     int fthresh; // 32 * (14 - lb2(q)), bmc.c:408
 };
 
+struct Planes3 {
+    DPlane p[3];
+};
+
+// one stream's operands for the lockstep-batched MC / filter kernels
+struct McJob {
+    const DSV_MV *mvs;
+    const uint8_t *bd;
+    MCParams p;
+    FilterParams f;
+    Planes3 ref, pred, res;
+};
+
 inline int spatial_psy_factor_host(int bw, int bh, int nbh, int nbv, int sub) { return spatial_psy_factor(bw, bh, nbh, nbv, sub); }
 
 FilterParams make_filter_params(const MCParams &p, int q, int do_filter, int inter_sharpen);
@@ -34,6 +47,11 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
                  int do_filter, int inter_sharpen);
 // dsv_intra_filter (bmc.c:391), luma plane only
 void intra_filter_luma(hipStream_t s, const uint8_t *d_bd, const MCParams &p, int q, const DPlane &luma);
+
+// lockstep batches over n streams (job tables resident on the device)
+void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv);
+void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter);
+void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n);
 
 // dsv_post_process (bmc.c:340): de-gradient sharpen of every interior 4x4 cell
 void post_process_plane(hipStream_t s, const DPlane &dp);

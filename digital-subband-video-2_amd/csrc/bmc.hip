@@ -198,6 +198,134 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
     }
 }
 
+// stream-batched form of k_predict: gridDim.z = 3 * n, job = blockIdx.z / 3, plane = blockIdx.z % 3
+template <int MODE>
+__global__ __launch_bounds__(256) void k_predict_b(const McJob *__restrict__ tab)
+{
+    __shared__ int qsum[4];
+    const McJob &jb = tab[blockIdx.z / 3];
+    const MCParams p = jb.p;
+    const DSV_MV *mvs = jb.mvs;
+    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z % 3;
+    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
+    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+    const DPlane rp = jb.ref.p[c], dp = jb.pred.p[c], sp = jb.res.p[c];
+    DSV_MV mv = mvs[i + j * p.nbh];
+    int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
+    uint32_t flags = mv.flags;
+    bool intra = flags & (1u << DSV_MV_BIT_INTRA);
+    int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
+    int x = i * bw, y = j * bh;
+    int px = x + sar(mvx, 2 + sh), py = y + sar(mvy, 2 + sv);
+    int sbw = bw >> 1, sbh = bh >> 1;
+    bool subpel_luma = (c == 0) && !intra && ((mvx | mvy) & 3);
+    if (subpel_luma) {
+        px = clampi(px - 1, -kBorder, limx);
+        py = clampi(py - 1, -kBorder, limy);
+    } else {
+        px = clampi(px, -kBorder, limx);
+        py = clampi(py, -kBorder, limy);
+    }
+    const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
+    bool need_mean = intra && !(c == 0 && mv.dc);
+    int dcq[4] = {0, 0, 0, 0};
+    if (intra) {
+        if (need_mean) {
+            if (threadIdx.x < 4) {
+                qsum[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            int part[4] = {0, 0, 0, 0};
+            for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+                int m = idx % bw, n = idx / bw;
+                int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+                part[k] += rbase[(ptrdiff_t) n * rp.stride + m];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (part[k]) {
+                    atomicAdd(&qsum[k], part[k]);
+                }
+            }
+            __syncthreads();
+            if (mv.submask == DSV_MASK_ALL_INTRA) {
+                int all = (qsum[0] + qsum[1] + qsum[2] + qsum[3]) / (bw * bh);
+                dcq[0] = dcq[1] = dcq[2] = dcq[3] = all;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    dcq[k] = qsum[k] / (sbw * sbh);
+                }
+            }
+        } else {
+            dcq[0] = dcq[1] = dcq[2] = dcq[3] = mv.dc;
+        }
+    }
+    int fx = 0, fy = 0;
+    bool soft_x = false, soft_y = false;
+    int f0 = 0, f1 = 0, f2 = 0, f3 = 0, sf = 0, af = 0;
+    bool chroma_frac = false;
+    if (subpel_luma) {
+        bool large = abs(mvx) >= 8 || abs(mvy) >= 8;
+        fx = mvx & 3;
+        fy = mvy & 3;
+        soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
+        soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
+    } else if (c != 0 && !intra) {
+        int hb = 2 + sh, vb = 2 + sv, hf = 1 << hb, vf = 1 << vb;
+        int dx = mvx & (hf - 1), dy = mvy & (vf - 1);
+        chroma_frac = (dx | dy) != 0;
+        f0 = (hf - dx) * (vf - dy);
+        f1 = dx * (vf - dy);
+        f2 = (hf - dx) * dy;
+        f3 = dx * dy;
+        sf = hb + vb;
+        af = 1 << (sf - 1);
+    }
+    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+        int m = idx % bw, n = idx / bw;
+        const uint8_t *r = rbase + (ptrdiff_t) n * rp.stride + m;
+        int pv;
+        if (intra) {
+            int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+            bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
+            pv = fill ? (dcq[k] & 0xff) : r[0];
+        } else if (subpel_luma) {
+            pv = clamp_u8(luma_subpel_px(r, rp.stride, fx, fy, soft_x, soft_y));
+        } else if (chroma_frac) {
+            pv = (f0 * r[0] + f1 * r[1] + f2 * r[rp.stride] + f3 * r[rp.stride + 1] + af) >> sf;
+            pv &= 0xff;
+        } else {
+            pv = r[0];
+        }
+        ptrdiff_t o = (ptrdiff_t) (y + n) * dp.stride + (x + m);
+        ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
+        if (MODE == MC_SUBTRACT) {
+            dp.data[o] = (uint8_t) pv;
+            sp.data[so] = residual_px(sp.data[so], pv, flags, c, p.lossless);
+        } else {
+            dp.data[o] = recon_px(sp.data[so], pv, flags, p.lossless);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reconstruct_b(const McJob *__restrict__ tab)
+{
+    const McJob &jb = tab[blockIdx.z / 3];
+    const MCParams p = jb.p;
+    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z % 3;
+    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
+    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+    const DPlane dp = jb.pred.p[c], sp = jb.res.p[c];
+    uint32_t flags = jb.mvs[i + j * p.nbh].flags;
+    int x = i * bw, y = j * bh;
+    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+        int m = idx % bw, n = idx / bw;
+        ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
+        sp.data[so] = recon_px(sp.data[so], dp.data[(ptrdiff_t) (y + n) * dp.stride + (x + m)], flags, p.lossless);
+    }
+}
+
 // encoder-side reconstruction in place: res <- recon(pred, res)   (dsv_add_res, bmc.c:1082)
 __global__ __launch_bounds__(256) void k_reconstruct(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 predp, Planes3 resp)
 {
@@ -580,6 +708,35 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
     }
 }
 
+// stream-batched filters: grid = (3 planes, n jobs) / (n jobs)
+__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab)
+{
+    const McJob &jb = tab[blockIdx.y];
+    int c = blockIdx.x;
+    const DPlane dp = jb.res.p[c];
+    const FilterParams f = jb.f;
+    const DSV_MV *vecs = jb.mvs;
+    if (f.lossless) {
+        return;
+    }
+    if (c == 0) {
+        int nsbx = dp.w / 4, nsby = dp.h / 4;
+        sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(dp, f, vecs, i, j, nsbx, nsby); });
+    } else {
+        sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
+    }
+}
+
+__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab)
+{
+    const McJob &jb = tab[blockIdx.x];
+    const DPlane dp = jb.res.p[0];
+    const FilterParams f = jb.f;
+    const uint8_t *bd = jb.bd;
+    int nsbx = dp.w / 4, nsby = dp.h / 4;
+    sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(dp, f, bd, i, j, nsbx, nsby); });
+}
+
 __global__ __launch_bounds__(256) void k_intra_filter(const uint8_t *__restrict__ bd, FilterParams f, DPlane dp)
 {
     int nsbx = dp.w / 4, nsby = dp.h / 4;
@@ -678,6 +835,31 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
                            planes_of(out));
     }
     HIPCHK(hipGetLastError());
+}
+
+// ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
+void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
+{
+    if (n > 0) {
+        hipLaunchKernelGGL((k_predict_b<MC_SUBTRACT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
+    }
+}
+
+void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter)
+{
+    if (n > 0) {
+        hipLaunchKernelGGL(k_reconstruct_b, dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
+        if (any_filter) {
+            hipLaunchKernelGGL(k_inter_filters_b, dim3(3, n), dim3(256), 0, s, d_tab);
+        }
+    }
+}
+
+void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n)
+{
+    if (n > 0) {
+        hipLaunchKernelGGL(k_intra_filter_b, dim3(n), dim3(256), 0, s, d_tab);
+    }
 }
 
 void intra_filter_luma(hipStream_t s, const uint8_t *d_bd, const MCParams &p, int q, const DPlane &luma)

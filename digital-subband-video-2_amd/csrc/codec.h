@@ -73,6 +73,7 @@ struct CodecDev {
     uint8_t *h_frame = nullptr; // one packed planar picture
     size_t h_frame_bytes = 0;
     DSV_MV *h_mvs = nullptr;
+    DSV_MV *h_intra = nullptr; // intra-analysis flags read-back
     int *h_counters = nullptr;
     int32_t *h_ll = nullptr;
     uint8_t *h_small = nullptr; // coarsest pyramid level readback

@@ -181,6 +181,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     }
     HIPCHK(hipHostMalloc((void **) &h_frame, h_frame_bytes, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &h_mvs, nb * sizeof(DSV_MV), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h_intra, nb * sizeof(DSV_MV), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &h_counters, 16 * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &h_ll, 4 * sizeof(int32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &h_small, (size_t) 1 << 20, hipHostMallocDefault));
@@ -254,6 +255,7 @@ void CodecDev::destroy()
     }
     HIPCHK(hipHostFree(h_frame));
     HIPCHK(hipHostFree(h_mvs));
+    HIPCHK(hipHostFree(h_intra));
     HIPCHK(hipHostFree(h_counters));
     HIPCHK(hipHostFree(h_ll));
     HIPCHK(hipHostFree(h_small));

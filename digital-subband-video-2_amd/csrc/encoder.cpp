@@ -13,6 +13,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "codec.h"
@@ -712,12 +713,12 @@ void encode_intra_meta(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, const
 }
 
 // ---- device pipeline pieces -----------------------------------------------------------------
-void build_pyramid(CodecDev &dv, const DFrame &base, DFrame *pyr) // mk_pyramid, dsv_encoder.c:493
+void build_pyramid_on(hipStream_t s, CodecDev &dv, const DFrame &base, DFrame *pyr) // mk_pyramid, dsv_encoder.c:493
 {
     const DFrame *prev = &base;
     for (int l = 0; l < dv.pyr_levels; l++) {
-        ds2x_luma(dv.stream, prev->p[0], pyr[l].p[0]);
-        extend_plane(dv.stream, pyr[l].p[0]);
+        ds2x_luma(s, prev->p[0], pyr[l].p[0]);
+        extend_plane(s, pyr[l].p[0]);
         prev = &pyr[l];
     }
 }
@@ -746,268 +747,6 @@ __global__ void k_grab_ll(const int32_t *c0, const int32_t *c1, const int32_t *c
 }
 
 // dsv_encode_picture (dsv_encoder.c:1039): returns the picture packet in `out`
-void encode_picture(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
-{
-    CodecDev &dv = im->dev;
-    PicSet &cur = dv.pics[im->cur];
-    PicSet &ref = dv.pics[im->cur ^ 1];
-    const DSV_PARAMS *p = &d->params;
-    size_t nb = dv.nblocks();
-    bool isP = p->has_ref;
-    unsigned upper = (unsigned) (dv.w * dv.h);
-    switch (enc->vidmeta.subsamp) {
-        case DSV_SUBSAMP_444: upper *= 6; break;
-        case DSV_SUBSAMP_422:
-        case DSV_SUBSAMP_UYVY: upper *= 4; break;
-        default: upper *= 2; break;
-    }
-    dsv_mk_buf(out, (int) upper);
-    BitWriter bs{out->data, 0};
-    put_packet_hdr(bs, DSV_PT_PIC | (p->is_ref << 1) | p->has_ref);
-    bs.align();
-    bs.put_bits(32, d->fnum);
-
-    DSV_MV *intramv = nullptr;
-    if (!isP) {
-        intra_analysis(dv.stream, cur.src, analysis_params(dv, p->do_psy), dv.d_mvs_stage);
-        HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvs_stage, nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, dv.stream));
-        HIPCHK(hipStreamSynchronize(dv.stream));
-        im->intramv.assign(dv.h_mvs, dv.h_mvs + nb);
-        intramv = im->intramv.data();
-    }
-    int stats[ST_MAX] = {0, 0, 0, 0, 0};
-    if (enc->effort >= 7) {
-        gather_stats(enc, d, im->mvs.data(), intramv, stats);
-        for (int i = 0; i < ST_MAX; i++) {
-            stats[i] = stats[i] > 0 ? 1 : 0; // 1 = DSV_ZERO_MARKER
-        }
-    } else {
-        stats[ST_MAINTAIN] = stats[ST_RINGING] = 1;
-    }
-    bs.align();
-    bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_w) - 4));
-    bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_h) - 4));
-    bs.align();
-    bs.put_bit(stats[ST_STABLE]);
-    int inter_filter = 0;
-    if (isP) {
-        bs.put_bit(stats[ST_MODE]);
-        bs.put_bit(stats[ST_EPRM]);
-        inter_filter = enc->do_inter_filter == 1 || (enc->do_inter_filter == -1 && enc->auto_filter);
-        bs.put_bit(inter_filter);
-    } else {
-        bs.put_bit(stats[ST_MAINTAIN]);
-        bs.put_bit(stats[ST_RINGING]);
-        bs.put_bit(enc->do_intra_filter);
-    }
-    bs.put_bits(DSV_MAX_QP_BITS, (unsigned) d->quant);
-    bs.put_bit(0);
-    bs.align();
-
-    encode_stable_blocks(enc, d, bs, im->mvs.data(), intramv, stats);
-    MCParams mc = dv.mc_params(p->temporal_mc, p->lossless);
-    if (isP) {
-        // the motion field as transmitted: uploaded once, used by MC now and as the temporal
-        // candidate source of the next frame
-        HIPCHK(hipMemcpyAsync(cur.d_final_mvs, im->mvs.data(), nb * sizeof(DSV_MV), hipMemcpyHostToDevice, dv.stream));
-        dv.prof.begin(dv.stream, ST_PREDICT);
-        mc_sub_pred(dv.stream, cur.d_final_mvs, mc, dv.pred, cur.recon, ref.recon);
-        dv.prof.end(dv.stream, ST_PREDICT, 1);
-        bs.align();
-        encode_motion(enc, d, bs, im->mvs.data(), stats);
-    } else {
-        encode_intra_meta(enc, d, bs, intramv, stats);
-    }
-    HIPCHK(hipMemcpyAsync(dv.d_blockdata, enc->blockdata, nb, hipMemcpyHostToDevice, dv.stream));
-
-    BlockMap bm{dv.d_blockdata, dv.nbh, dv.nbv};
-    dv.prof.begin(dv.stream, ST_FWD_SBT);
-    for (int c = 0; c < 3; c++) {
-        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-        sbt_forward(dv.stream, cur.recon.p[c], co, dv.scratch, c, isP, p->lossless, bm);
-    }
-    dv.prof.end(dv.stream, ST_FWD_SBT, 3);
-    dv.prof.begin(dv.stream, ST_QUANT);
-    hipLaunchKernelGGL(k_grab_ll, dim3(1), dim3(1), 0, dv.stream, dv.coefs[0], dv.coefs[1], dv.coefs[2], dv.d_ll);
-    for (int c = 0; c < 3; c++) {
-        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-        quant_plane(dv.stream, co, dv.qv + dv.qv_off[c], dv.quant_cfg(c, isP, p->lossless, p->do_psy, cur.d_final_mvs), d->quant);
-    }
-    dv.comp.run(dv.stream, dv.qv, dv.qv_off[3]);
-    dv.prof.end(dv.stream, ST_QUANT, 3);
-    HIPCHK(hipMemcpyAsync(dv.h_ll, dv.d_ll, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, dv.stream));
-    dv.prof.begin(dv.stream, ST_INV_SBT);
-    // reconstruction continues on the device while the host packs bits
-    for (int c = 0; c < 3; c++) {
-        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-        sbt_inverse(dv.stream, cur.recon.p[c], co, dv.scratch, d->quant, c, isP, p->lossless, bm);
-    }
-    dv.prof.end(dv.stream, ST_INV_SBT, 3);
-    dv.prof.begin(dv.stream, ST_RECON_FILTER);
-    if (!isP) {
-        if (enc->do_intra_filter) {
-            intra_filter_luma(dv.stream, dv.d_blockdata, mc, d->quant, cur.recon.p[0]);
-        }
-    } else {
-        mc_add_res(dv.stream, cur.d_final_mvs, mc, d->quant, cur.recon, dv.pred, inter_filter, enc->vidmeta.inter_sharpen);
-    }
-    dv.prof.end(dv.stream, ST_RECON_FILTER, 2);
-    HIPCHK(hipStreamSynchronize(dv.stream));
-    int nsym = *dv.comp.h_total;
-    dv.ensure_host_syms((size_t) nsym);
-    if (nsym) {
-        HIPCHK(hipMemcpyAsync(dv.h_pos, dv.comp.d_pos, (size_t) nsym * sizeof(uint32_t), hipMemcpyDeviceToHost, dv.stream));
-        HIPCHK(hipMemcpyAsync(dv.h_val, dv.comp.d_val, (size_t) nsym * sizeof(int32_t), hipMemcpyDeviceToHost, dv.stream));
-        HIPCHK(hipStreamSynchronize(dv.stream));
-    }
-    // split the concatenated symbol list at the plane boundaries and pack each plane
-    bs.align();
-    int at = 0;
-    for (int c = 0; c < 3; c++) {
-        uint32_t lo = (uint32_t) dv.qv_off[c], hi = (uint32_t) dv.qv_off[c + 1];
-        int begin = at;
-        while (at < nsym && dv.h_pos[at] < hi) {
-            dv.h_pos[at] -= lo;
-            at++;
-        }
-        entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
-    }
-    bs.align();
-    out->len = bs.byte_pos();
-}
-
-void fill_params(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d)
-{
-    DSV_PARAMS *p = &d->params;
-    memset(p, 0, sizeof(*p));
-    p->vidmeta = &enc->vidmeta;
-    p->effort = enc->effort;
-    p->do_psy = enc->do_psy;
-    p->temporal_mc = (int) (d->fnum % 2);
-    p->lossless = enc->quality == DSV_RC_QUAL_MAX;
-    p->blk_w = im->dev.blk_w;
-    p->blk_h = im->dev.blk_h;
-    p->nblocks_h = im->dev.nbh;
-    p->nblocks_v = im->dev.nbv;
-}
-
-// encode_one_frame (dsv_encoder.c:1184); returns 1 when a metadata packet must precede the picture
-int encode_one_frame(DSV_ENCODER *enc, EncImpl *im, FrameCtl *d, DSV_BUF *out)
-{
-    CodecDev &dv = im->dev;
-    PicSet &cur = dv.pics[im->cur];
-    PicSet &ref = dv.pics[im->cur ^ 1];
-    DSV_PARAMS *p = &d->params;
-    size_t nb = dv.nblocks();
-    int gop_start = 0, forced_intra = 0;
-    DSV_FNUM prev_I = enc->prev_gop;
-
-    fill_params(enc, im, d);
-    build_pyramid(dv, cur.src, cur.src_pyr);
-    dv.prof.end(dv.stream, ST_INGEST, 2 * dv.pyr_levels + 3);
-    // mean luma of the coarsest level feeds the dark-scene quality boost (dsv_encoder.c:296,403)
-    {
-        const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
-        HIPCHK(hipMemcpy2DAsync(dv.h_small, cp.w, cp.data, cp.stride, cp.w, cp.h, hipMemcpyDeviceToHost, dv.stream));
-    }
-    if (enc->force_metadata || ((DSV_FNUM) (enc->prev_gop + (DSV_FNUM) enc->gop) <= d->fnum)) {
-        gop_start = 1;
-        enc->prev_gop = d->fnum;
-        enc->force_metadata = 0;
-    }
-    if (enc->gop == DSV_GOP_INTRA) {
-        p->is_ref = 0;
-        p->has_ref = 0;
-    } else {
-        p->is_ref = 1;
-        p->has_ref = gop_start ? 0 : 1;
-        if (p->has_ref && !im->have_ref) {
-            fatal("P frame requested without a reference picture", __FILE__, __LINE__);
-        }
-    }
-    enc->avg_err = 0;
-    cur.has_final_mvs = false;
-    if (!p->has_ref) {
-        if (!enc->intra_map) {
-            enc->intra_map = (uint8_t *) dsv_alloc((int) nb);
-        }
-    } else {
-        // motion_est (dsv_encoder.c:653)
-        if (!ref.recon_pyr_valid) {
-            build_pyramid(dv, ref.recon, ref.recon_pyr);
-            ref.recon_pyr_valid = true;
-        }
-        HmeParams hp;
-        hp.a = analysis_params(dv, p->do_psy);
-        hp.effort = p->effort;
-        hp.lossless = p->lossless;
-        hp.quant = enc->prev_quant;
-        hp.skip_block_thresh = enc->skip_block_thresh;
-        hp.pyr_levels = dv.pyr_levels;
-        dv.prof.begin(dv.stream, ST_HME);
-        int nfronts = hme_estimate(dv.stream, dv, cur, ref, hp);
-        dv.prof.end(dv.stream, ST_HME, nfronts);
-        HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, dv.stream));
-        HIPCHK(hipMemcpyAsync(dv.h_counters, dv.d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, dv.stream));
-        HIPCHK(hipStreamSynchronize(dv.stream));
-        im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
-        // hme.c:1825-1832, 2015
-        int nintra = dv.h_counters[0], ndiff = dv.h_counters[1], eligible = dv.h_counters[2];
-        unsigned total_err = (unsigned) dv.h_counters[3];
-        enc->curr_scblocks = ndiff * 100 / (eligible ? eligible : 1);
-        enc->avg_err = (int) (total_err / (unsigned) nb);
-        enc->curr_intra_pct = nintra * 100 / (int) nb;
-        // the HME result of a frame that is flipped to intra below still serves as the next
-        // frame's temporal candidates (dsv_encoder.c:680, hme.c:1651)
-        HIPCHK(hipMemcpyAsync(cur.d_final_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToDevice, dv.stream));
-        cur.has_final_mvs = true;
-        forced_intra = scene_change_detection(enc, d, im->mvs.data());
-    }
-    if (enc->variable_i_interval && forced_intra) {
-        enc->prev_gop = d->fnum;
-    }
-    if (!p->has_ref) {
-        memset(enc->intra_map, 0, nb);
-    }
-    HIPCHK(hipStreamSynchronize(dv.stream));
-    {
-        const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
-        d->coarse_luma_avg = luma_avg_rows(dv.h_small, cp.w, cp.h);
-    }
-    quality2quant(enc, d, prev_I, forced_intra);
-    compute_auto_filter(enc, d);
-
-    // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
-    copy_frame_full(dv.stream, cur.recon, cur.src);
-    cur.recon_pyr_valid = false;
-
-    encode_picture(enc, im, d, out);
-
-    bool keep = enc->frame_callback || (p->is_ref && enc->gop != DSV_GOP_INTRA);
-    if (keep) {
-        dv.prof.begin(dv.stream, ST_EXTEND);
-        extend_frame(dv.stream, cur.recon, false);
-        dv.prof.end(dv.stream, ST_EXTEND, 3);
-        if (dv.prof.on) {
-            HIPCHK(hipStreamSynchronize(dv.stream));
-        }
-    }
-    dv.prof.collect();
-    if (enc->frame_callback) {
-        DSV_FRAME *orig = dsv_mk_frame(dv.format, dv.w, dv.h, 1), *rec = dsv_mk_frame(dv.format, dv.w, dv.h, 1);
-        dframe_download_full(&cur.src, orig, dv.stream);
-        dframe_download_full(&cur.recon, rec, dv.stream);
-        HIPCHK(hipStreamSynchronize(dv.stream));
-        enc->frame_callback(&enc->vidmeta, orig, rec);
-        dsv_frame_ref_dec(orig);
-        dsv_frame_ref_dec(rec);
-    }
-    if (p->is_ref && enc->gop != DSV_GOP_INTRA) {
-        im->cur ^= 1; // this picture set becomes the reference of the next frame
-        im->have_ref = true;
-    }
-    return gop_start;
-}
 
 void account(DSV_ENCODER *enc, EncImpl *im, const FrameCtl *d, unsigned len) // dsv_enc tail, dsv_encoder.c:1471-1570
 {
@@ -1092,7 +831,502 @@ void account(DSV_ENCODER *enc, EncImpl *im, const FrameCtl *d, unsigned len) // 
     }
 }
 
+
+// ---- lockstep batch engine ----------------------------------------------------------------------
+// One step encodes ONE frame on each of n independent encoder instances of identical geometry.
+// The per-frame control flow of the reference (encode_one_frame dsv_encoder.c:1185, encode_picture
+// :1040) is cut into phases; device phases enqueue the work of all streams on one HIP stream with
+// the latency-bound kernels (ME fronts, MC, in-loop filters) launched ONCE for all streams
+// (stream index = a grid dimension), host phases run the per-stream serial logic on a thread per
+// stream.  n = 1 is the plain dsv_enc() path: same code, same results.
+//
+//   P0 host   frame number, params, GOP decision
+//   G1 device ingest + extend + pyramid, intra analysis, [P] reference pyramid, batched HME, read-backs
+//   H1 host   scene-change decision, rate control, packet header, per-block metadata coding
+//   G2 device [P] batched predict+subtract, forward SBT, quantise+compact, inverse SBT,
+//             batched reconstruct + filters, border extension, symbol read-back
+//   H2 host   entropy packing, packet framing, statistics
+
+struct Job {
+    DSV_ENCODER *enc;
+    EncImpl *im;
+    DSV_FRAME *frame;          // host picture (dsv_enc) ...
+    const uint8_t *dev_planar; // ... or packed planar picture already in HBM
+    DSV_BUF *bufs;
+    int nbuf;
+    FrameCtl d;
+    DSV_BUF out;
+    BitWriter bs;
+    int gop_start, forced_intra, ran_hme, inter_filter, nsym;
+    DSV_FNUM prev_I;
+    int stats[ST_MAX];
+};
+
+struct BatchScratch { // per calling thread: pinned + device memory for the job tables
+    void *h_hme = nullptr, *d_hme = nullptr;
+    McJob *h_mc = nullptr, *d_mc = nullptr;
+    int cap = 0;
+    void ensure(int n)
+    {
+        if (n <= cap) {
+            return;
+        }
+        if (cap) {
+            HIPCHK(hipHostFree(h_hme));
+            HIPCHK(hipFree(d_hme));
+            HIPCHK(hipHostFree(h_mc));
+            HIPCHK(hipFree(d_mc));
+        }
+        HIPCHK(hipHostMalloc(&h_hme, hme_table_bytes(n), hipHostMallocDefault));
+        HIPCHK(hipMalloc(&d_hme, hme_table_bytes(n)));
+        HIPCHK(hipHostMalloc((void **) &h_mc, 2 * (size_t) n * sizeof(McJob), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d_mc, 2 * (size_t) n * sizeof(McJob)));
+        cap = n;
+    }
+};
+thread_local BatchScratch t_scratch;
+
+template <class F> void parallel_for(int n, F fn)
+{
+    if (n == 1) {
+        fn(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t) n);
+    for (int k = 0; k < n; k++) {
+        th.emplace_back([&fn, k]() { fn(k); });
+    }
+    for (auto &t : th) {
+        t.join();
+    }
+}
+
+void ensure_ready(DSV_ENCODER *enc, EncImpl *im)
+{
+    if (im->ready) {
+        return;
+    }
+    int w = enc->vidmeta.width, h = enc->vidmeta.height;
+    if ((w & 1) || (h & 1) || w < 16 || h < 16) {
+        fatal("DSV2 needs even picture dimensions of at least 16x16 (dsv_main.c:621, sbt.c:384-388)", __FILE__, __LINE__);
+    }
+    int bw, bh, nbh, nbv;
+    block_geometry(w, h, enc->block_size_override_x, enc->block_size_override_y, &bw, &bh, &nbh, &nbv);
+    if (enc->pyramid_levels == 0) { // dsv_encoder.c:1229-1241
+        int lvls = dsv_lb2((unsigned) (w < h ? w : h));
+        int maxdim = nbh > nbv ? nbh : nbv;
+        while ((1 << lvls) > maxdim) {
+            lvls--;
+        }
+        enc->pyramid_levels = clampi(lvls, 3, DSV_MAX_PYRAMID_LEVELS);
+    }
+    im->dev.init(enc->vidmeta.subsamp, w, h, bw, bh, enc->pyramid_levels, true);
+    im->ready = true;
+    im->mvs.assign((size_t) nbh * nbv, DSV_MV{});
+    enc->stability = (struct DSV_STAB_ACC *) dsv_alloc((int) (sizeof(struct DSV_STAB_ACC) * (size_t) nbh * nbv));
+    enc->blockdata = (uint8_t *) dsv_alloc(nbh * nbv);
+}
+
+// P0: frame number, parameters, GOP / reference decision (dsv_encoder.c:1193-1278)
+void phase_p0(Job &jb)
+{
+    DSV_ENCODER *enc = jb.enc;
+    EncImpl *im = jb.im;
+    memset(&jb.d, 0, sizeof(jb.d));
+    jb.d.fnum = enc->next_fnum++;
+    DSV_PARAMS *p = &jb.d.params;
+    p->vidmeta = &enc->vidmeta;
+    p->effort = enc->effort;
+    p->do_psy = enc->do_psy;
+    p->temporal_mc = (int) (jb.d.fnum % 2);
+    p->lossless = enc->quality == DSV_RC_QUAL_MAX;
+    p->blk_w = im->dev.blk_w;
+    p->blk_h = im->dev.blk_h;
+    p->nblocks_h = im->dev.nbh;
+    p->nblocks_v = im->dev.nbv;
+    jb.gop_start = jb.forced_intra = jb.ran_hme = jb.inter_filter = jb.nsym = 0;
+    jb.prev_I = enc->prev_gop;
+    if (enc->force_metadata || ((DSV_FNUM) (enc->prev_gop + (DSV_FNUM) enc->gop) <= jb.d.fnum)) {
+        jb.gop_start = 1;
+        enc->prev_gop = jb.d.fnum;
+        enc->force_metadata = 0;
+    }
+    if (enc->gop == DSV_GOP_INTRA) {
+        p->is_ref = 0;
+        p->has_ref = 0;
+    } else {
+        p->is_ref = 1;
+        p->has_ref = jb.gop_start ? 0 : 1;
+        if (p->has_ref && !im->have_ref) {
+            fatal("P frame requested without a reference picture", __FILE__, __LINE__);
+        }
+    }
+    enc->avg_err = 0;
+    im->dev.pics[im->cur].has_final_mvs = false;
+    if (!p->has_ref && !enc->intra_map) {
+        enc->intra_map = (uint8_t *) dsv_alloc((int) im->dev.nblocks());
+    }
+}
+
+// H1: everything the host decides between motion estimation and the residual pipeline
+void phase_h1(Job &jb)
+{
+    DSV_ENCODER *enc = jb.enc;
+    EncImpl *im = jb.im;
+    CodecDev &dv = im->dev;
+    FrameCtl *d = &jb.d;
+    DSV_PARAMS *p = &d->params;
+    size_t nb = dv.nblocks();
+    if (jb.ran_hme) {
+        im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
+        int nintra = dv.h_counters[0], ndiff = dv.h_counters[1], eligible = dv.h_counters[2]; // hme.c:1825-1832, 2015
+        unsigned total_err = (unsigned) dv.h_counters[3];
+        enc->curr_scblocks = ndiff * 100 / (eligible ? eligible : 1);
+        enc->avg_err = (int) (total_err / (unsigned) nb);
+        enc->curr_intra_pct = nintra * 100 / (int) nb;
+        jb.forced_intra = scene_change_detection(enc, d, im->mvs.data());
+    }
+    if (enc->variable_i_interval && jb.forced_intra) {
+        enc->prev_gop = d->fnum;
+    }
+    if (!p->has_ref) {
+        memset(enc->intra_map, 0, nb);
+    }
+    {
+        const DPlane &cp = dv.pics[im->cur].src_pyr[dv.pyr_levels - 1].p[0];
+        d->coarse_luma_avg = luma_avg_rows(dv.h_small, cp.w, cp.h);
+    }
+    quality2quant(enc, d, jb.prev_I, jb.forced_intra);
+    compute_auto_filter(enc, d);
+
+    // encode_picture, host half (dsv_encoder.c:1051-1132)
+    bool isP = p->has_ref;
+    unsigned upper = (unsigned) (dv.w * dv.h);
+    switch (enc->vidmeta.subsamp) {
+        case DSV_SUBSAMP_444: upper *= 6; break;
+        case DSV_SUBSAMP_422:
+        case DSV_SUBSAMP_UYVY: upper *= 4; break;
+        default: upper *= 2; break;
+    }
+    dsv_mk_buf(&jb.out, (int) upper);
+    jb.bs = BitWriter{jb.out.data, 0};
+    BitWriter &bs = jb.bs;
+    put_packet_hdr(bs, DSV_PT_PIC | (p->is_ref << 1) | p->has_ref);
+    bs.align();
+    bs.put_bits(32, d->fnum);
+    DSV_MV *intramv = nullptr;
+    if (!isP) {
+        im->intramv.assign(dv.h_intra, dv.h_intra + nb);
+        intramv = im->intramv.data();
+    }
+    int *stats = jb.stats;
+    for (int i = 0; i < ST_MAX; i++) {
+        stats[i] = 0;
+    }
+    if (enc->effort >= 7) {
+        gather_stats(enc, d, im->mvs.data(), intramv, stats);
+        for (int i = 0; i < ST_MAX; i++) {
+            stats[i] = stats[i] > 0 ? 1 : 0; // 1 = DSV_ZERO_MARKER
+        }
+    } else {
+        stats[ST_MAINTAIN] = stats[ST_RINGING] = 1;
+    }
+    bs.align();
+    bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_w) - 4));
+    bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_h) - 4));
+    bs.align();
+    bs.put_bit(stats[ST_STABLE]);
+    if (isP) {
+        bs.put_bit(stats[ST_MODE]);
+        bs.put_bit(stats[ST_EPRM]);
+        jb.inter_filter = enc->do_inter_filter == 1 || (enc->do_inter_filter == -1 && enc->auto_filter);
+        bs.put_bit(jb.inter_filter);
+    } else {
+        bs.put_bit(stats[ST_MAINTAIN]);
+        bs.put_bit(stats[ST_RINGING]);
+        bs.put_bit(enc->do_intra_filter);
+    }
+    bs.put_bits(DSV_MAX_QP_BITS, (unsigned) d->quant);
+    bs.put_bit(0);
+    bs.align();
+    encode_stable_blocks(enc, d, bs, im->mvs.data(), intramv, stats);
+    if (isP) {
+        // (the reference predicts between these two calls; the vectors are final after the first)
+        bs.align();
+        encode_motion(enc, d, bs, im->mvs.data(), stats);
+    } else {
+        encode_intra_meta(enc, d, bs, intramv, stats);
+    }
+}
+
+// H2: entropy packing + packet framing + statistics (dsv_encoder.c:1147-1165, 1461-1570)
+void phase_h2(Job &jb)
+{
+    DSV_ENCODER *enc = jb.enc;
+    EncImpl *im = jb.im;
+    CodecDev &dv = im->dev;
+    BitWriter &bs = jb.bs;
+    bs.align();
+    int at = 0;
+    for (int c = 0; c < 3; c++) {
+        uint32_t lo = (uint32_t) dv.qv_off[c], hi = (uint32_t) dv.qv_off[c + 1];
+        int begin = at;
+        while (at < jb.nsym && dv.h_pos[at] < hi) {
+            dv.h_pos[at] -= lo;
+            at++;
+        }
+        entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
+    }
+    bs.align();
+    jb.out.len = bs.byte_pos();
+    jb.nbuf = 0;
+    if (jb.gop_start) {
+        DSV_BUF metabuf;
+        encode_metadata(enc, &metabuf);
+        jb.bufs[jb.nbuf++] = metabuf;
+        set_link_offsets(enc, &jb.bufs[jb.nbuf - 1], 0);
+    }
+    jb.bufs[jb.nbuf++] = jb.out;
+    set_link_offsets(enc, &jb.bufs[jb.nbuf - 1], 0);
+    account(enc, im, &jb.d, jb.out.len);
+    if (jb.d.params.is_ref && enc->gop != DSV_GOP_INTRA) {
+        im->cur ^= 1; // this picture set becomes the reference of the next frame
+        im->have_ref = true;
+    }
+}
+
+void enc_batch(Job *jobs, int n)
+{
+    bind_device();
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        if (!jb.enc->ref) {
+            jb.enc->ref = new EncImpl();
+        }
+        jb.im = (EncImpl *) jb.enc->ref;
+        ensure_ready(jb.enc, jb.im);
+        if (k > 0 && (jb.im->dev.w != jobs[0].im->dev.w || jb.im->dev.h != jobs[0].im->dev.h || jb.im->dev.format != jobs[0].im->dev.format ||
+                      jb.im->dev.blk_w != jobs[0].im->dev.blk_w || jb.im->dev.blk_h != jobs[0].im->dev.blk_h ||
+                      jb.im->dev.pyr_levels != jobs[0].im->dev.pyr_levels)) {
+            fatal("dsv2hip_enc_batch: all encoders of a batch must share one picture geometry", __FILE__, __LINE__);
+        }
+        phase_p0(jb);
+    }
+    hipStream_t bs = jobs[0].im->dev.stream;
+    StageProf &prof = jobs[0].im->dev.prof;
+    BatchScratch &sc = t_scratch;
+    sc.ensure(n);
+    const int nbh = jobs[0].im->dev.nbh, nbv = jobs[0].im->dev.nbv;
+
+    // ---- G1 ----
+    prof.begin(bs, ST_INGEST);
+    std::vector<HmeFrames> hf;
+    std::vector<HmeParams> hp;
+    std::vector<int> pjobs;
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        CodecDev &dv = jb.im->dev;
+        PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
+        size_t nb = dv.nblocks();
+        if (jb.frame) {
+            dframe_upload(&cur.src, jb.frame, bs);
+        } else {
+            const uint8_t *sp = jb.dev_planar;
+            for (int c = 0; c < 3; c++) {
+                const DPlane &pl = cur.src.p[c];
+                HIPCHK(hipMemcpy2DAsync(pl.data, pl.stride, sp, pl.w, pl.w, pl.h, hipMemcpyDeviceToDevice, bs));
+                sp += (size_t) pl.w * pl.h;
+            }
+        }
+        extend_frame(bs, cur.src, false);
+        build_pyramid_on(bs, dv, cur.src, cur.src_pyr);
+        {
+            const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
+            HIPCHK(hipMemcpy2DAsync(dv.h_small, cp.w, cp.data, cp.stride, cp.w, cp.h, hipMemcpyDeviceToHost, bs));
+        }
+        // the block analysis of an intra picture; also needed when a P frame is flipped to intra in H1
+        intra_analysis(bs, cur.src, analysis_params(dv, jb.d.params.do_psy), dv.d_mvs_stage);
+        HIPCHK(hipMemcpyAsync(dv.h_intra, dv.d_mvs_stage, nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, bs));
+        if (jb.d.params.has_ref) { // motion_est (dsv_encoder.c:653)
+            if (!ref.recon_pyr_valid) {
+                build_pyramid_on(bs, dv, ref.recon, ref.recon_pyr);
+                ref.recon_pyr_valid = true;
+            }
+            HmeFrames f;
+            f.src[0] = cur.src.p[0];
+            f.ref[0] = ref.recon.p[0];
+            f.ogr[0] = ref.src.p[0];
+            for (int l = 0; l < dv.pyr_levels; l++) {
+                f.src[l + 1] = cur.src_pyr[l].p[0];
+                f.ref[l + 1] = ref.recon_pyr[l].p[0];
+                f.ogr[l + 1] = ref.src_pyr[l].p[0];
+            }
+            for (int c = 0; c < 2; c++) {
+                f.srcc[c] = cur.src.p[c + 1];
+                f.refc[c] = ref.recon.p[c + 1];
+            }
+            for (int l = 0; l <= dv.pyr_levels; l++) {
+                f.mvf[l] = dv.d_mvf[l];
+            }
+            f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
+            f.counters = dv.d_counters;
+            HmeParams h;
+            h.a = analysis_params(dv, jb.d.params.do_psy);
+            h.effort = jb.d.params.effort;
+            h.lossless = jb.d.params.lossless;
+            h.quant = jb.enc->prev_quant;
+            h.skip_block_thresh = jb.enc->skip_block_thresh;
+            h.pyr_levels = dv.pyr_levels;
+            hf.push_back(f);
+            hp.push_back(h);
+            pjobs.push_back(k);
+            jb.ran_hme = 1;
+        }
+    }
+    prof.end(bs, ST_INGEST, 2 * jobs[0].im->dev.pyr_levels + 4);
+    if (!pjobs.empty()) {
+        prof.begin(bs, ST_HME);
+        int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme);
+        prof.end(bs, ST_HME, nfronts);
+        for (int k : pjobs) {
+            CodecDev &dv = jobs[k].im->dev;
+            PicSet &cur = dv.pics[jobs[k].im->cur];
+            size_t nb = dv.nblocks();
+            HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, bs));
+            HIPCHK(hipMemcpyAsync(dv.h_counters, dv.d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, bs));
+            // the HME result of a frame that H1 flips to intra still serves as the next frame's temporal
+            // candidates (dsv_encoder.c:680, hme.c:1651); a real P frame overwrites it in G2
+            HIPCHK(hipMemcpyAsync(cur.d_final_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToDevice, bs));
+            cur.has_final_mvs = true;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(bs));
+    for (int k = 0; k < n; k++) {
+        if (jobs[k].frame) {
+            dsv_frame_ref_dec(jobs[k].frame); // the caller's pixels are in HBM now (dsv_encoder.c:1457)
+        }
+    }
+
+    // ---- H1 ----
+    parallel_for(n, [&](int k) { phase_h1(jobs[k]); });
+
+    // ---- G2 ----
+    int nP = 0, nI = 0;
+    bool any_filter = false;
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        CodecDev &dv = jb.im->dev;
+        PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
+        const DSV_PARAMS *p = &jb.d.params;
+        size_t nb = dv.nblocks();
+        // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
+        copy_frame_full(bs, cur.recon, cur.src);
+        cur.recon_pyr_valid = false;
+        HIPCHK(hipMemcpyAsync(dv.d_blockdata, jb.enc->blockdata, nb, hipMemcpyHostToDevice, bs));
+        McJob mj;
+        mj.mvs = cur.d_final_mvs;
+        mj.bd = dv.d_blockdata;
+        mj.p = dv.mc_params(p->temporal_mc, p->lossless);
+        for (int c = 0; c < 3; c++) {
+            mj.ref.p[c] = ref.recon.p[c];
+            mj.pred.p[c] = dv.pred.p[c];
+            mj.res.p[c] = cur.recon.p[c];
+        }
+        if (p->has_ref) {
+            // the motion field as transmitted: used by MC now and as temporal candidates of the next frame
+            HIPCHK(hipMemcpyAsync(cur.d_final_mvs, jb.im->mvs.data(), nb * sizeof(DSV_MV), hipMemcpyHostToDevice, bs));
+            mj.f = make_filter_params(mj.p, jb.d.quant, jb.inter_filter, jb.enc->vidmeta.inter_sharpen);
+            any_filter = any_filter || !p->lossless;
+            sc.h_mc[nP++] = mj;
+        } else {
+            mj.f = make_filter_params(mj.p, jb.d.quant, 1, 0);
+            if (jb.enc->do_intra_filter && !p->lossless) {
+                sc.h_mc[n + nI++] = mj;
+            }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(sc.d_mc, sc.h_mc, 2 * (size_t) n * sizeof(McJob), hipMemcpyHostToDevice, bs));
+    prof.begin(bs, ST_PREDICT);
+    mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv);
+    prof.end(bs, ST_PREDICT, 1);
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        CodecDev &dv = jb.im->dev;
+        PicSet &cur = dv.pics[jb.im->cur];
+        const DSV_PARAMS *p = &jb.d.params;
+        bool isP = p->has_ref;
+        BlockMap bm{dv.d_blockdata, dv.nbh, dv.nbv};
+        prof.begin(bs, ST_FWD_SBT);
+        for (int c = 0; c < 3; c++) {
+            DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
+            sbt_forward(bs, cur.recon.p[c], co, dv.scratch, c, isP, p->lossless, bm);
+        }
+        prof.end(bs, ST_FWD_SBT, 3);
+        prof.begin(bs, ST_QUANT);
+        hipLaunchKernelGGL(k_grab_ll, dim3(1), dim3(1), 0, bs, dv.coefs[0], dv.coefs[1], dv.coefs[2], dv.d_ll);
+        for (int c = 0; c < 3; c++) {
+            DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
+            quant_plane(bs, co, dv.qv + dv.qv_off[c], dv.quant_cfg(c, isP, p->lossless, p->do_psy, cur.d_final_mvs), jb.d.quant);
+        }
+        dv.comp.run(bs, dv.qv, dv.qv_off[3]);
+        prof.end(bs, ST_QUANT, 3);
+        HIPCHK(hipMemcpyAsync(dv.h_ll, dv.d_ll, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, bs));
+        prof.begin(bs, ST_INV_SBT);
+        for (int c = 0; c < 3; c++) {
+            DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
+            sbt_inverse(bs, cur.recon.p[c], co, dv.scratch, jb.d.quant, c, isP, p->lossless, bm);
+        }
+        prof.end(bs, ST_INV_SBT, 3);
+    }
+    prof.begin(bs, ST_RECON_FILTER);
+    intra_filter_batch(bs, sc.d_mc + n, nI);
+    mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter);
+    prof.end(bs, ST_RECON_FILTER, 2);
+    prof.begin(bs, ST_EXTEND);
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        const DSV_PARAMS *p = &jb.d.params;
+        if (jb.enc->frame_callback || (p->is_ref && jb.enc->gop != DSV_GOP_INTRA)) {
+            extend_frame(bs, jb.im->dev.pics[jb.im->cur].recon, false);
+        }
+    }
+    prof.end(bs, ST_EXTEND, 3);
+    HIPCHK(hipStreamSynchronize(bs));
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        CodecDev &dv = jb.im->dev;
+        jb.nsym = *dv.comp.h_total;
+        dv.ensure_host_syms((size_t) jb.nsym);
+        if (jb.nsym) {
+            HIPCHK(hipMemcpyAsync(dv.h_pos, dv.comp.d_pos, (size_t) jb.nsym * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+            HIPCHK(hipMemcpyAsync(dv.h_val, dv.comp.d_val, (size_t) jb.nsym * sizeof(int32_t), hipMemcpyDeviceToHost, bs));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(bs));
+    prof.collect();
+
+    // ---- H2 ----
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        if (jb.enc->frame_callback) { // before the picture sets swap
+            CodecDev &dv = jb.im->dev;
+            PicSet &cur = dv.pics[jb.im->cur];
+            DSV_FRAME *orig = dsv_mk_frame(dv.format, dv.w, dv.h, 1), *rec = dsv_mk_frame(dv.format, dv.w, dv.h, 1);
+            dframe_download_full(&cur.src, orig, bs);
+            dframe_download_full(&cur.recon, rec, bs);
+            HIPCHK(hipStreamSynchronize(bs));
+            jb.enc->frame_callback(&jb.enc->vidmeta, orig, rec);
+            dsv_frame_ref_dec(orig);
+            dsv_frame_ref_dec(rec);
+        }
+    }
+    parallel_for(n, [&](int k) { phase_h2(jobs[k]); });
+}
+
 } // namespace
+
+
 
 extern "C" {
 
@@ -1182,77 +1416,19 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs) // dsv_encoder.c:141
     set_link_offsets(enc, &bufs[0], 1);
 }
 
-static int enc_common(DSV_ENCODER *enc, DSV_FRAME *frame, const uint8_t *dev_planar, DSV_BUF *bufs)
-{
-    bind_device();
-    EncImpl *im = (EncImpl *) enc->ref;
-    if (!im) {
-        im = new EncImpl();
-        enc->ref = im;
-    }
-    int w = enc->vidmeta.width, h = enc->vidmeta.height;
-    if (!im->ready) {
-        if ((w & 1) || (h & 1) || w < 16 || h < 16) {
-            fatal("DSV2 needs even picture dimensions of at least 16x16 (dsv_main.c:621, sbt.c:384-388)", __FILE__, __LINE__);
-        }
-        int bw, bh, nbh, nbv;
-        block_geometry(w, h, enc->block_size_override_x, enc->block_size_override_y, &bw, &bh, &nbh, &nbv);
-        if (enc->pyramid_levels == 0) { // dsv_encoder.c:1229-1241
-            int lvls = dsv_lb2((unsigned) (w < h ? w : h));
-            int maxdim = nbh > nbv ? nbh : nbv;
-            while ((1 << lvls) > maxdim) {
-                lvls--;
-            }
-            enc->pyramid_levels = clampi(lvls, 3, DSV_MAX_PYRAMID_LEVELS);
-        }
-        im->dev.init(enc->vidmeta.subsamp, w, h, bw, bh, enc->pyramid_levels, true);
-        im->ready = true;
-        im->mvs.assign((size_t) nbh * nbv, DSV_MV{});
-        enc->stability = (struct DSV_STAB_ACC *) dsv_alloc((int) (sizeof(struct DSV_STAB_ACC) * (size_t) nbh * nbv));
-        enc->blockdata = (uint8_t *) dsv_alloc(nbh * nbv);
-    }
-    CodecDev &dv = im->dev;
-    PicSet &cur = dv.pics[im->cur];
-    // ingest: the picture goes to HBM once; the border is synthesised there (dsv_encoder.c:1455-1456)
-    dv.prof.begin(dv.stream, ST_INGEST);
-    if (frame) {
-        dframe_upload(&cur.src, frame, dv.stream);
-        extend_frame(dv.stream, cur.src, false);
-        HIPCHK(hipStreamSynchronize(dv.stream)); // the caller's pixels may be released below
-        dsv_frame_ref_dec(frame);
-    } else { // packed planar picture already resident in HBM
-        const uint8_t *sp = dev_planar;
-        for (int c = 0; c < 3; c++) {
-            const DPlane &pl = cur.src.p[c];
-            HIPCHK(hipMemcpy2DAsync(pl.data, pl.stride, sp, pl.w, pl.w, pl.h, hipMemcpyDeviceToDevice, dv.stream));
-            sp += (size_t) pl.w * pl.h;
-        }
-        extend_frame(dv.stream, cur.src, false);
-    }
-
-    FrameCtl d;
-    memset(&d, 0, sizeof(d));
-    d.fnum = enc->next_fnum++;
-    int nbuf = 0;
-    DSV_BUF outbuf;
-    if (encode_one_frame(enc, im, &d, &outbuf)) {
-        DSV_BUF metabuf;
-        encode_metadata(enc, &metabuf);
-        bufs[nbuf++] = metabuf;
-        set_link_offsets(enc, &bufs[nbuf - 1], 0);
-    }
-    bufs[nbuf++] = outbuf;
-    set_link_offsets(enc, &bufs[nbuf - 1], 0);
-    account(enc, im, &d, outbuf.len);
-    return nbuf;
-}
 
 int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:1430
 {
     if (frame == NULL || bufs == NULL) {
         return 0;
     }
-    return enc_common(enc, frame, NULL, bufs);
+    Job jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.enc = enc;
+    jb.frame = frame;
+    jb.bufs = bufs;
+    enc_batch(&jb, 1);
+    return jb.nbuf;
 }
 
 /* same as dsv_enc for a packed planar 8-bit picture (Y, then U, then V, no padding) that is
@@ -1262,7 +1438,35 @@ int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *
     if (dev_planar == NULL || bufs == NULL) {
         return 0;
     }
-    return enc_common(enc, NULL, (const uint8_t *) dev_planar, bufs);
+    Job jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.enc = enc;
+    jb.dev_planar = (const uint8_t *) dev_planar;
+    jb.bufs = bufs;
+    enc_batch(&jb, 1);
+    return jb.nbuf;
+}
+
+/* lockstep step: one frame on each of n encoders (identical geometry).  dev_planar[k] is stream k's
+ * picture in device memory; bufs holds 4 DSV_BUF slots per stream, nbufs[k] receives the packet count.
+ * Results are identical to calling dsv2hip_enc_device_frame on every encoder separately. */
+int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, DSV_BUF *bufs, int *nbufs)
+{
+    if (n <= 0 || !encs || !dev_planar || !bufs || !nbufs) {
+        return -1;
+    }
+    std::vector<Job> jobs((size_t) n);
+    for (int k = 0; k < n; k++) {
+        memset(&jobs[(size_t) k], 0, sizeof(Job));
+        jobs[(size_t) k].enc = encs[k];
+        jobs[(size_t) k].dev_planar = (const uint8_t *) dev_planar[k];
+        jobs[(size_t) k].bufs = bufs + 4 * k;
+    }
+    enc_batch(jobs.data(), n);
+    for (int k = 0; k < n; k++) {
+        nbufs[k] = jobs[(size_t) k].nbuf;
+    }
+    return 0;
 }
 
 } // extern "C"

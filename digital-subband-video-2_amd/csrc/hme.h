@@ -1,13 +1,10 @@
 // hme.h -- interfaces of the analysis / motion-estimation kernels (intra.hip, hme.hip).
 #pragma once
 
+#include "bmc.h"
 #include "dev.h"
 
 namespace dsv2 {
-
-struct Planes3 {
-    DPlane p[3];
-};
 
 struct AnalysisParams {
     int width, height; // luma picture size
@@ -39,6 +36,10 @@ struct HmeFrames {
 
 // dsv_hme (hme.c:2001): all levels coarse to fine, asynchronous on `s`
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns the number of front launches
+
+// lockstep variant for n streams of identical geometry; h_table (pinned) / d_table hold hme_table_bytes(n)
+size_t hme_table_bytes(int n);
+int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table);
 
 struct CodecDev;
 struct PicSet;

@@ -912,6 +912,9 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
 
 #include "hme_fast.h"
 
+// DSV2_HME_FAST=0 forces the generic per-block routine (A/B checks); default: fast path on
+static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
+
 // true when hme_block_fast() handles this block (see hme_fast.h preconditions)
 __device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, int j)
 {
@@ -949,7 +952,67 @@ __global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, in
     }
 }
 
+// ---- stream-batched variants: blockIdx.y selects one of n independent streams (same geometry) ----
+__global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ tab, int level, int t, int nbx, int nby, int allow_fast)
+{
+    __shared__ FastLds S;
+    const HmeDev &c = tab[blockIdx.y];
+    int bj_hi = min(nby - 1, t);
+    int bj = bj_hi - (int) blockIdx.x;
+    int bi = t - bj;
+    if (bj < 0 || bi >= nbx) {
+        return;
+    }
+    int gx = c.counters[4], gy = c.counters[5];
+    int i = bi << level, j = bj << level;
+    if (allow_fast && fast_path_ok(c, level, i, j)) {
+        hme_block_fast(c, level, i, j, gx, gy, S);
+    } else {
+        hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
+{
+    const HmeDev &c = tab[blockIdx.y];
+    uint32_t *p = (uint32_t *) c.mvf[level];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) {
+        p[i] = 0;
+    }
+    if (clear_counters && blockIdx.x == 0 && threadIdx.x < 16) {
+        c.counters[threadIdx.x] = 0;
+    }
+}
+
 // global_motion (hme.c:1973): mean vector of the level just finished, scaled up for the next one
+__global__ __launch_bounds__(256) void k_global_motion_b(const HmeDev *__restrict__ tab, int level)
+{
+    __shared__ int sx[4], sy[4];
+    const HmeDev &c = tab[blockIdx.x];
+    int step = 1 << level;
+    int nbx = (c.a.nbh + step - 1) / step, nby = (c.a.nbv + step - 1) / step;
+    int ax = 0, ay = 0;
+    for (int idx = threadIdx.x; idx < nbx * nby; idx += 256) {
+        int i = (idx % nbx) * step, j = (idx / nbx) * step;
+        const DSV_MV *m = &c.mvf[level][i + j * c.a.nbh];
+        ax += m->u.mv.x;
+        ay += m->u.mv.y;
+    }
+    ax = wave_sum(ax);
+    ay = wave_sum(ay);
+    if ((threadIdx.x & 63) == 0) {
+        sx[threadIdx.x >> 6] = ax;
+        sy[threadIdx.x >> 6] = ay;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nblk = nbx * nby;
+        int tx = sx[0] + sx[1] + sx[2] + sx[3], ty = sy[0] + sy[1] + sy[2] + sy[3];
+        c.counters[4] = nblk ? tx * 2 / nblk : 0;
+        c.counters[5] = nblk ? ty * 2 / nblk : 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_global_motion(HmeDev c, int level)
 {
     __shared__ int sx[4], sy[4];
@@ -1000,8 +1063,63 @@ int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &r
     return hme_run(s, f, hp);
 }
 
-// DSV2_HME_FAST=0 forces the generic per-block routine (A/B checks); default: fast path on
-static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
+static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
+{
+    c.a = hp.a;
+    c.effort = hp.effort;
+    c.lossless = hp.lossless;
+    c.quant = hp.quant;
+    c.skip_block_thresh = hp.skip_block_thresh;
+    c.pyr_levels = hp.pyr_levels;
+    c.psyscale = spatial_psy_factor(hp.a.blk_w, hp.a.blk_h, hp.a.nbh, hp.a.nbv, -1);
+    for (int l = 0; l <= hp.pyr_levels; l++) {
+        c.src[l] = f.src[l];
+        c.ref[l] = f.ref[l];
+        c.ogr[l] = f.ogr[l];
+        c.mvf[l] = f.mvf[l];
+    }
+    for (int k = 0; k < 2; k++) {
+        c.srcc[k] = f.srcc[k];
+        c.refc[k] = f.refc[k];
+    }
+    c.ref_mvf = f.ref_mvf;
+    c.counters = f.counters;
+}
+
+size_t hme_table_bytes(int n) { return (size_t) n * sizeof(HmeDev); }
+
+// n independent streams of identical geometry in lockstep: every front is ONE launch for all of them
+int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table)
+{
+    if (n <= 0) {
+        return 0;
+    }
+    HmeDev *ht = (HmeDev *) h_table;
+    for (int k = 0; k < n; k++) {
+        fill_hme_dev(ht[k], f[k], hp[k]);
+    }
+    HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
+    const HmeDev *tab = (const HmeDev *) d_table;
+    const HmeParams &g = hp[0];
+    int nlaunch = 0;
+    int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
+    for (int level = g.pyr_levels; level >= 0; level--) {
+        int step = 1 << level;
+        int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
+        hipLaunchKernelGGL(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
+        for (int t = 0; t <= nbx + nby - 2; t++) {
+            int jhi = nby - 1 < t ? nby - 1 : t;
+            int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
+            hipLaunchKernelGGL(k_hme_front_b, dim3(jhi - jlo + 1, n), dim3(64), 0, s, tab, level, t, nbx, nby, g_hme_fast);
+            nlaunch++;
+        }
+        if (level != 0) {
+            hipLaunchKernelGGL(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return nlaunch;
+}
 
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
 {

@@ -16,32 +16,58 @@
 // level 0 additionally block width/height multiples of 8.
 #pragma once
 
+// a 2x2 pixel quad packed in one register: byte 0 = top-left, 1 = top-right, 2 = bottom-left,
+// 3 = bottom-right, so the packed-byte instructions (v_sad_u8, v_dot4_u32_u8) do the per-quad
+// arithmetic of METR_CALC (hme.c:126) in a handful of operations
 struct Quad {
-    int p1, p2, p3, p4;
+    uint32_t w;
+    __device__ __forceinline__ int p1() const { return (int) (w & 0xff); }
+    __device__ __forceinline__ int p2() const { return (int) ((w >> 8) & 0xff); }
+    __device__ __forceinline__ int p3() const { return (int) ((w >> 16) & 0xff); }
+    __device__ __forceinline__ int p4() const { return (int) (w >> 24); }
+};
+
+struct __attribute__((packed)) U16u { // possibly unaligned 16-bit load (one global_load_ushort)
+    uint16_t v;
 };
 
 __device__ __forceinline__ Quad ldq(const uint8_t *blk, int stride, int qi, int qj, bool act)
 {
-    Quad q = {0, 0, 0, 0};
+    Quad q = {0};
     if (act) {
         const uint8_t *p = blk + (ptrdiff_t) (2 * qj) * stride + 2 * qi;
-        q.p1 = p[0];
-        q.p2 = p[1];
-        q.p3 = p[stride];
-        q.p4 = p[stride + 1];
+        uint32_t top = ((const U16u *) p)->v, bot = ((const U16u *) (p + stride))->v;
+        q.w = top | (bot << 16);
     }
     return q;
 }
 
-__device__ __forceinline__ unsigned qmetric(const Quad &a, const Quad &b, const Psy &psy)
+__device__ __forceinline__ Quad mkq(int s1, int s2, int s3, int s4)
 {
-    return quad_metric(a.p1, a.p2, a.p3, a.p4, b.p1, b.p2, b.p3, b.p4, psy);
+    Quad q;
+    q.w = (uint32_t) s1 | ((uint32_t) s2 << 8) | ((uint32_t) s3 << 16) | ((uint32_t) s4 << 24);
+    return q;
 }
 
-__device__ __forceinline__ unsigned qsse(const Quad &a, const Quad &b)
+__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b) { return __builtin_amdgcn_sad_u8(a, b, 0u); }
+__device__ __forceinline__ uint32_t rot8(uint32_t a) { return (a >> 8) | (a << 24); } // (p1,p2,p3,p4) -> (p2,p3,p4,p1)
+__device__ __forceinline__ uint32_t rep4(int v) { return (uint32_t) v * 0x01010101u; }
+
+// METR_CALC (hme.c:126): UAVG4 of four absolute differences == (sad + 2) >> 2
+__device__ __forceinline__ unsigned qmetric(const Quad &a, const Quad &b, const Psy &psy)
 {
-    int d1 = a.p1 - b.p1, d2 = a.p2 - b.p2, d3 = a.p3 - b.p3, d4 = a.p4 - b.p4;
-    return (unsigned) (d1 * d1 + d2 * d2 + d3 * d3 + d4 * d4);
+    int se = (int) ((sad4(a.w, b.w) + 2) >> 2);
+    int ta = (int) ((sad4(a.w, rot8(a.w)) + 2) >> 2), tb = (int) ((sad4(b.w, rot8(b.w)) + 2) >> 2);
+    int s0 = (int) ((sad4(a.w, 0) + 2) >> 2), s1 = (int) ((sad4(b.w, 0) + 2) >> 2);
+    return (unsigned) (SQR(se) << psy.err_weight) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
+           (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+}
+
+__device__ __forceinline__ unsigned qsse(const Quad &a, const Quad &b) // sum of squared differences of the 4 bytes
+{
+    unsigned aa = __builtin_amdgcn_udot4(a.w, a.w, 0u, false), bb = __builtin_amdgcn_udot4(b.w, b.w, 0u, false);
+    unsigned ab = __builtin_amdgcn_udot4(a.w, b.w, 0u, false);
+    return aa + bb - 2u * ab;
 }
 
 // Folds N (power of two <= 16) per-lane partial sums across the wavefront.  On return lane L
@@ -96,25 +122,25 @@ struct FastLds {
 __device__ __forceinline__ void quad_grad_partials(const Quad &q, bool act, int qi, int qj, int qi0, int qj0, int &sum, int &sh, int &sv)
 {
     // (qi0, qj0): first quad column / row of the (sub-)block this lane's quad belongs to
-    int l2 = __shfl_up(q.p2, 1, 64), l4 = __shfl_up(q.p4, 1, 64);
-    int u3 = __shfl_up(q.p3, 8, 64), u4 = __shfl_up(q.p4, 8, 64);
+    int l2 = __shfl_up(q.p2(), 1, 64), l4 = __shfl_up(q.p4(), 1, 64);
+    int u3 = __shfl_up(q.p3(), 8, 64), u4 = __shfl_up(q.p4(), 8, 64);
     sum = sh = sv = 0;
     if (act) {
-        sum = q.p1 + q.p2 + q.p3 + q.p4;
-        sh = abs(q.p2 - q.p1) + abs(q.p4 - q.p3);
-        sv = abs(q.p3 - q.p1) + abs(q.p4 - q.p2);
+        sum = q.p1() + q.p2() + q.p3() + q.p4();
+        sh = abs(q.p2() - q.p1()) + abs(q.p4() - q.p3());
+        sv = abs(q.p3() - q.p1()) + abs(q.p4() - q.p2());
         if (qi > qi0) {
-            sh += abs(q.p1 - l2) + abs(q.p3 - l4);
+            sh += abs(q.p1() - l2) + abs(q.p3() - l4);
         }
         if (qj > qj0) {
-            sv += abs(q.p1 - u3) + abs(q.p2 - u4);
+            sv += abs(q.p1() - u3) + abs(q.p2() - u4);
         }
     }
 }
 
 __device__ __forceinline__ int quad_absdev(const Quad &q, bool act, int mean)
 {
-    return act ? abs(q.p1 - mean) + abs(q.p2 - mean) + abs(q.p3 - mean) + abs(q.p4 - mean) : 0;
+    return act ? (int) sad4(q.w, rep4(mean)) : 0;
 }
 
 // hist_var / quant_tex / peaks of the source block from its register-resident quads (hme.c:586-749)
@@ -131,10 +157,10 @@ __device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int 
     }
     __syncthreads();
     if (act) {
-        atomicAdd(&hist[min((int) ((unsigned) q.p1 * q16 >> 16), 15)], 1);
-        atomicAdd(&hist[min((int) ((unsigned) q.p2 * q16 >> 16), 15)], 1);
-        atomicAdd(&hist[min((int) ((unsigned) q.p3 * q16 >> 16), 15)], 1);
-        atomicAdd(&hist[min((int) ((unsigned) q.p4 * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p1() * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p2() * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p3() * q16 >> 16), 15)], 1);
+        atomicAdd(&hist[min((int) ((unsigned) q.p4() * q16 >> 16), 15)], 1);
     }
     __syncthreads();
     avg = (unsigned) (w * h) / 16;
@@ -150,7 +176,7 @@ __device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int 
 
 __device__ int src_quant_tex(const Quad &q, bool act, int qi, int qj, int qw, int w, int h)
 {
-    int a1 = q.p1 >> 4, a2 = q.p2 >> 4, a3 = q.p3 >> 4, a4 = q.p4 >> 4;
+    int a1 = q.p1() >> 4, a2 = q.p2() >> 4, a3 = q.p3() >> 4, a4 = q.p4() >> 4;
     int r1 = __shfl_down(a1, 1, 64), r3 = __shfl_down(a3, 1, 64); // right neighbour quad's left column
     int u3 = __shfl_up(a3, 8, 64), u4 = __shfl_up(a4, 8, 64);     // upper neighbour quad's bottom row
     unsigned sh = 0, sv = 0;
@@ -175,7 +201,7 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
     }
     __syncthreads();
     if (act) {
-        int ds = (int) ((unsigned) (q.p1 + q.p2 + q.p3 + q.p4 + 2) >> 2);
+        int ds = (int) ((unsigned) (q.p1() + q.p2() + q.p3() + q.p4() + 2) >> 2);
         atomicAdd(&hist[min(ds * q16 >> 16, 15)], 1);
     }
     __syncthreads();
@@ -227,15 +253,14 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
                                                unsigned &isrc)
 {
     const Psy psy = {0, 1, 2};
-    int s0 = (int) UAVG4(a.p1, a.p2, a.p3, a.p4), s1 = (int) UAVG4(b.p1, b.p2, b.p3, b.p4);
-    int ae = (int) UAVG4(abs(a.p1 - b.p1), abs(a.p2 - b.p2), abs(a.p3 - b.p3), abs(a.p4 - b.p4));
-    int ta = (int) UAVG4(abs(a.p1 - a.p2), abs(a.p2 - a.p3), abs(a.p3 - a.p4), abs(a.p4 - a.p1));
-    int tb = (int) UAVG4(abs(b.p1 - b.p2), abs(b.p2 - b.p3), abs(b.p3 - b.p4), abs(b.p4 - b.p1));
+    int s0 = (int) ((sad4(a.w, 0) + 2) >> 2), s1 = (int) ((sad4(b.w, 0) + 2) >> 2);
+    int ae = (int) ((sad4(a.w, b.w) + 2) >> 2);
+    int ta = (int) ((sad4(a.w, rot8(a.w)) + 2) >> 2), tb = (int) ((sad4(b.w, rot8(b.w)) + 2) >> 2);
     inter = (unsigned) (SQR(ae) * ratio >> (5 - psy.err_weight)) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
             (unsigned) (SQR(s0 - s1) << psy.avg_weight);
-    ae = (int) UAVG4(abs(a.p1 - avg_sb), abs(a.p2 - avg_sb), abs(a.p3 - avg_sb), abs(a.p4 - avg_sb));
+    ae = (int) ((sad4(a.w, rep4(avg_sb)) + 2) >> 2);
     isb = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - avg_sb) << (psy.avg_weight + 1));
-    ae = (int) UAVG4(abs(a.p1 - dc), abs(a.p2 - dc), abs(a.p3 - dc), abs(a.p4 - dc));
+    ae = (int) ((sad4(a.w, rep4(dc)) + 2) >> 2);
     isrc = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - dc) << (psy.avg_weight + 1));
 }
 
@@ -299,8 +324,8 @@ __device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx 
         tx[n] = t0;
         ty[n] = t1;
         int X = 4 + 8 * qi + t0, Y = 4 + 8 * qj + t1;
-        v8[n] = n < 7 ? (int) quad_metric(aw.p1, aw.p2, aw.p3, aw.p4, qsample(S.sp.h, X, Y), qsample(S.sp.h, X + 4, Y),
-                                          qsample(S.sp.h, X, Y + 4), qsample(S.sp.h, X + 4, Y + 4), psy)
+        v8[n] = n < 7 ? (int) qmetric(aw, mkq(qsample(S.sp.h, X, Y), qsample(S.sp.h, X + 4, Y), qsample(S.sp.h, X, Y + 4),
+                                                qsample(S.sp.h, X + 4, Y + 4)), psy)
                       : 0;
     }
     int r8 = reduceN<8>(v8);
@@ -467,9 +492,9 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
         int as128 = (int) avg_src - 128, ar128 = (int) avg_ref - 128;
         int ci = 0, cd = 0, cr = 0;
         if (act) {
-            cr = (((a.p1 - r.p1) + 128) | ((a.p2 - r.p2) + 128) | ((a.p3 - r.p3) + 128) | ((a.p4 - r.p4) + 128)) & ~0xff;
-            ci = ((a.p1 - ar128) | (a.p2 - ar128) | (a.p3 - ar128) | (a.p4 - ar128)) & ~0xff;
-            cd = ((a.p1 - as128) | (a.p2 - as128) | (a.p3 - as128) | (a.p4 - as128)) & ~0xff;
+            cr = (((a.p1() - r.p1()) + 128) | ((a.p2() - r.p2()) + 128) | ((a.p3() - r.p3()) + 128) | ((a.p4() - r.p4()) + 128)) & ~0xff;
+            ci = ((a.p1() - ar128) | (a.p2() - ar128) | (a.p3() - ar128) | (a.p4() - ar128)) & ~0xff;
+            cd = ((a.p1() - as128) | (a.p2() - as128) | (a.p3() - as128) | (a.p4() - as128)) & ~0xff;
         }
         eprmi = __any(ci != 0) ? 1 : 0;
         eprmd = __any(cd != 0) ? 1 : 0;
@@ -561,7 +586,7 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
             if (run) {
                 int ss, sh, sv2;
                 quad_grad_partials(a, act, qi, qj, (kq & 1) ? (qw >> 1) : 0, (kq & 2) ? (qh >> 1) : 0, ss, sh, sv2);
-                int rsum = act ? r.p1 + r.p2 + r.p3 + r.p4 : 0;
+                int rsum = act ? r.p1() + r.p2() + r.p3() + r.p4() : 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     bool in = act && kq == k;

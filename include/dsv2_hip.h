@@ -368,6 +368,10 @@ int dsv2hip_set_device(int ordinal);
  * lives in device memory: the picture is not copied from the host.  Used by bench.py so that
  * the timed region starts with inputs resident in HBM. */
 int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *bufs);
+/* lockstep step over n independent encoders of identical geometry: one frame each, the latency-bound
+ * kernels (motion-estimation fronts, MC, in-loop filters) are launched once for all streams.  bufs has
+ * 4 slots per stream; nbufs[k] = packets of stream k.  Output is identical to n separate dsv_enc calls. */
+int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, DSV_BUF *bufs, int *nbufs);
 /* stage timing with HIP events on each codec instance's own stream.  Enable before creating
  * encoders; dsv2hip_prof_read fills 8 entries (ingest+pyramid, HME, predict, fwd SBT,
  * quant+compact, inv SBT, reconstruct+filters, extend): milliseconds and kernel launches. */
