@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "1")),
+                    help="batch mode: split the streams into this many lockstep groups, one host thread + HIP stream each")
     ap.add_argument("--mode", choices=["batch", "threads"], default=os.environ.get("DSV2_BENCH_MODE", "batch"),
                     help="batch: lockstep dsv2hip_enc_batch over all streams; threads: one host thread + HIP stream per stream")
     return ap.parse_args()
@@ -130,23 +132,44 @@ def main():
     bbufs = (A.BUF * (4 * S))()
     bn = (C.c_int * S)()
 
+    G = max(1, min(args.groups, S))
+    group_of = [list(range(g, S, G)) for g in range(G)]
+
+    def group_worker(g, t0, t1, gbar):
+        ids = group_of[g]
+        m = len(ids)
+        gp = (C.POINTER(A.ENCODER) * m)(*[C.pointer(encs[s]) for s in ids])
+        gb = (A.BUF * (4 * m))()
+        gn = (C.c_int * m)()
+        gbar.wait()
+        for t in range(t0, t1):
+            ptrs = (C.c_void_p * m)(*[dev_frames[s][frame_index(t)].data_ptr() for s in ids])
+            hip.dsv2hip_enc_batch(m, gp, ptrs, gb, gn)
+            for k, s in enumerate(ids):
+                for i in range(gn[k]):
+                    b = gb[4 * k + i]
+                    out_bytes[s].append(C.string_at(b.data, b.len))
+                    hip.dsv_buf_free(C.byref(b))
+        gbar.wait()
+
     def run_phase_batch(t0, t1):
+        gbar = threading.Barrier(G + 1)
+        ths = [threading.Thread(target=group_worker, args=(g, t0, t1, gbar)) for g in range(G)]
+        for th in ths:
+            th.start()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        for t in range(t0, t1):
-            ptrs = (C.c_void_p * S)(*[dev_frames[s][frame_index(t)].data_ptr() for s in range(S)])
-            hip.dsv2hip_enc_batch(S, encp, ptrs, bbufs, bn)
-            for s in range(S):
-                for i in range(bn[s]):
-                    b = bbufs[4 * s + i]
-                    out_bytes[s].append(C.string_at(b.data, b.len))
-                    hip.dsv_buf_free(C.byref(b))
+        gbar.wait()
+        gbar.wait()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        return time.perf_counter() - t_start
+        t_end = time.perf_counter()
+        for th in ths:
+            th.join()
+        return t_end - t_start
 
     def run_phase(t0, t1):
         if args.mode == "batch":
@@ -228,7 +251,7 @@ def main():
         "dtype": "u8/int32",
         "data": "synthetic",
         "config": {"workload": "1920x1080 4:2:0 -qp=60 -gop=48 effort=10 CRF, %d closed-GOP streams per GPU" % S,
-                   "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mode": args.mode, "mpix_per_s": round(fps * N_PIX / 1e6, 1),
+                   "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mode": args.mode, "groups": G, "mpix_per_s": round(fps * N_PIX / 1e6, 1),
                    "stream_bytes_total": total_bytes, "host_cpus": ncpu},
     }
     if stage_ms is not None and prof_frames:

@@ -13,6 +13,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -1096,9 +1097,33 @@ void phase_h2(Job &jb)
     }
 }
 
+struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, printed every 16 steps
+    bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+    double acc[10] = {0};
+    int steps = 0;
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int i)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+    }
+    void done(int n)
+    {
+        if (!on || ++steps % 16) return;
+        fprintf(stderr, "[batch n=%d] ms/step: p0 %.2f | g1 enqueue %.2f wait %.2f | h1 %.2f | g2 enqueue %.2f wait %.2f | syms %.2f | h2 %.2f\n", n,
+                acc[0] / 16, acc[1] / 16, acc[2] / 16, acc[3] / 16, acc[4] / 16, acc[5] / 16, acc[6] / 16, acc[7] / 16);
+        for (double &a : acc) a = 0;
+    }
+};
+thread_local PhaseClock t_clock;
+
 void enc_batch(Job *jobs, int n)
 {
     bind_device();
+    t_clock.start();
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         if (!jb.enc->ref) {
@@ -1113,6 +1138,7 @@ void enc_batch(Job *jobs, int n)
         }
         phase_p0(jb);
     }
+    t_clock.lap(0);
     hipStream_t bs = jobs[0].im->dev.stream;
     StageProf &prof = jobs[0].im->dev.prof;
     BatchScratch &sc = t_scratch;
@@ -1201,7 +1227,9 @@ void enc_batch(Job *jobs, int n)
             cur.has_final_mvs = true;
         }
     }
+    t_clock.lap(1);
     HIPCHK(hipStreamSynchronize(bs));
+    t_clock.lap(2);
     for (int k = 0; k < n; k++) {
         if (jobs[k].frame) {
             dsv_frame_ref_dec(jobs[k].frame); // the caller's pixels are in HBM now (dsv_encoder.c:1457)
@@ -1210,6 +1238,7 @@ void enc_batch(Job *jobs, int n)
 
     // ---- H1 ----
     parallel_for(n, [&](int k) { phase_h1(jobs[k]); });
+    t_clock.lap(3);
 
     // ---- G2 ----
     int nP = 0, nI = 0;
@@ -1292,7 +1321,9 @@ void enc_batch(Job *jobs, int n)
         }
     }
     prof.end(bs, ST_EXTEND, 3);
+    t_clock.lap(4);
     HIPCHK(hipStreamSynchronize(bs));
+    t_clock.lap(5);
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
@@ -1304,6 +1335,7 @@ void enc_batch(Job *jobs, int n)
         }
     }
     HIPCHK(hipStreamSynchronize(bs));
+    t_clock.lap(6);
     prof.collect();
 
     // ---- H2 ----
@@ -1322,6 +1354,8 @@ void enc_batch(Job *jobs, int n)
         }
     }
     parallel_for(n, [&](int k) { phase_h2(jobs[k]); });
+    t_clock.lap(7);
+    t_clock.done(n);
 }
 
 } // namespace
