@@ -456,7 +456,7 @@ int dsv_hme(DSV_HME *hme, int *scene_change_blocks, int *avg_err) // hme.c:2001
     }
     f.ref_mvf = c.put_mvs(hme->ref_mvf, nb);
     int *d_counters;
-    HIPCHK(hipMalloc((void **) &d_counters, 16 * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &d_counters, hme_counter_words(p->nblocks_v) * sizeof(int)));
     f.counters = d_counters;
     HmeParams hp;
     hp.a.width = p->vidmeta->width;
@@ -489,6 +489,9 @@ int dsv_hme(DSV_HME *hme, int *scene_change_blocks, int *avg_err) // hme.c:2001
         HIPCHK(hipFree(f.mvf[l]));
     }
     HIPCHK(hipFree(d_counters));
+    if (counters[7]) {
+        fatal("motion estimation row pipeline timed out", __FILE__, __LINE__);
+    }
     *scene_change_blocks = counters[1] * 100 / (counters[2] ? counters[2] : 1); // hme.c:1825-1832
     *avg_err = (int) ((unsigned) counters[3] / (unsigned) nb);
     return counters[0] * 100 / (int) nb;

@@ -173,7 +173,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     for (int l = 0; l <= pyr_levels; l++) {
         HIPCHK(hipMalloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
     }
-    HIPCHK(hipMalloc((void **) &d_counters, 16 * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
     HIPCHK(hipMalloc((void **) &d_ll, 4 * sizeof(int32_t)));
     h_frame_bytes = 0;
     for (int c = 0; c < 3; c++) {

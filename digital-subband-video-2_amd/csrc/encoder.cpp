@@ -981,6 +981,9 @@ void phase_h1(Job &jb)
     size_t nb = dv.nblocks();
     if (jb.ran_hme) {
         im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
+        if (dv.h_counters[7]) {
+            fatal("motion estimation row pipeline timed out", __FILE__, __LINE__);
+        }
         int nintra = dv.h_counters[0], ndiff = dv.h_counters[1], eligible = dv.h_counters[2]; // hme.c:1825-1832, 2015
         unsigned total_err = (unsigned) dv.h_counters[3];
         enc->curr_scblocks = ndiff * 100 / (eligible ? eligible : 1);

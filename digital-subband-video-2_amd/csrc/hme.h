@@ -31,10 +31,12 @@ struct HmeFrames {
     DPlane srcc[2], refc[2];
     DSV_MV *mvf[6];        // out: one field per level, nblocks entries each
     const DSV_MV *ref_mvf; // previous frame's transmitted field or null
-    int *counters;         // out: [0] nintra [1] ndiff [2] eligible [3] total_err ([4],[5] scratch)
+    int *counters;         // hme_counter_words(nbv) ints. out: [0] nintra [1] ndiff [2] eligible [3] total_err
+                           // ([4],[5] global motion, [7] row-pipeline timeout flag, [16..] row progress)
 };
 
 // dsv_hme (hme.c:2001): all levels coarse to fine, asynchronous on `s`
+inline size_t hme_counter_words(int nbv) { return 16 + (size_t) nbv; }
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns the number of front launches
 
 // lockstep variant for n streams of identical geometry; h_table (pinned) / d_table hold hme_table_bytes(n)

@@ -109,6 +109,36 @@ __device__ __forceinline__ bool invalid_block(const DPlane &f, int bx, int by, i
     return (bx - pad) < -kBorder || (by - pad) < -kBorder || (bx + bw + pad) >= (f.w + kBorder) || (by + bh + pad) >= (f.h + kBorder);
 }
 
+// ---- same-level motion field hand-off ----------------------------------------------------------
+// A block reads the vectors of its left / top / top-left neighbours of the SAME level.  In the
+// row-pipelined kernel those were stored by other workgroups of the same launch, possibly on another
+// XCD whose L2 is not coherent with ours: the first 8 bytes of a DSV_MV ({x,y}, flags -- all a
+// neighbour ever looks at) are therefore stored and loaded as ONE agent-scope 8-byte access
+// (write-through store, L1-bypassing load); a per-row progress word published after the store has
+// drained orders them.  In the launch-per-front kernels the same accessors are merely redundant.
+struct MvHead {
+    int x, y;
+    uint32_t all, flags;
+};
+
+__device__ __forceinline__ MvHead ld_mv_head(const DSV_MV *m)
+{
+    unsigned long long v = __hip_atomic_load((const unsigned long long *) m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MvHead h;
+    h.all = (uint32_t) v;
+    h.flags = (uint32_t) (v >> 32);
+    h.x = (int) (int16_t) (h.all & 0xffffu);
+    h.y = (int) (int16_t) (h.all >> 16);
+    return h;
+}
+
+__device__ __forceinline__ void st_mv(DSV_MV *out, const DSV_MV &mv)
+{
+    unsigned long long head = (unsigned long long) (uint32_t) mv.u.all | ((unsigned long long) mv.flags << 32);
+    ((unsigned long long *) out)[1] = (unsigned long long) mv.err | ((unsigned long long) mv.dc << 16) | ((unsigned long long) mv.submask << 32);
+    __hip_atomic_store((unsigned long long *) out, head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- motion vector cost ---------------------------------------------------------------------
 __device__ __forceinline__ int pred1(int left, int top, int topleft)
 {
@@ -120,16 +150,19 @@ __device__ __forceinline__ void movec_pred(const DSV_MV *v, int nbh, int x, int 
 {
     int vx0 = 0, vx1 = 0, vx2 = 0, vy0 = 0, vy1 = 0, vy2 = 0;
     if (x > 0) {
-        vx0 = v[y * nbh + x - 1].u.mv.x;
-        vy0 = v[y * nbh + x - 1].u.mv.y;
+        MvHead m = ld_mv_head(&v[y * nbh + x - 1]);
+        vx0 = m.x;
+        vy0 = m.y;
     }
     if (y > 0) {
-        vx1 = v[(y - 1) * nbh + x].u.mv.x;
-        vy1 = v[(y - 1) * nbh + x].u.mv.y;
+        MvHead m = ld_mv_head(&v[(y - 1) * nbh + x]);
+        vx1 = m.x;
+        vy1 = m.y;
     }
     if (x > 0 && y > 0) {
-        vx2 = v[(y - 1) * nbh + x - 1].u.mv.x;
-        vy2 = v[(y - 1) * nbh + x - 1].u.mv.y;
+        MvHead m = ld_mv_head(&v[(y - 1) * nbh + x - 1]);
+        vx2 = m.x;
+        vy2 = m.y;
     }
     px = pred1(vx0, vx1, vx2);
     py = pred1(vy0, vy1, vy2);
@@ -169,17 +202,17 @@ __device__ __forceinline__ void neighbordif2_cur(const DSV_MV *v, int nbh, int x
         return;
     }
     if (x > 0) {
-        const DSV_MV *m = &v[x - 1 + y * nbh];
-        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
-            lx = m->u.mv.x;
-            ly = m->u.mv.y;
+        MvHead m = ld_mv_head(&v[x - 1 + y * nbh]);
+        if (m.all && !(m.flags & (1u << DSV_MV_BIT_SKIP))) {
+            lx = m.x;
+            ly = m.y;
         }
     }
     if (y > 0) {
-        const DSV_MV *m = &v[x + (y - 1) * nbh];
-        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
-            tx = m->u.mv.x;
-            ty = m->u.mv.y;
+        MvHead m = ld_mv_head(&v[x + (y - 1) * nbh]);
+        if (m.all && !(m.flags & (1u << DSV_MV_BIT_SKIP))) {
+            tx = m.x;
+            ty = m.y;
         }
     }
     dx = abs(lx - cx) + abs(ly - cy);
@@ -533,7 +566,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     int bx = (i * y_w) >> level, by = (j * y_h) >> level;
     if (bx >= src.w || by >= src.h) {
         if (lane == 0) {
-            *out = mv;
+            st_mv(out, mv);
         }
         return;
     }
@@ -592,16 +625,16 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
                 cands[n++] = Vec2{qp2fp(px), qp2fp(py)};
             }
             if (i > 0) {
-                const DSV_MV *m = &mvf[(i - step) + j * nxb];
-                cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+                MvHead m = ld_mv_head(&mvf[(i - step) + j * nxb]);
+                cands[n++] = Vec2{qp2fp(m.x), qp2fp(m.y)};
             }
             if (j > 0) {
-                const DSV_MV *m = &mvf[i + (j - step) * nxb];
-                cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+                MvHead m = ld_mv_head(&mvf[i + (j - step) * nxb]);
+                cands[n++] = Vec2{qp2fp(m.x), qp2fp(m.y)};
             }
             if (i > 0 && j > 0) {
-                const DSV_MV *m = &mvf[(i - step) + (j - step) * nxb];
-                cands[n++] = Vec2{qp2fp(m->u.mv.x), qp2fp(m->u.mv.y)};
+                MvHead m = ld_mv_head(&mvf[(i - step) + (j - step) * nxb]);
+                cands[n++] = Vec2{qp2fp(m.x), qp2fp(m.y)};
             }
             if (c.ref_mvf != nullptr) {
                 for (int k = 0; k < 9; k++) {
@@ -734,7 +767,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     mv.u.mv.y = (int16_t) (dy * step);
     if (level != 0) {
         if (lane == 0) {
-            *out = mv;
+            st_mv(out, mv);
         }
         return;
     }
@@ -894,7 +927,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
     if (lane == 0) {
-        *out = mv;
+        st_mv(out, mv);
         if (is_intra) {
             atomicAdd(&c.counters[0], 1);
         }
@@ -914,6 +947,9 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
 
 // DSV2_HME_FAST=0 forces the generic per-block routine (A/B checks); default: fast path on
 static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
+// DSV2_HME_ROWS=0 falls back to one launch per anti-diagonal front in the batched driver
+static int g_hme_rows = getenv("DSV2_HME_ROWS") ? atoi(getenv("DSV2_HME_ROWS")) : 1;
+static int g_hme_fence = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 1; // 1 acquire, 2 release, 3 both
 
 // true when hme_block_fast() handles this block (see hme_fast.h preconditions)
 __device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, int j)
@@ -972,6 +1008,88 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
     }
 }
 
+// ---- row-pipelined level: ONE launch per pyramid level for all streams --------------------------
+// blockIdx.x = block row, blockIdx.y = stream; one wavefront walks its row left to right.  Block
+// (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and (bi, bj-1), (bi-1, bj-1) of the
+// row above, so a row only ever waits for the progress word of the row above it: a slow block
+// delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front
+// does.  A waiting row depends on a lower workgroup index only, so the lowest unfinished workgroup
+// can always run; every spin is bounded by the wall clock and reports through counters[7].
+constexpr int kHmeErrWord = 7, kHmeProgress = 16;
+constexpr unsigned long long kHmeSpinLimit = 400000000ull; // 100 MHz ticks = 4 s
+
+__device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned need, int *err)
+{
+    unsigned long long t0 = 0;
+    for (unsigned spins = 0;; spins++) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) {
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if ((spins & 1023u) == 1023u) {
+            unsigned long long now = wall_clock64();
+            if (t0 == 0) {
+                t0 = now;
+            } else if (now - t0 > kHmeSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void hme_row(const HmeDev &c, int level, int nbx, int allow_fast, FastLds &S)
+{
+    int bj = blockIdx.x;
+    int gx = c.counters[4], gy = c.counters[5];
+    unsigned *progress = (unsigned *) c.counters + kHmeProgress;
+    int j = bj << level;
+    for (int bi = 0; bi < nbx; bi++) {
+        if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // no neighbour load may move above the poll
+        if (allow_fast & 2) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();                                       // LDS scratch of the previous block is dead
+        int i = bi << level;
+        if ((allow_fast & 1) && fast_path_ok(c, level, i, j)) {
+            hme_block_fast(c, level, i, j, gx, gy, S);
+        } else {
+            hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
+        }
+        if (allow_fast & 4) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        // the vector was stored write-through by lane 0: drain it, then publish
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store(&progress[bj], (unsigned) bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// occupancy variants (waves per SIMD) of the batched kernel; DSV2_HME_WAVES picks one
+#define HME_ROWS_B(W)                                                                                                    \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_w##W(                  \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        hme_row(tab[blockIdx.y], level, nbx, allow_fast, S);                                                             \
+    }
+HME_ROWS_B(1)
+HME_ROWS_B(2)
+HME_ROWS_B(3)
+HME_ROWS_B(4)
+static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 4;
+
+__global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
+{
+    __shared__ FastLds S;
+    hme_row(c, level, nbx, allow_fast, S);
+}
+
 __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
 {
     const HmeDev &c = tab[blockIdx.y];
@@ -981,6 +1099,11 @@ __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ 
     }
     if (clear_counters && blockIdx.x == 0 && threadIdx.x < 16) {
         c.counters[threadIdx.x] = 0;
+    }
+    if (blockIdx.x == 0) { // row progress words of the level about to run
+        for (int r = threadIdx.x; r < c.a.nbv; r += 256) {
+            c.counters[kHmeProgress + r] = 0;
+        }
     }
 }
 
@@ -1107,11 +1230,17 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         int step = 1 << level;
         int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
         hipLaunchKernelGGL(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
-        for (int t = 0; t <= nbx + nby - 2; t++) {
-            int jhi = nby - 1 < t ? nby - 1 : t;
-            int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-            hipLaunchKernelGGL(k_hme_front_b, dim3(jhi - jlo + 1, n), dim3(64), 0, s, tab, level, t, nbx, nby, g_hme_fast);
+        if (g_hme_rows) {
+            auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
+            hipLaunchKernelGGL(kern, dim3(nby, n), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
+        } else {
+            for (int t = 0; t <= nbx + nby - 2; t++) {
+                int jhi = nby - 1 < t ? nby - 1 : t;
+                int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
+                hipLaunchKernelGGL(k_hme_front_b, dim3(jhi - jlo + 1, n), dim3(64), 0, s, tab, level, t, nbx, nby, g_hme_fast);
+                nlaunch++;
+            }
         }
         if (level != 0) {
             hipLaunchKernelGGL(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
@@ -1145,16 +1274,24 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
     c.ref_mvf = f.ref_mvf;
     c.counters = f.counters;
     size_t nb = (size_t) hp.a.nbh * hp.a.nbv;
-    HIPCHK(hipMemsetAsync(f.counters, 0, 16 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(f.counters, 0, hme_counter_words(hp.a.nbv) * sizeof(int), s));
     for (int level = hp.pyr_levels; level >= 0; level--) {
         int step = 1 << level;
         int nbx = (hp.a.nbh + step - 1) / step, nby = (hp.a.nbv + step - 1) / step;
         HIPCHK(hipMemsetAsync(f.mvf[level], 0, nb * sizeof(DSV_MV), s));
-        for (int t = 0; t <= nbx + nby - 2; t++) {
-            int jhi = nby - 1 < t ? nby - 1 : t;
-            int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-            hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby, g_hme_fast);
+        if (g_hme_rows) {
+            if (level != hp.pyr_levels) {
+                HIPCHK(hipMemsetAsync(f.counters + kHmeProgress, 0, (size_t) hp.a.nbv * sizeof(int), s));
+            }
+            hipLaunchKernelGGL(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
+        } else {
+            for (int t = 0; t <= nbx + nby - 2; t++) {
+                int jhi = nby - 1 < t ? nby - 1 : t;
+                int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
+                hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby, g_hme_fast);
+                nlaunch++;
+            }
         }
         if (level != 0) {
             hipLaunchKernelGGL(k_global_motion, dim3(1), dim3(256), 0, s, c, level);

@@ -710,7 +710,7 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
     if (lane == 0) {
-        *out = mv;
+        st_mv(out, mv);
         if (is_intra) {
             atomicAdd(&c.counters[0], 1);
         }
@@ -837,10 +837,10 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
             } else if (lane >= 3 && lane <= 5) {
                 bool need_i = lane != 4, need_j = lane != 3;
                 if ((!need_i || i > 0) && (!need_j || j > 0)) {
-                    const DSV_MV *m = &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb];
+                    MvHead m = ld_mv_head(&mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb]);
                     exist = true;
-                    cxv = qp2fp(m->u.mv.x);
-                    cyv = qp2fp(m->u.mv.y);
+                    cxv = qp2fp(m.x);
+                    cyv = qp2fp(m.y);
                 }
             } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
                 int k = lane - 6;
@@ -1022,7 +1022,7 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
     mv.u.mv.y = (int16_t) (dy * step);
     if (level != 0) {
         if (lane == 0) {
-            *out = mv;
+            st_mv(out, mv);
         }
         return;
     }
