@@ -594,7 +594,7 @@ dsv2hip_planeset *dsv2hip_planeset_create(int format, int width, int height)
     for (int c = 0; c < 3; c++) {
         size_t n = (size_t) ps->cw[c] * ps->ch[c];
         HIPCHK(hipMalloc((void **) &ps->coefs[c], n * sizeof(int32_t)));
-        HIPCHK(hipMemset(ps->coefs[c], 0, n * sizeof(int32_t)));
+        dev_zero(ps->coefs[c], n * sizeof(int32_t));
     }
     ps->scratch.ensure((size_t) ps->cw[0] * ps->ch[0]);
     ps->bd = nullptr;

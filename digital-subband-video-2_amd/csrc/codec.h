@@ -57,7 +57,8 @@ struct CodecDev {
     int32_t *qv = nullptr; // dense quantised values of the 3 planes, concatenated
     size_t qv_off[4] = {0, 0, 0, 0};
     ScanGeom scan[3];
-    SbtScratch scratch;
+    SbtScratch scratch;        // luma (and, one plane at a time, any plane of the single-stream calls)
+    SbtScratch scratch_uv[2];  // chroma planes of the table-driven encoder path, where U and V share a launch
     Compactor comp;
     uint8_t *d_blockdata = nullptr;
     DSV_MV *d_mvs_stage = nullptr; // analysis output / upload staging

@@ -142,7 +142,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     for (int i = 0; i < 2; i++) {
         dframe_alloc(&pics[i].recon, format, w, h);
         HIPCHK(hipMalloc((void **) &pics[i].d_final_mvs, nb * sizeof(DSV_MV)));
-        HIPCHK(hipMemset(pics[i].d_final_mvs, 0, nb * sizeof(DSV_MV)));
+        dev_zero(pics[i].d_final_mvs, nb * sizeof(DSV_MV));
         if (encoder) {
             dframe_alloc(&pics[i].src, format, w, h);
             for (int l = 0; l < pyr_levels; l++) {
@@ -157,7 +157,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     for (int c = 0; c < 3; c++) {
         size_t n = (size_t) cw[c] * ch[c];
         HIPCHK(hipMalloc((void **) &coefs[c], n * sizeof(int32_t)));
-        HIPCHK(hipMemset(coefs[c], 0, n * sizeof(int32_t)));
+        dev_zero(coefs[c], n * sizeof(int32_t));
         make_scan(&scan[c], cw[c], ch[c]);
         qv_off[c + 1] = qv_off[c] + (size_t) scan[c].base[10];
     }
@@ -165,11 +165,13 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     scratch.ensure((size_t) cw[0] * ch[0]);
     if (encoder) {
         comp.ensure(qv_off[3]);
+        scratch_uv[0].ensure((size_t) cw[1] * ch[1]);
+        scratch_uv[1].ensure((size_t) cw[2] * ch[2]);
     }
     HIPCHK(hipMalloc((void **) &d_blockdata, nb));
-    HIPCHK(hipMemset(d_blockdata, 0, nb));
+    dev_zero(d_blockdata, nb);
     HIPCHK(hipMalloc((void **) &d_mvs_stage, nb * sizeof(DSV_MV)));
-    HIPCHK(hipMemset(d_mvs_stage, 0, nb * sizeof(DSV_MV)));
+    dev_zero(d_mvs_stage, nb * sizeof(DSV_MV));
     for (int l = 0; l <= pyr_levels; l++) {
         HIPCHK(hipMalloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
     }
@@ -239,6 +241,8 @@ void CodecDev::destroy()
     }
     HIPCHK(hipFree(qv));
     scratch.release();
+    scratch_uv[0].release();
+    scratch_uv[1].release();
     comp.release();
     HIPCHK(hipFree(d_blockdata));
     HIPCHK(hipFree(d_mvs_stage));

@@ -61,6 +61,14 @@ void coef_dims(int format, int w, int h, int cw[3], int ch[3]) // frame.c:30-60
     ch[1] = ch[2] = c_h;
 }
 
+// hipMemset is asynchronous to the host and runs on the null stream, which the codec's non-blocking
+// streams do not wait for: finish it before anything may be enqueued on those streams
+void dev_zero(void *p, size_t bytes)
+{
+    HIPCHK(hipMemset(p, 0, bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));
+}
+
 void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-113, always bordered
 {
     ensure_device();
@@ -83,7 +91,7 @@ void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-1
     f->bytes = off;
     // slack after the last plane: block reads may run a few bytes past the final border row
     HIPCHK(hipMalloc((void **) &f->alloc, off + 4096));
-    HIPCHK(hipMemset(f->alloc, 0, off + 4096));
+    dev_zero(f->alloc, off + 4096);
     for (int c = 0; c < 3; c++) {
         f->p[c].data = f->alloc + f->plane_off[c] + (size_t) f->p[c].stride * kBorder + kBorder;
     }

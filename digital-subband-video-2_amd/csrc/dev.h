@@ -58,6 +58,7 @@ struct BlockMap {
     int nbh, nbv;
 };
 
+void dev_zero(void *p, size_t bytes); // synchronous zero fill of device memory
 void dframe_alloc(DFrame *f, int format, int w, int h);
 void dframe_free(DFrame *f);
 // copy between a host DSV_FRAME (any stride, bordered or not) and a device frame: visible pixels only
@@ -77,6 +78,20 @@ struct SbtScratch {
     void release();
 };
 
+// One plane of one stream as the transform and the quantiser see it.  A device table of these
+// (one per stream and plane of a lockstep batch) lets a single launch serve every stream.
+struct PlaneJob {
+    DPlane pic;        // working picture plane: residual in (forward level 1), reconstruction out (inverse level 1)
+    int32_t *coefs;    // coefficient plane
+    int32_t *t[3];     // scratch images, each >= coefficient plane size
+    const uint8_t *bd; // per-block flag bytes
+    int32_t *qv;       // dense quantised values of this plane, scan order
+    const DSV_MV *mvs; // motion field (P frames)
+    int q;             // frame quantiser
+    int qll;           // LL step size
+    int qp[3][3];      // detail step sizes [level][subband - 1]
+};
+
 // --- subband transform (sbt.hip) ------------------------------------------------
 // forward: u8 plane -> coefs (cw x ch).  inverse: coefs -> u8 plane (coefs preserved).
 void sbt_forward(hipStream_t s, const DPlane &src, DCoefs dst, SbtScratch &sc, int plane_idx, int isP,
@@ -84,12 +99,35 @@ void sbt_forward(hipStream_t s, const DPlane &src, DCoefs dst, SbtScratch &sc, i
 void sbt_inverse(hipStream_t s, DPlane dst, DCoefs src, SbtScratch &sc, int q, int plane_idx, int isP,
                  int lossless, BlockMap bm);
 
+// table forms: n jobs of identical geometry (cw x ch coefficient plane)
+void sbt_forward_jobs(hipStream_t s, const PlaneJob *d_jobs, int n, int cw, int ch, int plane_idx, int isP, int lossless, int nbh,
+                      int nbv);
+void sbt_inverse_jobs(hipStream_t s, const PlaneJob *d_jobs, int n, int cw, int ch, int plane_idx, int isP, int lossless, int nbh,
+                      int nbv);
+
 // --- picture helpers (frame.hip) ---------------------------------------------------
 void extend_plane(hipStream_t s, const DPlane &p);
 void extend_frame(hipStream_t s, const DFrame &f, bool luma_only);
 void ds2x_luma(hipStream_t s, const DPlane &src, const DPlane &dst);
 void copy_frame_pixels(hipStream_t s, const DFrame &dst, const DFrame &src);
 void copy_frame_full(hipStream_t s, const DFrame &dst, const DFrame &src);
+// stream-batched forms: one launch works through a device-resident table of jobs
+struct PlanePair {
+    DPlane src, dst;
+};
+struct CopyJob {
+    const void *src;
+    void *dst;
+    size_t bytes;
+};
+struct IngestJob {
+    const uint8_t *src; // packed planar picture in HBM
+    DPlane dst[3];
+};
+void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int max_h);
+void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h);
+void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes);
+void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int total_rows);
 
 void ensure_device();
 void set_default_device(int ordinal);

@@ -13,6 +13,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -740,11 +741,16 @@ AnalysisParams analysis_params(const CodecDev &dv, int do_psy)
     return a;
 }
 
-__global__ void k_grab_ll(const int32_t *c0, const int32_t *c1, const int32_t *c2, int32_t *out)
+// DC coefficient of every plane of every stream of the batch (sent raw, hzcc.c:599-602): table
+// entry i of `luma`, entries 2i / 2i+1 of `chroma` -> out[3i .. 3i+2]
+__global__ void k_grab_ll(const PlaneJob *luma, const PlaneJob *chroma, int n, int32_t *out)
 {
-    out[0] = c0[0];
-    out[1] = c1[0];
-    out[2] = c2[0];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[3 * i] = luma[i].coefs[0];
+        out[3 * i + 1] = chroma[2 * i].coefs[0];
+        out[3 * i + 2] = chroma[2 * i + 1].coefs[0];
+    }
 }
 
 // dsv_encode_picture (dsv_encoder.c:1039): returns the picture packet in `out`
@@ -863,12 +869,55 @@ struct Job {
     int stats[ST_MAX];
 };
 
+// Job tables of one step: built in pinned host memory, mirrored at the same offsets in device memory.
+// take() hands out matching host / device views, upload() ships what was added since the last upload.
+struct TableArena {
+    uint8_t *h = nullptr, *d = nullptr;
+    size_t cap = 0, used = 0, sent = 0;
+    void reserve(size_t bytes)
+    {
+        used = sent = 0;
+        if (bytes <= cap) {
+            return;
+        }
+        if (cap) {
+            HIPCHK(hipHostFree(h));
+            HIPCHK(hipFree(d));
+        }
+        HIPCHK(hipHostMalloc((void **) &h, bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d, bytes));
+        cap = bytes;
+    }
+    template <class T> T *take(size_t n, const T **dev)
+    {
+        used = (used + 15) & ~(size_t) 15;
+        if (used + n * sizeof(T) > cap) {
+            fatal("batch job table arena exhausted", __FILE__, __LINE__);
+        }
+        T *hp = (T *) (h + used);
+        *dev = (const T *) (d + used);
+        used += n * sizeof(T);
+        return hp;
+    }
+    void upload(hipStream_t s)
+    {
+        if (used > sent) {
+            HIPCHK(hipMemcpyAsync(d + sent, h + sent, used - sent, hipMemcpyHostToDevice, s));
+            sent = used;
+        }
+    }
+};
+
 struct BatchScratch { // per calling thread: pinned + device memory for the job tables
     void *h_hme = nullptr, *d_hme = nullptr;
     McJob *h_mc = nullptr, *d_mc = nullptr;
+    int32_t *h_ll = nullptr, *d_ll = nullptr; // [3 * n] DC coefficients
+    int *h_totals = nullptr, *d_totals = nullptr; // [n] symbol counts
+    TableArena tabs;
     int cap = 0;
     void ensure(int n)
     {
+        tabs.reserve((size_t) n * 8192 + 65536);
         if (n <= cap) {
             return;
         }
@@ -877,11 +926,19 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
             HIPCHK(hipFree(d_hme));
             HIPCHK(hipHostFree(h_mc));
             HIPCHK(hipFree(d_mc));
+            HIPCHK(hipHostFree(h_ll));
+            HIPCHK(hipFree(d_ll));
+            HIPCHK(hipHostFree(h_totals));
+            HIPCHK(hipFree(d_totals));
         }
         HIPCHK(hipHostMalloc(&h_hme, hme_table_bytes(n), hipHostMallocDefault));
         HIPCHK(hipMalloc(&d_hme, hme_table_bytes(n)));
         HIPCHK(hipHostMalloc((void **) &h_mc, 2 * (size_t) n * sizeof(McJob), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **) &d_mc, 2 * (size_t) n * sizeof(McJob)));
+        HIPCHK(hipHostMalloc((void **) &h_ll, 3 * (size_t) n * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d_ll, 3 * (size_t) n * sizeof(int32_t)));
+        HIPCHK(hipHostMalloc((void **) &h_totals, (size_t) n * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d_totals, (size_t) n * sizeof(int)));
         cap = n;
     }
 };
@@ -1149,39 +1206,90 @@ void enc_batch(Job *jobs, int n)
     const int nbh = jobs[0].im->dev.nbh, nbv = jobs[0].im->dev.nbv;
 
     // ---- G1 ----
+    // every per-picture helper runs ONCE for the whole batch over a device table of jobs
+    CodecDev &dv0 = jobs[0].im->dev;
+    const int L = dv0.pyr_levels;
     prof.begin(bs, ST_INGEST);
     std::vector<HmeFrames> hf;
     std::vector<HmeParams> hp;
     std::vector<int> pjobs;
+    const IngestJob *d_ing;
+    IngestJob *h_ing = sc.tabs.take<IngestJob>((size_t) n, &d_ing);
+    const DPlane *d_ext_y, *d_ext_c;
+    DPlane *h_ext_y = sc.tabs.take<DPlane>((size_t) n, &d_ext_y), *h_ext_c = sc.tabs.take<DPlane>(2 * (size_t) n, &d_ext_c);
+    const PlanePair *d_pair[DSV_MAX_PYRAMID_LEVELS];
+    PlanePair *h_pair[DSV_MAX_PYRAMID_LEVELS];
+    const DPlane *d_pext[DSV_MAX_PYRAMID_LEVELS];
+    DPlane *h_pext[DSV_MAX_PYRAMID_LEVELS];
+    for (int l = 0; l < L; l++) {
+        h_pair[l] = sc.tabs.take<PlanePair>(2 * (size_t) n, &d_pair[l]);
+        h_pext[l] = sc.tabs.take<DPlane>(2 * (size_t) n, &d_pext[l]);
+    }
+    const IntraJob *d_intra;
+    IntraJob *h_intra = sc.tabs.take<IntraJob>((size_t) n, &d_intra);
+    int n_ing = 0, n_pyr = 0;
+    for (int k = 0; k < n; k++) {
+        Job &jb = jobs[k];
+        CodecDev &dv = jb.im->dev;
+        PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
+        if (jb.d.params.do_psy != jobs[0].d.params.do_psy) {
+            fatal("dsv2hip_enc_batch: all encoders of a batch must share one do_psy setting", __FILE__, __LINE__);
+        }
+        if (jb.frame) {
+            dframe_upload(&cur.src, jb.frame, bs);
+        } else {
+            h_ing[n_ing].src = jb.dev_planar;
+            for (int c = 0; c < 3; c++) {
+                h_ing[n_ing].dst[c] = cur.src.p[c];
+            }
+            n_ing++;
+        }
+        h_ext_y[k] = cur.src.p[0];
+        h_ext_c[2 * k] = cur.src.p[1];
+        h_ext_c[2 * k + 1] = cur.src.p[2];
+        for (int l = 0; l < L; l++) { // mk_pyramid, dsv_encoder.c:493
+            h_pair[l][n_pyr] = PlanePair{l ? cur.src_pyr[l - 1].p[0] : cur.src.p[0], cur.src_pyr[l].p[0]};
+            h_pext[l][n_pyr] = cur.src_pyr[l].p[0];
+        }
+        n_pyr++;
+        if (jb.d.params.has_ref && !ref.recon_pyr_valid) {
+            for (int l = 0; l < L; l++) {
+                h_pair[l][n_pyr] = PlanePair{l ? ref.recon_pyr[l - 1].p[0] : ref.recon.p[0], ref.recon_pyr[l].p[0]};
+                h_pext[l][n_pyr] = ref.recon_pyr[l].p[0];
+            }
+            n_pyr++;
+            ref.recon_pyr_valid = true;
+        }
+        // the block analysis of an intra picture; also needed when a P frame is flipped to intra in H1
+        for (int c = 0; c < 3; c++) {
+            h_intra[k].src.p[c] = cur.src.p[c];
+        }
+        h_intra[k].out = dv.d_mvs_stage;
+    }
+    sc.tabs.upload(bs);
+    {
+        const DFrame &f0 = dv0.pics[0].src;
+        ingest_batch(bs, d_ing, n_ing, f0.p[0].w, f0.p[0].h + f0.p[1].h + f0.p[2].h);
+        extend_planes(bs, d_ext_y, n, f0.p[0].w, f0.p[0].h);
+        extend_planes(bs, d_ext_c, 2 * n, f0.p[1].w, f0.p[1].h);
+        for (int l = 0; l < L; l++) {
+            const DPlane &lp = dv0.pics[0].src_pyr[l].p[0];
+            ds2x_planes(bs, d_pair[l], n_pyr, lp.w, lp.h);
+            extend_planes(bs, d_pext[l], n_pyr, lp.w, lp.h);
+        }
+        intra_analysis_batch(bs, d_intra, n, analysis_params(dv0, jobs[0].d.params.do_psy));
+    }
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
         PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
         size_t nb = dv.nblocks();
-        if (jb.frame) {
-            dframe_upload(&cur.src, jb.frame, bs);
-        } else {
-            const uint8_t *sp = jb.dev_planar;
-            for (int c = 0; c < 3; c++) {
-                const DPlane &pl = cur.src.p[c];
-                HIPCHK(hipMemcpy2DAsync(pl.data, pl.stride, sp, pl.w, pl.w, pl.h, hipMemcpyDeviceToDevice, bs));
-                sp += (size_t) pl.w * pl.h;
-            }
-        }
-        extend_frame(bs, cur.src, false);
-        build_pyramid_on(bs, dv, cur.src, cur.src_pyr);
         {
             const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
             HIPCHK(hipMemcpy2DAsync(dv.h_small, cp.w, cp.data, cp.stride, cp.w, cp.h, hipMemcpyDeviceToHost, bs));
         }
-        // the block analysis of an intra picture; also needed when a P frame is flipped to intra in H1
-        intra_analysis(bs, cur.src, analysis_params(dv, jb.d.params.do_psy), dv.d_mvs_stage);
         HIPCHK(hipMemcpyAsync(dv.h_intra, dv.d_mvs_stage, nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, bs));
         if (jb.d.params.has_ref) { // motion_est (dsv_encoder.c:653)
-            if (!ref.recon_pyr_valid) {
-                build_pyramid_on(bs, dv, ref.recon, ref.recon_pyr);
-                ref.recon_pyr_valid = true;
-            }
             HmeFrames f;
             f.src[0] = cur.src.p[0];
             f.ref[0] = ref.recon.p[0];
@@ -1213,7 +1321,7 @@ void enc_batch(Job *jobs, int n)
             jb.ran_hme = 1;
         }
     }
-    prof.end(bs, ST_INGEST, 2 * jobs[0].im->dev.pyr_levels + 4);
+    prof.end(bs, ST_INGEST, 2 * L + 4);
     if (!pjobs.empty()) {
         prof.begin(bs, ST_HME);
         int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme);
@@ -1244,16 +1352,33 @@ void enc_batch(Job *jobs, int n)
     t_clock.lap(3);
 
     // ---- G2 ----
-    int nP = 0, nI = 0;
-    bool any_filter = false;
+    // streams are ordered by (frame type, lossless): the transform / quantiser kernels are specialised
+    // on those, so each class is one set of launches over its slice of the job tables
+    std::vector<int> order((size_t) n);
     for (int k = 0; k < n; k++) {
+        order[(size_t) k] = k;
+    }
+    auto cls = [&](int k) { return jobs[k].d.params.has_ref * 2 + jobs[k].d.params.lossless; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls(a) > cls(b); });
+    const CopyJob *d_copy;
+    CopyJob *h_copy = sc.tabs.take<CopyJob>((size_t) n, &d_copy);
+    const PlaneJob *d_py, *d_pc;
+    PlaneJob *h_py = sc.tabs.take<PlaneJob>((size_t) n, &d_py), *h_pc = sc.tabs.take<PlaneJob>(2 * (size_t) n, &d_pc);
+    const CompactJob *d_comp;
+    CompactJob *h_comp = sc.tabs.take<CompactJob>((size_t) n, &d_comp);
+    const DPlane *d_rext_y, *d_rext_c;
+    DPlane *h_rext_y = sc.tabs.take<DPlane>((size_t) n, &d_rext_y), *h_rext_c = sc.tabs.take<DPlane>(2 * (size_t) n, &d_rext_c);
+    int nP = 0, nI = 0, n_rext = 0;
+    bool any_filter = false;
+    for (int i = 0; i < n; i++) {
+        int k = order[(size_t) i];
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
         PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
         const DSV_PARAMS *p = &jb.d.params;
         size_t nb = dv.nblocks();
         // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
-        copy_frame_full(bs, cur.recon, cur.src);
+        h_copy[i] = CopyJob{cur.src.alloc, cur.recon.alloc, cur.src.bytes};
         cur.recon_pyr_valid = false;
         HIPCHK(hipMemcpyAsync(dv.d_blockdata, jb.enc->blockdata, nb, hipMemcpyHostToDevice, bs));
         McJob mj;
@@ -1277,52 +1402,75 @@ void enc_batch(Job *jobs, int n)
                 sc.h_mc[n + nI++] = mj;
             }
         }
+        for (int c = 0; c < 3; c++) {
+            PlaneJob &pj = c ? h_pc[2 * i + c - 1] : h_py[i];
+            pj.pic = cur.recon.p[c];
+            pj.coefs = dv.coefs[c];
+            for (int t = 0; t < 3; t++) {
+                pj.t[t] = c ? dv.scratch_uv[c - 1].t[t] : dv.scratch.t[t];
+            }
+            pj.bd = dv.d_blockdata;
+            pj.qv = dv.qv + dv.qv_off[c];
+            pj.mvs = cur.d_final_mvs;
+            quant_steps(&pj, dv.quant_cfg(c, p->has_ref, p->lossless, p->do_psy, nullptr), jb.d.quant);
+        }
+        h_comp[i] = dv.comp.job(dv.qv, dv.qv_off[3]);
+        h_comp[i].total = sc.d_totals + i;
+        if (jb.enc->frame_callback || (p->is_ref && jb.enc->gop != DSV_GOP_INTRA)) {
+            h_rext_y[n_rext] = cur.recon.p[0];
+            h_rext_c[2 * n_rext] = cur.recon.p[1];
+            h_rext_c[2 * n_rext + 1] = cur.recon.p[2];
+            n_rext++;
+        }
     }
+    sc.tabs.upload(bs);
     HIPCHK(hipMemcpyAsync(sc.d_mc, sc.h_mc, 2 * (size_t) n * sizeof(McJob), hipMemcpyHostToDevice, bs));
+    copy_linear_batch(bs, d_copy, n, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
     mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv);
     prof.end(bs, ST_PREDICT, 1);
-    for (int k = 0; k < n; k++) {
-        Job &jb = jobs[k];
-        CodecDev &dv = jb.im->dev;
-        PicSet &cur = dv.pics[jb.im->cur];
-        const DSV_PARAMS *p = &jb.d.params;
-        bool isP = p->has_ref;
-        BlockMap bm{dv.d_blockdata, dv.nbh, dv.nbv};
-        prof.begin(bs, ST_FWD_SBT);
-        for (int c = 0; c < 3; c++) {
-            DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-            sbt_forward(bs, cur.recon.p[c], co, dv.scratch, c, isP, p->lossless, bm);
+    struct Slice {
+        int first, count, isP, lossless;
+    };
+    std::vector<Slice> slices;
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && cls(order[(size_t) j]) == cls(order[(size_t) i])) {
+            j++;
         }
-        prof.end(bs, ST_FWD_SBT, 3);
-        prof.begin(bs, ST_QUANT);
-        hipLaunchKernelGGL(k_grab_ll, dim3(1), dim3(1), 0, bs, dv.coefs[0], dv.coefs[1], dv.coefs[2], dv.d_ll);
-        for (int c = 0; c < 3; c++) {
-            DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-            quant_plane(bs, co, dv.qv + dv.qv_off[c], dv.quant_cfg(c, isP, p->lossless, p->do_psy, cur.d_final_mvs), jb.d.quant);
-        }
-        dv.comp.run(bs, dv.qv, dv.qv_off[3]);
-        prof.end(bs, ST_QUANT, 3);
-        HIPCHK(hipMemcpyAsync(dv.h_ll, dv.d_ll, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, bs));
-        prof.begin(bs, ST_INV_SBT);
-        for (int c = 0; c < 3; c++) {
-            DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-            sbt_inverse(bs, cur.recon.p[c], co, dv.scratch, jb.d.quant, c, isP, p->lossless, bm);
-        }
-        prof.end(bs, ST_INV_SBT, 3);
+        slices.push_back(Slice{i, j - i, jobs[order[(size_t) i]].d.params.has_ref, jobs[order[(size_t) i]].d.params.lossless});
+        i = j;
     }
+    const int do_psy = jobs[0].d.params.do_psy;
+    prof.begin(bs, ST_FWD_SBT);
+    for (const Slice &sl : slices) {
+        sbt_forward_jobs(bs, d_py + sl.first, sl.count, dv0.cw[0], dv0.ch[0], 0, sl.isP, sl.lossless, nbh, nbv);
+        sbt_forward_jobs(bs, d_pc + 2 * sl.first, 2 * sl.count, dv0.cw[1], dv0.ch[1], 1, sl.isP, sl.lossless, nbh, nbv);
+    }
+    prof.end(bs, ST_FWD_SBT, 3);
+    prof.begin(bs, ST_QUANT);
+    hipLaunchKernelGGL(k_grab_ll, dim3((n + 63) / 64), dim3(64), 0, bs, d_py, d_pc, n, sc.d_ll);
+    HIPCHK(hipMemcpyAsync(sc.h_ll, sc.d_ll, 3 * (size_t) n * sizeof(int32_t), hipMemcpyDeviceToHost, bs));
+    for (const Slice &sl : slices) {
+        quant_jobs(bs, d_py + sl.first, sl.count, dv0.quant_cfg(0, sl.isP, sl.lossless, do_psy, nullptr));
+        quant_jobs(bs, d_pc + 2 * sl.first, 2 * sl.count, dv0.quant_cfg(1, sl.isP, sl.lossless, do_psy, nullptr));
+    }
+    compact_jobs(bs, d_comp, n, dv0.qv_off[3]);
+    HIPCHK(hipMemcpyAsync(sc.h_totals, sc.d_totals, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, bs));
+    prof.end(bs, ST_QUANT, 3);
+    prof.begin(bs, ST_INV_SBT);
+    for (const Slice &sl : slices) {
+        sbt_inverse_jobs(bs, d_py + sl.first, sl.count, dv0.cw[0], dv0.ch[0], 0, sl.isP, sl.lossless, nbh, nbv);
+        sbt_inverse_jobs(bs, d_pc + 2 * sl.first, 2 * sl.count, dv0.cw[1], dv0.ch[1], 1, sl.isP, sl.lossless, nbh, nbv);
+    }
+    prof.end(bs, ST_INV_SBT, 3);
     prof.begin(bs, ST_RECON_FILTER);
     intra_filter_batch(bs, sc.d_mc + n, nI);
     mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter);
     prof.end(bs, ST_RECON_FILTER, 2);
     prof.begin(bs, ST_EXTEND);
-    for (int k = 0; k < n; k++) {
-        Job &jb = jobs[k];
-        const DSV_PARAMS *p = &jb.d.params;
-        if (jb.enc->frame_callback || (p->is_ref && jb.enc->gop != DSV_GOP_INTRA)) {
-            extend_frame(bs, jb.im->dev.pics[jb.im->cur].recon, false);
-        }
-    }
+    extend_planes(bs, d_rext_y, n_rext, dv0.pics[0].recon.p[0].w, dv0.pics[0].recon.p[0].h);
+    extend_planes(bs, d_rext_c, 2 * n_rext, dv0.pics[0].recon.p[1].w, dv0.pics[0].recon.p[1].h);
     prof.end(bs, ST_EXTEND, 3);
     t_clock.lap(4);
     HIPCHK(hipStreamSynchronize(bs));
@@ -1330,7 +1478,11 @@ void enc_batch(Job *jobs, int n)
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
-        jb.nsym = *dv.comp.h_total;
+        int ti = (int) (std::find(order.begin(), order.end(), k) - order.begin()); // this stream's table slot
+        jb.nsym = sc.h_totals[ti];
+        for (int c = 0; c < 3; c++) {
+            dv.h_ll[c] = sc.h_ll[3 * ti + c];
+        }
         dv.ensure_host_syms((size_t) jb.nsym);
         if (jb.nsym) {
             HIPCHK(hipMemcpyAsync(dv.h_pos, dv.comp.d_pos, (size_t) jb.nsym * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));

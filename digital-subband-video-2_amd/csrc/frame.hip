@@ -31,44 +31,44 @@ __device__ __forceinline__ int strip_value(const uint8_t *p, int step, int n, in
     return sum / rem;
 }
 
-// One thread per border row segment / column group.  Roles by linear id:
-//   [0, h)                : row y       -> left and right 32-pixel runs
-//   [h, h + ngx)          : column group -> top and bottom 32 rows of 4 pixels
-//   [h + ngx, h + ngx + 4*32): corner rows
-__global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ base, int stride, int w, int h)
+// One work item per 4-byte piece of border.  Roles by linear id:
+//   [0, 16h)                   : row y, side, piece -> the 32-pixel runs left and right of the row
+//   [.., + 64 * ngx)           : border row, side, column group -> the 32 rows above / below
+//   [.., + 4 * 32 * 8)         : the four corners
+__device__ __forceinline__ void put4(uint8_t *dst, int v, int n)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 4 && (((uintptr_t) dst) & 3) == 0) {
+        *(uint32_t *) dst = (uint32_t) v * 0x01010101u;
+    } else {
+        for (int i = 0; i < n; i++) {
+            dst[i] = (uint8_t) v;
+        }
+    }
+}
+
+__device__ __forceinline__ void extend_item(const DPlane &pl, int id)
+{
+    uint8_t *base = pl.data;
+    int stride = pl.stride, w = pl.w, h = pl.h;
     int ngx = (w + 3) >> 2;
-    if (id < h) {
-        int y = id;
-        int lv = strip_value(base, stride, h, y >> 2);
-        int rv = strip_value(base + (w - 1), stride, h, y >> 2);
+    if (id < 16 * h) {
+        int y = id >> 4, side = (id >> 3) & 1, piece = id & 7;
+        int v = strip_value(side ? base + (w - 1) : base, stride, h, y >> 2);
         uint8_t *row = base + (size_t) y * stride;
-        for (int i = 0; i < kBorder; i++) {
-            row[-kBorder + i] = (uint8_t) lv;
-            row[w + i] = (uint8_t) rv;
-        }
+        put4(side ? row + w + 4 * piece : row - kBorder + 4 * piece, v, 4);
         return;
     }
-    id -= h;
-    if (id < ngx) {
-        int k = id;
-        int tv = strip_value(base, 1, w, k);
-        int bv = strip_value(base + (size_t) (h - 1) * stride, 1, w, k);
-        int x0 = 4 * k, x1 = min(w, x0 + 4);
-        for (int j = 0; j < kBorder; j++) {
-            uint8_t *t = base - (size_t) (j + 1) * stride;
-            uint8_t *b = base + (size_t) (h + j) * stride;
-            for (int x = x0; x < x1; x++) {
-                t[x] = (uint8_t) tv;
-                b[x] = (uint8_t) bv;
-            }
-        }
+    id -= 16 * h;
+    if (id < 2 * kBorder * ngx) {
+        int k = id % ngx, j = (id / ngx) % kBorder, side = id / (ngx * kBorder);
+        int v = strip_value(side ? base + (size_t) (h - 1) * stride : base, 1, w, k);
+        uint8_t *line = side ? base + (size_t) (h + j) * stride : base - (size_t) (j + 1) * stride;
+        put4(line + 4 * k, v, min(4, w - 4 * k));
         return;
     }
-    id -= ngx;
-    if (id < 4 * kBorder) {
-        int corner = id / kBorder, j = id % kBorder;
+    id -= 2 * kBorder * ngx;
+    if (id < 4 * kBorder * 8) {
+        int piece = id & 7, j = (id >> 3) % kBorder, corner = id / (8 * kBorder);
         int lastx = (w >> 2) - 1, lasty = (h >> 2) - 1;
         int v;
         uint8_t *dst;
@@ -85,16 +85,22 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ base, int 
             v = (strip_value(base + (size_t) (h - 1) * stride, 1, w, lastx) + strip_value(base + (w - 1), stride, h, lasty) + 1) >> 1;
             dst = base + (size_t) (h + j) * stride + w;
         }
-        for (int i = 0; i < kBorder; i++) {
-            dst[i] = (uint8_t) v;
-        }
+        put4(dst + 4 * piece, v, 4);
     }
+}
+
+static int extend_items(int w, int h) { return 16 * h + 2 * kBorder * ((w + 3) >> 2) + 4 * kBorder * 8; }
+
+// tab == nullptr: the single plane `one`; otherwise blockIdx.y indexes a device table of planes
+__global__ __launch_bounds__(256) void k_extend(const DPlane *__restrict__ tab, DPlane one)
+{
+    const DPlane &pl = tab ? tab[blockIdx.y] : one;
+    extend_item(pl, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 void extend_plane(hipStream_t s, const DPlane &p)
 {
-    int total = p.h + ((p.w + 3) >> 2) + 4 * kBorder;
-    hipLaunchKernelGGL(k_extend, dim3((total + 255) / 256), dim3(256), 0, s, p.data, p.stride, p.w, p.h);
+    hipLaunchKernelGGL(k_extend, dim3((extend_items(p.w, p.h) + 255) / 256), dim3(256), 0, s, nullptr, p);
 }
 
 void extend_frame(hipStream_t s, const DFrame &f, bool luma_only)
@@ -104,23 +110,40 @@ void extend_frame(hipStream_t s, const DFrame &f, bool luma_only)
     }
 }
 
-// 2x2 rounded mean decimation of the luma plane (frame.c:211-234)
-__global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ src, int sstride, uint8_t *__restrict__ dst,
-                                              int dstride, int dw, int dh)
+// n planes (device table d_planes); max_w / max_h bound the largest of them
+void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int max_h)
 {
-    int x = blockIdx.x * 64 + threadIdx.x;
-    int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= dw || y >= dh) {
+    if (n <= 0) {
         return;
     }
-    const uint8_t *sp = src + (size_t) (2 * y) * sstride + 2 * x;
-    dst[(size_t) y * dstride + x] = (uint8_t) ((sp[0] + sp[1] + sp[sstride] + sp[sstride + 1] + 2) >> 2);
+    hipLaunchKernelGGL(k_extend, dim3((extend_items(max_w, max_h) + 255) / 256, n), dim3(256), 0, s, d_planes, DPlane{});
+}
+
+// 2x2 rounded mean decimation of the luma plane (frame.c:211-234)
+__global__ __launch_bounds__(256) void k_ds2x(const PlanePair *__restrict__ tab, PlanePair one)
+{
+    const PlanePair &pp = tab ? tab[blockIdx.z] : one;
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= pp.dst.w || y >= pp.dst.h) {
+        return;
+    }
+    int sstride = pp.src.stride;
+    const uint8_t *sp = pp.src.data + (size_t) (2 * y) * sstride + 2 * x;
+    pp.dst.data[(size_t) y * pp.dst.stride + x] = (uint8_t) ((sp[0] + sp[1] + sp[sstride] + sp[sstride + 1] + 2) >> 2);
 }
 
 void ds2x_luma(hipStream_t s, const DPlane &src, const DPlane &dst)
 {
-    hipLaunchKernelGGL(k_ds2x, dim3((dst.w + 63) / 64, (dst.h + 3) / 4), dim3(64, 4), 0, s, src.data, src.stride, dst.data,
-                       dst.stride, dst.w, dst.h);
+    hipLaunchKernelGGL(k_ds2x, dim3((dst.w + 63) / 64, (dst.h + 3) / 4), dim3(64, 4), 0, s, nullptr, PlanePair{src, dst});
+}
+
+void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h)
+{
+    if (n <= 0) {
+        return;
+    }
+    hipLaunchKernelGGL(k_ds2x, dim3((dst_w + 63) / 64, (dst_h + 3) / 4, n), dim3(64, 4), 0, s, d_pairs, PlanePair{});
 }
 
 // visible pixels of all planes, device to device (frame.c:186-203 without the extension)
@@ -136,6 +159,68 @@ void copy_frame_pixels(hipStream_t s, const DFrame &dst, const DFrame &src)
 void copy_frame_full(hipStream_t s, const DFrame &dst, const DFrame &src)
 {
     HIPCHK(hipMemcpyAsync(dst.alloc, src.alloc, src.bytes, hipMemcpyDeviceToDevice, s));
+}
+
+// ---- batched copies: blockIdx.y indexes a device table --------------------------------------------
+// linear copy of `bytes` (multiple of 16, 16-byte aligned both sides)
+__global__ __launch_bounds__(256) void k_copy_linear(const CopyJob *__restrict__ tab)
+{
+    const CopyJob &j = tab[blockIdx.y];
+    const uint4 *sp = (const uint4 *) j.src;
+    uint4 *dp = (uint4 *) j.dst;
+    size_t n = j.bytes >> 4;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) {
+        dp[i] = sp[i];
+    }
+}
+
+void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes)
+{
+    if (n <= 0) {
+        return;
+    }
+    size_t vecs = max_bytes >> 4;
+    int gx = (int) ((vecs + 256 * 8 - 1) / (256 * 8));
+    hipLaunchKernelGGL(k_copy_linear, dim3(gx < 1 ? 1 : gx, n), dim3(256), 0, s, d_jobs);
+}
+
+// packed planar picture (rows of exactly w bytes, planes back to back) -> the three padded planes
+__global__ __launch_bounds__(256) void k_ingest(const IngestJob *__restrict__ tab)
+{
+    const IngestJob &j = tab[blockIdx.z];
+    int y = blockIdx.y;
+    const uint8_t *sp = j.src;
+    int c = 0;
+    while (c < 2 && y >= j.dst[c].h) { // plane of this row
+        sp += (size_t) j.dst[c].w * j.dst[c].h;
+        y -= j.dst[c].h;
+        c++;
+    }
+    const DPlane &pl = j.dst[c];
+    if (y >= pl.h) {
+        return;
+    }
+    int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= pl.w) {
+        return;
+    }
+    const uint8_t *srow = sp + (size_t) y * pl.w + x;
+    uint8_t *drow = pl.data + (size_t) y * pl.stride + x;
+    if (x + 4 <= pl.w && ((((uintptr_t) srow) | ((uintptr_t) drow)) & 3) == 0) {
+        *(uint32_t *) drow = *(const uint32_t *) srow;
+    } else {
+        for (int i = 0; i < 4 && x + i < pl.w; i++) {
+            drow[i] = srow[i];
+        }
+    }
+}
+
+void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int total_rows)
+{
+    if (n <= 0) {
+        return;
+    }
+    hipLaunchKernelGGL(k_ingest, dim3((w + 1023) / 1024, total_rows, n), dim3(256), 0, s, d_jobs);
 }
 
 } // namespace dsv2

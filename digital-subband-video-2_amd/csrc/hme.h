@@ -15,6 +15,11 @@ struct AnalysisParams {
 
 // dsv_intra_analysis (hme.c:1836): flags-only DSV_MV field for an I frame
 void intra_analysis(hipStream_t s, const DFrame &src, const AnalysisParams &p, DSV_MV *d_out);
+struct IntraJob {
+    Planes3 src;
+    DSV_MV *out;
+};
+void intra_analysis_batch(hipStream_t s, const IntraJob *d_jobs, int n, const AnalysisParams &p);
 
 struct HmeParams {
     AnalysisParams a;

@@ -11,9 +11,13 @@
 
 namespace dsv2 {
 
-__global__ __launch_bounds__(64) void k_intra_analysis(Planes3 src, AnalysisParams p, DSV_MV *__restrict__ out)
+// tab == nullptr: the single picture `one`; otherwise blockIdx.z indexes a device table of pictures
+__global__ __launch_bounds__(64) void k_intra_analysis(const IntraJob *__restrict__ tab, IntraJob one, AnalysisParams p)
 {
     __shared__ int hist[16];
+    const IntraJob &job = tab ? tab[blockIdx.z] : one;
+    const Planes3 &src = job.src;
+    DSV_MV *out = job.out;
     int i = blockIdx.x, j = blockIdx.y;
     int lane = threadIdx.x;
     DSV_MV *mv = &out[i + j * p.nbh];
@@ -101,7 +105,16 @@ void intra_analysis(hipStream_t s, const DFrame &src, const AnalysisParams &p, D
     for (int c = 0; c < 3; c++) {
         pl.p[c] = src.p[c];
     }
-    hipLaunchKernelGGL(k_intra_analysis, dim3(p.nbh, p.nbv), dim3(64), 0, s, pl, p, d_out);
+    hipLaunchKernelGGL(k_intra_analysis, dim3(p.nbh, p.nbv), dim3(64), 0, s, nullptr, IntraJob{pl, d_out}, p);
+    HIPCHK(hipGetLastError());
+}
+
+void intra_analysis_batch(hipStream_t s, const IntraJob *d_jobs, int n, const AnalysisParams &p)
+{
+    if (n <= 0) {
+        return;
+    }
+    hipLaunchKernelGGL(k_intra_analysis, dim3(p.nbh, p.nbv, n), dim3(64), 0, s, d_jobs, IntraJob{}, p);
     HIPCHK(hipGetLastError());
 }
 

@@ -25,6 +25,17 @@ int spatial_psy_factor(int blk_w, int blk_h, int nbh, int nbv, int sub);
 
 // quantise + dequantise `coefs` in place, dense quantised values to qv[scan position]
 void quant_plane(hipStream_t s, DCoefs coefs, int32_t *qv, const QuantCfg &cfg, int q);
+// table form: n PlaneJob records (coefs, qv, bd, mvs and the step sizes filled by quant_steps) sharing `cfg`
+void quant_steps(PlaneJob *job, const QuantCfg &cfg, int q);
+void quant_jobs(hipStream_t s, const PlaneJob *d_jobs, int n, const QuantCfg &cfg);
+
+struct CompactJob {
+    const int32_t *qv;
+    int n;
+    int *tile_count, *tile_base, *total;
+    uint32_t *pos;
+    int32_t *val;
+};
 
 // ordered stream compaction of nonzero entries of a dense int32 array
 struct Compactor {
@@ -37,7 +48,10 @@ struct Compactor {
     void release();
     // after the stream reaches this point *h_total holds the count and d_pos/d_val the symbols
     void run(hipStream_t s, const int32_t *qv, size_t n);
+    CompactJob job(const int32_t *qv, size_t n); // this compactor's buffers as a table entry
 };
+// njobs compactions of n values each in one set of launches; each job's count lands in *job.total
+void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n);
 
 // decoder: scatter + dequantise symbols sorted by scan position; seg_count = {LL, l0, l1, l2}
 void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int32_t *d_val, const int seg_count[4],

@@ -139,7 +139,7 @@ struct LevelArgs {
     int sw, sh;
     int dbx, dby;
     int xdep, ydep;
-    int off[3], par[3], gpar[3], qp[3], base[3];
+    int off[3], par[3], gpar[3], base[3];
 };
 
 __device__ __forceinline__ int quant_sub(int v, int q, int sub) { return (v >= 0 ? v - sub : v + sub) / q; }
@@ -182,15 +182,15 @@ __device__ __forceinline__ int tmq_for_I(int tmq, int flags, int parc, int l) //
     return tmq;
 }
 
-__device__ __forceinline__ int quant_detail(const QuantCfg &c, int val, int qp, int l, int flags, int bi, int parc, int gparc,
-                                            int &tmq_out)
+__device__ __forceinline__ int quant_detail(const QuantCfg &c, const DSV_MV *mvs, int val, int qp, int l, int flags, int bi, int parc,
+                                            int gparc, int &tmq_out)
 {
     int tmq = qp, v;
     bool texture = !parc, gtexture = !gparc;
     if (c.isP) {
         tmq = tmq_for_P(tmq, flags, parc);
         if ((c.do_psy & DSV_PSY_P_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:371-380
-            DSV_MV mv = c.mvs[bi];
+            DSV_MV mv = mvs[bi];
             bool small_mv = abs((int) mv.u.mv.x) < 32 && abs((int) mv.u.mv.y) < 32;
             if ((gtexture && texture) || (mv.flags & (1u << DSV_MV_BIT_EPRM)) ||
                 ((mv.flags & (1u << DSV_MV_BIT_MAINTAIN)) && small_mv)) {
@@ -233,18 +233,22 @@ __device__ __forceinline__ int quant_detail(const QuantCfg &c, int val, int qp, 
     return v;
 }
 
+// Kernels work through PlaneJob records (dev.h): tab == nullptr runs the single job `one`,
+// otherwise a grid dimension indexes a device table whose entries share the geometry in `c`.
+
 // LL region: hzcc.c:308-328
-__global__ __launch_bounds__(256) void k_quant_ll(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, QuantCfg c, int sw,
-                                                  int sh, int qp)
+__global__ __launch_bounds__(256) void k_quant_ll(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, int sw, int sh)
 {
+    const PlaneJob &J = tab ? tab[blockIdx.z] : one;
     int x = blockIdx.x * 64 + threadIdx.x;
     int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= sw || y >= sh) {
         return;
     }
+    int qp = J.qll;
     int v = 0;
     if (x | y) { // the global DC is transmitted separately and never quantised (hzcc.c:265,599-602)
-        int32_t *cell = coefs + (size_t) y * c.w + x;
+        int32_t *cell = J.coefs + (size_t) y * c.w + x;
         if (c.lossless) {
             v = *cell;
         } else {
@@ -253,12 +257,12 @@ __global__ __launch_bounds__(256) void k_quant_ll(int32_t *__restrict__ coefs, i
             *cell = v ? (c.isP ? dequant_D(v, (unsigned) qp) : dequant_S(v, (unsigned) qp)) : 0;
         }
     }
-    qv[(size_t) y * sw + x] = v;
+    J.qv[(size_t) y * sw + x] = v;
 }
 
-__device__ __forceinline__ void quant_cell(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, const QuantCfg &c,
-                                           const LevelArgs &a, int si, int x, int y)
+__device__ __forceinline__ void quant_cell(const PlaneJob &J, const QuantCfg &c, const LevelArgs &a, int si, int x, int y)
 {
+    int32_t *coefs = J.coefs;
     int32_t *cell = coefs + a.off[si] + (size_t) y * c.w + x;
     int v;
     if (c.lossless) {
@@ -268,10 +272,10 @@ __device__ __forceinline__ void quant_cell(int32_t *__restrict__ coefs, int32_t 
         int parc = coefs[a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1)];
         int gparc = coefs[a.gpar[si] + (size_t) (y >> 2) * c.w + (x >> 2)];
         int tmq;
-        v = quant_detail(c, *cell, a.qp[si], a.l, c.bd[bi], bi, parc, gparc, tmq);
+        v = quant_detail(c, J.mvs, *cell, J.qp[a.l][si], a.l, J.bd[bi], bi, parc, gparc, tmq);
         *cell = v ? dequant_D(v, (unsigned) tmq) : 0;
     }
-    qv[a.base[si] + (size_t) y * a.sw + x] = v;
+    J.qv[a.base[si] + (size_t) y * a.sw + x] = v;
 }
 
 __device__ __forceinline__ bool is_dependent(const LevelArgs &a, int s, int x, int y)
@@ -279,23 +283,23 @@ __device__ __forceinline__ bool is_dependent(const LevelArgs &a, int s, int x, i
     return ((s & 1) && a.xdep && x == a.sw - 1) || ((s & 2) && a.ydep && y == a.sh - 1);
 }
 
-// phase A of a detail level: every cell that is not a dependent; blockIdx.z = subband - 1
-__global__ __launch_bounds__(256) void k_quant_level(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, QuantCfg c,
-                                                     LevelArgs a)
+// phase A of a detail level: every cell that is not a dependent; blockIdx.z = 3 * job + (subband - 1)
+__global__ __launch_bounds__(256) void k_quant_level(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
 {
     int x = blockIdx.x * 64 + threadIdx.x;
     int y = blockIdx.y * 4 + threadIdx.y;
-    int si = blockIdx.z;
+    int si = blockIdx.z % 3;
+    const PlaneJob &J = tab ? tab[blockIdx.z / 3] : one;
     if (x >= a.sw || y >= a.sh || is_dependent(a, si + 1, x, y)) {
         return;
     }
-    quant_cell(coefs, qv, c, a, si, x, y);
+    quant_cell(J, c, a, si, x, y);
 }
 
-// phase B: the dependents (last column, then last row without the shared corner)
-__global__ __launch_bounds__(256) void k_quant_level_dep(int32_t *__restrict__ coefs, int32_t *__restrict__ qv, QuantCfg c,
-                                                         LevelArgs a)
+// phase B: the dependents (last column, then last row without the shared corner); blockIdx.y = subband - 1
+__global__ __launch_bounds__(256) void k_quant_level_dep(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
 {
+    const PlaneJob &J = tab ? tab[blockIdx.z] : one;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int si = blockIdx.y;
     int x, y;
@@ -311,39 +315,67 @@ __global__ __launch_bounds__(256) void k_quant_level_dep(int32_t *__restrict__ c
     if (!is_dependent(a, si + 1, x, y)) {
         return;
     }
-    quant_cell(coefs, qv, c, a, si, x, y);
+    quant_cell(J, c, a, si, x, y);
+}
+
+void quant_steps(PlaneJob *job, const QuantCfg &cfg, int q)
+{
+    int qf = q * 3 / 2; // fix_quant, hzcc.c:59
+    job->q = q;
+    job->qll = cfg.lossless ? 1 : lfquant(cfg, qf);
+    for (int l = 0; l < 3; l++) {
+        for (int si = 0; si < 3; si++) {
+            job->qp[l][si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
+        }
+    }
+}
+
+static void quant_launch(hipStream_t s, const PlaneJob *tab, const PlaneJob &one, int n, const QuantCfg &cfg)
+{
+    ScanGeom g;
+    make_scan(&g, cfg.w, cfg.h);
+    const dim3 blk(64, 4);
+    unsigned nz = tab ? (unsigned) n : 1u;
+    hipLaunchKernelGGL(k_quant_ll, dim3((g.sw[0] + 63) / 64, (g.sh[0] + 3) / 4, nz), blk, 0, s, tab, one, cfg, g.sw[0], g.sh[0]);
+    for (int l = 0; l < 3; l++) {
+        LevelArgs a;
+        a.l = l;
+        a.sw = h_dimat(l, cfg.w);
+        a.sh = h_dimat(l, cfg.h);
+        a.dbx = (cfg.nbh << kBlockP) / a.sw;
+        a.dby = (cfg.nbv << kBlockP) / a.sh;
+        a.xdep = 2 * h_dimat(l - 1, cfg.w) > a.sw;
+        a.ydep = 2 * h_dimat(l - 1, cfg.h) > a.sh;
+        for (int si = 0; si < 3; si++) {
+            a.off[si] = g.off[1 + 3 * l + si];
+            a.base[si] = g.base[1 + 3 * l + si];
+            a.par[si] = h_subband_off(l - 1, si + 1, cfg.w, cfg.h);
+            a.gpar[si] = h_subband_off(l - 2, si + 1, cfg.w, cfg.h);
+        }
+        hipLaunchKernelGGL(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
+        if (a.xdep || a.ydep) {
+            hipLaunchKernelGGL(k_quant_level_dep, dim3((a.sw + a.sh + 255) / 256, 3, nz), dim3(256), 0, s, tab, one, cfg, a);
+        }
+    }
+    HIPCHK(hipGetLastError());
 }
 
 void quant_plane(hipStream_t s, DCoefs coefs, int32_t *qv, const QuantCfg &cfg, int q)
 {
-    ScanGeom g;
-    make_scan(&g, coefs.w, coefs.h);
-    int qf = q * 3 / 2; // fix_quant, hzcc.c:59
-    const dim3 blk(64, 4);
-    hipLaunchKernelGGL(k_quant_ll, dim3((g.sw[0] + 63) / 64, (g.sh[0] + 3) / 4), blk, 0, s, coefs.data, qv, cfg, g.sw[0], g.sh[0],
-                       cfg.lossless ? 1 : lfquant(cfg, qf));
-    for (int l = 0; l < 3; l++) {
-        LevelArgs a;
-        a.l = l;
-        a.sw = h_dimat(l, coefs.w);
-        a.sh = h_dimat(l, coefs.h);
-        a.dbx = (cfg.nbh << kBlockP) / a.sw;
-        a.dby = (cfg.nbv << kBlockP) / a.sh;
-        a.xdep = 2 * h_dimat(l - 1, coefs.w) > a.sw;
-        a.ydep = 2 * h_dimat(l - 1, coefs.h) > a.sh;
-        for (int si = 0; si < 3; si++) {
-            a.off[si] = g.off[1 + 3 * l + si];
-            a.base[si] = g.base[1 + 3 * l + si];
-            a.par[si] = h_subband_off(l - 1, si + 1, coefs.w, coefs.h);
-            a.gpar[si] = h_subband_off(l - 2, si + 1, coefs.w, coefs.h);
-            a.qp[si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
-        }
-        hipLaunchKernelGGL(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3), blk, 0, s, coefs.data, qv, cfg, a);
-        if (a.xdep || a.ydep) {
-            hipLaunchKernelGGL(k_quant_level_dep, dim3((a.sw + a.sh + 255) / 256, 3), dim3(256), 0, s, coefs.data, qv, cfg, a);
-        }
+    PlaneJob one = {};
+    one.coefs = coefs.data;
+    one.qv = qv;
+    one.bd = cfg.bd;
+    one.mvs = cfg.mvs;
+    quant_steps(&one, cfg, q);
+    quant_launch(s, nullptr, one, 1, cfg);
+}
+
+void quant_jobs(hipStream_t s, const PlaneJob *d_jobs, int n, const QuantCfg &cfg)
+{
+    if (n > 0) {
+        quant_launch(s, d_jobs, PlaneJob{}, n, cfg);
     }
-    HIPCHK(hipGetLastError());
 }
 
 // ---- ordered compaction of the nonzero symbols ---------------------------------------
@@ -363,9 +395,13 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_count(const int32_t *__restrict__ qv, int n, int *__restrict__ tile_count)
+__global__ __launch_bounds__(256) void k_count(const CompactJob *__restrict__ tab, CompactJob one)
 {
     __shared__ int wsum[4];
+    const CompactJob &J = tab ? tab[blockIdx.y] : one;
+    const int32_t *qv = J.qv;
+    int n = J.n;
+    int *tile_count = J.tile_count;
     int base = blockIdx.x * kTile;
     int cnt = 0;
 #pragma unroll
@@ -385,10 +421,13 @@ __global__ __launch_bounds__(256) void k_count(const int32_t *__restrict__ qv, i
 }
 
 // exclusive scan of up to 1024*ntile_per_thread tile counts by one workgroup; also emits the total
-__global__ __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ tile_count, int ntiles, int *__restrict__ tile_base,
-                                                     int *__restrict__ total)
+__global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restrict__ tab, CompactJob one)
 {
     __shared__ int wsum[16];
+    const CompactJob &J = tab ? tab[blockIdx.y] : one;
+    const int *tile_count = J.tile_count;
+    int ntiles = (J.n + kTile - 1) / kTile;
+    int *tile_base = J.tile_base, *total = J.total;
     __shared__ int carry;
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
@@ -422,10 +461,15 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ til
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter(const int32_t *__restrict__ qv, int n, const int *__restrict__ tile_base,
-                                                 uint32_t *__restrict__ out_pos, int32_t *__restrict__ out_val)
+__global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ tab, CompactJob one)
 {
     __shared__ int wsum[4];
+    const CompactJob &J = tab ? tab[blockIdx.y] : one;
+    const int32_t *qv = J.qv;
+    int n = J.n;
+    const int *tile_base = J.tile_base;
+    uint32_t *out_pos = J.pos;
+    int32_t *out_val = J.val;
     int base = blockIdx.x * kTile;
     int vals[4];
     int cnt = 0;
@@ -485,14 +529,32 @@ void Compactor::release()
     cap = 0;
 }
 
-void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
+CompactJob Compactor::job(const int32_t *qv, size_t n)
 {
     ensure(n);
+    return CompactJob{qv, (int) n, tile_count, tile_base, d_total, d_pos, d_val};
+}
+
+void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
+{
+    CompactJob one = job(qv, n);
     int ntiles = (int) ((n + kTile - 1) / kTile);
-    hipLaunchKernelGGL(k_count, dim3(ntiles), dim3(256), 0, s, qv, (int) n, tile_count);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntiles, tile_base, d_total);
-    hipLaunchKernelGGL(k_scatter, dim3(ntiles), dim3(256), 0, s, qv, (int) n, tile_base, d_pos, d_val);
+    hipLaunchKernelGGL(k_count, dim3(ntiles), dim3(256), 0, s, nullptr, one);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, nullptr, one);
+    hipLaunchKernelGGL(k_scatter, dim3(ntiles), dim3(256), 0, s, nullptr, one);
     HIPCHK(hipMemcpyAsync(h_total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipGetLastError());
+}
+
+void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n)
+{
+    if (njobs <= 0) {
+        return;
+    }
+    int ntiles = (int) ((n + kTile - 1) / kTile);
+    hipLaunchKernelGGL(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1, njobs), dim3(1024), 0, s, d_jobs, CompactJob{});
+    hipLaunchKernelGGL(k_scatter, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     HIPCHK(hipGetLastError());
 }
 

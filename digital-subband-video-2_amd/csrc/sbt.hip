@@ -263,31 +263,44 @@ template <int F> __device__ __forceinline__ void synthesis_pair(const Syn &v, co
 }
 
 // ---- kernels ----------------------------------------------------------------------
+// Every kernel works through PlaneJob records: tab == nullptr runs the single job `one`, otherwise
+// blockIdx.z indexes a device table (one entry per stream and plane of a lockstep batch; all entries
+// share the geometry `g`).  Images are named by selector: 0..2 = the job's scratch images, 3 = its
+// coefficient plane.
 struct LevelGeom {
     int w;      // row stride of every int32 image (= coefficient plane width)
     int sw, sh; // size of the LL image being analysed / synthesised at this level
     int hw, hh; // ceil halves
-    const uint8_t *bd;
+    int use_bd; // adaptive filter: consult the job's block flag bytes
     int nbh;
     int dbx, dby;
 };
 
-template <int F, bool U8>
-__global__ __launch_bounds__(256) void k_fwd_rows(const int32_t *__restrict__ S, const uint8_t *__restrict__ U, int ustride,
-                                                  int ph, int32_t *__restrict__ R, LevelGeom g)
+enum { IMG_COEFS = 3 };
+
+__device__ __forceinline__ const PlaneJob &pick_job(const PlaneJob *tab, const PlaneJob &one)
 {
+    return tab ? tab[blockIdx.z] : one;
+}
+__device__ __forceinline__ int32_t *img(const PlaneJob &J, int sel) { return sel == IMG_COEFS ? J.coefs : J.t[sel]; }
+
+template <int F, bool U8>
+__global__ __launch_bounds__(256) void k_fwd_rows(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel)
+{
+    const PlaneJob &J = pick_job(tab, one);
     int k = blockIdx.x * 64 + threadIdx.x;
     int j = blockIdx.y * 4 + threadIdx.y;
     if (k >= g.hw || j >= g.sh) {
         return;
     }
-    Ring r{g.bd ? g.bd + ((j * g.dby) >> kBlockP) * g.nbh : nullptr, 2 * g.dbx, 1};
+    int32_t *R = J.t[2];
+    Ring r{g.use_bd ? J.bd + ((j * g.dby) >> kBlockP) * g.nbh : nullptr, 2 * g.dbx, 1};
     int L, H;
     if (U8) {
-        VecU8 v{U + (size_t) j * ustride, g.sw, j < ph};
+        VecU8 v{J.pic.data + (size_t) j * J.pic.stride, g.sw, j < J.pic.h};
         analysis_pair<F>(v, r, k, L, H);
     } else {
-        VecI v{S + (size_t) j * g.w, 1, g.sw};
+        VecI v{img(J, s_sel) + (size_t) j * g.w, 1, g.sw};
         analysis_pair<F>(v, r, k, L, H);
     }
     R[(size_t) j * g.w + k] = L;
@@ -297,16 +310,17 @@ __global__ __launch_bounds__(256) void k_fwd_rows(const int32_t *__restrict__ S,
 }
 
 template <int F>
-__global__ __launch_bounds__(256) void k_fwd_cols(const int32_t *__restrict__ R, int32_t *__restrict__ D,
-                                                  int32_t *__restrict__ C, LevelGeom g)
+__global__ __launch_bounds__(256) void k_fwd_cols(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel)
 {
+    const PlaneJob &J = pick_job(tab, one);
     int i = blockIdx.x * 64 + threadIdx.x;
     int k = blockIdx.y * 4 + threadIdx.y;
     if (i >= g.sw || k >= g.hh) {
         return;
     }
-    Ring r{g.bd ? g.bd + ((i * g.dbx) >> kBlockP) : nullptr, 2 * g.dby, g.nbh};
-    VecI v{R + i, g.w, g.sh};
+    int32_t *D = img(J, d_sel), *C = J.coefs;
+    Ring r{g.use_bd ? J.bd + ((i * g.dbx) >> kBlockP) : nullptr, 2 * g.dby, g.nbh};
+    VecI v{J.t[2] + i, g.w, g.sh};
     int L, H;
     analysis_pair<F>(v, r, k, L, H);
     if (i < g.hw) {
@@ -320,20 +334,22 @@ __global__ __launch_bounds__(256) void k_fwd_cols(const int32_t *__restrict__ R,
 }
 
 template <bool U8>
-__global__ __launch_bounds__(256) void k_fwd_haar(const int32_t *__restrict__ S, const uint8_t *__restrict__ U, int ustride,
-                                                  int ph, int32_t *__restrict__ D, int32_t *__restrict__ C, LevelGeom g,
-                                                  int ovf)
+__global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel,
+                                                  int d_sel, int ovf)
 {
+    const PlaneJob &J = pick_job(tab, one);
     int idx = blockIdx.x * 64 + threadIdx.x;
     int jy = blockIdx.y * 4 + threadIdx.y;
     if (idx >= g.hw || jy >= g.hh) {
         return;
     }
+    int32_t *D = img(J, d_sel), *C = J.coefs;
     int x = 2 * idx, y = 2 * jy;
     bool hasx = (x + 1) < g.sw, hasy = (y + 1) < g.sh;
     int x0, x1 = 0, x2 = 0, x3 = 0;
     if (U8) {
-        const uint8_t *r0 = U + (size_t) y * ustride + x;
+        int ustride = J.pic.stride, ph = J.pic.h;
+        const uint8_t *r0 = J.pic.data + (size_t) y * ustride + x;
         const uint8_t *r1 = r0 + ustride;
         bool l0 = y < ph, l1 = (y + 1) < ph;
         x0 = l0 ? (int) r0[0] - 128 : 0;
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar(const int32_t *__restrict__ S,
             }
         }
     } else {
-        const int32_t *r0 = S + (size_t) y * g.w + x;
+        const int32_t *r0 = img(J, s_sel) + (size_t) y * g.w + x;
         x0 = r0[0];
         if (hasx) {
             x1 = r0[1];
@@ -400,17 +416,20 @@ __device__ __forceinline__ int nudge(int LL, int lp, int ln, int band, int hqp) 
 
 __device__ __forceinline__ uint8_t to_px(int v) { return (uint8_t) clampi(v + 128, 0, 255); }
 
-// LLp: image holding the LL quadrant of this level; C: coefficient plane with the high bands.
+// ll_sel: image holding the LL quadrant of this level; the coefficient plane holds the high bands.
+// hdiv: the smoothing clamp is the job's quantiser / hdiv (sbt.c:903)
 template <bool OUT_U8>
-__global__ __launch_bounds__(256) void k_inv_haar(const int32_t *__restrict__ LLp, const int32_t *__restrict__ C,
-                                                  int32_t *__restrict__ D, uint8_t *__restrict__ U, int ustride, int pw,
-                                                  int ph, LevelGeom g, int ovf, int filtered, int hqp)
+__global__ __launch_bounds__(256) void k_inv_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel,
+                                                  int d_sel, int ovf, int filtered, int hdiv)
 {
+    const PlaneJob &J = pick_job(tab, one);
     int idx = blockIdx.x * 64 + threadIdx.x;
     int jy = blockIdx.y * 4 + threadIdx.y;
     if (idx >= g.hw || jy >= g.hh) {
         return;
     }
+    const int32_t *LLp = img(J, ll_sel), *C = J.coefs;
+    int hqp = J.q / hdiv;
     int x = 2 * idx, y = 2 * jy;
     bool hasx = (x + 1) < g.sw, hasy = (y + 1) < g.sh;
     size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
@@ -448,7 +467,8 @@ __global__ __launch_bounds__(256) void k_inv_haar(const int32_t *__restrict__ LL
         v00 = LL / 4;
     }
     if (OUT_U8) {
-        uint8_t *r0 = U + (size_t) y * ustride + x;
+        int ustride = J.pic.stride, pw = J.pic.w, ph = J.pic.h;
+        uint8_t *r0 = J.pic.data + (size_t) y * ustride + x;
         if (y < ph) {
             if (x < pw) {
                 r0[0] = to_px(v00);
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(256) void k_inv_haar(const int32_t *__restrict__ LL
             }
         }
     } else {
-        int32_t *r0 = D + (size_t) y * g.w + x;
+        int32_t *r0 = J.t[d_sel] + (size_t) y * g.w + x;
         r0[0] = v00;
         if (hasx) {
             r0[1] = v01;
@@ -480,17 +500,19 @@ __global__ __launch_bounds__(256) void k_inv_haar(const int32_t *__restrict__ LL
     }
 }
 
-// columns first (sbt.c:467-469): packed column i of the Mallat image -> full column in R
+// columns first (sbt.c:467-469): packed column i of the Mallat image -> full column in scratch image 2
 template <int F>
-__global__ __launch_bounds__(256) void k_inv_cols(const int32_t *__restrict__ LLp, const int32_t *__restrict__ C,
-                                                  int32_t *__restrict__ R, LevelGeom g)
+__global__ __launch_bounds__(256) void k_inv_cols(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel)
 {
+    const PlaneJob &J = pick_job(tab, one);
     int i = blockIdx.x * 64 + threadIdx.x;
     int k = blockIdx.y * 4 + threadIdx.y;
     if (i >= g.sw || k >= g.hh) {
         return;
     }
-    Ring r{g.bd ? g.bd + ((i * g.dbx) >> kBlockP) : nullptr, 2 * g.dby, g.nbh};
+    const int32_t *LLp = img(J, ll_sel), *C = J.coefs;
+    int32_t *R = J.t[2];
+    Ring r{g.use_bd ? J.bd + ((i * g.dbx) >> kBlockP) : nullptr, 2 * g.dby, g.nbh};
     Syn v{(i < g.hw) ? LLp + i : C + i, C + (size_t) g.hh * g.w + i, g.w, g.sh};
     int xe, xo;
     synthesis_pair<F>(v, r, k, xe, xo);
@@ -501,21 +523,23 @@ __global__ __launch_bounds__(256) void k_inv_cols(const int32_t *__restrict__ LL
 }
 
 template <int F, bool OUT_U8>
-__global__ __launch_bounds__(256) void k_inv_rows(const int32_t *__restrict__ R, int32_t *__restrict__ D,
-                                                  uint8_t *__restrict__ U, int ustride, int pw, int ph, LevelGeom g)
+__global__ __launch_bounds__(256) void k_inv_rows(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel)
 {
+    const PlaneJob &J = pick_job(tab, one);
     int k = blockIdx.x * 64 + threadIdx.x;
     int j = blockIdx.y * 4 + threadIdx.y;
     if (k >= g.hw || j >= g.sh) {
         return;
     }
-    Ring r{g.bd ? g.bd + ((j * g.dby) >> kBlockP) * g.nbh : nullptr, 2 * g.dbx, 1};
+    const int32_t *R = J.t[2];
+    Ring r{g.use_bd ? J.bd + ((j * g.dby) >> kBlockP) * g.nbh : nullptr, 2 * g.dbx, 1};
     Syn v{R + (size_t) j * g.w, R + (size_t) j * g.w + g.hw, 1, g.sw};
     int xe, xo;
     synthesis_pair<F>(v, r, k, xe, xo);
     if (OUT_U8) {
-        if (j < ph) {
-            uint8_t *o = U + (size_t) j * ustride + 2 * k;
+        int pw = J.pic.w;
+        if (j < J.pic.h) {
+            uint8_t *o = J.pic.data + (size_t) j * J.pic.stride + 2 * k;
             if (2 * k < pw) {
                 o[0] = to_px(xe);
             }
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(256) void k_inv_rows(const int32_t *__restrict__ R,
             }
         }
     } else {
-        int32_t *o = D + (size_t) j * g.w + 2 * k;
+        int32_t *o = J.t[d_sel] + (size_t) j * g.w + 2 * k;
         o[0] = xe;
         if (2 * k + 1 < g.sw) {
             o[1] = xo;
@@ -533,35 +557,35 @@ __global__ __launch_bounds__(256) void k_inv_rows(const int32_t *__restrict__ R,
 }
 
 // ---- host drivers -------------------------------------------------------------------
-static dim3 grid2(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4); }
+struct Batch { // what a launch iterates over: a device table of n jobs, or the one job passed by value
+    const PlaneJob *tab;
+    PlaneJob one;
+    int n;
+};
+static dim3 grid3(int nx, int ny, const Batch &b) { return dim3((nx + 63) / 64, (ny + 3) / 4, b.tab ? b.n : 1); }
 static const dim3 kBlk(64, 4);
 
-template <int F>
-static void launch_fwd_sep(hipStream_t s, bool u8, const int32_t *S, const DPlane &src, int32_t *R, int32_t *D,
-                           int32_t *C, const LevelGeom &g)
+template <int F> static void launch_fwd_sep(hipStream_t s, const Batch &b, bool u8, const LevelGeom &g, int s_sel, int d_sel)
 {
     if (u8) {
-        hipLaunchKernelGGL((k_fwd_rows<F, true>), grid2(g.hw, g.sh), kBlk, 0, s, nullptr, src.data, src.stride, src.h, R, g);
+        hipLaunchKernelGGL((k_fwd_rows<F, true>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, s_sel);
     } else {
-        hipLaunchKernelGGL((k_fwd_rows<F, false>), grid2(g.hw, g.sh), kBlk, 0, s, S, nullptr, 0, 0, R, g);
+        hipLaunchKernelGGL((k_fwd_rows<F, false>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, s_sel);
     }
-    hipLaunchKernelGGL((k_fwd_cols<F>), grid2(g.sw, g.hh), kBlk, 0, s, R, D, C, g);
+    hipLaunchKernelGGL((k_fwd_cols<F>), grid3(g.sw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
 }
 
-template <int F>
-static void launch_inv_sep(hipStream_t s, bool u8, const int32_t *LLp, const int32_t *C, int32_t *R, int32_t *D,
-                           const DPlane &dst, const LevelGeom &g)
+template <int F> static void launch_inv_sep(hipStream_t s, const Batch &b, bool u8, const LevelGeom &g, int ll_sel, int d_sel)
 {
-    hipLaunchKernelGGL((k_inv_cols<F>), grid2(g.sw, g.hh), kBlk, 0, s, LLp, C, R, g);
+    hipLaunchKernelGGL((k_inv_cols<F>), grid3(g.sw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel);
     if (u8) {
-        hipLaunchKernelGGL((k_inv_rows<F, true>), grid2(g.hw, g.sh), kBlk, 0, s, R, nullptr, dst.data, dst.stride, dst.w,
-                           dst.h, g);
+        hipLaunchKernelGGL((k_inv_rows<F, true>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
     } else {
-        hipLaunchKernelGGL((k_inv_rows<F, false>), grid2(g.hw, g.sh), kBlk, 0, s, R, D, nullptr, 0, 0, 0, g);
+        hipLaunchKernelGGL((k_inv_rows<F, false>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
     }
 }
 
-static LevelGeom level_geom(int cw, int ch, int l, int filter, BlockMap bm, bool forward)
+static LevelGeom level_geom(int cw, int ch, int l, int filter, int nbh, int nbv, bool have_bd, bool forward)
 {
     LevelGeom g;
     g.w = cw;
@@ -569,96 +593,130 @@ static LevelGeom level_geom(int cw, int ch, int l, int filter, BlockMap bm, bool
     g.sh = rshift_up(ch, l - 1);
     g.hw = (g.sw + 1) / 2;
     g.hh = (g.sh + 1) / 2;
-    g.bd = nullptr;
-    g.nbh = bm.nbh;
+    g.use_bd = 0;
+    g.nbh = nbh;
     g.dbx = g.dby = 0;
     if (filter == F_L2A || (filter == F_L1 && forward)) {
-        if (!bm.bd) {
+        if (!have_bd) {
             fatal("adaptive subband filter needs blockdata", __FILE__, __LINE__);
         }
-        g.bd = bm.bd;
-        g.dbx = (bm.nbh << kBlockP) / g.sw;
-        g.dby = (bm.nbv << kBlockP) / g.sh;
+        g.use_bd = 1;
+        g.dbx = (nbh << kBlockP) / g.sw;
+        g.dby = (nbv << kBlockP) / g.sh;
     }
     return g;
+}
+
+static void fwd_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_idx, int isP, int lossless, int nbh, int nbv,
+                       bool have_bd)
+{
+    int lvls = host_lb2((unsigned) (cw > ch ? cw : ch));
+    for (int l = 1; l <= lvls; l++) {
+        // level l reads the LL image written by level l-1 and writes its own LL to the other scratch
+        int s_sel = l & 1;
+        int d_sel = (l == lvls) ? IMG_COEFS : ((l - 1) & 1);
+        int filter = pick_filter(plane_idx, isP, lossless, l, lvls);
+        LevelGeom g = level_geom(cw, ch, l, filter, nbh, nbv, have_bd, true);
+        int ovf = (l >= 6 && l >= (lvls - 3) && !lossless); // sbt.c:29
+        bool u8 = (l == 1);
+        switch (filter) {
+            case F_HAAR:
+                if (u8) {
+                    hipLaunchKernelGGL((k_fwd_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
+                } else {
+                    hipLaunchKernelGGL((k_fwd_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
+                }
+                break;
+            case F_LLI: launch_fwd_sep<F_LLI>(s, b, u8, g, s_sel, d_sel); break;
+            case F_LLP: launch_fwd_sep<F_LLP>(s, b, u8, g, s_sel, d_sel); break;
+            case F_CC: launch_fwd_sep<F_CC>(s, b, u8, g, s_sel, d_sel); break;
+            case F_L2A: launch_fwd_sep<F_L2A>(s, b, u8, g, s_sel, d_sel); break;
+            case F_L1: launch_fwd_sep<F_L1>(s, b, u8, g, s_sel, d_sel); break;
+            default: launch_fwd_sep<F_LOSSLESS>(s, b, u8, g, s_sel, d_sel); break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+}
+
+static void inv_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_idx, int isP, int lossless, int nbh, int nbv,
+                       bool have_bd)
+{
+    int lvls = host_lb2((unsigned) (cw > ch ? cw : ch));
+    int ll_sel = IMG_COEFS, d_sel = 0;
+    for (int l = lvls; l > 0; l--) {
+        int filter = pick_filter(plane_idx, isP, lossless, l, lvls);
+        LevelGeom g = level_geom(cw, ch, l, filter, nbh, nbv, have_bd, false);
+        int ovf = (l >= 6 && l >= (lvls - 3) && !lossless);
+        bool u8 = (l == 1);
+        switch (filter) {
+            case F_HAAR: {
+                int hdiv = (plane_idx == 0) ? (isP ? 14 : (l > 4 ? 2 : 8)) : 2;   // sbt.c:903
+                int filtered = !lossless && (plane_idx == 0 || !isP);               // sbt.c:925
+                if (u8) {
+                    hipLaunchKernelGGL((k_inv_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
+                                       filtered, hdiv);
+                } else {
+                    hipLaunchKernelGGL((k_inv_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
+                                       filtered, hdiv);
+                }
+                break;
+            }
+            case F_LLI: launch_inv_sep<F_LLI>(s, b, u8, g, ll_sel, d_sel); break;
+            case F_LLP: launch_inv_sep<F_LLP>(s, b, u8, g, ll_sel, d_sel); break;
+            case F_CC: launch_inv_sep<F_CC>(s, b, u8, g, ll_sel, d_sel); break;
+            case F_L2A: launch_inv_sep<F_L2A>(s, b, u8, g, ll_sel, d_sel); break;
+            case F_L1: launch_inv_sep<F_L1>(s, b, u8, g, ll_sel, d_sel); break;
+            default: launch_inv_sep<F_LOSSLESS>(s, b, u8, g, ll_sel, d_sel); break;
+        }
+        ll_sel = d_sel;
+        d_sel ^= 1;
+    }
+    HIPCHK(hipGetLastError());
 }
 
 void sbt_forward(hipStream_t s, const DPlane &src, DCoefs dst, SbtScratch &sc, int plane_idx, int isP, int lossless,
                  BlockMap bm)
 {
-    int cw = dst.w, ch = dst.h;
-    sc.ensure((size_t) cw * ch);
-    int lvls = host_lb2((unsigned) (cw > ch ? cw : ch));
-    int32_t *R = sc.t[2];
-    for (int l = 1; l <= lvls; l++) {
-        // level l reads the LL image written by level l-1 and writes its own LL to the other scratch
-        const int32_t *S = (l >= 2) ? sc.t[l & 1] : nullptr;
-        int32_t *D = sc.t[(l - 1) & 1];
-        int filter = pick_filter(plane_idx, isP, lossless, l, lvls);
-        LevelGeom g = level_geom(cw, ch, l, filter, bm, true);
-        int ovf = (l >= 6 && l >= (lvls - 3) && !lossless); // sbt.c:29
-        bool u8 = (l == 1);
-        int32_t *ll_out = (l == lvls) ? dst.data : D;
-        switch (filter) {
-            case F_HAAR:
-                if (u8) {
-                    hipLaunchKernelGGL((k_fwd_haar<true>), grid2(g.hw, g.hh), kBlk, 0, s, nullptr, src.data, src.stride,
-                                       src.h, ll_out, dst.data, g, ovf);
-                } else {
-                    hipLaunchKernelGGL((k_fwd_haar<false>), grid2(g.hw, g.hh), kBlk, 0, s, S, nullptr, 0, 0, ll_out,
-                                       dst.data, g, ovf);
-                }
-                break;
-            case F_LLI: launch_fwd_sep<F_LLI>(s, u8, S, src, R, ll_out, dst.data, g); break;
-            case F_LLP: launch_fwd_sep<F_LLP>(s, u8, S, src, R, ll_out, dst.data, g); break;
-            case F_CC: launch_fwd_sep<F_CC>(s, u8, S, src, R, ll_out, dst.data, g); break;
-            case F_L2A: launch_fwd_sep<F_L2A>(s, u8, S, src, R, ll_out, dst.data, g); break;
-            case F_L1: launch_fwd_sep<F_L1>(s, u8, S, src, R, ll_out, dst.data, g); break;
-            default: launch_fwd_sep<F_LOSSLESS>(s, u8, S, src, R, ll_out, dst.data, g); break;
-        }
+    sc.ensure((size_t) dst.w * dst.h);
+    Batch b{nullptr, PlaneJob{}, 1};
+    b.one.pic = src;
+    b.one.coefs = dst.data;
+    for (int k = 0; k < 3; k++) {
+        b.one.t[k] = sc.t[k];
     }
-    HIPCHK(hipGetLastError());
+    b.one.bd = bm.bd;
+    fwd_levels(s, b, dst.w, dst.h, plane_idx, isP, lossless, bm.nbh, bm.nbv, bm.bd != nullptr);
 }
 
 void sbt_inverse(hipStream_t s, DPlane dst, DCoefs src, SbtScratch &sc, int q, int plane_idx, int isP, int lossless,
                  BlockMap bm)
 {
-    int cw = src.w, ch = src.h;
-    sc.ensure((size_t) cw * ch);
-    int lvls = host_lb2((unsigned) (cw > ch ? cw : ch));
-    const int32_t *LLp = src.data;
-    int32_t *D = sc.t[0], *other = sc.t[1], *R = sc.t[2];
-    for (int l = lvls; l > 0; l--) {
-        int filter = pick_filter(plane_idx, isP, lossless, l, lvls);
-        LevelGeom g = level_geom(cw, ch, l, filter, bm, false);
-        int ovf = (l >= 6 && l >= (lvls - 3) && !lossless);
-        bool u8 = (l == 1);
-        switch (filter) {
-            case F_HAAR: {
-                int hqp = (plane_idx == 0) ? (q / (isP ? 14 : (l > 4 ? 2 : 8))) : (q / 2); // sbt.c:903
-                int filtered = !lossless && (plane_idx == 0 || !isP);                     // sbt.c:925
-                if (u8) {
-                    hipLaunchKernelGGL((k_inv_haar<true>), grid2(g.hw, g.hh), kBlk, 0, s, LLp, src.data, nullptr, dst.data,
-                                       dst.stride, dst.w, dst.h, g, ovf, filtered, hqp);
-                } else {
-                    hipLaunchKernelGGL((k_inv_haar<false>), grid2(g.hw, g.hh), kBlk, 0, s, LLp, src.data, D, nullptr, 0, 0,
-                                       0, g, ovf, filtered, hqp);
-                }
-                break;
-            }
-            case F_LLI: launch_inv_sep<F_LLI>(s, u8, LLp, src.data, R, D, dst, g); break;
-            case F_LLP: launch_inv_sep<F_LLP>(s, u8, LLp, src.data, R, D, dst, g); break;
-            case F_CC: launch_inv_sep<F_CC>(s, u8, LLp, src.data, R, D, dst, g); break;
-            case F_L2A: launch_inv_sep<F_L2A>(s, u8, LLp, src.data, R, D, dst, g); break;
-            case F_L1: launch_inv_sep<F_L1>(s, u8, LLp, src.data, R, D, dst, g); break;
-            default: launch_inv_sep<F_LOSSLESS>(s, u8, LLp, src.data, R, D, dst, g); break;
-        }
-        LLp = D;
-        int32_t *t = D;
-        D = other;
-        other = t;
+    sc.ensure((size_t) src.w * src.h);
+    Batch b{nullptr, PlaneJob{}, 1};
+    b.one.pic = dst;
+    b.one.coefs = src.data;
+    for (int k = 0; k < 3; k++) {
+        b.one.t[k] = sc.t[k];
     }
-    HIPCHK(hipGetLastError());
+    b.one.bd = bm.bd;
+    b.one.q = q;
+    inv_levels(s, b, src.w, src.h, plane_idx, isP, lossless, bm.nbh, bm.nbv, bm.bd != nullptr);
+}
+
+void sbt_forward_jobs(hipStream_t s, const PlaneJob *d_jobs, int n, int cw, int ch, int plane_idx, int isP, int lossless, int nbh,
+                      int nbv)
+{
+    if (n > 0) {
+        fwd_levels(s, Batch{d_jobs, PlaneJob{}, n}, cw, ch, plane_idx, isP, lossless, nbh, nbv, true);
+    }
+}
+
+void sbt_inverse_jobs(hipStream_t s, const PlaneJob *d_jobs, int n, int cw, int ch, int plane_idx, int isP, int lossless, int nbh,
+                      int nbv)
+{
+    if (n > 0) {
+        inv_levels(s, Batch{d_jobs, PlaneJob{}, n}, cw, ch, plane_idx, isP, lossless, nbh, nbv, true);
+    }
 }
 
 } // namespace dsv2
