@@ -1009,7 +1009,9 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
 }
 
 // ---- row-pipelined level: ONE launch per pyramid level for all streams --------------------------
-// blockIdx.x = block row, blockIdx.y = stream; one wavefront walks its row left to right.  Block
+// blockIdx.x = stream, blockIdx.y = block row (workgroups are dispatched row-major ACROSS streams, so
+// by the time row j of any stream gets a slot its row j-1 is well under way and few resident
+// wavefronts sit spinning); one wavefront walks its row left to right.  Block
 // (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and (bi, bj-1), (bi-1, bj-1) of the
 // row above, so a row only ever waits for the progress word of the row above it: a slow block
 // delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front
@@ -1038,9 +1040,8 @@ __device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned
     }
 }
 
-__device__ __forceinline__ void hme_row(const HmeDev &c, int level, int nbx, int allow_fast, FastLds &S)
+__device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int nbx, int allow_fast, FastLds &S)
 {
-    int bj = blockIdx.x;
     int gx = c.counters[4], gy = c.counters[5];
     unsigned *progress = (unsigned *) c.counters + kHmeProgress;
     int j = bj << level;
@@ -1076,7 +1077,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int level, int nbx, int
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row(tab[blockIdx.y], level, nbx, allow_fast, S);                                                             \
+        hme_row(tab[blockIdx.x], (int) blockIdx.y, level, nbx, allow_fast, S);                                           \
     }
 HME_ROWS_B(1)
 HME_ROWS_B(2)
@@ -1087,7 +1088,7 @@ static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES"
 __global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
 {
     __shared__ FastLds S;
-    hme_row(c, level, nbx, allow_fast, S);
+    hme_row(c, (int) blockIdx.x, level, nbx, allow_fast, S);
 }
 
 __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
@@ -1232,7 +1233,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         hipLaunchKernelGGL(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
         if (g_hme_rows) {
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
-            hipLaunchKernelGGL(kern, dim3(nby, n), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
+            hipLaunchKernelGGL(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
             for (int t = 0; t <= nbx + nby - 2; t++) {
