@@ -124,6 +124,11 @@ struct IngestJob {
     const uint8_t *src; // packed planar picture in HBM
     DPlane dst[3];
 };
+struct PlaneOutJob {
+    DPlane src;
+    uint8_t *dst; // pinned host memory, w * h bytes
+};
+void planes_to_host_batch(hipStream_t s, const PlaneOutJob *d_jobs, int n, int h);
 void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int max_h);
 void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h);
 void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes);

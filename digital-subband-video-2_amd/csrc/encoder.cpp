@@ -911,6 +911,21 @@ struct TableArena {
 struct BatchScratch { // per calling thread: pinned + device memory for the job tables
     void *h_hme = nullptr, *d_hme = nullptr;
     McJob *h_mc = nullptr, *d_mc = nullptr;
+    uint8_t *h_stage = nullptr, *d_stage = nullptr; // per stream: transmitted motion field + block flag bytes
+    size_t stage_cap = 0;
+    void ensure_stage(size_t bytes)
+    {
+        if (bytes <= stage_cap) {
+            return;
+        }
+        if (stage_cap) {
+            HIPCHK(hipHostFree(h_stage));
+            HIPCHK(hipFree(d_stage));
+        }
+        HIPCHK(hipHostMalloc((void **) &h_stage, bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d_stage, bytes));
+        stage_cap = bytes;
+    }
     int32_t *h_ll = nullptr, *d_ll = nullptr; // [3 * n] DC coefficients
     int *h_totals = nullptr, *d_totals = nullptr; // [n] symbol counts
     TableArena tabs;
@@ -1027,8 +1042,8 @@ void phase_p0(Job &jb)
     }
 }
 
-// H1: everything the host decides between motion estimation and the residual pipeline
-void phase_h1(Job &jb)
+// H1, first half: scene-change decision and rate control (dsv_encoder.c:1279-1290)
+void phase_h1a(Job &jb)
 {
     DSV_ENCODER *enc = jb.enc;
     EncImpl *im = jb.im;
@@ -1060,8 +1075,18 @@ void phase_h1(Job &jb)
     }
     quality2quant(enc, d, jb.prev_I, jb.forced_intra);
     compute_auto_filter(enc, d);
+}
 
-    // encode_picture, host half (dsv_encoder.c:1051-1132)
+// H1, second half: encode_picture's host part (dsv_encoder.c:1051-1132); needs the intra analysis of
+// a picture that is coded as intra -- for a P frame flipped by H1a that analysis runs in between
+void phase_h1b(Job &jb)
+{
+    DSV_ENCODER *enc = jb.enc;
+    EncImpl *im = jb.im;
+    CodecDev &dv = im->dev;
+    FrameCtl *d = &jb.d;
+    DSV_PARAMS *p = &d->params;
+    size_t nb = dv.nblocks();
     bool isP = p->has_ref;
     unsigned upper = (unsigned) (dv.w * dv.h);
     switch (enc->vidmeta.subsamp) {
@@ -1227,7 +1252,9 @@ void enc_batch(Job *jobs, int n)
     }
     const IntraJob *d_intra;
     IntraJob *h_intra = sc.tabs.take<IntraJob>((size_t) n, &d_intra);
-    int n_ing = 0, n_pyr = 0;
+    const PlaneOutJob *d_small;
+    PlaneOutJob *h_small = sc.tabs.take<PlaneOutJob>((size_t) n, &d_small);
+    int n_ing = 0, n_pyr = 0, n_intra = 0;
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
@@ -1260,11 +1287,16 @@ void enc_batch(Job *jobs, int n)
             n_pyr++;
             ref.recon_pyr_valid = true;
         }
-        // the block analysis of an intra picture; also needed when a P frame is flipped to intra in H1
-        for (int c = 0; c < 3; c++) {
-            h_intra[k].src.p[c] = cur.src.p[c];
+        // the block analysis of an intra picture, written straight into the host's pinned array (a P
+        // frame that H1 flips to intra gets its analysis then)
+        if (!jb.d.params.has_ref) {
+            for (int c = 0; c < 3; c++) {
+                h_intra[n_intra].src.p[c] = cur.src.p[c];
+            }
+            h_intra[n_intra].out = dv.h_intra;
+            n_intra++;
         }
-        h_intra[k].out = dv.d_mvs_stage;
+        h_small[k] = PlaneOutJob{cur.src_pyr[L - 1].p[0], dv.h_small};
     }
     sc.tabs.upload(bs);
     {
@@ -1277,18 +1309,13 @@ void enc_batch(Job *jobs, int n)
             ds2x_planes(bs, d_pair[l], n_pyr, lp.w, lp.h);
             extend_planes(bs, d_pext[l], n_pyr, lp.w, lp.h);
         }
-        intra_analysis_batch(bs, d_intra, n, analysis_params(dv0, jobs[0].d.params.do_psy));
+        planes_to_host_batch(bs, d_small, n, dv0.pics[0].src_pyr[L - 1].p[0].h);
+        intra_analysis_batch(bs, d_intra, n_intra, analysis_params(dv0, jobs[0].d.params.do_psy));
     }
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
         PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
-        size_t nb = dv.nblocks();
-        {
-            const DPlane &cp = cur.src_pyr[dv.pyr_levels - 1].p[0];
-            HIPCHK(hipMemcpy2DAsync(dv.h_small, cp.w, cp.data, cp.stride, cp.w, cp.h, hipMemcpyDeviceToHost, bs));
-        }
-        HIPCHK(hipMemcpyAsync(dv.h_intra, dv.d_mvs_stage, nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, bs));
         if (jb.d.params.has_ref) { // motion_est (dsv_encoder.c:653)
             HmeFrames f;
             f.src[0] = cur.src.p[0];
@@ -1308,6 +1335,8 @@ void enc_batch(Job *jobs, int n)
             }
             f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
             f.counters = dv.d_counters;
+            f.host_mvs = dv.h_mvs; // the search itself delivers its results to the host
+            f.host_counters = dv.h_counters;
             HmeParams h;
             h.a = analysis_params(dv, jb.d.params.do_psy);
             h.effort = jb.d.params.effort;
@@ -1326,17 +1355,6 @@ void enc_batch(Job *jobs, int n)
         prof.begin(bs, ST_HME);
         int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme);
         prof.end(bs, ST_HME, nfronts);
-        for (int k : pjobs) {
-            CodecDev &dv = jobs[k].im->dev;
-            PicSet &cur = dv.pics[jobs[k].im->cur];
-            size_t nb = dv.nblocks();
-            HIPCHK(hipMemcpyAsync(dv.h_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToHost, bs));
-            HIPCHK(hipMemcpyAsync(dv.h_counters, dv.d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, bs));
-            // the HME result of a frame that H1 flips to intra still serves as the next frame's temporal
-            // candidates (dsv_encoder.c:680, hme.c:1651); a real P frame overwrites it in G2
-            HIPCHK(hipMemcpyAsync(cur.d_final_mvs, dv.d_mvf[0], nb * sizeof(DSV_MV), hipMemcpyDeviceToDevice, bs));
-            cur.has_final_mvs = true;
-        }
     }
     t_clock.lap(1);
     HIPCHK(hipStreamSynchronize(bs));
@@ -1348,7 +1366,30 @@ void enc_batch(Job *jobs, int n)
     }
 
     // ---- H1 ----
-    parallel_for(n, [&](int k) { phase_h1(jobs[k]); });
+    parallel_for(n, [&](int k) { phase_h1a(jobs[k]); });
+    {
+        // P frames flipped to intra by the scene-change test: their block analysis is due now
+        const IntraJob *d_late;
+        IntraJob *h_late = sc.tabs.take<IntraJob>((size_t) n, &d_late);
+        int n_late = 0;
+        for (int k = 0; k < n; k++) {
+            Job &jb = jobs[k];
+            if (jb.ran_hme && !jb.d.params.has_ref) {
+                PicSet &cur = jb.im->dev.pics[jb.im->cur];
+                for (int c = 0; c < 3; c++) {
+                    h_late[n_late].src.p[c] = cur.src.p[c];
+                }
+                h_late[n_late].out = jb.im->dev.h_intra;
+                n_late++;
+            }
+        }
+        if (n_late) {
+            sc.tabs.upload(bs);
+            intra_analysis_batch(bs, d_late, n_late, analysis_params(dv0, jobs[0].d.params.do_psy));
+            HIPCHK(hipStreamSynchronize(bs));
+        }
+    }
+    parallel_for(n, [&](int k) { phase_h1b(jobs[k]); });
     t_clock.lap(3);
 
     // ---- G2 ----
@@ -1368,7 +1409,14 @@ void enc_batch(Job *jobs, int n)
     CompactJob *h_comp = sc.tabs.take<CompactJob>((size_t) n, &d_comp);
     const DPlane *d_rext_y, *d_rext_c;
     DPlane *h_rext_y = sc.tabs.take<DPlane>((size_t) n, &d_rext_y), *h_rext_c = sc.tabs.take<DPlane>(2 * (size_t) n, &d_rext_c);
-    int nP = 0, nI = 0, n_rext = 0;
+    // host -> device hand-over of what H1 decided: per stream the transmitted motion field and the
+    // block flag bytes, packed into ONE pinned buffer and shipped with one copy
+    const size_t nb0 = dv0.nblocks();
+    const size_t mv_bytes = nb0 * sizeof(DSV_MV), bd_bytes = (nb0 + 15) & ~(size_t) 15, slot = mv_bytes + bd_bytes;
+    sc.ensure_stage(slot * (size_t) n);
+    const CopyJob *d_mvcopy;
+    CopyJob *h_mvcopy = sc.tabs.take<CopyJob>((size_t) n, &d_mvcopy);
+    int nP = 0, nI = 0, n_rext = 0, n_mvcopy = 0;
     bool any_filter = false;
     for (int i = 0; i < n; i++) {
         int k = order[(size_t) i];
@@ -1380,10 +1428,12 @@ void enc_batch(Job *jobs, int n)
         // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
         h_copy[i] = CopyJob{cur.src.alloc, cur.recon.alloc, cur.src.bytes};
         cur.recon_pyr_valid = false;
-        HIPCHK(hipMemcpyAsync(dv.d_blockdata, jb.enc->blockdata, nb, hipMemcpyHostToDevice, bs));
+        uint8_t *h_slot = sc.h_stage + slot * (size_t) i, *d_slot = sc.d_stage + slot * (size_t) i;
+        const uint8_t *d_bd = d_slot + mv_bytes;
+        memcpy(h_slot + mv_bytes, jb.enc->blockdata, nb);
         McJob mj;
         mj.mvs = cur.d_final_mvs;
-        mj.bd = dv.d_blockdata;
+        mj.bd = d_bd;
         mj.p = dv.mc_params(p->temporal_mc, p->lossless);
         for (int c = 0; c < 3; c++) {
             mj.ref.p[c] = ref.recon.p[c];
@@ -1392,7 +1442,9 @@ void enc_batch(Job *jobs, int n)
         }
         if (p->has_ref) {
             // the motion field as transmitted: used by MC now and as temporal candidates of the next frame
-            HIPCHK(hipMemcpyAsync(cur.d_final_mvs, jb.im->mvs.data(), nb * sizeof(DSV_MV), hipMemcpyHostToDevice, bs));
+            memcpy(h_slot, jb.im->mvs.data(), mv_bytes);
+            h_mvcopy[n_mvcopy++] = CopyJob{d_slot, cur.d_final_mvs, mv_bytes};
+            cur.has_final_mvs = true;
             mj.f = make_filter_params(mj.p, jb.d.quant, jb.inter_filter, jb.enc->vidmeta.inter_sharpen);
             any_filter = any_filter || !p->lossless;
             sc.h_mc[nP++] = mj;
@@ -1400,6 +1452,12 @@ void enc_batch(Job *jobs, int n)
             mj.f = make_filter_params(mj.p, jb.d.quant, 1, 0);
             if (jb.enc->do_intra_filter && !p->lossless) {
                 sc.h_mc[n + nI++] = mj;
+            }
+            if (jb.ran_hme) {
+                // the search result of a frame that H1 flipped to intra still serves as the next frame's
+                // temporal candidates (dsv_encoder.c:680, hme.c:1651)
+                h_mvcopy[n_mvcopy++] = CopyJob{dv.d_mvf[0], cur.d_final_mvs, mv_bytes};
+                cur.has_final_mvs = true;
             }
         }
         for (int c = 0; c < 3; c++) {
@@ -1409,13 +1467,17 @@ void enc_batch(Job *jobs, int n)
             for (int t = 0; t < 3; t++) {
                 pj.t[t] = c ? dv.scratch_uv[c - 1].t[t] : dv.scratch.t[t];
             }
-            pj.bd = dv.d_blockdata;
+            pj.bd = d_bd;
             pj.qv = dv.qv + dv.qv_off[c];
             pj.mvs = cur.d_final_mvs;
             quant_steps(&pj, dv.quant_cfg(c, p->has_ref, p->lossless, p->do_psy, nullptr), jb.d.quant);
         }
         h_comp[i] = dv.comp.job(dv.qv, dv.qv_off[3]);
         h_comp[i].total = sc.d_totals + i;
+        dv.ensure_host_syms(dv.qv_off[3] / 8); // usual symbol counts fit; a larger frame falls back to a copy
+        h_comp[i].host_pos = dv.h_pos;
+        h_comp[i].host_val = dv.h_val;
+        h_comp[i].host_cap = (int) dv.h_sym_cap;
         if (jb.enc->frame_callback || (p->is_ref && jb.enc->gop != DSV_GOP_INTRA)) {
             h_rext_y[n_rext] = cur.recon.p[0];
             h_rext_c[2 * n_rext] = cur.recon.p[1];
@@ -1425,6 +1487,8 @@ void enc_batch(Job *jobs, int n)
     }
     sc.tabs.upload(bs);
     HIPCHK(hipMemcpyAsync(sc.d_mc, sc.h_mc, 2 * (size_t) n * sizeof(McJob), hipMemcpyHostToDevice, bs));
+    HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, slot * (size_t) n, hipMemcpyHostToDevice, bs));
+    copy_linear_batch(bs, d_mvcopy, n_mvcopy, mv_bytes);
     copy_linear_batch(bs, d_copy, n, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
     mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv);
@@ -1475,6 +1539,7 @@ void enc_batch(Job *jobs, int n)
     t_clock.lap(4);
     HIPCHK(hipStreamSynchronize(bs));
     t_clock.lap(5);
+    bool late_copy = false;
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
@@ -1483,13 +1548,16 @@ void enc_batch(Job *jobs, int n)
         for (int c = 0; c < 3; c++) {
             dv.h_ll[c] = sc.h_ll[3 * ti + c];
         }
-        dv.ensure_host_syms((size_t) jb.nsym);
-        if (jb.nsym) {
+        if ((size_t) jb.nsym > dv.h_sym_cap) { // rare: more symbols than the pinned mirror held
+            dv.ensure_host_syms((size_t) jb.nsym);
             HIPCHK(hipMemcpyAsync(dv.h_pos, dv.comp.d_pos, (size_t) jb.nsym * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
             HIPCHK(hipMemcpyAsync(dv.h_val, dv.comp.d_val, (size_t) jb.nsym * sizeof(int32_t), hipMemcpyDeviceToHost, bs));
+            late_copy = true;
         }
     }
-    HIPCHK(hipStreamSynchronize(bs));
+    if (late_copy) {
+        HIPCHK(hipStreamSynchronize(bs));
+    }
     t_clock.lap(6);
     prof.collect();
 

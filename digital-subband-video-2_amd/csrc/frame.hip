@@ -215,6 +215,26 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestJob *__restrict__ ta
     }
 }
 
+// small planes (the coarsest pyramid level) packed row after row into pinned host memory
+__global__ __launch_bounds__(64) void k_plane_to_host(const PlaneOutJob *__restrict__ tab)
+{
+    const PlaneOutJob &j = tab[blockIdx.y];
+    int y = blockIdx.x;
+    if (y >= j.src.h) {
+        return;
+    }
+    for (int x = threadIdx.x; x < j.src.w; x += 64) {
+        j.dst[(size_t) y * j.src.w + x] = j.src.data[(size_t) y * j.src.stride + x];
+    }
+}
+
+void planes_to_host_batch(hipStream_t s, const PlaneOutJob *d_jobs, int n, int h)
+{
+    if (n > 0) {
+        hipLaunchKernelGGL(k_plane_to_host, dim3(h, n), dim3(64), 0, s, d_jobs);
+    }
+}
+
 void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int total_rows)
 {
     if (n <= 0) {

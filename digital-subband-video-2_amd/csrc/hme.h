@@ -36,6 +36,8 @@ struct HmeFrames {
     DPlane srcc[2], refc[2];
     DSV_MV *mvf[6];        // out: one field per level, nblocks entries each
     const DSV_MV *ref_mvf; // previous frame's transmitted field or null
+    DSV_MV *host_mvs = nullptr;   // batched driver only: pinned host mirror of mvf[0], filled by the search itself
+    int *host_counters = nullptr; // batched driver only: pinned host copy of counters[0..7]
     int *counters;         // hme_counter_words(nbv) ints. out: [0] nintra [1] ndiff [2] eligible [3] total_err
                            // ([4],[5] global motion, [7] row-pipeline timeout flag, [16..] row progress)
 };

@@ -32,6 +32,8 @@ struct HmeDev {
     DSV_MV *mvf[6];
     const DSV_MV *ref_mvf;
     int *counters; // [0] nintra [1] ndiff [2] eligible [3] total_err [4] gx [5] gy
+    DSV_MV *host_mvs;   // optional pinned host mirror of the level-0 field (written straight over PCIe)
+    int *host_counters; // optional pinned host copy of counters[0..7]
 };
 
 struct Psy {
@@ -137,6 +139,17 @@ __device__ __forceinline__ void st_mv(DSV_MV *out, const DSV_MV &mv)
     unsigned long long head = (unsigned long long) (uint32_t) mv.u.all | ((unsigned long long) mv.flags << 32);
     ((unsigned long long *) out)[1] = (unsigned long long) mv.err | ((unsigned long long) mv.dc << 16) | ((unsigned long long) mv.submask << 32);
     __hip_atomic_store((unsigned long long *) out, head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// level-0 result: device field + (when asked for) the host's pinned copy, so no read-back copy is needed
+__device__ __forceinline__ void st_mv_final(const HmeDev &c, DSV_MV *out, const DSV_MV &mv)
+{
+    st_mv(out, mv);
+    if (c.host_mvs) {
+        unsigned long long *h = (unsigned long long *) (c.host_mvs + (out - c.mvf[0]));
+        h[0] = (unsigned long long) (uint32_t) mv.u.all | ((unsigned long long) mv.flags << 32);
+        h[1] = (unsigned long long) mv.err | ((unsigned long long) mv.dc << 16) | ((unsigned long long) mv.submask << 32);
+    }
 }
 
 // ---- motion vector cost ---------------------------------------------------------------------
@@ -927,7 +940,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
     if (lane == 0) {
-        st_mv(out, mv);
+        st_mv_final(c, out, mv);
         if (is_intra) {
             atomicAdd(&c.counters[0], 1);
         }
@@ -1137,6 +1150,18 @@ __global__ __launch_bounds__(256) void k_global_motion_b(const HmeDev *__restric
     }
 }
 
+// end of the search: the scalars the host controller needs, straight into its pinned memory
+__global__ void k_hme_finish_b(const HmeDev *__restrict__ tab, int n)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n * 8) {
+        const HmeDev &c = tab[k >> 3];
+        if (c.host_counters) {
+            c.host_counters[k & 7] = c.counters[k & 7];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_global_motion(HmeDev c, int level)
 {
     __shared__ int sx[4], sy[4];
@@ -1208,6 +1233,8 @@ static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
     }
     c.ref_mvf = f.ref_mvf;
     c.counters = f.counters;
+    c.host_mvs = f.host_mvs;
+    c.host_counters = f.host_counters;
 }
 
 size_t hme_table_bytes(int n) { return (size_t) n * sizeof(HmeDev); }
@@ -1247,6 +1274,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             hipLaunchKernelGGL(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
         }
     }
+    hipLaunchKernelGGL(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
     HIPCHK(hipGetLastError());
     return nlaunch;
 }
@@ -1274,6 +1302,8 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
     }
     c.ref_mvf = f.ref_mvf;
     c.counters = f.counters;
+    c.host_mvs = nullptr;
+    c.host_counters = nullptr;
     size_t nb = (size_t) hp.a.nbh * hp.a.nbv;
     HIPCHK(hipMemsetAsync(f.counters, 0, hme_counter_words(hp.a.nbv) * sizeof(int), s));
     for (int level = hp.pyr_levels; level >= 0; level--) {

@@ -710,7 +710,7 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
     if (lane == 0) {
-        st_mv(out, mv);
+        st_mv_final(c, out, mv);
         if (is_intra) {
             atomicAdd(&c.counters[0], 1);
         }

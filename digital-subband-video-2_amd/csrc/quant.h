@@ -35,6 +35,10 @@ struct CompactJob {
     int *tile_count, *tile_base, *total;
     uint32_t *pos;
     int32_t *val;
+    // optional pinned host mirror of the first host_cap symbols (spares the read-back copy)
+    uint32_t *host_pos;
+    int32_t *host_val;
+    int host_cap;
 };
 
 // ordered stream compaction of nonzero entries of a dense int32 array

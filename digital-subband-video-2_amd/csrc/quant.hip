@@ -470,6 +470,9 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
     const int *tile_base = J.tile_base;
     uint32_t *out_pos = J.pos;
     int32_t *out_val = J.val;
+    uint32_t *host_pos = J.host_pos;
+    int32_t *host_val = J.host_val;
+    int host_cap = host_pos ? J.host_cap : 0;
     int base = blockIdx.x * kTile;
     int vals[4];
     int cnt = 0;
@@ -494,6 +497,10 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
         if (vals[j] != 0) {
             out_pos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
             out_val[o] = vals[j];
+            if (o < host_cap) {
+                host_pos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
+                host_val[o] = vals[j];
+            }
             o++;
         }
     }
@@ -532,7 +539,7 @@ void Compactor::release()
 CompactJob Compactor::job(const int32_t *qv, size_t n)
 {
     ensure(n);
-    return CompactJob{qv, (int) n, tile_count, tile_base, d_total, d_pos, d_val};
+    return CompactJob{qv, (int) n, tile_count, tile_base, d_total, d_pos, d_val, nullptr, nullptr, 0};
 }
 
 void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
