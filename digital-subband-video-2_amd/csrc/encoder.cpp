@@ -14,7 +14,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -26,6 +32,7 @@ namespace {
 
 struct EncImpl {
     CodecDev dev;
+    std::vector<uint8_t> pkt; // picture packet under construction (all zero between frames)
     bool ready = false;
     int cur = 0;          // picture set receiving the current frame
     bool have_ref = false; // pics[cur ^ 1] holds a usable reference
@@ -959,20 +966,95 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
 };
 thread_local BatchScratch t_scratch;
 
+// Host phases run one task per stream on a process-wide pool of worker threads (created on first
+// use, sized to the machine); the calling thread works too, and several lockstep groups may share
+// the pool concurrently.
+class WorkerPool {
+  public:
+    struct Batch {
+        std::function<void(int)> fn;
+        int n = 0;
+        std::atomic<int> next{0}, left{0};
+    };
+    static WorkerPool &get()
+    {
+        static WorkerPool *pool = new WorkerPool(); // never destroyed: workers may outlive static teardown
+        return *pool;
+    }
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        auto b = std::make_shared<Batch>();
+        b->fn = fn;
+        b->n = n;
+        b->left.store(n);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            active_.push_back(b);
+        }
+        cv_.notify_all();
+        work(*b);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return b->left.load() == 0; });
+    }
+
+  private:
+    WorkerPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned nthreads = hw ? (hw > 128 ? 128 : hw) : 8;
+        if (const char *e = getenv("DSV2_HOST_THREADS")) {
+            nthreads = (unsigned) atoi(e);
+        }
+        for (unsigned i = 0; i + 1 < nthreads; i++) {
+            std::thread([this] { loop(); }).detach();
+        }
+    }
+    void work(Batch &b)
+    {
+        for (;;) {
+            int k = b.next.fetch_add(1);
+            if (k >= b.n) {
+                return;
+            }
+            b.fn(k);
+            if (b.left.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(mu_);
+                done_.notify_all();
+            }
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            std::shared_ptr<Batch> b;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                for (;;) {
+                    while (!active_.empty() && active_.front()->next.load() >= active_.front()->n) {
+                        active_.pop_front(); // fully handed out
+                    }
+                    if (!active_.empty()) {
+                        b = active_.front();
+                        break;
+                    }
+                    cv_.wait(lk);
+                }
+            }
+            work(*b);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::deque<std::shared_ptr<Batch>> active_;
+};
+
 template <class F> void parallel_for(int n, F fn)
 {
     if (n == 1) {
         fn(0);
         return;
     }
-    std::vector<std::thread> th;
-    th.reserve((size_t) n);
-    for (int k = 0; k < n; k++) {
-        th.emplace_back([&fn, k]() { fn(k); });
-    }
-    for (auto &t : th) {
-        t.join();
-    }
+    WorkerPool::get().run(n, std::function<void(int)>(fn));
 }
 
 void ensure_ready(DSV_ENCODER *enc, EncImpl *im)
@@ -1095,8 +1177,12 @@ void phase_h1b(Job &jb)
         case DSV_SUBSAMP_UYVY: upper *= 4; break;
         default: upper *= 2; break;
     }
-    dsv_mk_buf(&jb.out, (int) upper);
-    jb.bs = BitWriter{jb.out.data, 0};
+    // the packet is assembled in a per-encoder buffer that stays mapped and zeroed between frames (the bit
+    // writer needs zeroed memory, bs.c:143); H2 hands the caller a right-sized copy
+    if (im->pkt.size() < (size_t) upper) {
+        im->pkt.assign((size_t) upper, 0);
+    }
+    jb.bs = BitWriter{im->pkt.data(), 0};
     BitWriter &bs = jb.bs;
     put_packet_hdr(bs, DSV_PT_PIC | (p->is_ref << 1) | p->has_ref);
     bs.align();
@@ -1165,7 +1251,13 @@ void phase_h2(Job &jb)
         entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
     }
     bs.align();
-    jb.out.len = bs.byte_pos();
+    {
+        unsigned len = bs.byte_pos();
+        dsv_mk_buf(&jb.out, (int) len);
+        memcpy(jb.out.data, im->pkt.data(), len);
+        memset(im->pkt.data(), 0, len);
+        jb.out.len = len;
+    }
     jb.nbuf = 0;
     if (jb.gop_start) {
         DSV_BUF metabuf;
