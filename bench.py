@@ -5,16 +5,17 @@
 
 Workload (BASELINE.json north-star headline): synthetic 1920x1080 4:2:0, -qp=60 -gop=48, CRF,
 effort 10 (quarter-pel + EPRM + in-loop filters).  Every rank drives S independent closed-GOP
-streams on its GPU (one encoder instance + one host thread per stream, exactly the reference's
-own segment-parallel recipe, parallel_encode_yuv.sh).  A "step" is one frame of every stream:
-S frames per rank per step.  Frames are resident in HBM before the timed region starts
-(dsv2hip_enc_device_frame); the stream position is arranged so that each timed window of 48
-steps contains exactly one I frame (W warm-up steps put the first timed frame right after an
-I frame boundary... see `first_frame`).
+streams on its GPU -- the reference's own segment-parallel recipe (parallel_encode_yuv.sh) -- as
+G lockstep groups: each group is one host thread calling dsv2hip_enc_batch() for its S/G encoder
+instances on one HIP stream, so a kernel launch serves a whole group and the groups overlap each
+other's host and device phases.  A "step" is one frame of every stream: S frames per rank per
+step.  Frames are resident in HBM before the timed region starts.  A default run (48 timed steps)
+covers one full GOP of every stream: 1 I frame + 47 P frames each.
 
 One JSON line is printed by rank 0: frames/s aggregated over all ranks (weak scaling), the
-roofline object of the dominant kernel (stage timing with HIP events on the codec streams) and
-the CPU baseline (the real reference, oracle/_ref, one thread, bounded sample) at N=1.
+roofline object of the dominant kernel (HIP-event stage spans measured in a short extra pass of
+the same configuration) and the CPU baseline (the real reference, oracle/_ref, one thread, bounded
+sample) at N=1.
 """
 import argparse
 import ctypes as C
@@ -31,7 +32,7 @@ W_, H_ = 1920, 1080
 GOP, QP = 48, 60
 STAGES = ["ingest_pyramid", "hme", "predict_subtract", "fwd_sbt", "quant_compact", "inv_sbt", "recon_filters", "extend"]
 # dominant-kernel name per stage (rocprofv3 --kernel-trace name prefix)
-STAGE_KERNEL = {"hme": "k_hme_front", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
+STAGE_KERNEL = {"hme": "k_hme_rows_b_w4", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
                 "quant_compact": "k_quant_level", "recon_filters": "k_inter_filters", "predict_subtract": "k_predict",
                 "ingest_pyramid": "k_extend/k_ds2x", "extend": "k_extend"}
 N_PIX = W_ * H_
@@ -48,9 +49,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "0")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "256")),
+                    help="independent closed-GOP streams (encoder instances) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "1")),
+    ap.add_argument("--no-profile", action="store_true", help="skip the extra stage-timing pass that feeds the roofline object")
+    ap.add_argument("--profile-steps", type=int, default=6)
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "4")),
                     help="batch mode: split the streams into this many lockstep groups, one host thread + HIP stream each")
     ap.add_argument("--mode", choices=["batch", "threads"], default=os.environ.get("DSV2_BENCH_MODE", "batch"),
                     help="batch: lockstep dsv2hip_enc_batch over all streams; threads: one host thread + HIP stream per stream")
@@ -79,17 +83,18 @@ def main():
     hip.dsv2hip_set_device(local)
     hip.dsv2hip_prof_enable.argtypes = [C.c_int]
     hip.dsv2hip_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    hip.dsv2hip_prof_read_units.argtypes = [C.POINTER(C.c_longlong)]
     hip.dsv2hip_enc_device_frame.argtypes = [C.POINTER(A.ENCODER), C.c_void_p, C.POINTER(A.BUF)]
     hip.dsv2hip_enc_device_frame.restype = C.c_int
 
     ncpu = os.cpu_count() or 8
-    S = args.streams or max(1, min(16, (ncpu // max(1, world)) - 1))
+    S = max(1, args.streams)
     K, Wm = args.steps, args.warmup
     total = Wm + K
     pkg = load_pkg()
 
     # distinct picture content per stream; frames pre-generated on the host, then parked in HBM
-    nuniq = min(total, 24)  # frames repeat ping-pong fashion beyond this to bound generation time
+    nuniq = min(total + 8, 24)  # frames repeat ping-pong fashion beyond this to bound generation time
     nvid = min(S, 4)        # distinct videos; further streams start at a different frame of one of them
     vids = []
     for k in range(nvid):
@@ -195,23 +200,19 @@ def main():
     hip.dsv2hip_prof_enable(0)
     elapsed = run_phase(Wm, total)        # timed: exactly K steps
 
-    # stage profile: a short separate pass with event timing enabled on fresh encoders (not timed)
-    stage_ms, stage_launches, prof_frames = None, None, 0
-    if rank == 0:
+    # stage profile: a few more steps of the SAME configuration with HIP-event stage timing on (not timed)
+    stage_ms, stage_launches, stage_units, prof_steps = None, None, None, 0
+    if args.mode == "batch" and not args.no_profile:
         hip.dsv2hip_prof_enable(1)
-        e = A.ENCODER()
-        configure_encoder(hip, e, meta, qp=QP, gop=GOP, effort=10)
-        bufs = (A.BUF * 4)()
-        for t in range(min(total, 13)):
-            n = hip.dsv2hip_enc_device_frame(C.byref(e), C.c_void_p(dev_frames[0][frame_index(t)].data_ptr()), bufs)
-            for i in range(n):
-                hip.dsv_buf_free(C.byref(bufs[i]))
-        ms = (C.c_double * 8)()
-        ln = (C.c_longlong * 8)()
-        fr = C.c_longlong(0)
-        hip.dsv2hip_prof_read(ms, ln, C.byref(fr))
-        stage_ms, stage_launches, prof_frames = list(ms), list(ln), fr.value
-        hip.dsv_enc_free(C.byref(e))
+        run_phase(total, total + args.profile_steps)
+        if rank == 0:
+            ms = (C.c_double * 8)()
+            ln = (C.c_longlong * 8)()
+            un = (C.c_longlong * 8)()
+            fr = C.c_longlong(0)
+            hip.dsv2hip_prof_read(ms, ln, C.byref(fr))
+            hip.dsv2hip_prof_read_units(un)
+            stage_ms, stage_launches, stage_units, prof_steps = list(ms), list(ln), list(un), fr.value
         hip.dsv2hip_prof_enable(0)
 
     # final ordered gather of the segment bytes (the only collective of the path)
@@ -254,20 +255,25 @@ def main():
                    "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mode": args.mode, "groups": G, "mpix_per_s": round(fps * N_PIX / 1e6, 1),
                    "stream_bytes_total": total_bytes, "host_cpus": ncpu},
     }
-    if stage_ms is not None and prof_frames:
-        per_frame = {STAGES[i]: stage_ms[i] / prof_frames for i in range(8)}
-        dom = max(per_frame, key=lambda k: per_frame[k])
+    if stage_ms is not None and prof_steps:
+        # per stage: span (HIP events on the group's stream) per stream-frame, and the algorithmic
+        # bytes of SURVEY.md 8(d) moved in that span
+        per_unit = {STAGES[i]: (stage_ms[i] / stage_units[i] if stage_units[i] else 0.0) for i in range(8)}
+        total_ms = {STAGES[i]: stage_ms[i] for i in range(8)}
+        dom = max(total_ms, key=lambda k: total_ms[k])
         i = STAGES.index(dom)
         nl = max(1, stage_launches[i])
         avg_launch_ms = stage_ms[i] / nl
-        bytes_per_launch = STAGE_BYTES[dom] * prof_frames / nl
+        bytes_per_launch = STAGE_BYTES[dom] * stage_units[i] / nl
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom,
                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                              "avg_launch_us": round(avg_launch_ms * 1e3, 2), "launches_per_frame": round(nl / prof_frames, 1),
-                              "stage_ms_per_frame": {k: round(v, 3) for k, v in per_frame.items()},
-                              "single_stream_gpu_ms_per_frame": round(sum(per_frame.values()), 3)}
+                              "avg_launch_us": round(avg_launch_ms * 1e3, 2),
+                              "launches_per_step": round(nl / prof_steps * G, 1),
+                              "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                              "stage_us_per_frame": {k: round(1e3 * v, 2) for k, v in per_unit.items()},
+                              "whole_frame_algorithmic_GBps": round(104.0e6 * fps / 1e9, 1)}
     if not args.no_cpu_baseline and world == 1 and os.path.exists(A.REF_SO):
         from codec_run import encode_stream
         ref = A.load_ref()

@@ -359,30 +359,91 @@ __device__ __forceinline__ bool smooth6(int e2, int e1, int e0, int i0, int i1, 
     return false;
 }
 
-__device__ __forceinline__ void edge_filter(uint8_t *b, int across, int along, bool in_edge, int tE, int tM)
-{
-    int o[4];
-    for (int n = 0; n < 4; n++) {
-        uint8_t *p = b + (ptrdiff_t) n * along;
-        if (smooth6(p[-3 * across], p[-2 * across], p[-across], p[0], p[across], p[2 * across], tE, o)) {
-            p[-2 * across] = (uint8_t) o[0];
-            p[0] = (uint8_t) o[2];
-            p[-across] = (uint8_t) o[1];
-            p[across] = (uint8_t) o[3];
+// ---- the filters of one 4x4 cell, evaluated in registers ---------------------------------------
+// Every pixel a cell's horizontal / vertical smoothing can touch is fetched once (19 aligned dword
+// loads), all filter passes then run on registers and only modified rows go back (dword stores):
+// two memory round trips per cell instead of one per 6-tap line.  t[r][c] = pixel (x - 4 + c,
+// y - 3 + r): rows 3..6 hold 12 columns, rows 0..2 and 7..10 hold only the cell's own columns 4..7.
+// None of these bytes is written by another cell of the same sweep front (cells (i-2, j+1) and
+// (i+2, j-1) reach at most column x-5 / row y-1 of our rows), so whole-dword stores are safe.
+struct Tile {
+    int t[11][12];
+    unsigned dirty; // bit r: row r modified
+
+    __device__ __forceinline__ void load(const DPlane &dp, int x, int y)
+    {
+        const uint8_t *base = dp.data + (ptrdiff_t) (y - 3) * dp.stride + (x - 4);
+#pragma unroll
+        for (int r = 0; r < 11; r++) {
+            const uint32_t *row = (const uint32_t *) (base + (ptrdiff_t) r * dp.stride);
+            if (r >= 3 && r <= 6) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    uint32_t v = row[d];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        t[r][4 * d + k] = (int) ((v >> (8 * k)) & 0xffu);
+                    }
+                }
+            } else {
+                uint32_t v = row[1];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    t[r][4 + k] = (int) ((v >> (8 * k)) & 0xffu);
+                }
+            }
         }
-        if (in_edge) {
-            uint8_t *k = p + 4 * across;
-            if (smooth6(k[3 * across], k[2 * across], k[across], k[0], k[-across], k[-2 * across], tM, o)) {
-                k[0] = (uint8_t) o[2];
-                k[2 * across] = (uint8_t) o[0];
-                k[-across] = (uint8_t) o[3];
-                k[across] = (uint8_t) o[1];
+        dirty = 0;
+    }
+
+    __device__ __forceinline__ void store(const DPlane &dp, int x, int y) const
+    {
+        if (!dirty) {
+            return;
+        }
+        uint8_t *base = dp.data + (ptrdiff_t) (y - 3) * dp.stride + (x - 4);
+#pragma unroll
+        for (int r = 0; r < 11; r++) {
+            if (!(dirty & (1u << r))) {
+                continue;
+            }
+            uint32_t *row = (uint32_t *) (base + (ptrdiff_t) r * dp.stride);
+            if (r >= 3 && r <= 6) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    row[d] = (uint32_t) t[r][4 * d] | ((uint32_t) t[r][4 * d + 1] << 8) | ((uint32_t) t[r][4 * d + 2] << 16) |
+                             ((uint32_t) t[r][4 * d + 3] << 24);
+                }
+            } else {
+                row[1] = (uint32_t) t[r][4] | ((uint32_t) t[r][5] << 8) | ((uint32_t) t[r][6] << 16) | ((uint32_t) t[r][7] << 24);
             }
         }
     }
+};
+
+// one 11-sample line through the cell: l[3] is the cell's first sample (bmc.c:71-191)
+__device__ __forceinline__ bool line_filter(int (&l)[11], bool in_edge, int tE, int tM)
+{
+    int o[4];
+    bool hit = false;
+    if (smooth6(l[0], l[1], l[2], l[3], l[4], l[5], tE, o)) {
+        l[1] = o[0] & 0xff;
+        l[3] = o[2] & 0xff;
+        l[2] = o[1] & 0xff;
+        l[4] = o[3] & 0xff;
+        hit = true;
+    }
+    if (in_edge && smooth6(l[10], l[9], l[8], l[7], l[6], l[5], tM, o)) {
+        l[7] = o[2] & 0xff;
+        l[9] = o[0] & 0xff;
+        l[6] = o[3] & 0xff;
+        l[8] = o[1] & 0xff;
+        hit = true;
+    }
+    return hit;
 }
 
-__device__ __forceinline__ void hfilter(const DPlane &dp, int x, int y, bool edge, int tE, int tM)
+__device__ __forceinline__ void hfilter(Tile &T, const DPlane &dp, int x, bool edge, int tE, int tM)
 {
     if (x < 4 || x > dp.w - 4 || (edge && tE <= 0) || tM <= 0) {
         return;
@@ -390,10 +451,25 @@ __device__ __forceinline__ void hfilter(const DPlane &dp, int x, int y, bool edg
     if (!edge) {
         tE = tM;
     }
-    edge_filter(dp.data + (ptrdiff_t) y * dp.stride + x, 1, dp.stride, x < dp.w - 8, tE, tM);
+    bool in_edge = x < dp.w - 8;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        int l[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            l[k] = T.t[3 + n][1 + k];
+        }
+        if (line_filter(l, in_edge, tE, tM)) {
+#pragma unroll
+            for (int k = 1; k < 10; k++) {
+                T.t[3 + n][1 + k] = l[k];
+            }
+            T.dirty |= 1u << (3 + n);
+        }
+    }
 }
 
-__device__ __forceinline__ void vfilter(const DPlane &dp, int x, int y, bool edge, int tE, int tM)
+__device__ __forceinline__ void vfilter(Tile &T, const DPlane &dp, int y, bool edge, int tE, int tM)
 {
     if (y < 4 || y > dp.h - 4 || (edge && tE <= 0) || tM <= 0) {
         return;
@@ -401,22 +477,100 @@ __device__ __forceinline__ void vfilter(const DPlane &dp, int x, int y, bool edg
     if (!edge) {
         tE = tM;
     }
-    edge_filter(dp.data + (ptrdiff_t) y * dp.stride + x, dp.stride, 1, y < dp.h - 8, tE, tM);
+    bool in_edge = y < dp.h - 8;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        int l[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            l[k] = T.t[k][4 + n];
+        }
+        if (line_filter(l, in_edge, tE, tM)) {
+#pragma unroll
+            for (int k = 1; k < 10; k++) {
+                T.t[k][4 + n] = l[k];
+            }
+            T.dirty |= 0x3deu; // rows 1..4 and 6..9
+        }
+    }
 }
 
-__device__ __forceinline__ void ds2x2(const uint8_t *a, int as, int d[4])
+// chroma: one horizontal (4 rows x 11 columns at (x, y)) or vertical (11 rows x 4 columns) pass on
+// its own, fetched and written back as aligned dwords
+__device__ __forceinline__ void hfilter_mem(const DPlane &dp, int x, int y, int tE, int tM)
 {
-    d[0] = (a[0] + a[1] + a[as] + a[as + 1] + 2) >> 2;
-    d[1] = (a[2] + a[3] + a[as + 2] + a[as + 3] + 2) >> 2;
-    a += 2 * as;
-    d[2] = (a[0] + a[1] + a[as] + a[as + 1] + 2) >> 2;
-    d[3] = (a[2] + a[3] + a[as + 2] + a[as + 3] + 2) >> 2;
+    if (x < 4 || x > dp.w - 4 || tM <= 0) {
+        return;
+    }
+    (void) tE;
+    bool in_edge = x < dp.w - 8;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        uint32_t *row = (uint32_t *) (dp.data + (ptrdiff_t) (y + n) * dp.stride + (x - 4));
+        uint32_t d[3] = {row[0], row[1], row[2]};
+        int l[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            l[k] = (int) ((d[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu);
+        }
+        if (line_filter(l, in_edge, tM, tM)) {
+            int c0 = (int) (d[0] & 0xffu);
+            row[0] = (uint32_t) c0 | ((uint32_t) l[0] << 8) | ((uint32_t) l[1] << 16) | ((uint32_t) l[2] << 24);
+            row[1] = (uint32_t) l[3] | ((uint32_t) l[4] << 8) | ((uint32_t) l[5] << 16) | ((uint32_t) l[6] << 24);
+            row[2] = (uint32_t) l[7] | ((uint32_t) l[8] << 8) | ((uint32_t) l[9] << 16) | ((uint32_t) l[10] << 24);
+        }
+    }
 }
 
-__device__ __forceinline__ unsigned dsff(const uint8_t *a, int as) // bmc.c:194
+__device__ __forceinline__ void vfilter_mem(const DPlane &dp, int x, int y, int tE, int tM)
 {
-    int d[4];
-    ds2x2(a, as, d);
+    if (y < 4 || y > dp.h - 4 || tM <= 0) {
+        return;
+    }
+    (void) tE;
+    bool in_edge = y < dp.h - 8;
+    uint32_t d[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        d[k] = *(const uint32_t *) (dp.data + (ptrdiff_t) (y - 3 + k) * dp.stride + x);
+    }
+    unsigned dirty = 0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        int l[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            l[k] = (int) ((d[k] >> (8 * n)) & 0xffu);
+        }
+        if (line_filter(l, in_edge, tM, tM)) {
+#pragma unroll
+            for (int k = 1; k < 10; k++) {
+                d[k] = (d[k] & ~(0xffu << (8 * n))) | ((uint32_t) l[k] << (8 * n));
+            }
+            dirty = 1;
+        }
+    }
+    if (dirty) {
+#pragma unroll
+        for (int k = 1; k < 10; k++) {
+            if (k != 5) {
+                *(uint32_t *) (dp.data + (ptrdiff_t) (y - 3 + k) * dp.stride + x) = d[k];
+            }
+        }
+    }
+}
+
+// ---- 4x4 cell statistics; CELL(y, x) yields the cell's pixel ---------------------------------------
+#define DS2X2(CELL, d)                                                        \
+    do {                                                                      \
+        d[0] = (CELL(0, 0) + CELL(0, 1) + CELL(1, 0) + CELL(1, 1) + 2) >> 2;  \
+        d[1] = (CELL(0, 2) + CELL(0, 3) + CELL(1, 2) + CELL(1, 3) + 2) >> 2;  \
+        d[2] = (CELL(2, 0) + CELL(2, 1) + CELL(3, 0) + CELL(3, 1) + 2) >> 2;  \
+        d[3] = (CELL(2, 2) + CELL(2, 3) + CELL(3, 2) + CELL(3, 3) + 2) >> 2;  \
+    } while (0)
+
+__device__ __forceinline__ unsigned dsff_d(int d[4]) // bmc.c:194
+{
     unsigned sh = (unsigned) abs((d[0] + d[1]) - (d[3] + d[2]));
     unsigned sv = (unsigned) abs((d[2] + d[1]) - (d[3] + d[0]));
     if (max(sh, sv) < 8) {
@@ -429,40 +583,48 @@ __device__ __forceinline__ unsigned dsff(const uint8_t *a, int as) // bmc.c:194
     return sh > sv ? (3 * sh + sv + 2) >> 2 : (3 * sv + sh + 2) >> 2;
 }
 
-__device__ __forceinline__ void artf(const uint8_t *a, int as, int &sh, int &sv, int &slh, int &slv) // bmc.c:224-270
+__device__ __forceinline__ unsigned dsff(const Tile &T)
+{
+    int d[4];
+#define TCELL(yy, xx) T.t[3 + (yy)][4 + (xx)]
+    DS2X2(TCELL, d);
+    return dsff_d(d);
+}
+
+__device__ __forceinline__ void artf(const Tile &T, int &sh, int &sv, int &slh, int &slv) // bmc.c:224-270
 {
     sh = sv = 0;
+#pragma unroll
     for (int y = 0; y < 4; y += 2) {
+#pragma unroll
         for (int x = 0; x < 4; x += 2) {
-            int x0 = a[y * as + x], x1 = a[y * as + x + 1], x2 = a[(y + 1) * as + x], x3 = a[(y + 1) * as + x + 1];
+            int x0 = TCELL(y, x), x1 = TCELL(y, x + 1), x2 = TCELL(y + 1, x), x3 = TCELL(y + 1, x + 1);
             int hh = abs(x0 - x1 - x2 + x3) >> 1;
             sh += abs(x0 - x1 + x2 - x3) + hh;
             sv += abs(x0 + x1 - x2 - x3) + hh;
         }
     }
     int d[4];
-    ds2x2(a, as, d);
+    DS2X2(TCELL, d);
     int hh = abs(d[0] - d[1] - d[2] + d[3]) >> 1;
     slh = abs(d[0] - d[1] + d[2] - d[3]) + hh;
     slv = abs(d[0] + d[1] - d[2] - d[3]) + hh;
 }
 
-__device__ void degrad(uint8_t *a, int as) // bmc.c:276
+// de-gradient sharpening of 16 pixels px[y * 4 + x] in place (bmc.c:276); returns true when it changed them
+__device__ __forceinline__ bool degrad16(int (&px)[16])
 {
-    int px[16];
     int lo = 16, hi = -1;
-    for (int y = 0; y < 4; y++) {
-        for (int x = 0; x < 4; x++) {
-            int v = a[y * as + x];
-            px[y * 4 + x] = v;
-            lo = min(lo, v >> 4);
-            hi = max(hi, v >> 4);
-        }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo = min(lo, px[k] >> 4);
+        hi = max(hi, px[k] >> 4);
     }
     if (lo >= hi) {
-        return;
+        return false;
     }
     int nlo = 0, nhi = 0, slo = 0, shi = 0;
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         int b = px[k] >> 4;
         if (b == lo) {
@@ -482,14 +644,46 @@ __device__ void degrad(uint8_t *a, int as) // bmc.c:276
         ahi = 1;
     }
     int t = (alo + ahi + 1) >> 1;
-    for (int y = 0; y < 4; y++) {
-        for (int x = 0; x < 4; x++) {
-            int os = px[y * 4 + x];
-            if (os < t) {
-                a[y * as + x] = (uint8_t) (os + (nlo * (alo - os)) / 16);
-            } else if (os > t) {
-                a[y * as + x] = (uint8_t) (os + (nhi * (ahi - os)) / 16);
-            }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int os = px[k];
+        if (os < t) {
+            px[k] = (os + (nlo * (alo - os)) / 16) & 0xff;
+        } else if (os > t) {
+            px[k] = (os + (nhi * (ahi - os)) / 16) & 0xff;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ void degrad(Tile &T)
+{
+    int px[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        px[k] = TCELL(k >> 2, k & 3);
+    }
+    if (degrad16(px)) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            T.t[3 + (k >> 2)][4 + (k & 3)] = px[k];
+        }
+        T.dirty |= 0x78u;
+    }
+}
+
+// the same on memory (decoder post-processing: every cell is independent)
+__device__ void degrad(uint8_t *a, int as)
+{
+    int px[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        px[k] = a[(k >> 2) * as + (k & 3)];
+    }
+    if (degrad16(px)) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            a[(k >> 2) * as + (k & 3)] = (uint8_t) px[k];
         }
     }
 }
@@ -543,16 +737,17 @@ __device__ void intra_cell(const DPlane &dp, const FilterParams &f, const uint8_
     if (flags & DSV_IS_RINGING) {
         return;
     }
-    uint8_t *a = dp.data + (ptrdiff_t) y * dp.stride + x;
+    Tile T;
+    T.load(dp, x, y);
     int sh, sv, shl, svl;
-    artf(a, dp.stride, sh, sv, shl, svl);
+    artf(T, sh, sv, shl, svl);
     int mx = max(sh, sv);
     if (!(mx < 256 && mx > 8)) {
         return;
     }
     int tt = 32;
     if (flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE)) {
-        tt = (int) dsff(a, dp.stride);
+        tt = (int) dsff(T);
         if (flags & DSV_IS_STABLE) {
             tt = tt * 5 >> 2;
         }
@@ -562,15 +757,16 @@ __device__ void intra_cell(const DPlane &dp, const FilterParams &f, const uint8_
     tt = tt * 2 / 3;
     tt = (tt * f.q) >> 12;
     tt = clampi(tt, 0, f.fthresh);
-    hfilter(dp, x, y, false, tt, tt);
-    vfilter(dp, x, y, false, tt, tt);
+    hfilter(T, dp, x, false, tt, tt);
+    vfilter(T, dp, y, false, tt, tt);
     tt = sh > sv ? (3 * sh + sv) : (3 * sv + sh);
     tt = curve_tex(tt);
     tt = 16 + ((tt + 2) >> 2);
     tt = (tt * f.q) >> 12;
     tt = clampi(tt, 0, f.fthresh);
-    hfilter(dp, x, y, false, tt, tt);
-    vfilter(dp, x, y, false, tt, tt);
+    hfilter(T, dp, x, false, tt, tt);
+    vfilter(T, dp, y, false, tt, tt);
+    T.store(dp, x, y);
 }
 
 __device__ void luma_cell(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j, int nsbx, int nsby)
@@ -586,7 +782,6 @@ __device__ void luma_cell(const DPlane &dp, const FilterParams &f, const DSV_MV 
     bool edgev = (y % f.blk_h) == 0, edgevs = (y % (f.blk_h / 2)) == 0;
     int mvx = mv->u.mv.x, mvy = mv->u.mv.y;
     int amx = abs(mvx), amy = abs(mvy);
-    uint8_t *a = dp.data + (ptrdiff_t) y * dp.stride + x;
     if (flags & (1u << DSV_MV_BIT_INTRA)) {
         int tH = clampi((64 * f.q) >> 12, 2, 32), tL = clampi((32 * f.q) >> 12, 2, 32);
         bool eh = edgeh, ev = edgev;
@@ -594,19 +789,32 @@ __device__ void luma_cell(const DPlane &dp, const FilterParams &f, const DSV_MV 
             eh |= edgehs;
             ev |= edgevs;
         }
-        hfilter(dp, x, y, eh, tH, tL);
-        vfilter(dp, x, y, ev, tH, tL);
+        Tile T;
+        T.load(dp, x, y);
+        hfilter(T, dp, x, eh, tH, tL);
+        vfilter(T, dp, y, ev, tH, tL);
+        T.store(dp, x, y);
         return;
     }
+    int ndx = 0, ndy = 0;
+    bool filt = false;
     if (f.do_filter) {
-        int ndx, ndy;
         neighbordif2(vecs, f.nbh, fx, fy, ndx, ndy);
-        if (ndx || ndy) {
+        filt = ndx || ndy;
+    }
+    bool sharp = f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8;
+    if (!filt && !sharp) {
+        return;
+    }
+    Tile T;
+    T.load(dp, x, y);
+    if (filt) {
+        {
             bool eprm = flags & (1u << DSV_MV_BIT_EPRM);
             bool eh = edgeh || eprm, ev = edgev || eprm;
             int tndc = (ndx + ndy + 1) >> 1;
             int sh, sv, shl, svl, tt;
-            artf(a, dp.stride, sh, sv, shl, svl);
+            artf(T, sh, sv, shl, svl);
             if (sh < 2 * sv && sv < 2 * sh) {
                 if (ndx < amx) {
                     ndx >>= 1;
@@ -631,18 +839,19 @@ __device__ void luma_cell(const DPlane &dp, const FilterParams &f, const DSV_MV 
             int addx = (min(ndy, f.fthresh) * f.q) >> 12;
             int addy = (min(ndx, f.fthresh) * f.q) >> 12;
             if (sh > 2 * sv || amy > 2 * amx) {
-                vfilter(dp, x, y, ev, tt + addy, tt);
+                vfilter(T, dp, y, ev, tt + addy, tt);
             } else if (sv > 2 * sh || amx > 2 * amy) {
-                hfilter(dp, x, y, eh, tt + addx, tt);
+                hfilter(T, dp, x, eh, tt + addx, tt);
             } else {
-                hfilter(dp, x, y, eh, tt + addx, tt);
-                vfilter(dp, x, y, ev, tt + addy, tt);
+                hfilter(T, dp, x, eh, tt + addx, tt);
+                vfilter(T, dp, y, ev, tt + addy, tt);
             }
         }
     }
-    if (f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8) {
-        degrad(a, dp.stride);
+    if (sharp) {
+        degrad(T);
     }
+    T.store(dp, x, y);
 }
 
 __device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j)
@@ -668,12 +877,12 @@ __device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_
     }
     for (int z = 0; z < bh; z += 4) {
         if (y + z + 4 < dp.h) {
-            hfilter(dp, x, y + z, false, tx, tx);
+            hfilter_mem(dp, x, y + z, tx, tx);
         }
     }
     for (int z = 0; z < bw; z += 4) {
         if (x + z + 4 < dp.w) {
-            vfilter(dp, x + z, y, false, ty, ty);
+            vfilter_mem(dp, x + z, y, ty, ty);
         }
     }
 }
@@ -756,7 +965,7 @@ __global__ __launch_bounds__(256) void k_post_process(DPlane dp)
 
 void post_process_plane(hipStream_t s, const DPlane &dp)
 {
-    hipLaunchKernelGGL(k_post_process, dim3((dp.w / 4 + 63) / 64, (dp.h / 4 + 3) / 4), dim3(64, 4), 0, s, dp);
+    DSV2_LAUNCH(k_post_process, dim3((dp.w / 4 + 63) / 64, (dp.h / 4 + 3) / 4), dim3(64, 4), 0, s, dp);
     HIPCHK(hipGetLastError());
 }
 
@@ -809,7 +1018,7 @@ static Planes3 planes_of(const DFrame &f)
 
 void mc_sub_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DFrame &pred, const DFrame &resd, const DFrame &ref)
 {
-    hipLaunchKernelGGL((k_predict<MC_SUBTRACT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(pred),
+    DSV2_LAUNCH((k_predict<MC_SUBTRACT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(pred),
                        planes_of(resd));
     HIPCHK(hipGetLastError());
 }
@@ -817,9 +1026,9 @@ void mc_sub_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DF
 void mc_add_res(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &pred, int do_filter,
                 int inter_sharpen)
 {
-    hipLaunchKernelGGL(k_reconstruct, dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(pred), planes_of(resd));
+    DSV2_LAUNCH(k_reconstruct, dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(pred), planes_of(resd));
     if (!p.lossless) {
-        hipLaunchKernelGGL(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
+        DSV2_LAUNCH(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
                            planes_of(resd));
     }
     HIPCHK(hipGetLastError());
@@ -828,10 +1037,10 @@ void mc_add_res(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, co
 void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &out, const DFrame &ref,
                  int do_filter, int inter_sharpen)
 {
-    hipLaunchKernelGGL((k_predict<MC_RECONSTRUCT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(out),
+    DSV2_LAUNCH((k_predict<MC_RECONSTRUCT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(out),
                        planes_of(resd));
     if (!p.lossless) {
-        hipLaunchKernelGGL(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
+        DSV2_LAUNCH(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
                            planes_of(out));
     }
     HIPCHK(hipGetLastError());
@@ -841,16 +1050,16 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
 void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
 {
     if (n > 0) {
-        hipLaunchKernelGGL((k_predict_b<MC_SUBTRACT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH((k_predict_b<MC_SUBTRACT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
     }
 }
 
 void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter)
 {
     if (n > 0) {
-        hipLaunchKernelGGL(k_reconstruct_b, dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH(k_reconstruct_b, dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            hipLaunchKernelGGL(k_inter_filters_b, dim3(3, n), dim3(256), 0, s, d_tab);
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), 0, s, d_tab);
         }
     }
 }
@@ -858,7 +1067,7 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n)
 {
     if (n > 0) {
-        hipLaunchKernelGGL(k_intra_filter_b, dim3(n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), 0, s, d_tab);
     }
 }
 
@@ -867,7 +1076,7 @@ void intra_filter_luma(hipStream_t s, const uint8_t *d_bd, const MCParams &p, in
     if (p.lossless) {
         return;
     }
-    hipLaunchKernelGGL(k_intra_filter, dim3(1), dim3(256), 0, s, d_bd, make_filter_params(p, q, 1, 0), luma);
+    DSV2_LAUNCH(k_intra_filter, dim3(1), dim3(256), 0, s, d_bd, make_filter_params(p, q, 1, 0), luma);
     HIPCHK(hipGetLastError());
 }
 

@@ -33,15 +33,14 @@ struct PlaneSyms { // host view of one plane's entropy input
 enum Stage { ST_INGEST = 0, ST_HME, ST_PREDICT, ST_FWD_SBT, ST_QUANT, ST_INV_SBT, ST_RECON_FILTER, ST_EXTEND, ST_COUNT };
 
 struct StageProf {
-    bool on = false;
+    bool created = false;
     hipEvent_t ev[ST_COUNT][2];
     bool used[ST_COUNT];
-    long long launches[ST_COUNT];
-    void init();
+    long long launches[ST_COUNT], units[ST_COUNT], mark = 0;
     void destroy();
     void begin(hipStream_t s, int st);
-    void end(hipStream_t s, int st, int nlaunch);
-    void collect(); // after a stream synchronise: fold the frame's event pairs into the global totals
+    void end(hipStream_t s, int st, int nunits); // nunits = stream-frames the stage processed
+    void collect(); // after a stream synchronise: fold the step's event pairs into the global totals
 };
 bool prof_enabled();
 

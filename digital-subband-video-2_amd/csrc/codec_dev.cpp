@@ -14,56 +14,57 @@ namespace dsv2 {
 static std::atomic<int> g_prof_on{0};
 static std::mutex g_prof_mu;
 static double g_prof_ms[ST_COUNT];
-static long long g_prof_launches[ST_COUNT];
+static long long g_prof_launches[ST_COUNT], g_prof_units[ST_COUNT];
 static long long g_prof_frames;
 
 bool prof_enabled() { return g_prof_on.load() != 0; }
 
-void StageProf::init()
-{
-    on = prof_enabled();
-    if (!on) {
-        return;
-    }
-    for (int i = 0; i < ST_COUNT; i++) {
-        HIPCHK(hipEventCreate(&ev[i][0]));
-        HIPCHK(hipEventCreate(&ev[i][1]));
-        used[i] = false;
-        launches[i] = 0;
-    }
-}
-
 void StageProf::destroy()
 {
-    if (!on) {
+    if (!created) {
         return;
     }
     for (int i = 0; i < ST_COUNT; i++) {
         HIPCHK(hipEventDestroy(ev[i][0]));
         HIPCHK(hipEventDestroy(ev[i][1]));
     }
-    on = false;
+    created = false;
 }
 
 void StageProf::begin(hipStream_t s, int st)
 {
-    if (on && !used[st]) {
+    if (!prof_enabled()) {
+        return;
+    }
+    if (!created) { // events exist only once profiling has been asked for
+        for (int i = 0; i < ST_COUNT; i++) {
+            HIPCHK(hipEventCreate(&ev[i][0]));
+            HIPCHK(hipEventCreate(&ev[i][1]));
+            used[i] = false;
+            launches[i] = units[i] = 0;
+        }
+        created = true;
+    }
+    if (!used[st]) {
         HIPCHK(hipEventRecord(ev[st][0], s));
     }
+    mark = t_launch_count;
 }
 
-void StageProf::end(hipStream_t s, int st, int nlaunch)
+void StageProf::end(hipStream_t s, int st, int nunits)
 {
-    if (on) {
-        HIPCHK(hipEventRecord(ev[st][1], s)); // the last end() of a frame closes the stage's span
-        used[st] = true;
-        launches[st] += nlaunch;
+    if (!prof_enabled() || !created) {
+        return;
     }
+    HIPCHK(hipEventRecord(ev[st][1], s)); // the last end() of a step closes the stage's span
+    used[st] = true;
+    launches[st] += t_launch_count - mark;
+    units[st] += nunits;
 }
 
 void StageProf::collect()
 {
-    if (!on) {
+    if (!created) {
         return;
     }
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -73,8 +74,9 @@ void StageProf::collect()
             HIPCHK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1]));
             g_prof_ms[i] += ms;
             g_prof_launches[i] += launches[i];
+            g_prof_units[i] += units[i];
             used[i] = false;
-            launches[i] = 0;
+            launches[i] = units[i] = 0;
         }
     }
     g_prof_frames++;
@@ -87,8 +89,19 @@ extern "C" void dsv2hip_prof_enable(int on)
     for (int i = 0; i < ST_COUNT; i++) {
         g_prof_ms[i] = 0;
         g_prof_launches[i] = 0;
+        g_prof_units[i] = 0;
     }
     g_prof_frames = 0;
+}
+
+// stream-frames each stage processed since profiling was switched on (same order as dsv2hip_prof_read)
+extern "C" int dsv2hip_prof_read_units(long long *units)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < ST_COUNT; i++) {
+        units[i] = g_prof_units[i];
+    }
+    return ST_COUNT;
 }
 
 extern "C" int dsv2hip_prof_read(double *ms, long long *launches, long long *frames)
@@ -136,7 +149,6 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     nbv = (h + blk_h - 1) / blk_h;
     pyr_levels = pyr_levels_;
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    prof.init();
     coef_dims(format, w, h, cw, ch);
     size_t nb = nblocks();
     for (int i = 0; i < 2; i++) {

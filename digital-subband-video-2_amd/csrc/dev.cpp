@@ -5,6 +5,9 @@
 
 namespace dsv2 {
 
+thread_local long long t_launch_count = 0;
+
+
 [[noreturn]] void fatal(const char *what, const char *file, int line)
 {
     fprintf(stderr, "[dsv2hip] FATAL: %s (%s:%d)\n", what, file, line);

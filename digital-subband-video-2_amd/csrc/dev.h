@@ -29,6 +29,14 @@ namespace dsv2 {
         }                                                              \
     } while (0)
 
+// every kernel launch goes through this macro so that the stage profile can report launch counts
+extern thread_local long long t_launch_count;
+#define DSV2_LAUNCH(...)                \
+    do {                                \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+        dsv2::t_launch_count++;         \
+    } while (0)
+
 constexpr int kBorder = 32; // dsv_internal.h:38
 constexpr int kBlockP = 14; // dsv_internal.h:127
 

@@ -1442,11 +1442,12 @@ void enc_batch(Job *jobs, int n)
             jb.ran_hme = 1;
         }
     }
-    prof.end(bs, ST_INGEST, 2 * L + 4);
+    prof.end(bs, ST_INGEST, n);
     if (!pjobs.empty()) {
         prof.begin(bs, ST_HME);
         int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme);
-        prof.end(bs, ST_HME, nfronts);
+        (void) nfronts;
+        prof.end(bs, ST_HME, (int) pjobs.size());
     }
     t_clock.lap(1);
     HIPCHK(hipStreamSynchronize(bs));
@@ -1584,7 +1585,7 @@ void enc_batch(Job *jobs, int n)
     copy_linear_batch(bs, d_copy, n, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
     mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv);
-    prof.end(bs, ST_PREDICT, 1);
+    prof.end(bs, ST_PREDICT, nP);
     struct Slice {
         int first, count, isP, lossless;
     };
@@ -1603,9 +1604,9 @@ void enc_batch(Job *jobs, int n)
         sbt_forward_jobs(bs, d_py + sl.first, sl.count, dv0.cw[0], dv0.ch[0], 0, sl.isP, sl.lossless, nbh, nbv);
         sbt_forward_jobs(bs, d_pc + 2 * sl.first, 2 * sl.count, dv0.cw[1], dv0.ch[1], 1, sl.isP, sl.lossless, nbh, nbv);
     }
-    prof.end(bs, ST_FWD_SBT, 3);
+    prof.end(bs, ST_FWD_SBT, n);
     prof.begin(bs, ST_QUANT);
-    hipLaunchKernelGGL(k_grab_ll, dim3((n + 63) / 64), dim3(64), 0, bs, d_py, d_pc, n, sc.d_ll);
+    DSV2_LAUNCH(k_grab_ll, dim3((n + 63) / 64), dim3(64), 0, bs, d_py, d_pc, n, sc.d_ll);
     HIPCHK(hipMemcpyAsync(sc.h_ll, sc.d_ll, 3 * (size_t) n * sizeof(int32_t), hipMemcpyDeviceToHost, bs));
     for (const Slice &sl : slices) {
         quant_jobs(bs, d_py + sl.first, sl.count, dv0.quant_cfg(0, sl.isP, sl.lossless, do_psy, nullptr));
@@ -1613,21 +1614,21 @@ void enc_batch(Job *jobs, int n)
     }
     compact_jobs(bs, d_comp, n, dv0.qv_off[3]);
     HIPCHK(hipMemcpyAsync(sc.h_totals, sc.d_totals, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, bs));
-    prof.end(bs, ST_QUANT, 3);
+    prof.end(bs, ST_QUANT, n);
     prof.begin(bs, ST_INV_SBT);
     for (const Slice &sl : slices) {
         sbt_inverse_jobs(bs, d_py + sl.first, sl.count, dv0.cw[0], dv0.ch[0], 0, sl.isP, sl.lossless, nbh, nbv);
         sbt_inverse_jobs(bs, d_pc + 2 * sl.first, 2 * sl.count, dv0.cw[1], dv0.ch[1], 1, sl.isP, sl.lossless, nbh, nbv);
     }
-    prof.end(bs, ST_INV_SBT, 3);
+    prof.end(bs, ST_INV_SBT, n);
     prof.begin(bs, ST_RECON_FILTER);
     intra_filter_batch(bs, sc.d_mc + n, nI);
     mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter);
-    prof.end(bs, ST_RECON_FILTER, 2);
+    prof.end(bs, ST_RECON_FILTER, nP + nI);
     prof.begin(bs, ST_EXTEND);
     extend_planes(bs, d_rext_y, n_rext, dv0.pics[0].recon.p[0].w, dv0.pics[0].recon.p[0].h);
     extend_planes(bs, d_rext_c, 2 * n_rext, dv0.pics[0].recon.p[1].w, dv0.pics[0].recon.p[1].h);
-    prof.end(bs, ST_EXTEND, 3);
+    prof.end(bs, ST_EXTEND, n_rext);
     t_clock.lap(4);
     HIPCHK(hipStreamSynchronize(bs));
     t_clock.lap(5);

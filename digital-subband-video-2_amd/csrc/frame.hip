@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_extend(const DPlane *__restrict__ tab, 
 
 void extend_plane(hipStream_t s, const DPlane &p)
 {
-    hipLaunchKernelGGL(k_extend, dim3((extend_items(p.w, p.h) + 255) / 256), dim3(256), 0, s, nullptr, p);
+    DSV2_LAUNCH(k_extend, dim3((extend_items(p.w, p.h) + 255) / 256), dim3(256), 0, s, nullptr, p);
 }
 
 void extend_frame(hipStream_t s, const DFrame &f, bool luma_only)
@@ -116,7 +116,7 @@ void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int 
     if (n <= 0) {
         return;
     }
-    hipLaunchKernelGGL(k_extend, dim3((extend_items(max_w, max_h) + 255) / 256, n), dim3(256), 0, s, d_planes, DPlane{});
+    DSV2_LAUNCH(k_extend, dim3((extend_items(max_w, max_h) + 255) / 256, n), dim3(256), 0, s, d_planes, DPlane{});
 }
 
 // 2x2 rounded mean decimation of the luma plane (frame.c:211-234)
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_ds2x(const PlanePair *__restrict__ tab,
 
 void ds2x_luma(hipStream_t s, const DPlane &src, const DPlane &dst)
 {
-    hipLaunchKernelGGL(k_ds2x, dim3((dst.w + 63) / 64, (dst.h + 3) / 4), dim3(64, 4), 0, s, nullptr, PlanePair{src, dst});
+    DSV2_LAUNCH(k_ds2x, dim3((dst.w + 63) / 64, (dst.h + 3) / 4), dim3(64, 4), 0, s, nullptr, PlanePair{src, dst});
 }
 
 void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h)
@@ -143,7 +143,7 @@ void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int 
     if (n <= 0) {
         return;
     }
-    hipLaunchKernelGGL(k_ds2x, dim3((dst_w + 63) / 64, (dst_h + 3) / 4, n), dim3(64, 4), 0, s, d_pairs, PlanePair{});
+    DSV2_LAUNCH(k_ds2x, dim3((dst_w + 63) / 64, (dst_h + 3) / 4, n), dim3(64, 4), 0, s, d_pairs, PlanePair{});
 }
 
 // visible pixels of all planes, device to device (frame.c:186-203 without the extension)
@@ -181,7 +181,7 @@ void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_b
     }
     size_t vecs = max_bytes >> 4;
     int gx = (int) ((vecs + 256 * 8 - 1) / (256 * 8));
-    hipLaunchKernelGGL(k_copy_linear, dim3(gx < 1 ? 1 : gx, n), dim3(256), 0, s, d_jobs);
+    DSV2_LAUNCH(k_copy_linear, dim3(gx < 1 ? 1 : gx, n), dim3(256), 0, s, d_jobs);
 }
 
 // packed planar picture (rows of exactly w bytes, planes back to back) -> the three padded planes
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_plane_to_host(const PlaneOutJob *__restr
 void planes_to_host_batch(hipStream_t s, const PlaneOutJob *d_jobs, int n, int h)
 {
     if (n > 0) {
-        hipLaunchKernelGGL(k_plane_to_host, dim3(h, n), dim3(64), 0, s, d_jobs);
+        DSV2_LAUNCH(k_plane_to_host, dim3(h, n), dim3(64), 0, s, d_jobs);
     }
 }
 
@@ -240,7 +240,7 @@ void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int tota
     if (n <= 0) {
         return;
     }
-    hipLaunchKernelGGL(k_ingest, dim3((w + 1023) / 1024, total_rows, n), dim3(256), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ingest, dim3((w + 1023) / 1024, total_rows, n), dim3(256), 0, s, d_jobs);
 }
 
 } // namespace dsv2

@@ -1257,24 +1257,24 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     for (int level = g.pyr_levels; level >= 0; level--) {
         int step = 1 << level;
         int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
-        hipLaunchKernelGGL(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
+        DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
         if (g_hme_rows) {
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
-            hipLaunchKernelGGL(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
+            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
             for (int t = 0; t <= nbx + nby - 2; t++) {
                 int jhi = nby - 1 < t ? nby - 1 : t;
                 int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-                hipLaunchKernelGGL(k_hme_front_b, dim3(jhi - jlo + 1, n), dim3(64), 0, s, tab, level, t, nbx, nby, g_hme_fast);
+                DSV2_LAUNCH(k_hme_front_b, dim3(jhi - jlo + 1, n), dim3(64), 0, s, tab, level, t, nbx, nby, g_hme_fast);
                 nlaunch++;
             }
         }
         if (level != 0) {
-            hipLaunchKernelGGL(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
+            DSV2_LAUNCH(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
         }
     }
-    hipLaunchKernelGGL(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
+    DSV2_LAUNCH(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
     HIPCHK(hipGetLastError());
     return nlaunch;
 }
@@ -1314,18 +1314,18 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
             if (level != hp.pyr_levels) {
                 HIPCHK(hipMemsetAsync(f.counters + kHmeProgress, 0, (size_t) hp.a.nbv * sizeof(int), s));
             }
-            hipLaunchKernelGGL(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
+            DSV2_LAUNCH(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
             for (int t = 0; t <= nbx + nby - 2; t++) {
                 int jhi = nby - 1 < t ? nby - 1 : t;
                 int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-                hipLaunchKernelGGL(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby, g_hme_fast);
+                DSV2_LAUNCH(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby, g_hme_fast);
                 nlaunch++;
             }
         }
         if (level != 0) {
-            hipLaunchKernelGGL(k_global_motion, dim3(1), dim3(256), 0, s, c, level);
+            DSV2_LAUNCH(k_global_motion, dim3(1), dim3(256), 0, s, c, level);
         }
     }
     HIPCHK(hipGetLastError());

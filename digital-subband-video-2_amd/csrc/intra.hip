@@ -105,7 +105,7 @@ void intra_analysis(hipStream_t s, const DFrame &src, const AnalysisParams &p, D
     for (int c = 0; c < 3; c++) {
         pl.p[c] = src.p[c];
     }
-    hipLaunchKernelGGL(k_intra_analysis, dim3(p.nbh, p.nbv), dim3(64), 0, s, nullptr, IntraJob{pl, d_out}, p);
+    DSV2_LAUNCH(k_intra_analysis, dim3(p.nbh, p.nbv), dim3(64), 0, s, nullptr, IntraJob{pl, d_out}, p);
     HIPCHK(hipGetLastError());
 }
 
@@ -114,7 +114,7 @@ void intra_analysis_batch(hipStream_t s, const IntraJob *d_jobs, int n, const An
     if (n <= 0) {
         return;
     }
-    hipLaunchKernelGGL(k_intra_analysis, dim3(p.nbh, p.nbv, n), dim3(64), 0, s, d_jobs, IntraJob{}, p);
+    DSV2_LAUNCH(k_intra_analysis, dim3(p.nbh, p.nbv, n), dim3(64), 0, s, d_jobs, IntraJob{}, p);
     HIPCHK(hipGetLastError());
 }
 

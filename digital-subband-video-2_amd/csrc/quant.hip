@@ -336,7 +336,7 @@ static void quant_launch(hipStream_t s, const PlaneJob *tab, const PlaneJob &one
     make_scan(&g, cfg.w, cfg.h);
     const dim3 blk(64, 4);
     unsigned nz = tab ? (unsigned) n : 1u;
-    hipLaunchKernelGGL(k_quant_ll, dim3((g.sw[0] + 63) / 64, (g.sh[0] + 3) / 4, nz), blk, 0, s, tab, one, cfg, g.sw[0], g.sh[0]);
+    DSV2_LAUNCH(k_quant_ll, dim3((g.sw[0] + 63) / 64, (g.sh[0] + 3) / 4, nz), blk, 0, s, tab, one, cfg, g.sw[0], g.sh[0]);
     for (int l = 0; l < 3; l++) {
         LevelArgs a;
         a.l = l;
@@ -352,9 +352,9 @@ static void quant_launch(hipStream_t s, const PlaneJob *tab, const PlaneJob &one
             a.par[si] = h_subband_off(l - 1, si + 1, cfg.w, cfg.h);
             a.gpar[si] = h_subband_off(l - 2, si + 1, cfg.w, cfg.h);
         }
-        hipLaunchKernelGGL(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
+        DSV2_LAUNCH(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
         if (a.xdep || a.ydep) {
-            hipLaunchKernelGGL(k_quant_level_dep, dim3((a.sw + a.sh + 255) / 256, 3, nz), dim3(256), 0, s, tab, one, cfg, a);
+            DSV2_LAUNCH(k_quant_level_dep, dim3((a.sw + a.sh + 255) / 256, 3, nz), dim3(256), 0, s, tab, one, cfg, a);
         }
     }
     HIPCHK(hipGetLastError());
@@ -546,9 +546,9 @@ void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
 {
     CompactJob one = job(qv, n);
     int ntiles = (int) ((n + kTile - 1) / kTile);
-    hipLaunchKernelGGL(k_count, dim3(ntiles), dim3(256), 0, s, nullptr, one);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, nullptr, one);
-    hipLaunchKernelGGL(k_scatter, dim3(ntiles), dim3(256), 0, s, nullptr, one);
+    DSV2_LAUNCH(k_count, dim3(ntiles), dim3(256), 0, s, nullptr, one);
+    DSV2_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, s, nullptr, one);
+    DSV2_LAUNCH(k_scatter, dim3(ntiles), dim3(256), 0, s, nullptr, one);
     HIPCHK(hipMemcpyAsync(h_total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
 }
@@ -559,9 +559,9 @@ void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n)
         return;
     }
     int ntiles = (int) ((n + kTile - 1) / kTile);
-    hipLaunchKernelGGL(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1, njobs), dim3(1024), 0, s, d_jobs, CompactJob{});
-    hipLaunchKernelGGL(k_scatter, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
+    DSV2_LAUNCH(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
+    DSV2_LAUNCH(k_scan_tiles, dim3(1, njobs), dim3(1024), 0, s, d_jobs, CompactJob{});
+    DSV2_LAUNCH(k_scatter, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     HIPCHK(hipGetLastError());
 }
 
@@ -624,7 +624,7 @@ void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int
     int qf = q * 3 / 2;
     int done = 0;
     if (seg_count[0] > 0) {
-        hipLaunchKernelGGL(k_dequant_ll, dim3((seg_count[0] + 255) / 256), dim3(256), 0, s, coefs.data, d_pos, d_val, seg_count[0],
+        DSV2_LAUNCH(k_dequant_ll, dim3((seg_count[0] + 255) / 256), dim3(256), 0, s, coefs.data, d_pos, d_val, seg_count[0],
                            cfg, g.sw[0], cfg.lossless ? 1 : lfquant(cfg, qf));
     }
     done = seg_count[0];
@@ -644,10 +644,10 @@ void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int
                 a.par[si] = h_subband_off(l - 1, si + 1, coefs.w, coefs.h);
                 a.qp[si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
             }
-            hipLaunchKernelGGL(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done, d_val + done, n,
+            DSV2_LAUNCH(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done, d_val + done, n,
                                cfg, a, xdep, ydep, 0);
             if (xdep || ydep) {
-                hipLaunchKernelGGL(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done,
+                DSV2_LAUNCH(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done,
                                    d_val + done, n, cfg, a, xdep, ydep, 1);
             }
         }

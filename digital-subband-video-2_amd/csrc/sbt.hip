@@ -568,20 +568,20 @@ static const dim3 kBlk(64, 4);
 template <int F> static void launch_fwd_sep(hipStream_t s, const Batch &b, bool u8, const LevelGeom &g, int s_sel, int d_sel)
 {
     if (u8) {
-        hipLaunchKernelGGL((k_fwd_rows<F, true>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, s_sel);
+        DSV2_LAUNCH((k_fwd_rows<F, true>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, s_sel);
     } else {
-        hipLaunchKernelGGL((k_fwd_rows<F, false>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, s_sel);
+        DSV2_LAUNCH((k_fwd_rows<F, false>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, s_sel);
     }
-    hipLaunchKernelGGL((k_fwd_cols<F>), grid3(g.sw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
+    DSV2_LAUNCH((k_fwd_cols<F>), grid3(g.sw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
 }
 
 template <int F> static void launch_inv_sep(hipStream_t s, const Batch &b, bool u8, const LevelGeom &g, int ll_sel, int d_sel)
 {
-    hipLaunchKernelGGL((k_inv_cols<F>), grid3(g.sw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel);
+    DSV2_LAUNCH((k_inv_cols<F>), grid3(g.sw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel);
     if (u8) {
-        hipLaunchKernelGGL((k_inv_rows<F, true>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
+        DSV2_LAUNCH((k_inv_rows<F, true>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
     } else {
-        hipLaunchKernelGGL((k_inv_rows<F, false>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
+        DSV2_LAUNCH((k_inv_rows<F, false>), grid3(g.hw, g.sh, b), kBlk, 0, s, b.tab, b.one, g, d_sel);
     }
 }
 
@@ -622,9 +622,9 @@ static void fwd_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
         switch (filter) {
             case F_HAAR:
                 if (u8) {
-                    hipLaunchKernelGGL((k_fwd_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
+                    DSV2_LAUNCH((k_fwd_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
                 } else {
-                    hipLaunchKernelGGL((k_fwd_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
+                    DSV2_LAUNCH((k_fwd_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
                 }
                 break;
             case F_LLI: launch_fwd_sep<F_LLI>(s, b, u8, g, s_sel, d_sel); break;
@@ -653,10 +653,10 @@ static void inv_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
                 int hdiv = (plane_idx == 0) ? (isP ? 14 : (l > 4 ? 2 : 8)) : 2;   // sbt.c:903
                 int filtered = !lossless && (plane_idx == 0 || !isP);               // sbt.c:925
                 if (u8) {
-                    hipLaunchKernelGGL((k_inv_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
+                    DSV2_LAUNCH((k_inv_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
                                        filtered, hdiv);
                 } else {
-                    hipLaunchKernelGGL((k_inv_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
+                    DSV2_LAUNCH((k_inv_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
                                        filtered, hdiv);
                 }
                 break;

@@ -372,11 +372,14 @@ int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *
  * kernels (motion-estimation fronts, MC, in-loop filters) are launched once for all streams.  bufs has
  * 4 slots per stream; nbufs[k] = packets of stream k.  Output is identical to n separate dsv_enc calls. */
 int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, DSV_BUF *bufs, int *nbufs);
-/* stage timing with HIP events on each codec instance's own stream.  Enable before creating
- * encoders; dsv2hip_prof_read fills 8 entries (ingest+pyramid, HME, predict, fwd SBT,
- * quant+compact, inv SBT, reconstruct+filters, extend): milliseconds and kernel launches. */
+/* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
+ * off at any time (resets the totals).  dsv2hip_prof_read fills 8 entries (ingest+pyramid, HME,
+ * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend): milliseconds of stage span,
+ * kernel launches, and *frames = steps folded in; dsv2hip_prof_read_units: stream-frames each
+ * stage processed (what the algorithmic byte counts of DESIGN.md are multiplied by). */
 void dsv2hip_prof_enable(int on);
 int dsv2hip_prof_read(double *ms, long long *launches, long long *frames);
+int dsv2hip_prof_read_units(long long *units);
 
 /* Device-resident transform benchmark/ops handle: a plane set kept in HBM. */
 typedef struct dsv2hip_planeset dsv2hip_planeset;
