@@ -25,6 +25,10 @@ import sys
 import threading
 import time
 
+# the lockstep groups each drive their own HIP stream; give them hardware queues of their own
+# (ROCm maps streams onto 4 by default).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -49,12 +53,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "256")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "384")),
                     help="independent closed-GOP streams (encoder instances) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the extra stage-timing pass that feeds the roofline object")
     ap.add_argument("--profile-steps", type=int, default=6)
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "4")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "6")),
                     help="batch mode: split the streams into this many lockstep groups, one host thread + HIP stream each")
     ap.add_argument("--mode", choices=["batch", "threads"], default=os.environ.get("DSV2_BENCH_MODE", "batch"),
                     help="batch: lockstep dsv2hip_enc_batch over all streams; threads: one host thread + HIP stream per stream")
@@ -266,9 +270,18 @@ def main():
         avg_launch_ms = stage_ms[i] / nl
         bytes_per_launch = STAGE_BYTES[dom] * stage_units[i] / nl
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        # HBM traffic per launch of the dominant kernel: from the committed PMC passes (tools/profile_round.sh ->
+        # profiles/pmc_traffic.json), valid for the configuration they were taken on
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("stage") == dom and pt.get("streams_per_gpu") == S and pt.get("groups") == G:
+                traffic = pt.get("bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         result["roofline"] = {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom,
                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                              "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                               "avg_launch_us": round(avg_launch_ms * 1e3, 2),
                               "launches_per_step": round(nl / prof_steps * G, 1),
                               "algorithmic_bytes_per_launch": round(bytes_per_launch),

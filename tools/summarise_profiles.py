@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turns the raw output of tools/profile_round.sh (gpurun_out/prof) into the committed summaries under profiles/.
+
+usage: tools/summarise_profiles.py r01   (prefix for the file names)
+Writes: profiles/<p>_bench.json, <p>_rocprof_kernel_stats.txt, <p>_pmc_hme.txt and profiles/pmc_traffic.json
+(the latter is what bench.py reports as roofline.traffic for the matching configuration)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
+json.dump(bench, open(os.path.join(dst, prefix + "_bench.json"), "w"), indent=1)
+traced = json.loads([l for l in open(os.path.join(src, "bench_traced.json")) if l.startswith("{")][-1])
+
+rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
+total = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
+    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (MI355X, %d streams / %d groups)\n"
+            % (traced["config"]["streams_per_gpu"], traced["config"]["groups"]))
+    f.write("bench line under the profiler: %.1f frames/s, %.2f ms/step; sum of kernel durations %.1f ms\n"
+            % (traced["value"], traced["ms_per_step"], total / 1e6))
+    f.write("(durations of concurrently running kernels overlap: the groups share the GPU)\n\n")
+    f.write("%-78s %8s %12s %12s %7s\n" % ("kernel", "calls", "total ms", "avg us", "%"))
+    for r in rows[:40]:
+        f.write("%-78s %8s %12.2f %12.2f %7.2f\n" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    # cross-check of the bench's HIP-event figure for the dominant kernel
+    tr = list(csv.DictReader(open(os.path.join(src, "kernel_trace_hme.csv"))))
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
+    f.write("\nk_hme_rows_b_w4: %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event stage span / launches: %.1f us\n"
+            % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
+    f.write("(the stage span also holds the per-level clear / global-motion / finish launches, hence it counts 3 launches per level)\n")
+
+# PMC: per-launch HBM-side bytes of the dominant kernel
+agg = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    rs = [r for r in csv.DictReader(open(os.path.join(src, "pmc_%s.csv" % c))) if r["Counter_Name"] == c]
+    by_grid = collections.defaultdict(list)
+    for r in rs:
+        by_grid[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    agg[c] = by_grid
+with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
+    f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows -- python3 bench.py "
+            "--steps 6 --warmup 3\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
+            "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width)\n\n")
+    f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
+    tot_f = tot_w = nl = 0
+    for g in sorted(agg["FETCH_SIZE"]):
+        fv, wv = agg["FETCH_SIZE"][g], agg["WRITE_SIZE"].get(g, [0.0])
+        f.write("%12d %8d %16.1f %16.1f\n" % (g, len(fv), sum(fv) / len(fv), sum(wv) / len(wv)))
+        tot_f += sum(fv)
+        tot_w += sum(wv) * len(fv) / len(wv)
+        nl += len(fv)
+    bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
+    f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
+json.dump({"stage": "hme", "kernel": "k_hme_rows_b_w4", "streams_per_gpu": traced["config"]["streams_per_gpu"],
+           "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
+           "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
+          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print("wrote", prefix, "summaries; traffic per launch %.2f MB" % (bytes_per_launch / 1e6))
