@@ -1053,6 +1053,9 @@ __device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned
     }
 }
 
+// FAST_ONLY: the host has established that every block of this level meets the preconditions of
+// hme_block_fast(); leaving the generic routine out of the kernel more than halves its register need
+template <bool FAST_ONLY>
 __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int nbx, int allow_fast, FastLds &S)
 {
     int gx = c.counters[4], gy = c.counters[5];
@@ -1068,7 +1071,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         }
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
-        if ((allow_fast & 1) && fast_path_ok(c, level, i, j)) {
+        if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
             hme_block_fast(c, level, i, j, gx, gy, S);
         } else {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
@@ -1090,18 +1093,41 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row(tab[blockIdx.x], (int) blockIdx.y, level, nbx, allow_fast, S);                                           \
+        hme_row<false>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, allow_fast, S);                                    \
+    }                                                                                                                    \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_w##W(             \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        hme_row<true>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, allow_fast, S);                                     \
     }
 HME_ROWS_B(1)
 HME_ROWS_B(2)
 HME_ROWS_B(3)
 HME_ROWS_B(4)
 static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 4;
+static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
+
+// host mirror of fast_path_ok() over a whole level
+static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level)
+{
+    if (a.blk_w != 16 || a.blk_h != 16 || a.hshift != 1 || a.vshift != 1) {
+        return false;
+    }
+    int step = 1 << level;
+    int nbx = (a.nbh + step - 1) / step, nby = (a.nbv + step - 1) / step;
+    int lx = (nbx - 1) * 16, ly = (nby - 1) * 16; // origin of the last block column / row
+    if (lx >= src.w || ly >= src.h) {
+        return false;
+    }
+    int bw = src.w - lx < 16 ? src.w - lx : 16, bh = src.h - ly < 16 ? src.h - ly : 16;
+    return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (!(bw & 1) && !(bh & 1));
+}
 
 __global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
 {
     __shared__ FastLds S;
-    hme_row(c, (int) blockIdx.x, level, nbx, allow_fast, S);
+    hme_row<false>(c, (int) blockIdx.x, level, nbx, allow_fast, S);
 }
 
 __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
@@ -1260,6 +1286,10 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
         if (g_hme_rows) {
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
+            if ((g_hme_fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
+                int w = g_hme_waves_fast;
+                kern = w >= 4 ? k_hme_rows_b_fast_w4 : w == 3 ? k_hme_rows_b_fast_w3 : w == 2 ? k_hme_rows_b_fast_w2 : k_hme_rows_b_fast_w1;
+            }
             DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
