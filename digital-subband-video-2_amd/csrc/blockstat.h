@@ -21,7 +21,9 @@ __device__ __forceinline__ int wave_sum(int v)
     for (int m = 32; m >= 1; m >>= 1) {
         v += __shfl_xor(v, m, 64);
     }
-    return v;
+    // every lane holds the total: hand it out as a wave-uniform scalar (SGPR), which keeps the many
+    // block statistics out of the vector register file
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) { return (unsigned) wave_sum((int) v); }
@@ -190,7 +192,7 @@ __device__ __forceinline__ int ws_peaks(const uint8_t *a, int as, int w, int h, 
     for (int m = 8; m >= 1; m >>= 1) {
         maxv = max(maxv, __shfl_xor(maxv, m, 64));
     }
-    maxv = __shfl(maxv, 0, 64) >> 2; // lanes 0..15 hold the maximum of the 16 bins
+    maxv = __builtin_amdgcn_readlane(maxv, 0) >> 2; // lanes 0..15 hold the maximum of the 16 bins
     int left = __shfl_up(c, 1, 64), right = __shfl_down(c, 1, 64);
     int pk = 0;
     if (lane < 16) {

@@ -96,7 +96,15 @@ template <int N> __device__ __forceinline__ int reduceN(int (&v)[N])
     return r;
 }
 
+// entry e (wave-uniform e): a scalar read of the owning lane -- the result lives in an SGPR
 template <int N> __device__ __forceinline__ int bcastN(int r, int e)
+{
+    constexpr int sh = N == 16 ? 2 : (N == 8 ? 3 : (N == 4 ? 4 : (N == 2 ? 5 : 6)));
+    return __builtin_amdgcn_readlane(r, e << sh);
+}
+
+// entry e chosen per lane
+template <int N> __device__ __forceinline__ int bcastL(int r, int e)
 {
     constexpr int sh = N == 16 ? 2 : (N == 8 ? 3 : (N == 4 ? 4 : (N == 2 ? 5 : 6)));
     return __shfl(r, e << sh, 64);
@@ -108,7 +116,7 @@ __device__ __forceinline__ unsigned wave_min_u(unsigned v)
     for (int m = 32; m >= 1; m >>= 1) {
         v = min(v, (unsigned) __shfl_xor((int) v, m, 64));
     }
-    return v;
+    return (unsigned) __builtin_amdgcn_readfirstlane((int) v);
 }
 
 struct FastLds {
@@ -212,7 +220,7 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
     for (int m = 8; m >= 1; m >>= 1) {
         maxv = max(maxv, __shfl_xor(maxv, m, 64));
     }
-    maxv = __shfl(maxv, 0, 64) >> 2;
+    maxv = __builtin_amdgcn_readlane(maxv, 0) >> 2;
     int left = __shfl_up(c, 1, 64), right = __shfl_down(c, 1, 64);
     int pk = 0;
     if (lane < 16) {
@@ -245,7 +253,7 @@ __device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt
         v[t] = (act && ok) ? (int) (level > 1 ? qsse(a, b) : qmetric(a, b, psy)) : 0;
     }
     int r = reduceN<16>(v);
-    return (unsigned) bcastN<16>(r, threadIdx.x & 15);
+    return (unsigned) bcastL<16>(r, threadIdx.x & 15);
 }
 
 // psy accumulator of one 2x2 quad pair for the three predictions compared by err_intra (hme.c:839)
@@ -330,7 +338,7 @@ __device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx 
     }
     int r8 = reduceN<8>(v8);
     // lane n finishes probe n: metric_return + vector cost
-    unsigned acc = (unsigned) bcastN<8>(r8, lane & 7);
+    unsigned acc = (unsigned) bcastL<8>(r8, lane & 7);
     int mtx = 0, mty = 0;
 #pragma unroll
     for (int n = 0; n < 7; n++) {
@@ -342,11 +350,11 @@ __device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx 
     unsigned sc = metric_return(acc, 16, 16) + (unsigned) mv_cost(cc, fpelx * 4 + mtx, fpely * 4 + mty, 0);
     int b0 = 0, b1 = 0;
     for (int n = 0; n <= 6; n++) {
-        int t0 = __shfl(mtx, n, 64), t1 = __shfl(mty, n, 64);
+        int t0 = __builtin_amdgcn_readlane(mtx, n), t1 = __builtin_amdgcn_readlane(mty, n);
         if (((t0 | t1) & 1) && c.effort < 8) {
             continue;
         }
-        unsigned s = (unsigned) __shfl((int) sc, n, 64);
+        unsigned s = (unsigned) __builtin_amdgcn_readlane((int) sc, n);
         if (best > s) {
             best = s;
             b0 = t0;
@@ -596,8 +604,8 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
                     v[4 * k + 3] = in ? sv2 : 0;
                 }
                 R = reduceN<16>(v);
-                int my_avg_local = bcastN<16>(R, 4 * kq + 0) / (sbw * sbh);
-                int my_avg_sub = bcastN<16>(R, 4 * kq + 1) / (sbw * sbh);
+                int my_avg_local = bcastL<16>(R, 4 * kq + 0) / (sbw * sbh);
+                int my_avg_sub = bcastL<16>(R, 4 * kq + 1) / (sbw * sbh);
                 int my_dc = (int) ((unsigned) my_avg_local + (unsigned) avg_src * 3 + 2) >> 2;
                 unsigned e_inter = 0, e_sb = 0, e_src = 0;
                 if (act) {
@@ -928,8 +936,8 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
         unsigned long long hit = __ballot(valid && sc == mn);
         int best_k = (mn != 0xffffffffu && hit) ? (int) __ffsll((long long) hit) - 1 : 0;
         best = mn;
-        bool z_valid = __shfl((int) valid, 0, 64) != 0;
-        unsigned z_raw = (unsigned) __shfl((int) raw, 0, 64);
+        bool z_valid = __builtin_amdgcn_readlane((int) valid, 0) != 0;
+        unsigned z_raw = (unsigned) __builtin_amdgcn_readlane((int) raw, 0);
         score_zero = z_valid ? z_raw : 0xffffffffu;
         dx = S.cx[best_k];
         dy = S.cy[best_k];
@@ -969,11 +977,11 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
             unsigned full = raw + (unsigned) mv_cost(cc, tx * step * 4, ty * step * 4, level);
             int cdx = dx, cdy = dy;
             for (int k = 0; k < 5; k++) {
-                bool vk = __shfl((int) valid, k, 64) != 0;
+                bool vk = __builtin_amdgcn_readlane((int) valid, k) != 0;
                 if (!vk) {
                     continue;
                 }
-                unsigned sk = (unsigned) __shfl((int) raw, k, 64);
+                unsigned sk = (unsigned) __builtin_amdgcn_readlane((int) raw, k);
                 int tvx = cdx + rectx[k], tvy = cdy + recty[k];
                 if (k == 1) {
                     metr0 = sk;
@@ -991,7 +999,7 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
                     good_enough = true;
                     break;
                 }
-                unsigned fk = (unsigned) __shfl((int) full, k, 64);
+                unsigned fk = (unsigned) __builtin_amdgcn_readlane((int) full, k);
                 if (best > fk) {
                     best = fk;
                     dx = tvx;
@@ -1005,11 +1013,11 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
             }
             int sxs = metr0 <= metr1 ? 1 : -1, sys = metr2 <= metr3 ? 1 : -1;
             int kd = sys < 0 ? (sxs < 0 ? 5 : 6) : (sxs < 0 ? 7 : 8); // index of (sxs, sys) in rect[]
-            bool vd = __shfl((int) valid, kd, 64) != 0;
+            bool vd = __builtin_amdgcn_readlane((int) valid, kd) != 0;
             if (!vd) {
                 break;
             }
-            unsigned fd = (unsigned) __shfl((int) full, kd, 64);
+            unsigned fd = (unsigned) __builtin_amdgcn_readlane((int) full, kd);
             if (best > fd) {
                 best = fd;
                 dx = cdx + sxs;
