@@ -134,6 +134,18 @@ __device__ __forceinline__ MvHead ld_mv_head(const DSV_MV *m)
     return h;
 }
 
+// the same for a wave-uniform address: the record comes back as scalars
+__device__ __forceinline__ MvHead ld_mv_head_u(const DSV_MV *m)
+{
+    unsigned long long v = __hip_atomic_load((const unsigned long long *) m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MvHead h;
+    h.all = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v);
+    h.flags = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (v >> 32));
+    h.x = (int) (int16_t) (h.all & 0xffffu);
+    h.y = (int) (int16_t) (h.all >> 16);
+    return h;
+}
+
 __device__ __forceinline__ void st_mv(DSV_MV *out, const DSV_MV &mv)
 {
     unsigned long long head = (unsigned long long) (uint32_t) mv.u.all | ((unsigned long long) mv.flags << 32);
@@ -163,17 +175,17 @@ __device__ __forceinline__ void movec_pred(const DSV_MV *v, int nbh, int x, int 
 {
     int vx0 = 0, vx1 = 0, vx2 = 0, vy0 = 0, vy1 = 0, vy2 = 0;
     if (x > 0) {
-        MvHead m = ld_mv_head(&v[y * nbh + x - 1]);
+        MvHead m = ld_mv_head_u(&v[y * nbh + x - 1]);
         vx0 = m.x;
         vy0 = m.y;
     }
     if (y > 0) {
-        MvHead m = ld_mv_head(&v[(y - 1) * nbh + x]);
+        MvHead m = ld_mv_head_u(&v[(y - 1) * nbh + x]);
         vx1 = m.x;
         vy1 = m.y;
     }
     if (x > 0 && y > 0) {
-        MvHead m = ld_mv_head(&v[(y - 1) * nbh + x - 1]);
+        MvHead m = ld_mv_head_u(&v[(y - 1) * nbh + x - 1]);
         vx2 = m.x;
         vy2 = m.y;
     }
@@ -215,14 +227,14 @@ __device__ __forceinline__ void neighbordif2_cur(const DSV_MV *v, int nbh, int x
         return;
     }
     if (x > 0) {
-        MvHead m = ld_mv_head(&v[x - 1 + y * nbh]);
+        MvHead m = ld_mv_head_u(&v[x - 1 + y * nbh]);
         if (m.all && !(m.flags & (1u << DSV_MV_BIT_SKIP))) {
             lx = m.x;
             ly = m.y;
         }
     }
     if (y > 0) {
-        MvHead m = ld_mv_head(&v[x + (y - 1) * nbh]);
+        MvHead m = ld_mv_head_u(&v[x + (y - 1) * nbh]);
         if (m.all && !(m.flags & (1u << DSV_MV_BIT_SKIP))) {
             tx = m.x;
             ty = m.y;

@@ -247,7 +247,8 @@ __device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt
     int v[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) {
-        int dx = s.cx[first + t], dy = s.cy[first + t];
+        // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
+        int dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]), dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
         bool ok = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
         Quad b = ldq(at(ref, bx + dx, by + dy), ref.stride, qi, qj, act && ok);
         v[t] = (act && ok) ? (int) (level > 1 ? qsse(a, b) : qmetric(a, b, psy)) : 0;
@@ -588,7 +589,7 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
         // ---- test_subblock_intra_y (hme.c:891), all four sub-blocks evaluated together ----
         {
             const DSV_MV *refmv = c.ref_mvf ? &c.ref_mvf[i + j * nxb] : nullptr;
-            int rx = refmv ? refmv->u.mv.x : mv.u.mv.x, ry = refmv ? refmv->u.mv.y : mv.u.mv.y;
+            int rx = __builtin_amdgcn_readfirstlane(refmv ? refmv->u.mv.x : mv.u.mv.x), ry = __builtin_amdgcn_readfirstlane(refmv ? refmv->u.mv.y : mv.u.mv.y);
             int sbw = bw / 2, sbh = bh / 2;
             bool run = !(mv.u.all && neidif < 3 && abs(rx - mv.u.mv.x) < 3 && abs(ry - mv.u.mv.y) < 3) && sbw != 0 && sbh != 0;
             if (run) {
@@ -939,8 +940,8 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
         bool z_valid = __builtin_amdgcn_readlane((int) valid, 0) != 0;
         unsigned z_raw = (unsigned) __builtin_amdgcn_readlane((int) raw, 0);
         score_zero = z_valid ? z_raw : 0xffffffffu;
-        dx = S.cx[best_k];
-        dy = S.cy[best_k];
+        dx = __builtin_amdgcn_readfirstlane(S.cx[best_k]);
+        dy = __builtin_amdgcn_readfirstlane(S.cy[best_k]);
     }
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
