@@ -1067,8 +1067,43 @@ __device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned
 
 // FAST_ONLY: the host has established that every block of this level meets the preconditions of
 // hme_block_fast(); leaving the generic routine out of the kernel more than halves its register need
+constexpr int kHmeRowsDone = 6;
+
+// The last row of a stream to finish closes the level for that stream: global_motion (hme.c:1973) of
+// the level for the next one -- or, after level 0, the host's copy of the counters -- and the reset
+// of the hand-off words.  Everything it reads was stored write-through or by atomics and drained
+// before the owner's arrival was counted.
+__device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, int nbx, int nby)
+{
+    const int lane = threadIdx.x & 63;
+    if (level != 0) {
+        int step = 1 << level, ax = 0, ay = 0;
+        for (int idx = lane; idx < nbx * nby; idx += 64) {
+            int i = (idx % nbx) * step, j = (idx / nbx) * step;
+            MvHead m = ld_mv_head(&c.mvf[level][i + j * c.a.nbh]);
+            ax += m.x;
+            ay += m.y;
+        }
+        ax = wave_sum(ax);
+        ay = wave_sum(ay);
+        if (lane == 0) {
+            int nblk = nbx * nby;
+            c.counters[4] = nblk ? ax * 2 / nblk : 0;
+            c.counters[5] = nblk ? ay * 2 / nblk : 0;
+        }
+    } else if (c.host_counters && lane < 8) {
+        c.host_counters[lane] = __hip_atomic_load(&c.counters[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int r = lane; r < c.a.nbv; r += 64) {
+        c.counters[kHmeProgress + r] = 0;
+    }
+    if (lane == 0) {
+        c.counters[kHmeRowsDone] = 0;
+    }
+}
+
 template <bool FAST_ONLY>
-__device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int nbx, int allow_fast, FastLds &S)
+__device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int nbx, int nby, int allow_fast, FastLds &S)
 {
     int gx = c.counters[4], gy = c.counters[5];
     unsigned *progress = (unsigned *) c.counters + kHmeProgress;
@@ -1097,6 +1132,15 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
             __hip_atomic_store(&progress[bj], (unsigned) bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // arrival of this row; its vectors and counter updates were drained above
+    int done = 0;
+    if ((threadIdx.x & 63) == 0) {
+        done = __hip_atomic_fetch_add(&c.counters[kHmeRowsDone], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done == nby - 1) {
+        hme_level_epilogue(c, level, nbx, nby);
+    }
 }
 
 // occupancy variants (waves per SIMD) of the batched kernel; DSV2_HME_WAVES picks one
@@ -1105,13 +1149,13 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row<false>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, allow_fast, S);                                    \
+        hme_row<false>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                                    \
     }                                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_w##W(             \
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row<true>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, allow_fast, S);                                     \
+        hme_row<true>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                                    \
     }
 HME_ROWS_B(1)
 HME_ROWS_B(2)
@@ -1139,20 +1183,25 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
 __global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
 {
     __shared__ FastLds S;
-    hme_row<false>(c, (int) blockIdx.x, level, nbx, allow_fast, S);
+    hme_row<false>(c, (int) blockIdx.x, level, nbx, (int) gridDim.x, allow_fast, S);
 }
 
+// level < 0: blockIdx.z enumerates the levels (row pipeline: one clear for the whole search)
 __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
 {
     const HmeDev &c = tab[blockIdx.y];
+    bool first = level >= 0 || blockIdx.z == 0;
+    if (level < 0) {
+        level = (int) blockIdx.z;
+    }
     uint32_t *p = (uint32_t *) c.mvf[level];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) {
         p[i] = 0;
     }
-    if (clear_counters && blockIdx.x == 0 && threadIdx.x < 16) {
+    if (clear_counters && first && blockIdx.x == 0 && threadIdx.x < 16) {
         c.counters[threadIdx.x] = 0;
     }
-    if (blockIdx.x == 0) { // row progress words of the level about to run
+    if (first && blockIdx.x == 0) { // row progress words of the level about to run
         for (int r = threadIdx.x; r < c.a.nbv; r += 256) {
             c.counters[kHmeProgress + r] = 0;
         }
@@ -1292,10 +1341,15 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     const HmeParams &g = hp[0];
     int nlaunch = 0;
     int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
+    if (g_hme_rows) { // one clear for all levels; each level's last row then re-arms the hand-off words itself
+        DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n, g.pyr_levels + 1), dim3(256), 0, s, tab, -1, nwords, 1);
+    }
     for (int level = g.pyr_levels; level >= 0; level--) {
         int step = 1 << level;
         int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
-        DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
+        if (!g_hme_rows) {
+            DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
+        }
         if (g_hme_rows) {
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
             if ((g_hme_fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
@@ -1312,11 +1366,13 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
                 nlaunch++;
             }
         }
-        if (level != 0) {
+        if (level != 0 && !g_hme_rows) {
             DSV2_LAUNCH(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
         }
     }
-    DSV2_LAUNCH(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
+    if (!g_hme_rows) {
+        DSV2_LAUNCH(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
+    }
     HIPCHK(hipGetLastError());
     return nlaunch;
 }
@@ -1353,9 +1409,6 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
         int nbx = (hp.a.nbh + step - 1) / step, nby = (hp.a.nbv + step - 1) / step;
         HIPCHK(hipMemsetAsync(f.mvf[level], 0, nb * sizeof(DSV_MV), s));
         if (g_hme_rows) {
-            if (level != hp.pyr_levels) {
-                HIPCHK(hipMemsetAsync(f.counters + kHmeProgress, 0, (size_t) hp.a.nbv * sizeof(int), s));
-            }
             DSV2_LAUNCH(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
@@ -1366,7 +1419,7 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
                 nlaunch++;
             }
         }
-        if (level != 0) {
+        if (level != 0 && !g_hme_rows) {
             DSV2_LAUNCH(k_global_motion, dim3(1), dim3(256), 0, s, c, level);
         }
     }
