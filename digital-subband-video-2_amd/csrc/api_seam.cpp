@@ -295,7 +295,7 @@ int dsv_decode_plane(DSV_BS *bs, DSV_COEFS *dst, int q, DSV_FMETA *fm)
     if (nsym) {
         HIPCHK(hipMemcpyAsync(c.sym_pos, pos.data(), (size_t) nsym * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
         HIPCHK(hipMemcpyAsync(c.sym_val, val.data(), (size_t) nsym * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
-        dequant_plane(c.stream, dc, c.sym_pos, c.sym_val, seg_count, cfg, q);
+        dequant_plane(c.stream, dc, c.sym_pos, c.sym_val, seg_count, dst->data[0], cfg, q); // DC handled below
     }
     HIPCHK(hipMemcpyAsync(dst->data, dc.data, n * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));

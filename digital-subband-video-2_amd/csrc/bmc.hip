@@ -1064,6 +1064,17 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
     }
 }
 
+// decoder: d_pred jobs {ref, pred = output picture, res = residual}; d_filt jobs {res = output picture}
+void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter)
+{
+    if (n > 0) {
+        DSV2_LAUNCH((k_predict_b<MC_RECONSTRUCT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_pred);
+        if (any_filter) {
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), 0, s, d_filt);
+        }
+    }
+}
+
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n)
 {
     if (n > 0) {

@@ -7,8 +7,10 @@
 // reference pictures.  Entropy *parsing* is serial adaptive-state work and stays on the host.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
+#include "batch.h"
 #include "codec.h"
 
 using namespace dsv2;
@@ -24,6 +26,7 @@ struct DecImpl {
     std::vector<uint8_t> blockdata;
     std::vector<uint32_t> pos;
     std::vector<int32_t> val;
+    uint8_t *h_out = nullptr; // pinned: the reconstructed picture as laid out on the device
 };
 
 inline int sar(int v, int s) { return v < 0 ? ~(~v >> s) : v >> s; }
@@ -200,6 +203,403 @@ void read_motion(DecImpl *im, BitReader &br, const uint8_t *base, const int *sta
     }
 }
 
+// ---- lockstep batch engine ------------------------------------------------------------------------
+// One step decodes ONE packet on each of n decoder instances (dsv_dec is the n = 1 case):
+//   A host   (one pool task per stream) packet header, metadata, per-block side information and the
+//            serial entropy parse of the three planes into (position, value) symbol lists
+//   B device every picture of the step in one set of launches over job tables: zero + scatter/dequantise
+//            the coefficient planes, inverse transform, intra filter or motion-compensated
+//            reconstruction + in-loop filters, border extension, picture to pinned host memory
+//   C host   (one pool task per stream) output frame, reference bookkeeping
+// Pictures of a step whose geometry differs from the first one are decoded in a second round.
+struct DecJob {
+    DSV_DECODER *d;
+    DSV_BUF *buf;
+    DSV_FRAME **out;
+    DSV_FNUM *fn;
+    int ret = DSV_DEC_OK;
+    bool pic = false; // a picture that takes part in the device phase
+    DecImpl *im = nullptr;
+    int has_ref = 0, is_ref = 0, do_filter = 0, quant = 0, lossless = 0;
+    DSV_FNUM fno = 0;
+    int ok[3] = {0, 0, 0};
+    int seg[3][4];
+    int32_t LL[3] = {0, 0, 0};
+    size_t sym_first[3] = {0, 0, 0}; // first symbol of each plane within the decoder's list
+    size_t nsym = 0, stage_off = 0;
+};
+
+struct DecScratch { // per calling thread
+    TableArena tabs;
+    uint8_t *h_stage = nullptr, *d_stage = nullptr;
+    size_t stage_cap = 0;
+    void ensure_stage(size_t bytes)
+    {
+        if (bytes <= stage_cap) {
+            return;
+        }
+        if (stage_cap) {
+            HIPCHK(hipHostFree(h_stage));
+            HIPCHK(hipFree(d_stage));
+        }
+        bytes += bytes / 4;
+        HIPCHK(hipHostMalloc((void **) &h_stage, bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d_stage, bytes));
+        stage_cap = bytes;
+    }
+};
+thread_local DecScratch t_dec_scratch;
+
+// phase A: everything dsv_dec does before it touches the device (dsv_decoder.c:393-503)
+void dec_parse(DecJob &jb)
+{
+    DSV_DECODER *d = jb.d;
+    DSV_BUF *buffer = jb.buf;
+    *jb.fn = (DSV_FNUM) -1;
+    BitReader br{buffer->data, 0};
+    int type = read_packet_hdr(br);
+    if (type == -1) {
+        jb.ret = DSV_DEC_ERROR;
+        return;
+    }
+    if (!(type & DSV_PT_PIC)) {
+        jb.ret = DSV_DEC_ERROR;
+        if (type == DSV_PT_META) {
+            read_meta(d, br);
+            d->got_metadata = 1;
+            jb.ret = DSV_DEC_GOT_META;
+        } else if (type == DSV_PT_EOS) {
+            jb.ret = DSV_DEC_EOS;
+        }
+        return;
+    }
+    if (!d->got_metadata) {
+        jb.ret = DSV_DEC_OK; /* picture before any metadata: skipped (dsv_decoder.c:436) */
+        return;
+    }
+    const DSV_META *meta = &d->vidmeta;
+    jb.has_ref = type & 1;
+    jb.is_ref = (type & 0x6) == 0x6;
+
+    br.align();
+    jb.fno = br.get_bits(32);
+    br.align();
+    int blk_w = 16 << br.get_ueg(), blk_h = 16 << br.get_ueg();
+    if (blk_w < 16 || blk_h < 16 || blk_w > 32 || blk_h > 32) {
+        jb.ret = DSV_DEC_ERROR;
+        return;
+    }
+    bind_device();
+    DecImpl *im = (DecImpl *) d->ref;
+    if (!im) {
+        im = new DecImpl();
+        d->ref = im;
+    }
+    jb.im = im;
+    if (im->ready && (im->dev.w != meta->width || im->dev.h != meta->height || im->dev.format != meta->subsamp ||
+                      im->dev.blk_w != blk_w || im->dev.blk_h != blk_h)) {
+        im->dev.destroy(); // stream parameters changed: start over
+        im->ready = false;
+        im->have_ref = false;
+    }
+    if (!im->ready) {
+        im->dev.init(meta->subsamp, meta->width, meta->height, blk_w, blk_h, 0, false);
+        im->dev.scratch_uv[0].ensure((size_t) im->dev.cw[1] * im->dev.ch[1]);
+        im->dev.scratch_uv[1].ensure((size_t) im->dev.cw[2] * im->dev.ch[2]);
+        HIPCHK(hipHostMalloc((void **) &im->h_out, im->dev.pics[0].recon.bytes, hipHostMallocDefault));
+        im->ready = true;
+    }
+    CodecDev &dv = im->dev;
+    size_t nb = dv.nblocks();
+
+    br.align();
+    int stats[ST_MAX] = {0, 0, 0, 0, 0};
+    stats[ST_STABLE] = (int) br.get_bit();
+    if (!jb.has_ref) {
+        stats[ST_MAINTAIN] = (int) br.get_bit();
+        stats[ST_RINGING] = (int) br.get_bit();
+    } else {
+        stats[ST_MODE] = (int) br.get_bit();
+        stats[ST_EPRM] = (int) br.get_bit();
+    }
+    jb.do_filter = (int) br.get_bit();
+    jb.quant = (int) br.get_bits(DSV_MAX_QP_BITS);
+    jb.lossless = jb.quant == 1;
+    if (br.get_bit()) {
+        br.get_bits(15);
+    }
+    br.align();
+
+    im->blockdata.assign(nb, 0);
+    read_stability(im, br, buffer->data, jb.has_ref, stats);
+    if (jb.has_ref) {
+        im->mvs.assign(nb, DSV_MV{});
+        read_motion(im, br, buffer->data, stats);
+    } else {
+        read_intra_meta(im, br, buffer->data, stats);
+    }
+    br.align();
+
+    // the three planes' symbols, one after the other in the decoder's list
+    size_t cap = (size_t) dv.scan[0].base[10] + (size_t) dv.scan[1].base[10] + (size_t) dv.scan[2].base[10];
+    if (im->pos.size() < cap) {
+        im->pos.resize(cap);
+        im->val.resize(cap);
+    }
+    size_t at = 0;
+    for (int c = 0; c < 3; c++) {
+        jb.sym_first[c] = at;
+        jb.LL[c] = 0;
+        jb.ok[c] = entropy_decode_plane(br, &jb.LL[c], im->pos.data() + at, im->val.data() + at, jb.seg[c], dv.scan[c]);
+        if (jb.ok[c] <= 0) { /* "decoding error in plane": the residual plane stays zero (dsv_decoder.c:516-523) */
+            jb.seg[c][0] = jb.seg[c][1] = jb.seg[c][2] = jb.seg[c][3] = 0;
+        }
+        at += (size_t) (jb.seg[c][0] + jb.seg[c][1] + jb.seg[c][2] + jb.seg[c][3]);
+    }
+    jb.nsym = at;
+    *jb.fn = jb.fno;
+    if (jb.has_ref && !im->have_ref) {
+        jb.ret = DSV_DEC_ERROR; /* reference frame not found (dsv_decoder.c:535) */
+        return;
+    }
+    jb.pic = true;
+}
+
+// phases B and C for the jobs listed in `ids` (pictures of one geometry)
+void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
+{
+    const int n = (int) ids.size();
+    DecScratch &sc = t_dec_scratch;
+    CodecDev &dv0 = jobs[ids[0]].im->dev;
+    hipStream_t bs = dv0.stream;
+    const size_t nb = dv0.nblocks();
+    const size_t mv_bytes = nb * sizeof(DSV_MV), bd_bytes = (nb + 15) & ~(size_t) 15;
+    sc.tabs.reserve((size_t) n * 8192 + 65536);
+
+    // stage layout: per stream {motion field, block flags, symbol positions, symbol values}
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        DecJob &jb = jobs[ids[(size_t) i]];
+        jb.stage_off = total;
+        total += mv_bytes + bd_bytes + ((jb.nsym * 8 + 15) & ~(size_t) 15);
+    }
+    sc.ensure_stage(total);
+    parallel_for(n, [&](int i) {
+        DecJob &jb = jobs[ids[(size_t) i]];
+        DecImpl *im = jb.im;
+        uint8_t *h = sc.h_stage + jb.stage_off;
+        if (jb.has_ref) {
+            memcpy(h, im->mvs.data(), mv_bytes);
+        }
+        memcpy(h + mv_bytes, im->blockdata.data(), nb);
+        memcpy(h + mv_bytes + bd_bytes, im->pos.data(), jb.nsym * 4);
+        memcpy(h + mv_bytes + bd_bytes + jb.nsym * 4, im->val.data(), jb.nsym * 4);
+    });
+
+    // order by (frame type, lossless): the kernels are specialised on those
+    std::vector<int> order(ids);
+    auto cls = [&](int k) { return jobs[k].has_ref * 2 + jobs[k].lossless; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls(a) > cls(b); });
+
+    const CopyJob *d_zero, *d_out;
+    CopyJob *h_zero = sc.tabs.take<CopyJob>(3 * (size_t) n, &d_zero), *h_out = sc.tabs.take<CopyJob>((size_t) n, &d_out);
+    const DequantJob *d_dq[3];
+    DequantJob *h_dq[3];
+    const PlaneJob *d_pj[3];
+    PlaneJob *h_pj[3];
+    for (int c = 0; c < 3; c++) {
+        h_dq[c] = sc.tabs.take<DequantJob>((size_t) n, &d_dq[c]);
+        h_pj[c] = sc.tabs.take<PlaneJob>((size_t) n, &d_pj[c]);
+    }
+    const McJob *d_mc_pred, *d_mc_filt, *d_mc_intra;
+    McJob *h_mc_pred = sc.tabs.take<McJob>((size_t) n, &d_mc_pred), *h_mc_filt = sc.tabs.take<McJob>((size_t) n, &d_mc_filt),
+          *h_mc_intra = sc.tabs.take<McJob>((size_t) n, &d_mc_intra);
+    const PlanePair *d_icopy[3];
+    PlanePair *h_icopy[3];
+    const DPlane *d_ext[3];
+    DPlane *h_ext[3];
+    for (int c = 0; c < 3; c++) {
+        h_icopy[c] = sc.tabs.take<PlanePair>((size_t) n, &d_icopy[c]);
+        h_ext[c] = sc.tabs.take<DPlane>((size_t) n, &d_ext[c]);
+    }
+    const CopyJob *d_zfail;
+    CopyJob *h_zfail = sc.tabs.take<CopyJob>(3 * (size_t) n, &d_zfail);
+    int nP = 0, nI = 0, nIf = 0, n_ext = 0, n_zfail = 0;
+    size_t max_plane_bytes = 0;
+    bool any_filter = false;
+    size_t max_coef_bytes = 0;
+    struct Slice {
+        int first, count, isP, lossless, max_seg[3][4];
+    };
+    std::vector<Slice> slices;
+    for (int i = 0; i < n; i++) {
+        DecJob &jb = jobs[order[(size_t) i]];
+        DecImpl *im = jb.im;
+        CodecDev &dv = im->dev;
+        PicSet &cur = dv.pics[im->cur], &ref = dv.pics[im->cur ^ 1];
+        DFrame &resid = dv.pred; // the decoder's residual picture
+        const uint8_t *d_slot = sc.d_stage + jb.stage_off;
+        const DSV_MV *d_mvs = (const DSV_MV *) d_slot;
+        const uint8_t *d_bd = d_slot + mv_bytes;
+        const uint32_t *d_pos = (const uint32_t *) (d_slot + mv_bytes + bd_bytes);
+        const int32_t *d_val = (const int32_t *) (d_slot + mv_bytes + bd_bytes + jb.nsym * 4);
+        if (slices.empty() || slices.back().isP != jb.has_ref || slices.back().lossless != jb.lossless) {
+            Slice sl = {};
+            sl.first = i;
+            sl.isP = jb.has_ref;
+            sl.lossless = jb.lossless;
+            slices.push_back(sl);
+        }
+        Slice &sl = slices.back();
+        sl.count++;
+        MCParams mc = dv.mc_params((int) (jb.fno % 2), jb.lossless);
+        for (int c = 0; c < 3; c++) {
+            size_t cbytes = (size_t) dv.cw[c] * dv.ch[c] * sizeof(int32_t);
+            h_zero[3 * i + c] = CopyJob{nullptr, dv.coefs[c], cbytes};
+            max_coef_bytes = cbytes > max_coef_bytes ? cbytes : max_coef_bytes;
+            DequantJob &dq = h_dq[c][i];
+            dq.coefs = dv.coefs[c];
+            dq.pos = d_pos + jb.sym_first[c];
+            dq.val = d_val + jb.sym_first[c];
+            for (int k = 0; k < 4; k++) {
+                dq.seg[k] = jb.seg[c][k];
+                sl.max_seg[c][k] = jb.seg[c][k] > sl.max_seg[c][k] ? jb.seg[c][k] : sl.max_seg[c][k];
+            }
+            dq.bd = d_bd;
+            dq.LL = jb.LL[c];
+            dequant_steps(&dq, dv.quant_cfg(c, jb.has_ref, jb.lossless, 0, nullptr), jb.quant);
+            PlaneJob &pj = h_pj[c][i];
+            pj = PlaneJob{};
+            pj.pic = resid.p[c];
+            pj.coefs = dv.coefs[c];
+            for (int t = 0; t < 3; t++) {
+                pj.t[t] = c ? dv.scratch_uv[c - 1].t[t] : dv.scratch.t[t];
+            }
+            pj.bd = d_bd;
+            pj.q = jb.quant;
+            if (jb.ok[c] <= 0) { // "decoding error in plane": its residual plane stays zero (dsv_decoder.c:516-523)
+                h_zfail[n_zfail++] = CopyJob{nullptr, resid.alloc + resid.plane_off[c], resid.plane_len[c]};
+                max_plane_bytes = resid.plane_len[c] > max_plane_bytes ? resid.plane_len[c] : max_plane_bytes;
+            }
+        }
+        McJob mj;
+        mj.mvs = d_mvs;
+        mj.bd = d_bd;
+        mj.p = mc;
+        if (jb.has_ref) {
+            mj.f = make_filter_params(mc, jb.quant, jb.do_filter, jb.d->vidmeta.inter_sharpen);
+            for (int c = 0; c < 3; c++) {
+                mj.ref.p[c] = ref.recon.p[c];
+                mj.pred.p[c] = cur.recon.p[c];
+                mj.res.p[c] = resid.p[c];
+            }
+            h_mc_pred[nP] = mj;
+            for (int c = 0; c < 3; c++) {
+                mj.res.p[c] = cur.recon.p[c];
+            }
+            h_mc_filt[nP] = mj;
+            nP++;
+            any_filter = any_filter || !jb.lossless;
+        } else {
+            mj.f = make_filter_params(mc, jb.quant, 1, 0);
+            for (int c = 0; c < 3; c++) {
+                mj.ref.p[c] = mj.pred.p[c] = mj.res.p[c] = resid.p[c];
+                h_icopy[c][nI] = PlanePair{resid.p[c], cur.recon.p[c]};
+            }
+            nI++;
+            if (jb.do_filter && !jb.lossless) { // dsv_intra_filter is a no-op for lossless pictures (bmc.c:398)
+                h_mc_intra[nIf++] = mj;
+            }
+        }
+        if (jb.is_ref || !jb.has_ref) {
+            for (int c = 0; c < 3; c++) {
+                h_ext[c][n_ext] = cur.recon.p[c];
+            }
+            n_ext++;
+        }
+        h_out[i] = CopyJob{cur.recon.alloc, im->h_out, cur.recon.bytes};
+    }
+
+    HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, total, hipMemcpyHostToDevice, bs));
+    sc.tabs.upload(bs);
+    zero_linear_batch(bs, d_zero, 3 * n, max_coef_bytes);
+    for (const Slice &sl : slices) {
+        for (int c = 0; c < 3; c++) {
+            dequant_jobs(bs, d_dq[c] + sl.first, sl.count, sl.max_seg[c], dv0.quant_cfg(c, sl.isP, sl.lossless, 0, nullptr));
+            sbt_inverse_jobs(bs, d_pj[c] + sl.first, sl.count, dv0.cw[c], dv0.ch[c], c, sl.isP, sl.lossless, dv0.nbh, dv0.nbv);
+        }
+    }
+    zero_linear_batch(bs, d_zfail, n_zfail, max_plane_bytes);
+    intra_filter_batch(bs, d_mc_intra, nIf);
+    mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter);
+    for (int c = 0; c < 3; c++) {
+        const DPlane &pl = dv0.pics[0].recon.p[c];
+        copy_planes_batch(bs, d_icopy[c], nI, pl.w, pl.h);
+        extend_planes(bs, d_ext[c], n_ext, pl.w, pl.h);
+    }
+    copy_linear_batch(bs, d_out, n, dv0.pics[0].recon.bytes);
+    HIPCHK(hipStreamSynchronize(bs));
+
+    // phase C
+    parallel_for(n, [&](int i) {
+        DecJob &jb = jobs[order[(size_t) i]];
+        DecImpl *im = jb.im;
+        CodecDev &dv = im->dev;
+        const DSV_META *meta = &jb.d->vidmeta;
+        const DFrame &rec = dv.pics[im->cur].recon;
+        DSV_FRAME *of = dsv_mk_frame(meta->subsamp, meta->width, meta->height, 1);
+        bool full = jb.is_ref || !jb.has_ref;
+        for (int c = 0; c < 3; c++) {
+            DSV_PLANE *hp = &of->planes[c];
+            if (full) { // pixels + border; the stride padding to the right of the border is left untouched
+                const uint8_t *src = im->h_out + rec.plane_off[c];
+                uint8_t *dst = hp->data - (size_t) hp->stride * kBorder - kBorder;
+                int wbytes = rec.p[c].w + 2 * kBorder, rows = rec.p[c].h + 2 * kBorder;
+                for (int y = 0; y < rows; y++) {
+                    memcpy(dst + (size_t) y * hp->stride, src + (size_t) y * rec.p[c].stride, (size_t) wbytes);
+                }
+            } else {
+                const uint8_t *src = im->h_out + rec.plane_off[c] + (size_t) rec.p[c].stride * kBorder + kBorder;
+                for (int y = 0; y < rec.p[c].h; y++) {
+                    memcpy(hp->data + (size_t) y * hp->stride, src + (size_t) y * rec.p[c].stride, (size_t) rec.p[c].w);
+                }
+            }
+        }
+        if (jb.is_ref) {
+            im->cur ^= 1;
+            im->have_ref = true;
+        }
+        *jb.out = of;
+        jb.ret = DSV_DEC_OK;
+    });
+}
+
+void dec_batch(DecJob *jobs, int n)
+{
+    bind_device();
+    parallel_for(n, [&](int k) { dec_parse(jobs[k]); });
+    std::vector<int> todo;
+    for (int k = 0; k < n; k++) {
+        if (jobs[k].pic) {
+            todo.push_back(k);
+        }
+    }
+    while (!todo.empty()) { // one round per picture geometry present in the step
+        const CodecDev &g = jobs[todo[0]].im->dev;
+        std::vector<int> ids, rest;
+        for (int k : todo) {
+            const CodecDev &dv = jobs[k].im->dev;
+            bool same = dv.w == g.w && dv.h == g.h && dv.format == g.format && dv.blk_w == g.blk_w && dv.blk_h == g.blk_h;
+            (same ? ids : rest).push_back(k);
+        }
+        dec_device_round(jobs, ids);
+        todo.swap(rest);
+    }
+    for (int k = 0; k < n; k++) {
+        dsv_buf_free(jobs[k].buf); /* the decoder frees its input on every path (dsv_decoder.c:414,432,438,581) */
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -210,6 +610,7 @@ void dsv_dec_free(DSV_DECODER *d)
         DecImpl *im = (DecImpl *) d->ref;
         if (im->ready) {
             im->dev.destroy();
+            HIPCHK(hipHostFree(im->h_out));
         }
         delete im;
         d->ref = NULL;
@@ -225,155 +626,34 @@ DSV_META *dsv_get_metadata(DSV_DECODER *d)
 
 int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn) // dsv_decoder.c:393
 {
-    *fn = (DSV_FNUM) -1;
-    BitReader br{buffer->data, 0};
-    int type = read_packet_hdr(br);
-    if (type == -1) {
-        dsv_buf_free(buffer);
-        return DSV_DEC_ERROR;
-    }
-    if (!(type & DSV_PT_PIC)) {
-        int ret = DSV_DEC_ERROR;
-        if (type == DSV_PT_META) {
-            read_meta(d, br);
-            d->got_metadata = 1;
-            ret = DSV_DEC_GOT_META;
-        } else if (type == DSV_PT_EOS) {
-            ret = DSV_DEC_EOS;
-        }
-        dsv_buf_free(buffer);
-        return ret;
-    }
-    if (!d->got_metadata) {
-        dsv_buf_free(buffer);
-        return DSV_DEC_OK; /* picture before any metadata: skipped (dsv_decoder.c:436) */
-    }
-    const DSV_META *meta = &d->vidmeta;
-    int has_ref = type & 1, is_ref = (type & 0x6) == 0x6;
+    DecJob jb;
+    jb.d = d;
+    jb.buf = buffer;
+    jb.out = out;
+    jb.fn = fn;
+    dec_batch(&jb, 1);
+    return jb.ret;
+}
 
-    br.align();
-    DSV_FNUM fno = br.get_bits(32);
-    br.align();
-    int blk_w = 16 << br.get_ueg(), blk_h = 16 << br.get_ueg();
-    if (blk_w < 16 || blk_h < 16 || blk_w > 32 || blk_h > 32) {
-        dsv_buf_free(buffer);
-        return DSV_DEC_ERROR;
+// lockstep decode: packet bufs[k] on decoder decs[k]; ret[k], out[k], fn[k] are what dsv_dec would return
+int dsv2hip_dec_batch(int n, DSV_DECODER **decs, DSV_BUF *bufs, DSV_FRAME **out, DSV_FNUM *fn, int *ret)
+{
+    if (n <= 0 || !decs || !bufs || !out || !fn || !ret) {
+        return 0;
     }
-    bind_device();
-    DecImpl *im = (DecImpl *) d->ref;
-    if (!im) {
-        im = new DecImpl();
-        d->ref = im;
+    std::vector<DecJob> jobs((size_t) n);
+    for (int k = 0; k < n; k++) {
+        jobs[(size_t) k].d = decs[k];
+        jobs[(size_t) k].buf = &bufs[k];
+        jobs[(size_t) k].out = &out[k];
+        jobs[(size_t) k].fn = &fn[k];
+        out[k] = NULL;
     }
-    if (im->ready && (im->dev.w != meta->width || im->dev.h != meta->height || im->dev.format != meta->subsamp ||
-                      im->dev.blk_w != blk_w || im->dev.blk_h != blk_h)) {
-        im->dev.destroy(); // stream parameters changed: start over
-        im->ready = false;
-        im->have_ref = false;
+    dec_batch(jobs.data(), n);
+    for (int k = 0; k < n; k++) {
+        ret[k] = jobs[(size_t) k].ret;
     }
-    if (!im->ready) {
-        im->dev.init(meta->subsamp, meta->width, meta->height, blk_w, blk_h, 0, false);
-        im->ready = true;
-    }
-    CodecDev &dv = im->dev;
-    size_t nb = dv.nblocks();
-
-    br.align();
-    int stats[ST_MAX] = {0, 0, 0, 0, 0};
-    stats[ST_STABLE] = (int) br.get_bit();
-    if (!has_ref) {
-        stats[ST_MAINTAIN] = (int) br.get_bit();
-        stats[ST_RINGING] = (int) br.get_bit();
-    } else {
-        stats[ST_MODE] = (int) br.get_bit();
-        stats[ST_EPRM] = (int) br.get_bit();
-    }
-    int do_filter = (int) br.get_bit();
-    int quant = (int) br.get_bits(DSV_MAX_QP_BITS);
-    int lossless = quant == 1;
-    if (br.get_bit()) {
-        br.get_bits(15);
-    }
-    br.align();
-
-    im->blockdata.assign(nb, 0);
-    read_stability(im, br, buffer->data, has_ref, stats);
-    if (has_ref) {
-        im->mvs.assign(nb, DSV_MV{});
-        read_motion(im, br, buffer->data, stats);
-    } else {
-        read_intra_meta(im, br, buffer->data, stats);
-    }
-    br.align();
-
-    // ---- device side ----
-    PicSet &cur = dv.pics[im->cur];
-    PicSet &ref = dv.pics[im->cur ^ 1];
-    DFrame &resid = dv.pred; // the decoder's residual picture
-    HIPCHK(hipMemsetAsync(resid.alloc, 0, resid.bytes, dv.stream)); // a fresh zeroed frame per picture (dsv_decoder.c:506)
-    HIPCHK(hipMemcpyAsync(dv.d_blockdata, im->blockdata.data(), nb, hipMemcpyHostToDevice, dv.stream));
-    if (has_ref) {
-        HIPCHK(hipMemcpyAsync(cur.d_final_mvs, im->mvs.data(), nb * sizeof(DSV_MV), hipMemcpyHostToDevice, dv.stream));
-    }
-    BlockMap bm{dv.d_blockdata, dv.nbh, dv.nbv};
-    MCParams mc = dv.mc_params((int) (fno % 2), lossless);
-    for (int c = 0; c < 3; c++) {
-        const ScanGeom &g = dv.scan[c];
-        im->pos.resize((size_t) g.base[10]);
-        im->val.resize((size_t) g.base[10]);
-        int seg_count[4];
-        int32_t LL = 0;
-        int ok = entropy_decode_plane(br, &LL, im->pos.data(), im->val.data(), seg_count, g);
-        if (ok <= 0) {
-            continue; /* "decoding error in plane": the residual plane stays zero (dsv_decoder.c:516-523) */
-        }
-        int nsym = seg_count[0] + seg_count[1] + seg_count[2] + seg_count[3];
-        size_t ncoef = (size_t) dv.cw[c] * dv.ch[c];
-        DCoefs co{dv.coefs[c], dv.cw[c], dv.ch[c]};
-        HIPCHK(hipStreamSynchronize(dv.stream)); // the symbol staging buffers are reused per plane
-        HIPCHK(hipMemsetAsync(co.data, 0, ncoef * sizeof(int32_t), dv.stream));
-        if (nsym) {
-            dv.ensure_dev_syms((size_t) nsym);
-            HIPCHK(hipMemcpyAsync(dv.d_sym_pos, im->pos.data(), (size_t) nsym * sizeof(uint32_t), hipMemcpyHostToDevice, dv.stream));
-            HIPCHK(hipMemcpyAsync(dv.d_sym_val, im->val.data(), (size_t) nsym * sizeof(int32_t), hipMemcpyHostToDevice, dv.stream));
-            dequant_plane(dv.stream, co, dv.d_sym_pos, dv.d_sym_val, seg_count, dv.quant_cfg(c, has_ref, lossless, 0, nullptr), quant);
-        }
-        HIPCHK(hipMemcpyAsync(co.data, &LL, sizeof(int32_t), hipMemcpyHostToDevice, dv.stream)); /* dst->data[0] = LL */
-        HIPCHK(hipStreamSynchronize(dv.stream));
-        sbt_inverse(dv.stream, resid.p[c], co, dv.scratch, quant, c, has_ref, lossless, bm);
-        if (!has_ref && c == 0 && do_filter) {
-            intra_filter_luma(dv.stream, dv.d_blockdata, mc, quant, resid.p[0]);
-        }
-    }
-    *fn = fno;
-    if (has_ref) {
-        if (!im->have_ref) {
-            HIPCHK(hipStreamSynchronize(dv.stream));
-            return DSV_DEC_ERROR; /* reference frame not found (dsv_decoder.c:535) */
-        }
-        HIPCHK(hipMemsetAsync(cur.recon.alloc, 0, cur.recon.bytes, dv.stream));
-        mc_add_pred(dv.stream, cur.d_final_mvs, mc, quant, resid, cur.recon, ref.recon, do_filter, meta->inter_sharpen);
-    } else {
-        copy_frame_pixels(dv.stream, cur.recon, resid);
-        extend_frame(dv.stream, cur.recon, false);
-    }
-    if (is_ref) {
-        extend_frame(dv.stream, cur.recon, false);
-    }
-    DSV_FRAME *of = dsv_mk_frame(meta->subsamp, meta->width, meta->height, 1);
-    if (is_ref || !has_ref) {
-        dframe_download_full(&cur.recon, of, dv.stream);
-    } else {
-        dframe_download(&cur.recon, of, dv.stream);
-    }
-    HIPCHK(hipStreamSynchronize(dv.stream));
-    if (is_ref) {
-        im->cur ^= 1;
-        im->have_ref = true;
-    }
-    dsv_buf_free(buffer);
-    *out = of;
-    return DSV_DEC_OK;
+    return n;
 }
 
 } // extern "C"

@@ -174,6 +174,54 @@ __global__ __launch_bounds__(256) void k_copy_linear(const CopyJob *__restrict__
     }
 }
 
+// zero fill of `bytes` (multiple of 16) at dst; src is ignored
+__global__ __launch_bounds__(256) void k_zero_linear(const CopyJob *__restrict__ tab)
+{
+    const CopyJob &j = tab[blockIdx.y];
+    uint4 *dp = (uint4 *) j.dst;
+    size_t n = j.bytes >> 4;
+    const uint4 z = {0, 0, 0, 0};
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) {
+        dp[i] = z;
+    }
+}
+
+void zero_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes)
+{
+    if (n <= 0) {
+        return;
+    }
+    size_t vecs = max_bytes >> 4;
+    int gx = (int) ((vecs + 256 * 8 - 1) / (256 * 8));
+    DSV2_LAUNCH(k_zero_linear, dim3(gx < 1 ? 1 : gx, n), dim3(256), 0, s, d_jobs);
+}
+
+// visible pixels of one plane to another plane of the same size (both 4-byte aligned rows)
+__global__ __launch_bounds__(256) void k_copy_plane(const PlanePair *__restrict__ tab)
+{
+    const PlanePair &pp = tab[blockIdx.z];
+    int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (y >= pp.dst.h || x >= pp.dst.w) {
+        return;
+    }
+    const uint8_t *sp = pp.src.data + (size_t) y * pp.src.stride + x;
+    uint8_t *dp = pp.dst.data + (size_t) y * pp.dst.stride + x;
+    if (x + 4 <= pp.dst.w) {
+        *(uint32_t *) dp = *(const uint32_t *) sp;
+    } else {
+        for (int i = 0; x + i < pp.dst.w; i++) {
+            dp[i] = sp[i];
+        }
+    }
+}
+
+void copy_planes_batch(hipStream_t s, const PlanePair *d_pairs, int n, int w, int h)
+{
+    if (n > 0) {
+        DSV2_LAUNCH(k_copy_plane, dim3((w + 1023) / 1024, h, n), dim3(256), 0, s, d_pairs);
+    }
+}
+
 void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes)
 {
     if (n <= 0) {

@@ -57,9 +57,22 @@ struct Compactor {
 // njobs compactions of n values each in one set of launches; each job's count lands in *job.total
 void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n);
 
-// decoder: scatter + dequantise symbols sorted by scan position; seg_count = {LL, l0, l1, l2}
-void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int32_t *d_val, const int seg_count[4],
+// decoder: scatter + dequantise symbols sorted by scan position into a ZEROED coefficient plane;
+// seg_count = {LL, l0, l1, l2}; LL = the separately transmitted DC, stored to coefs[0]
+void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int32_t *d_val, const int seg_count[4], int32_t LL,
                    const QuantCfg &cfg, int q);
+struct DequantJob {
+    int32_t *coefs;
+    const uint32_t *pos;
+    const int32_t *val;
+    int seg[4];
+    const uint8_t *bd;
+    int32_t LL;
+    int qll, qp[3][3];
+};
+void dequant_steps(DequantJob *job, const QuantCfg &cfg, int q);
+// table form: n jobs sharing `cfg`; max_seg[k] >= every job's seg[k]
+void dequant_jobs(hipStream_t s, const DequantJob *d_jobs, int n, const int max_seg[4], const QuantCfg &cfg);
 
 // ---- host entropy coder (entropy.cpp): bs.c codes + the serial part of hzcc.c ----
 struct BitWriter { // MSB-first, buffer must be zero-filled (bs.c:143)

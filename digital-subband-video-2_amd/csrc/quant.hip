@@ -566,36 +566,44 @@ void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n)
 }
 
 // ---- decoder side: scatter decoded symbols and dequantise (hzcc.c:451-583) -------------------
+// One DequantJob per plane (and stream): its symbol list sorted by scan position, split by seg[] into
+// {LL, level 0, level 1, level 2}.  tab == nullptr: the single job `one`; else blockIdx.y indexes the table.
 struct DequantArgs {
     int l;
     int sw, sh, dbx, dby;
-    int off[3], par[3], qp[3], base[3];
+    int off[3], par[3], base[3];
 };
 
-// LL symbols: dequantL (hzcc.c:530)
-__global__ __launch_bounds__(256) void k_dequant_ll(int32_t *__restrict__ coefs, const uint32_t *__restrict__ pos,
-                                                    const int32_t *__restrict__ val, int n, QuantCfg c, int sw, int qp)
+// LL symbols: dequantL (hzcc.c:530); thread 0 also plants the separately transmitted DC (hzcc.c:599-602)
+__global__ __launch_bounds__(256) void k_dequant_ll(const DequantJob *__restrict__ tab, DequantJob one, QuantCfg c, int sw)
 {
+    const DequantJob &J = tab ? tab[blockIdx.y] : one;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
+    if (i == 0) {
+        J.coefs[0] = J.LL;
+    }
+    if (i >= J.seg[0]) {
         return;
     }
-    int p = (int) pos[i], v = val[i];
+    int p = (int) J.pos[i], v = J.val[i];
     int x = p % sw, y = p / sw;
-    int32_t out = c.lossless ? v : (c.isP ? dequant_D(v, (unsigned) qp) : dequant_S(v, (unsigned) qp));
-    coefs[(size_t) y * c.w + x] = out;
+    unsigned qp = (unsigned) J.qll;
+    int32_t out = c.lossless ? v : (c.isP ? dequant_D(v, qp) : dequant_S(v, qp));
+    J.coefs[(size_t) y * c.w + x] = out;
 }
 
 // detail symbols of one level; `dep` selects the dependents phase (see header comment)
-__global__ __launch_bounds__(256) void k_dequant_level(int32_t *__restrict__ coefs, const uint32_t *__restrict__ pos,
-                                                       const int32_t *__restrict__ val, int n, QuantCfg c, DequantArgs a,
+__global__ __launch_bounds__(256) void k_dequant_level(const DequantJob *__restrict__ tab, DequantJob one, QuantCfg c, DequantArgs a,
                                                        int xdep, int ydep, int dep)
 {
+    const DequantJob &J = tab ? tab[blockIdx.y] : one;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
+    if (i >= J.seg[1 + a.l]) {
         return;
     }
-    int p = (int) pos[i], v = val[i];
+    int first = J.seg[0] + (a.l > 0 ? J.seg[1] : 0) + (a.l > 1 ? J.seg[2] : 0);
+    int p = (int) J.pos[first + i], v = J.val[first + i];
+    int32_t *coefs = J.coefs;
     int si = p >= a.base[2] ? 2 : (p >= a.base[1] ? 1 : 0);
     int local = p - a.base[si];
     int x = local % a.sw, y = local / a.sw;
@@ -608,52 +616,79 @@ __global__ __launch_bounds__(256) void k_dequant_level(int32_t *__restrict__ coe
     if (c.lossless) {
         out = v;
     } else {
-        int flags = c.bd[((y * a.dby) >> kBlockP) * c.nbh + ((x * a.dbx) >> kBlockP)];
+        int flags = J.bd[((y * a.dby) >> kBlockP) * c.nbh + ((x * a.dbx) >> kBlockP)];
         int parc = coefs[a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1)];
-        int tmq = c.isP ? tmq_for_P(a.qp[si], flags, parc) : tmq_for_I(a.qp[si], flags, parc, a.l);
+        int qp = J.qp[a.l][si];
+        int tmq = c.isP ? tmq_for_P(qp, flags, parc) : tmq_for_I(qp, flags, parc, a.l);
         out = dequant_D(v, (unsigned) tmq);
     }
     coefs[a.off[si] + (size_t) y * c.w + x] = out;
 }
 
-void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int32_t *d_val, const int seg_count[4],
-                   const QuantCfg &cfg, int q)
+void dequant_steps(DequantJob *job, const QuantCfg &cfg, int q)
+{
+    int qf = q * 3 / 2;
+    job->qll = cfg.lossless ? 1 : lfquant(cfg, qf);
+    for (int l = 0; l < 3; l++) {
+        for (int si = 0; si < 3; si++) {
+            job->qp[l][si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
+        }
+    }
+}
+
+// max_seg[k] bounds seg[k] over the jobs (grid size)
+static void dequant_launch(hipStream_t s, const DequantJob *tab, const DequantJob &one, int n, const int max_seg[4], const QuantCfg &cfg)
 {
     ScanGeom g;
-    make_scan(&g, coefs.w, coefs.h);
-    int qf = q * 3 / 2;
-    int done = 0;
-    if (seg_count[0] > 0) {
-        DSV2_LAUNCH(k_dequant_ll, dim3((seg_count[0] + 255) / 256), dim3(256), 0, s, coefs.data, d_pos, d_val, seg_count[0],
-                           cfg, g.sw[0], cfg.lossless ? 1 : lfquant(cfg, qf));
-    }
-    done = seg_count[0];
+    make_scan(&g, cfg.w, cfg.h);
+    unsigned ny = tab ? (unsigned) n : 1u;
+    DSV2_LAUNCH(k_dequant_ll, dim3((unsigned) (max_seg[0] + 255) / 256 + (max_seg[0] == 0), ny), dim3(256), 0, s, tab, one, cfg, g.sw[0]);
     for (int l = 0; l < 3; l++) {
-        int n = seg_count[1 + l];
-        if (n > 0) {
-            DequantArgs a;
-            a.l = l;
-            a.sw = h_dimat(l, coefs.w);
-            a.sh = h_dimat(l, coefs.h);
-            a.dbx = (cfg.nbh << kBlockP) / a.sw;
-            a.dby = (cfg.nbv << kBlockP) / a.sh;
-            int xdep = 2 * h_dimat(l - 1, coefs.w) > a.sw, ydep = 2 * h_dimat(l - 1, coefs.h) > a.sh;
-            for (int si = 0; si < 3; si++) {
-                a.off[si] = g.off[1 + 3 * l + si];
-                a.base[si] = g.base[1 + 3 * l + si];
-                a.par[si] = h_subband_off(l - 1, si + 1, coefs.w, coefs.h);
-                a.qp[si] = cfg.lossless ? 1 : hfquant(cfg, qf, si + 1, l);
-            }
-            DSV2_LAUNCH(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done, d_val + done, n,
-                               cfg, a, xdep, ydep, 0);
-            if (xdep || ydep) {
-                DSV2_LAUNCH(k_dequant_level, dim3((n + 255) / 256), dim3(256), 0, s, coefs.data, d_pos + done,
-                                   d_val + done, n, cfg, a, xdep, ydep, 1);
-            }
+        int nmax = max_seg[1 + l];
+        if (nmax <= 0) {
+            continue;
         }
-        done += n;
+        DequantArgs a;
+        a.l = l;
+        a.sw = h_dimat(l, cfg.w);
+        a.sh = h_dimat(l, cfg.h);
+        a.dbx = (cfg.nbh << kBlockP) / a.sw;
+        a.dby = (cfg.nbv << kBlockP) / a.sh;
+        int xdep = 2 * h_dimat(l - 1, cfg.w) > a.sw, ydep = 2 * h_dimat(l - 1, cfg.h) > a.sh;
+        for (int si = 0; si < 3; si++) {
+            a.off[si] = g.off[1 + 3 * l + si];
+            a.base[si] = g.base[1 + 3 * l + si];
+            a.par[si] = h_subband_off(l - 1, si + 1, cfg.w, cfg.h);
+        }
+        DSV2_LAUNCH(k_dequant_level, dim3((unsigned) (nmax + 255) / 256, ny), dim3(256), 0, s, tab, one, cfg, a, xdep, ydep, 0);
+        if (xdep || ydep) {
+            DSV2_LAUNCH(k_dequant_level, dim3((unsigned) (nmax + 255) / 256, ny), dim3(256), 0, s, tab, one, cfg, a, xdep, ydep, 1);
+        }
     }
     HIPCHK(hipGetLastError());
+}
+
+void dequant_plane(hipStream_t s, DCoefs coefs, const uint32_t *d_pos, const int32_t *d_val, const int seg_count[4], int32_t LL,
+                   const QuantCfg &cfg, int q)
+{
+    DequantJob one = {};
+    one.coefs = coefs.data;
+    one.pos = d_pos;
+    one.val = d_val;
+    for (int k = 0; k < 4; k++) {
+        one.seg[k] = seg_count[k];
+    }
+    one.bd = cfg.bd;
+    one.LL = LL;
+    dequant_steps(&one, cfg, q);
+    dequant_launch(s, nullptr, one, 1, seg_count, cfg);
+}
+
+void dequant_jobs(hipStream_t s, const DequantJob *d_jobs, int n, const int max_seg[4], const QuantCfg &cfg)
+{
+    if (n > 0) {
+        dequant_launch(s, d_jobs, DequantJob{}, n, max_seg, cfg);
+    }
 }
 
 } // namespace dsv2

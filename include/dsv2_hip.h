@@ -372,6 +372,10 @@ int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *
  * kernels (motion-estimation fronts, MC, in-loop filters) are launched once for all streams.  bufs has
  * 4 slots per stream; nbufs[k] = packets of stream k.  Output is identical to n separate dsv_enc calls. */
 int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, DSV_BUF *bufs, int *nbufs);
+/* lockstep decode over n independent decoder instances: packet bufs[k] goes to decs[k]; ret[k], out[k]
+ * and fn[k] are exactly what dsv_dec(decs[k], &bufs[k], &out[k], &fn[k]) would have produced (packets are
+ * consumed the same way).  All pictures of a step run through one set of kernel launches. */
+int dsv2hip_dec_batch(int n, DSV_DECODER **decs, DSV_BUF *bufs, DSV_FRAME **out, DSV_FNUM *fn, int *ret);
 /* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
  * off at any time (resets the totals).  dsv2hip_prof_read fills 8 entries (ingest+pyramid, HME,
  * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend): milliseconds of stage span,

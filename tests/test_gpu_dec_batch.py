@@ -1,0 +1,101 @@
+"""Lockstep batch decoding (dsv2hip_dec_batch): n packets per step == n independent reference decodes."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import dsvabi as A
+from codec_run import decode_stream, encode_stream
+from conftest import load_pkg
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+
+
+def bind(hip):
+    hip.dsv2hip_dec_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(A.DECODER)), C.POINTER(A.BUF), C.POINTER(C.POINTER(A.FRAME)),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    hip.dsv2hip_dec_batch.restype = C.c_int
+
+
+def planes_of(fp):
+    f = fp.contents
+    out = []
+    for c in range(3):
+        p = f.planes[c]
+        a = np.ctypeslib.as_array(p.data, shape=(p.h * p.stride,))
+        out.append(a.reshape(-1, p.stride)[:p.h, :p.w].copy())
+    return out
+
+
+def batch_decode(hip, streams):
+    """streams: list of packet lists.  Step t feeds packet t of every stream that still has one."""
+    n = len(streams)
+    decs = [A.DECODER() for _ in range(n)]
+    got = [[] for _ in range(n)]
+    for t in range(max(len(s) for s in streams)):
+        live = [k for k in range(n) if t < len(streams[k])]
+        m = len(live)
+        decp = (C.POINTER(A.DECODER) * m)(*[C.pointer(decs[k]) for k in live])
+        bufs = (A.BUF * m)()
+        for i, k in enumerate(live):
+            pk = streams[k][t]
+            hip.dsv_mk_buf(C.byref(bufs[i]), len(pk) + 64)
+            C.memmove(bufs[i].data, pk, len(pk))
+        outs = (C.POINTER(A.FRAME) * m)()
+        fns = (C.c_uint32 * m)()
+        rets = (C.c_int * m)()
+        assert hip.dsv2hip_dec_batch(m, decp, bufs, outs, fns, rets) == m
+        for i, k in enumerate(live):
+            assert rets[i] != A.DEC_ERROR
+            if rets[i] == A.DEC_OK and outs[i]:
+                got[k].append((fns[i], *planes_of(outs[i])))
+                hip.dsv_frame_ref_dec(outs[i])
+    for d in decs:
+        hip.dsv_dec_free(C.byref(d))
+    return got
+
+
+def check(want, got):
+    assert len(want) == len(got)
+    for (fa, *pa), (fb, *pb) in zip(want, got):
+        assert fa == fb
+        for c in range(3):
+            assert np.array_equal(pa[c], pb[c]), "frame %d plane %d differs" % (fa, c)
+
+
+def test_dec_batch_mixed_streams():
+    """Four streams in lockstep: two CIF IP streams of different length, one intra-only CIF stream, and a
+    720p stream (second geometry in the same step); metadata / picture / end-of-stream packets interleave."""
+    ref, hip = A.load_ref(), A.load_hip()
+    bind(hip)
+    pkg = load_pkg()
+    spec = [(352, 288, 9, dict(qp=60, gop=4)), (352, 288, 5, dict(qp=40, gop=12)), (352, 288, 4, dict(qp=85, gop=0)),
+            (1280, 720, 3, dict(qp=60, gop=48))]
+    streams = []
+    for s, (w, h, nfr, cfg) in enumerate(spec):
+        v = pkg.synth.SynthVideo(w, h, "420", seed=70 + s)
+        frames = [v.frame_bytes(t) for t in range(nfr)]
+        streams.append(encode_stream(ref, frames, w, h, A.SUBSAMP_420, eos=True, **cfg)[0])
+    want = [decode_stream(ref, pk) for pk in streams]
+    got = batch_decode(hip, streams)
+    for s in range(len(spec)):
+        check(want[s], got[s])
+
+
+def test_dec_batch_444_lossless_and_single_call_agree():
+    ref, hip = A.load_ref(), A.load_hip()
+    bind(hip)
+    pkg = load_pkg()
+    streams = []
+    for s in range(2):
+        v = pkg.synth.SynthVideo(354, 290, "444", seed=90 + s)
+        frames = [v.frame_bytes(t) for t in range(3)]
+        streams.append(encode_stream(ref, frames, 354, 290, A.SUBSAMP_444, eos=True, qp=100 if s else 70, gop=48)[0])
+    want = [decode_stream(ref, pk) for pk in streams]
+    got = batch_decode(hip, streams)
+    single = [decode_stream(hip, pk) for pk in streams]
+    for s in range(2):
+        check(want[s], got[s])
+        check(want[s], single[s])
