@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "batch.h"
@@ -26,7 +27,6 @@ struct DecImpl {
     std::vector<uint8_t> blockdata;
     std::vector<uint32_t> pos;
     std::vector<int32_t> val;
-    uint8_t *h_out = nullptr; // pinned: the reconstructed picture as laid out on the device
 };
 
 inline int sar(int v, int s) { return v < 0 ? ~(~v >> s) : v >> s; }
@@ -227,6 +227,7 @@ struct DecJob {
     int32_t LL[3] = {0, 0, 0};
     size_t sym_first[3] = {0, 0, 0}; // first symbol of each plane within the decoder's list
     size_t nsym = 0, stage_off = 0;
+    DSV_FRAME *of = nullptr; // output picture: a bordered frame on pinned memory the device writes directly
 };
 
 struct DecScratch { // per calling thread
@@ -249,6 +250,29 @@ struct DecScratch { // per calling thread
     }
 };
 thread_local DecScratch t_dec_scratch;
+
+struct DecClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep decode step, printed every 16 steps
+    bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+    double acc[6] = {0};
+    int steps = 0;
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int i)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+    }
+    void done(int n)
+    {
+        if (!on || ++steps % 16) return;
+        fprintf(stderr, "[dec batch n=%d] ms/step: parse %.2f | pack %.2f | enqueue %.2f | wait %.2f | deliver %.2f\n", n, acc[0] / 16, acc[1] / 16,
+                acc[2] / 16, acc[3] / 16, acc[4] / 16);
+        for (double &a : acc) a = 0;
+    }
+};
+thread_local DecClock t_dec_clock;
 
 // phase A: everything dsv_dec does before it touches the device (dsv_decoder.c:393-503)
 void dec_parse(DecJob &jb)
@@ -306,7 +330,6 @@ void dec_parse(DecJob &jb)
         im->dev.init(meta->subsamp, meta->width, meta->height, blk_w, blk_h, 0, false);
         im->dev.scratch_uv[0].ensure((size_t) im->dev.cw[1] * im->dev.ch[1]);
         im->dev.scratch_uv[1].ensure((size_t) im->dev.cw[2] * im->dev.ch[2]);
-        HIPCHK(hipHostMalloc((void **) &im->h_out, im->dev.pics[0].recon.bytes, hipHostMallocDefault));
         im->ready = true;
     }
     CodecDev &dv = im->dev;
@@ -357,11 +380,16 @@ void dec_parse(DecJob &jb)
         at += (size_t) (jb.seg[c][0] + jb.seg[c][1] + jb.seg[c][2] + jb.seg[c][3]);
     }
     jb.nsym = at;
+    // the device reads the symbols straight from pinned host memory (each is read exactly once)
+    dv.ensure_host_syms(at);
+    memcpy(dv.h_pos, im->pos.data(), at * sizeof(uint32_t));
+    memcpy(dv.h_val, im->val.data(), at * sizeof(int32_t));
     *jb.fn = jb.fno;
     if (jb.has_ref && !im->have_ref) {
         jb.ret = DSV_DEC_ERROR; /* reference frame not found (dsv_decoder.c:535) */
         return;
     }
+    jb.of = mk_frame_pinned(meta->subsamp, meta->width, meta->height);
     jb.pic = true;
 }
 
@@ -376,12 +404,12 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     const size_t mv_bytes = nb * sizeof(DSV_MV), bd_bytes = (nb + 15) & ~(size_t) 15;
     sc.tabs.reserve((size_t) n * 8192 + 65536);
 
-    // stage layout: per stream {motion field, block flags, symbol positions, symbol values}
+    // stage layout: per stream {motion field, block flags}
     size_t total = 0;
     for (int i = 0; i < n; i++) {
         DecJob &jb = jobs[ids[(size_t) i]];
         jb.stage_off = total;
-        total += mv_bytes + bd_bytes + ((jb.nsym * 8 + 15) & ~(size_t) 15);
+        total += mv_bytes + bd_bytes;
     }
     sc.ensure_stage(total);
     parallel_for(n, [&](int i) {
@@ -392,10 +420,9 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
             memcpy(h, im->mvs.data(), mv_bytes);
         }
         memcpy(h + mv_bytes, im->blockdata.data(), nb);
-        memcpy(h + mv_bytes + bd_bytes, im->pos.data(), jb.nsym * 4);
-        memcpy(h + mv_bytes + bd_bytes + jb.nsym * 4, im->val.data(), jb.nsym * 4);
     });
 
+    t_dec_clock.lap(1);
     // order by (frame type, lossless): the kernels are specialised on those
     std::vector<int> order(ids);
     auto cls = [&](int k) { return jobs[k].has_ref * 2 + jobs[k].lossless; };
@@ -441,8 +468,8 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
         const uint8_t *d_slot = sc.d_stage + jb.stage_off;
         const DSV_MV *d_mvs = (const DSV_MV *) d_slot;
         const uint8_t *d_bd = d_slot + mv_bytes;
-        const uint32_t *d_pos = (const uint32_t *) (d_slot + mv_bytes + bd_bytes);
-        const int32_t *d_val = (const int32_t *) (d_slot + mv_bytes + bd_bytes + jb.nsym * 4);
+        const uint32_t *d_pos = dv.h_pos; // pinned host memory, read in place
+        const int32_t *d_val = dv.h_val;
         if (slices.empty() || slices.back().isP != jb.has_ref || slices.back().lossless != jb.lossless) {
             Slice sl = {};
             sl.first = i;
@@ -517,7 +544,7 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
             }
             n_ext++;
         }
-        h_out[i] = CopyJob{cur.recon.alloc, im->h_out, cur.recon.bytes};
+        h_out[i] = CopyJob{cur.recon.alloc, jb.of->alloc, cur.recon.bytes};
     }
 
     HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, total, hipMemcpyHostToDevice, bs));
@@ -538,46 +565,29 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
         extend_planes(bs, d_ext[c], n_ext, pl.w, pl.h);
     }
     copy_linear_batch(bs, d_out, n, dv0.pics[0].recon.bytes);
+    t_dec_clock.lap(2);
     HIPCHK(hipStreamSynchronize(bs));
+    t_dec_clock.lap(3);
 
-    // phase C
-    parallel_for(n, [&](int i) {
+    // phase C: the pictures are already in their output frames
+    for (int i = 0; i < n; i++) {
         DecJob &jb = jobs[order[(size_t) i]];
         DecImpl *im = jb.im;
-        CodecDev &dv = im->dev;
-        const DSV_META *meta = &jb.d->vidmeta;
-        const DFrame &rec = dv.pics[im->cur].recon;
-        DSV_FRAME *of = dsv_mk_frame(meta->subsamp, meta->width, meta->height, 1);
-        bool full = jb.is_ref || !jb.has_ref;
-        for (int c = 0; c < 3; c++) {
-            DSV_PLANE *hp = &of->planes[c];
-            if (full) { // pixels + border; the stride padding to the right of the border is left untouched
-                const uint8_t *src = im->h_out + rec.plane_off[c];
-                uint8_t *dst = hp->data - (size_t) hp->stride * kBorder - kBorder;
-                int wbytes = rec.p[c].w + 2 * kBorder, rows = rec.p[c].h + 2 * kBorder;
-                for (int y = 0; y < rows; y++) {
-                    memcpy(dst + (size_t) y * hp->stride, src + (size_t) y * rec.p[c].stride, (size_t) wbytes);
-                }
-            } else {
-                const uint8_t *src = im->h_out + rec.plane_off[c] + (size_t) rec.p[c].stride * kBorder + kBorder;
-                for (int y = 0; y < rec.p[c].h; y++) {
-                    memcpy(hp->data + (size_t) y * hp->stride, src + (size_t) y * rec.p[c].stride, (size_t) rec.p[c].w);
-                }
-            }
-        }
         if (jb.is_ref) {
             im->cur ^= 1;
             im->have_ref = true;
         }
-        *jb.out = of;
+        *jb.out = jb.of;
         jb.ret = DSV_DEC_OK;
-    });
+    }
 }
 
 void dec_batch(DecJob *jobs, int n)
 {
     bind_device();
+    t_dec_clock.start();
     parallel_for(n, [&](int k) { dec_parse(jobs[k]); });
+    t_dec_clock.lap(0);
     std::vector<int> todo;
     for (int k = 0; k < n; k++) {
         if (jobs[k].pic) {
@@ -595,6 +605,8 @@ void dec_batch(DecJob *jobs, int n)
         dec_device_round(jobs, ids);
         todo.swap(rest);
     }
+    t_dec_clock.lap(4);
+    t_dec_clock.done(n);
     for (int k = 0; k < n; k++) {
         dsv_buf_free(jobs[k].buf); /* the decoder frees its input on every path (dsv_decoder.c:414,432,438,581) */
     }
@@ -610,7 +622,6 @@ void dsv_dec_free(DSV_DECODER *d)
         DecImpl *im = (DecImpl *) d->ref;
         if (im->ready) {
             im->dev.destroy();
-            HIPCHK(hipHostFree(im->h_out));
         }
         delete im;
         d->ref = NULL;

@@ -67,6 +67,10 @@ struct BlockMap {
 };
 
 void dev_zero(void *p, size_t bytes); // synchronous zero fill of device memory
+// pinned host blocks the GPU may write (hostutil.cpp): recycled through dsv_free
+void *pinned_pool_take(size_t bytes);
+bool pinned_pool_release(void *p);
+DSV_FRAME *mk_frame_pinned(int format, int width, int height);
 void dframe_alloc(DFrame *f, int format, int w, int h);
 void dframe_free(DFrame *f);
 // copy between a host DSV_FRAME (any stride, bordered or not) and a device frame: visible pixels only

@@ -8,6 +8,65 @@
 
 #include "dev.h"
 
+// ---- pool of pinned (device-writable) blocks for decoder output pictures ------------------------------
+// The batch decoder lets the GPU write a finished picture straight into the DSV_FRAME it returns; such a
+// frame's pixel block comes from here and finds its way back when the caller releases the frame
+// (dsv_frame_ref_dec -> dsv_free).  Blocks are recycled by exact size; the pool keeps at most kPoolMax idle.
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace dsv2 {
+namespace {
+std::mutex g_pool_mu;
+std::unordered_map<void *, size_t> g_pool_live;                 // block -> size, for every block handed out
+std::unordered_map<size_t, std::vector<void *>> g_pool_idle;    // size -> idle blocks
+size_t g_pool_idle_count = 0;
+constexpr size_t kPoolMax = 2048;
+} // namespace
+
+void *pinned_pool_take(size_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_idle.find(bytes);
+        if (it != g_pool_idle.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_pool_idle_count--;
+            g_pool_live[p] = bytes;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[p] = bytes;
+    return p;
+}
+
+bool pinned_pool_release(void *p)
+{
+    size_t bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_live.find(p);
+        if (it == g_pool_live.end()) {
+            return false;
+        }
+        bytes = it->second;
+        g_pool_live.erase(it);
+        if (g_pool_idle_count < kPoolMax) {
+            g_pool_idle[bytes].push_back(p);
+            g_pool_idle_count++;
+            return true;
+        }
+    }
+    HIPCHK(hipHostFree(p));
+    return true;
+}
+} // namespace dsv2
+
 extern "C" {
 
 char *dsv_lvlname[5] = {(char *) "NONE", (char *) "ERROR", (char *) "WARNING", (char *) "INFO", (char *) "DEBUG"};
@@ -31,6 +90,9 @@ void dsv_free(void *ptr)
 {
     if (ptr) {
         g_nfree++;
+        if (dsv2::pinned_pool_release(ptr)) {
+            return; // a pooled pinned block (decoder output picture): recycled, not freed
+        }
         free(ptr);
     }
 }
@@ -120,6 +182,41 @@ DSV_FRAME *dsv_mk_frame(int format, int width, int height, int border)
     }
     return f;
 }
+
+} // extern "C"
+
+namespace dsv2 {
+// a bordered frame whose pixel block is pinned host memory from the pool (contents undefined)
+DSV_FRAME *mk_frame_pinned(int format, int width, int height)
+{
+    DSV_FRAME *f = (DSV_FRAME *) dsv_alloc(sizeof(DSV_FRAME));
+    int pw[3], ph[3];
+    size_t total = 0, off[3];
+    plane_dims(format, width, height, pw, ph);
+    f->refcount = 1;
+    f->format = format;
+    f->width = width;
+    f->height = height;
+    f->border = 1;
+    for (int c = 0; c < 3; c++) {
+        DSV_PLANE *p = &f->planes[c];
+        p->format = format;
+        p->w = pw[c];
+        p->h = ph[c];
+        p->stride = (pw[c] + 2 * kBorder + 15) & ~15;
+        p->len = p->stride * (ph[c] + 2 * kBorder);
+        off[c] = total;
+        total += (size_t) p->len;
+    }
+    f->alloc = (uint8_t *) pinned_pool_take(total);
+    for (int c = 0; c < 3; c++) {
+        f->planes[c].data = f->alloc + off[c] + (size_t) f->planes[c].stride * kBorder + kBorder;
+    }
+    return f;
+}
+} // namespace dsv2
+
+extern "C" {
 
 DSV_FRAME *dsv_load_planar_frame(int format, void *data, int width, int height)
 {
