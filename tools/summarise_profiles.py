@@ -34,7 +34,7 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     # cross-check of the bench's HIP-event figure for the dominant kernel
     tr = list(csv.DictReader(open(os.path.join(src, "kernel_trace_hme.csv"))))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
-    f.write("\nk_hme_rows_b_w4: %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event stage span / launches: %.1f us\n"
+    f.write("\nk_hme_rows_b_*: %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event stage span / launches: %.1f us\n"
             % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
     f.write("(the stage span also holds the per-level clear / global-motion / finish launches, hence it counts 3 launches per level)\n")
 
@@ -60,7 +60,7 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
         nl += len(fv)
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
     f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
-json.dump({"stage": "hme", "kernel": "k_hme_rows_b_w4", "streams_per_gpu": traced["config"]["streams_per_gpu"],
+json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
            "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
