@@ -15,12 +15,57 @@
 
 namespace dsv2 {
 
+// ---- cross-lane exchange without the LDS crossbar ------------------------------------------------
+// lane_xor<B>(v) = v of lane (lane ^ B).  gfx950: the 32- and 16-lane halves swap with
+// v_permlane32_swap / v_permlane16_swap, everything inside a row of 16 is a DPP move.
+typedef unsigned uint2v_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+template <int B> __device__ __forceinline__ int lane_xor(int v)
+{
+    if (B == 32) {
+        uint2v_t r = __builtin_amdgcn_permlane32_swap((unsigned) v, (unsigned) v, false, false);
+        return (int) ((threadIdx.x & 32) ? r[0] : r[1]); // r0 = {lo, lo}, r1 = {hi, hi}
+    } else if (B == 16) {
+        uint2v_t r = __builtin_amdgcn_permlane16_swap((unsigned) v, (unsigned) v, false, false);
+        return (int) ((threadIdx.x & 16) ? r[0] : r[1]);
+    } else if (B == 8) {
+        return dpp_mov<0x128>(v); // row_ror:8
+    } else if (B == 4) {
+        int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false); // row_shl:4 into banks 0,2
+        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);  // row_shr:4 into banks 1,3
+    } else if (B == 2) {
+        return dpp_mov<0x4e>(v); // quad_perm [2,3,0,1]
+    } else {
+        return dpp_mov<0xb1>(v); // quad_perm [1,0,3,2]
+    }
+}
+
+// v[lane] + v[lane ^ B] in every lane (one all-reduce step)
+template <int B> __device__ __forceinline__ int fold_xor(int v)
+{
+    if (B == 32) {
+        uint2v_t r = __builtin_amdgcn_permlane32_swap((unsigned) v, (unsigned) v, false, false);
+        return (int) (r[0] + r[1]);
+    } else if (B == 16) {
+        uint2v_t r = __builtin_amdgcn_permlane16_swap((unsigned) v, (unsigned) v, false, false);
+        return (int) (r[0] + r[1]);
+    }
+    return v + lane_xor<B>(v);
+}
+
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        v += __shfl_xor(v, m, 64);
-    }
+    v = fold_xor<32>(v);
+    v = fold_xor<16>(v);
+    v = fold_xor<8>(v);
+    v = fold_xor<4>(v);
+    v = fold_xor<2>(v);
+    v = fold_xor<1>(v);
     // every lane holds the total: hand it out as a wave-uniform scalar (SGPR), which keeps the many
     // block statistics out of the vector register file
     return __builtin_amdgcn_readfirstlane(v);

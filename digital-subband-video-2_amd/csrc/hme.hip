@@ -1162,7 +1162,7 @@ HME_ROWS_B(2)
 HME_ROWS_B(3)
 HME_ROWS_B(4)
 static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 4;
-static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
+static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 3;
 
 // host mirror of fast_path_ok() over a whole level
 static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level)

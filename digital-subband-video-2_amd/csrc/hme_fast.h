@@ -72,27 +72,54 @@ __device__ __forceinline__ unsigned qsse(const Quad &a, const Quad &b) // sum of
 
 // Folds N (power of two <= 16) per-lane partial sums across the wavefront.  On return lane L
 // holds the total of entry (L >> (6 - log2 N)); fetch entry e with bcastN<N>(r, e).
+// one transposing step at lane distance B over the first 2*HALF entries: lanes with bit B clear end up
+// with a[lane] + a[lane ^ B] of entry t, the others with the same of entry t + HALF
+template <int B, int HALF, int N> __device__ __forceinline__ void fold_pairs(int (&v)[N])
+{
+#pragma unroll
+    for (int t = 0; t < HALF; t++) {
+        int a = v[t], b = v[t + HALF];
+        if (B == 32) {
+            uint2v_t r = __builtin_amdgcn_permlane32_swap((unsigned) a, (unsigned) b, false, false);
+            v[t] = (int) (r[0] + r[1]);
+        } else if (B == 16) {
+            uint2v_t r = __builtin_amdgcn_permlane16_swap((unsigned) a, (unsigned) b, false, false);
+            v[t] = (int) (r[0] + r[1]);
+        } else {
+            bool sel = (threadIdx.x & B) != 0;
+            int mine = sel ? b : a, other = sel ? a : b;
+            v[t] = mine + lane_xor<B>(other);
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ int reduceN(int (&v)[N])
 {
-    int lane = threadIdx.x & 63;
-    int bit = 32;
-#pragma unroll
-    for (int n = N; n > 1; n >>= 1) {
-        int half = n >> 1;
-        bool sel = (lane & bit) != 0;
-#pragma unroll
-        for (int t = 0; t < half; t++) {
-            int a = v[t], b = v[t + half];
-            int mine = sel ? b : a, other = sel ? a : b;
-            v[t] = mine + __shfl_xor(other, bit, 64);
-        }
-        bit >>= 1;
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16, "reduceN: N must be 2, 4, 8 or 16");
+    // transposing butterfly: each step halves the number of live entries
+    fold_pairs<32, N / 2, N>(v);
+    if constexpr (N >= 4) {
+        fold_pairs<16, N / 4, N>(v);
+    }
+    if constexpr (N >= 8) {
+        fold_pairs<8, N / 8, N>(v);
+    }
+    if constexpr (N >= 16) {
+        fold_pairs<4, 1, N>(v);
     }
     int r = v[0];
-#pragma unroll
-    for (; bit >= 1; bit >>= 1) {
-        r += __shfl_xor(r, bit, 64);
+    // plain all-reduce over the remaining lane bits
+    if constexpr (N < 4) {
+        r = fold_xor<16>(r);
     }
+    if constexpr (N < 8) {
+        r = fold_xor<8>(r);
+    }
+    if constexpr (N < 16) {
+        r = fold_xor<4>(r);
+    }
+    r = fold_xor<2>(r);
+    r = fold_xor<1>(r);
     return r;
 }
 
@@ -112,11 +139,30 @@ template <int N> __device__ __forceinline__ int bcastL(int r, int e)
 
 __device__ __forceinline__ unsigned wave_min_u(unsigned v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        v = min(v, (unsigned) __shfl_xor((int) v, m, 64));
-    }
+    v = min(v, (unsigned) lane_xor<32>((int) v));
+    v = min(v, (unsigned) lane_xor<16>((int) v));
+    v = min(v, (unsigned) lane_xor<8>((int) v));
+    v = min(v, (unsigned) lane_xor<4>((int) v));
+    v = min(v, (unsigned) lane_xor<2>((int) v));
+    v = min(v, (unsigned) lane_xor<1>((int) v));
     return (unsigned) __builtin_amdgcn_readfirstlane((int) v);
+}
+
+// n / d for n >= 0, d > 0: block areas are powers of two for every interior block, and an integer
+// division costs ~30 vector instructions on this machine
+__device__ __forceinline__ int div_nn(int n, int d)
+{
+    if ((d & (d - 1)) == 0) {
+        return n >> (31 - __clz(d));
+    }
+    return n / d;
+}
+__device__ __forceinline__ unsigned div_nn(unsigned n, unsigned d)
+{
+    if ((d & (d - 1)) == 0) {
+        return n >> (31 - __clz((int) d));
+    }
+    return n / d;
 }
 
 struct FastLds {
@@ -155,7 +201,7 @@ __device__ __forceinline__ int quad_absdev(const Quad &q, bool act, int mean)
 __device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int *hist)
 {
     int lane = threadIdx.x & 63;
-    unsigned avg = (unsigned) (sum / (w * h));
+    unsigned avg = (unsigned) div_nn(sum, w * h);
     if (avg == 0) {
         avg = 1;
     }
@@ -179,7 +225,7 @@ __device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int 
     }
     var = wave_sum(var);
     __syncthreads();
-    return (int) ((var * 16 * 16) / (16u * (unsigned) (w * h * w * h)));
+    return (int) div_nn(var * 16 * 16, 16u * (unsigned) (w * h * w * h));
 }
 
 __device__ int src_quant_tex(const Quad &q, bool act, int qi, int qj, int qw, int w, int h)
@@ -196,7 +242,7 @@ __device__ int src_quant_tex(const Quad &q, bool act, int qi, int qj, int qw, in
     }
     sh = wave_sum(sh);
     sv = wave_sum(sv);
-    return (int) (isqrt_u32(max(sh, sv)) / (unsigned) ((w + h + 1) >> 1));
+    return (int) div_nn(isqrt_u32(max(sh, sv)), (unsigned) ((w + h + 1) >> 1));
 }
 
 __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
@@ -294,7 +340,7 @@ __device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx 
     int r4 = reduceN<4>(v4);
     unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
              quad3 = (unsigned) bcastN<4>(r4, 3);
-    int area_ratio = (int) (8 * 256 / yarea), iarea_ratio = (int) (8 * yarea / 256);
+    int area_ratio = (int) div_nn(8u * 256u, yarea), iarea_ratio = (int) (8 * yarea / 256);
     best = best * (unsigned) area_ratio >> 3;
     int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
     Quad aw = ldq(at(src, xx, yy), src.stride, qi, qj, true); // the centred 16x16 source window
@@ -454,11 +500,11 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
     unsigned ogrerr = metric_return((unsigned) bcastN<16>(R, 0), bw, bh);
     int ref_sum = bcastN<16>(R, 1);
     unsigned ref_sh = (unsigned) bcastN<16>(R, 2), ref_sv = (unsigned) bcastN<16>(R, 3);
-    int uavg_src = bcastN<16>(R, 4) / (cbw * cbh), vavg_src = bcastN<16>(R, 5) / (cbw * cbh);
-    int uavg_ref = bcastN<16>(R, 6) / (cbw * cbh), vavg_ref = bcastN<16>(R, 7) / (cbw * cbh);
+    int uavg_src = div_nn(bcastN<16>(R, 4), cbw * cbh), vavg_src = div_nn(bcastN<16>(R, 5), cbw * cbh);
+    int uavg_ref = div_nn(bcastN<16>(R, 6), cbw * cbh), vavg_ref = div_nn(bcastN<16>(R, 7), cbw * cbh);
     int utex = (int) max((unsigned) bcastN<16>(R, 8), (unsigned) bcastN<16>(R, 9));
     int vtex = (int) max((unsigned) bcastN<16>(R, 10), (unsigned) bcastN<16>(R, 11));
-    unsigned avg_ref = (unsigned) (ref_sum / (bw * bh));
+    unsigned avg_ref = (unsigned) div_nn(ref_sum, bw * bh);
 
     // round 2: reference deviation + zero-motion sub-block metrics (skip test operands)
     {
@@ -483,16 +529,16 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
     int tex_ref = (int) (max(ref_sh, ref_sv) - (unsigned) ref_dev);
     unsigned var_ref = (unsigned) (ref_dev + max(tex_ref, 0));
 
-    unsigned ogrmad = (ogrerr + yarea / 2) / yarea;
+    unsigned ogrmad = div_nn(ogrerr + yarea / 2, yarea);
     ogrmad = ogrmad * ratio >> 5;
-    unsigned mad = (best + yarea / 2) / yarea;
+    unsigned mad = div_nn(best + yarea / 2, yarea);
     int dv = (int) min(ratio, 32u);
     int ipolvar = (int) ((var_src * (unsigned) dv + var_ref * (unsigned) (32 - dv)) >> 5);
     dv = abs((int) var_src - ipolvar);
     if (var_src > 16 * yarea && var_src < 32 * yarea) {
         mv.flags |= 1u << DSV_MV_BIT_MAINTAIN;
     }
-    unsigned chroma_ratio = (unsigned) ((cbw * cbh) << 4) / yarea;
+    unsigned chroma_ratio = div_nn((unsigned) ((cbw * cbh) << 4), yarea);
     ChromaPsy cpsy = chroma_analysis((int) avg_src, uavg_src, vavg_src);
     unsigned avg_y_dif = (unsigned) abs((int) avg_src - (int) avg_ref);
     unsigned avg_c_dif = (unsigned) AVG2(abs(uavg_src - uavg_ref), abs(vavg_src - vavg_ref));
@@ -605,8 +651,8 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
                     v[4 * k + 3] = in ? sv2 : 0;
                 }
                 R = reduceN<16>(v);
-                int my_avg_local = bcastL<16>(R, 4 * kq + 0) / (sbw * sbh);
-                int my_avg_sub = bcastL<16>(R, 4 * kq + 1) / (sbw * sbh);
+                int my_avg_local = div_nn(bcastL<16>(R, 4 * kq + 0), sbw * sbh);
+                int my_avg_sub = div_nn(bcastL<16>(R, 4 * kq + 1), sbw * sbh);
                 int my_dc = (int) ((unsigned) my_avg_local + (unsigned) avg_src * 3 + 2) >> 2;
                 unsigned e_inter = 0, e_sb = 0, e_src = 0;
                 if (act) {
@@ -629,8 +675,8 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
                     if (mv.submask & (1 << k)) {
                         continue;
                     }
-                    unsigned avg_local = (unsigned) (bcastN<16>(R, 4 * k + 0) / (sbw * sbh));
-                    unsigned avg_sub = (unsigned) (bcastN<16>(R, 4 * k + 1) / (sbw * sbh));
+                    unsigned avg_local = (unsigned) div_nn(bcastN<16>(R, 4 * k + 0), sbw * sbh);
+                    unsigned avg_sub = (unsigned) div_nn(bcastN<16>(R, 4 * k + 1), sbw * sbh);
                     unsigned g_sh = (unsigned) bcastN<16>(R, 4 * k + 2), g_sv = (unsigned) bcastN<16>(R, 4 * k + 3);
                     int var = bcastN<16>(R2, k) >> 1;
                     int tex = (int) (max(g_sh, g_sv) - (unsigned) var);
@@ -662,7 +708,7 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
         }
         // ---- test_subblock_intra_c (hme.c:987) ----
         if (c.effort >= 6) {
-            unsigned detail_c = (unsigned) (ipolvar / (bw * bh));
+            unsigned detail_c = (unsigned) div_nn(ipolvar, bw * bh);
             unsigned thr = (mv.flags & (1u << DSV_MV_BIT_INTRA)) ? detail_c : SQR(detail_c);
             int sbw = cbw / 2, sbh = cbh / 2;
             if (!(sbw == 0 || sbh == 0 || mad <= thr || thr > 64 || (abs((int) mv.u.mv.x) < 4 && abs((int) mv.u.mv.y) < 4))) {
@@ -680,8 +726,8 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
                     if (mv.submask & (1 << k)) {
                         continue;
                     }
-                    int a_us = bcastN<16>(R, 4 * k + 0) / (sbw * sbh), a_vs = bcastN<16>(R, 4 * k + 1) / (sbw * sbh);
-                    int a_um = bcastN<16>(R, 4 * k + 2) / (sbw * sbh), a_vm = bcastN<16>(R, 4 * k + 3) / (sbw * sbh);
+                    int a_us = div_nn(bcastN<16>(R, 4 * k + 0), sbw * sbh), a_vs = div_nn(bcastN<16>(R, 4 * k + 1), sbw * sbh);
+                    int a_um = div_nn(bcastN<16>(R, 4 * k + 2), sbw * sbh), a_vm = div_nn(bcastN<16>(R, 4 * k + 3), sbw * sbh);
                     unsigned dif = (unsigned) (SQR(a_us - a_um) + SQR(a_vs - a_vm)) * avg_ramp >> 8;
                     if (dif > thr) {
                         mv.submask |= (uint8_t) (1 << k);
@@ -766,13 +812,13 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
         int r = reduceN<4>(v4);
         int sum = bcastN<4>(r, 0);
         unsigned sh = (unsigned) bcastN<4>(r, 1), sv = (unsigned) bcastN<4>(r, 2);
-        int mean = sum / (bw * bh);
+        int mean = div_nn(sum, bw * bh);
         avg_src = (unsigned) mean;
         int var = wave_sum(quad_absdev(a, act, mean)) >> 1;
         int tex = (int) (max(sh, sv) - (unsigned) var);
         var_src = (unsigned) (var + max(tex, 0));
         int tvar = (int) (var_src + SQR(var_src >> 10));
-        tvar = (8 * tvar * c.quant >> 9) / (bw * bh);
+        tvar = div_nn(8 * tvar * c.quant >> 9, bw * bh);
         if (tvar) {
             int hvar = src_hist_var(a, act, sum, bw, bh, S.hist);
             int qtex = src_quant_tex(a, act, qi, qj, qw, bw, bh);
