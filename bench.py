@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "384")),
                     help="independent closed-GOP streams (encoder instances) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing the N>1 path "
+                                                      "on a box with fewer GPUs than ranks, together with DSV2_FORCE_DEVICE)")
     ap.add_argument("--no-profile", action="store_true", help="skip the extra stage-timing pass that feeds the roofline object")
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "6")),
@@ -75,12 +77,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("DSV2_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     hip = A.load_hip()
     assert hip.dsv2hip_device_ok() == 0, "no HIP device: the product has no CPU path"
@@ -221,12 +226,13 @@ def main():
 
     # final ordered gather of the segment bytes (the only collective of the path)
     seg_bytes = sum(len(b) for s in range(S) for b in out_bytes[s])
-    t_max = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    xdev = "cuda" if args.backend == "nccl" else "cpu"
+    t_max = torch.tensor([elapsed], device=xdev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         # segment id = global stream index: rank-major, so the gathered file is the ordered concatenation
         segs = {rank * S + s: b"".join(out_bytes[s]) for s in range(S)}
-        whole = pkg.sharding.gather_segments(dist, rank, world, segs, device="cuda")
+        whole = pkg.sharding.gather_segments(dist, rank, world, segs, device=xdev)
         total_bytes = len(whole) if rank == 0 else 0
     else:
         total_bytes = seg_bytes

@@ -47,9 +47,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         by_grid[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
     agg[c] = by_grid
 with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
-    f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows -- python3 bench.py "
+    f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows_b_fast -- python3 bench.py "
             "--steps 6 --warmup 3\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
-            "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width)\n\n")
+            "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width); only the launches of the "
+            "fast-path kernel (levels 0-2 at 1080p) are listed\n\n")
     f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
     tot_f = tot_w = nl = 0
     for g in sorted(agg["FETCH_SIZE"]):
@@ -64,4 +65,7 @@ json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_w2", "streams_per_gpu": 
            "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+dec = [l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")]
+if dec:
+    json.dump(json.loads(dec[-1]), open(os.path.join(dst, prefix + "_decode.json"), "w"), indent=1)
 print("wrote", prefix, "summaries; traffic per launch %.2f MB" % (bytes_per_launch / 1e6))
