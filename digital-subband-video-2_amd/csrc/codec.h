@@ -39,7 +39,8 @@ struct StageProf {
     long long launches[ST_COUNT], units[ST_COUNT], mark = 0;
     void destroy();
     void begin(hipStream_t s, int st);
-    void end(hipStream_t s, int st, int nunits); // nunits = stream-frames the stage processed
+    // nunits = stream-frames the stage processed; nlaunch >= 0 overrides the counted kernel launches
+    void end(hipStream_t s, int st, int nunits, int nlaunch = -1);
     void collect(); // after a stream synchronise: fold the step's event pairs into the global totals
 };
 bool prof_enabled();

@@ -51,14 +51,14 @@ void StageProf::begin(hipStream_t s, int st)
     mark = t_launch_count;
 }
 
-void StageProf::end(hipStream_t s, int st, int nunits)
+void StageProf::end(hipStream_t s, int st, int nunits, int nlaunch)
 {
     if (!prof_enabled() || !created) {
         return;
     }
     HIPCHK(hipEventRecord(ev[st][1], s)); // the last end() of a step closes the stage's span
     used[st] = true;
-    launches[st] += t_launch_count - mark;
+    launches[st] += nlaunch >= 0 ? nlaunch : t_launch_count - mark;
     units[st] += nunits;
 }
 

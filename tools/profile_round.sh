@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 be
 cp $out/trace/*/*_kernel_stats.csv $out/kernel_stats.csv
 # the trace itself is large: keep only the dominant kernel's rows for the duration cross-check
 head -1 $out/trace/*/*_kernel_trace.csv > $out/kernel_trace_hme.csv
-grep k_hme_rows_b_fast $out/trace/*/*_kernel_trace.csv >> $out/kernel_trace_hme.csv
+grep k_hme_rows_b $out/trace/*/*_kernel_trace.csv >> $out/kernel_trace_hme.csv
 rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_hme_rows_b_fast" --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_$c.err

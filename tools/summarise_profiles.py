@@ -36,7 +36,8 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
     f.write("\nk_hme_rows_b_*: %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event stage span / launches: %.1f us\n"
             % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
-    f.write("(the stage span also holds the per-level clear / global-motion / finish launches, hence it counts 3 launches per level)\n")
+    f.write("(all k_hme_rows_b_* variants: the fast-path kernel on the fine levels, the general one on the coarsest; the bench span also "
+            "holds one clear launch)\n")
 
 # PMC: per-launch HBM-side bytes of the dominant kernel
 agg = {}
