@@ -31,12 +31,18 @@ struct __attribute__((packed)) U16u { // possibly unaligned 16-bit load (one glo
     uint16_t v;
 };
 
+// the two 16-bit loads are explicit global-memory accesses (a generic pointer would make them flat loads,
+// which also tie up the LDS counter)
+typedef const __attribute__((address_space(1))) uint8_t *gbytes_t;
+typedef const __attribute__((address_space(1))) U16u *gu16_t;
+
 __device__ __forceinline__ Quad ldq(const uint8_t *blk, int stride, int qi, int qj, bool act)
 {
     Quad q = {0};
     if (act) {
-        const uint8_t *p = blk + (ptrdiff_t) (2 * qj) * stride + 2 * qi;
-        uint32_t top = ((const U16u *) p)->v, bot = ((const U16u *) (p + stride))->v;
+        gbytes_t g = (gbytes_t) blk;
+        unsigned off = (unsigned) ((2 * qj) * stride + 2 * qi);
+        uint32_t top = ((gu16_t) (g + off))->v, bot = ((gu16_t) (g + off + (unsigned) stride))->v;
         q.w = top | (bot << 16);
     }
     return q;
