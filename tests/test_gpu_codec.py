@@ -24,6 +24,8 @@ CASES = [
     ("cif_intra", 352, 288, A.SUBSAMP_420, 5, dict(qp=85, gop=0)),
     ("cif_ip", 352, 288, A.SUBSAMP_420, 8, dict(qp=60, gop=6)),
     ("cif_ip_loweffort", 352, 288, A.SUBSAMP_420, 5, dict(qp=40, gop=12, effort=5)),
+    ("cif_ip_effort3", 352, 288, A.SUBSAMP_420, 5, dict(qp=55, gop=12, effort=3)),
+    ("cif_ip_effort7", 352, 288, A.SUBSAMP_420, 5, dict(qp=55, gop=12, effort=7)),
     ("odd_ip", 354, 290, A.SUBSAMP_420, 4, dict(qp=70, gop=12)),
     ("444_lossless", 320, 240, A.SUBSAMP_444, 3, dict(qp=100, gop=12)),
     ("cif_cqp", 352, 288, A.SUBSAMP_420, 4, dict(qp=50, gop=12, rc_mode=2)),
