@@ -83,19 +83,25 @@ __device__ __forceinline__ uint8_t recon_px(int rv, int pv, uint32_t flags, int 
     return plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2);
 }
 
-// grid = (nblocks_h, nblocks_v, 3); 256 threads.
+// One workgroup (256 threads) forms the prediction of one block of one plane.
 // MODE MC_SUBTRACT: pred <- prediction, res <- residual(res - pred)      (dsv_sub_pred)
 // MODE MC_RECONSTRUCT: out(=pred plane) <- recon(prediction, res)        (dsv_add_pred: prediction is
 //                      formed straight into the output frame, then overwritten by the reconstruction)
+// A luma block with a fractional vector stages its (bw+3) x (bh+3) reference window in LDS once and
+// runs the two filter passes of luma_qp (bmc.c:662-727) from there: horizontal into a 16-bit image,
+// then vertical -- the same arithmetic per pixel as evaluating both passes from its own 4x4 window.
+struct PredLds {
+    int qsum[4];
+    uint8_t win[35 * 36];
+    int16_t hz[35 * 32];
+};
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 refp, Planes3 predp,
-                                                 Planes3 resp)
+__device__ __forceinline__ void predict_block(const DSV_MV *__restrict__ mvs, const MCParams &p, const DPlane &rp, const DPlane &dp,
+                                              const DPlane &sp, int i, int j, int c, PredLds &L)
 {
-    __shared__ int qsum[4];
-    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z;
     int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
     int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
-    const DPlane rp = refp.p[c], dp = predp.p[c], sp = resp.p[c];
     DSV_MV mv = mvs[i + j * p.nbh];
     int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
     uint32_t flags = mv.flags;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
     if (intra) {
         if (need_mean) {
             if (threadIdx.x < 4) {
-                qsum[threadIdx.x] = 0;
+                L.qsum[threadIdx.x] = 0;
             }
             __syncthreads();
             int part[4] = {0, 0, 0, 0};
@@ -130,17 +136,17 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (part[k]) {
-                    atomicAdd(&qsum[k], part[k]);
+                    atomicAdd(&L.qsum[k], part[k]);
                 }
             }
             __syncthreads();
             if (mv.submask == DSV_MASK_ALL_INTRA) {
-                int all = (qsum[0] + qsum[1] + qsum[2] + qsum[3]) / (bw * bh); // bmc.c:857
+                int all = (L.qsum[0] + L.qsum[1] + L.qsum[2] + L.qsum[3]) / (bw * bh); // bmc.c:857
                 dcq[0] = dcq[1] = dcq[2] = dcq[3] = all;
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    dcq[k] = qsum[k] / (sbw * sbh); // bmc.c:884
+                    dcq[k] = L.qsum[k] / (sbw * sbh); // bmc.c:884
                 }
             }
         } else {
@@ -157,6 +163,19 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
         fy = mvy & 3;
         soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
         soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
+        int ww = bw + 3, wh = bh + 3;
+        for (int idx = threadIdx.x; idx < ww * wh; idx += 256) {
+            int r = idx / ww, cc = idx % ww;
+            L.win[r * 36 + cc] = rbase[(ptrdiff_t) r * rp.stride + cc];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < wh * bw; idx += 256) {
+            int r = idx / bw, m = idx % bw;
+            const uint8_t *q = &L.win[r * 36 + m];
+            int a = q[0], b = q[1], cc = q[2], d = q[3];
+            L.hz[r * 32 + m] = (int16_t) qp_blend(hp_tap(a, b, cc, d, soft_x), b, cc, fx);
+        }
+        __syncthreads();
     } else if (c != 0 && !intra) {
         int hb = 2 + sh, vb = 2 + sv, hf = 1 << hb, vf = 1 << vb; // bmc.c:778-798
         int dx = mvx & (hf - 1), dy = mvy & (vf - 1);
@@ -177,7 +196,8 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
             bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
             pv = fill ? (dcq[k] & 0xff) : r[0];
         } else if (subpel_luma) {
-            pv = clamp_u8(luma_subpel_px(r, rp.stride, fx, fy, soft_x, soft_y));
+            const int16_t *t = &L.hz[n * 32 + m];
+            pv = clamp_u8(qp_blend(hp_tap(t[0], t[32], t[64], t[96], soft_y), t[32], t[64], fy));
         } else if (chroma_frac) {
             pv = (f0 * r[0] + f1 * r[1] + f2 * r[rp.stride] + f3 * r[rp.stride + 1] + af) >> sf;
             pv &= 0xff;
@@ -198,115 +218,24 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
     }
 }
 
-// stream-batched form of k_predict: gridDim.z = 3 * n, job = blockIdx.z / 3, plane = blockIdx.z % 3
+// grid = (nblocks_h, nblocks_v, 3)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 refp, Planes3 predp,
+                                                 Planes3 resp)
+{
+    __shared__ PredLds L;
+    int c = blockIdx.z;
+    predict_block<MODE>(mvs, p, refp.p[c], predp.p[c], resp.p[c], blockIdx.x, blockIdx.y, c, L);
+}
+
+// stream-batched form: gridDim.z = 3 * n, job = blockIdx.z / 3, plane = blockIdx.z % 3
 template <int MODE>
 __global__ __launch_bounds__(256) void k_predict_b(const McJob *__restrict__ tab)
 {
-    __shared__ int qsum[4];
+    __shared__ PredLds L;
     const McJob &jb = tab[blockIdx.z / 3];
-    const MCParams p = jb.p;
-    const DSV_MV *mvs = jb.mvs;
-    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z % 3;
-    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
-    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
-    const DPlane rp = jb.ref.p[c], dp = jb.pred.p[c], sp = jb.res.p[c];
-    DSV_MV mv = mvs[i + j * p.nbh];
-    int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
-    uint32_t flags = mv.flags;
-    bool intra = flags & (1u << DSV_MV_BIT_INTRA);
-    int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
-    int x = i * bw, y = j * bh;
-    int px = x + sar(mvx, 2 + sh), py = y + sar(mvy, 2 + sv);
-    int sbw = bw >> 1, sbh = bh >> 1;
-    bool subpel_luma = (c == 0) && !intra && ((mvx | mvy) & 3);
-    if (subpel_luma) {
-        px = clampi(px - 1, -kBorder, limx);
-        py = clampi(py - 1, -kBorder, limy);
-    } else {
-        px = clampi(px, -kBorder, limx);
-        py = clampi(py, -kBorder, limy);
-    }
-    const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
-    bool need_mean = intra && !(c == 0 && mv.dc);
-    int dcq[4] = {0, 0, 0, 0};
-    if (intra) {
-        if (need_mean) {
-            if (threadIdx.x < 4) {
-                qsum[threadIdx.x] = 0;
-            }
-            __syncthreads();
-            int part[4] = {0, 0, 0, 0};
-            for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
-                int m = idx % bw, n = idx / bw;
-                int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
-                part[k] += rbase[(ptrdiff_t) n * rp.stride + m];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (part[k]) {
-                    atomicAdd(&qsum[k], part[k]);
-                }
-            }
-            __syncthreads();
-            if (mv.submask == DSV_MASK_ALL_INTRA) {
-                int all = (qsum[0] + qsum[1] + qsum[2] + qsum[3]) / (bw * bh);
-                dcq[0] = dcq[1] = dcq[2] = dcq[3] = all;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    dcq[k] = qsum[k] / (sbw * sbh);
-                }
-            }
-        } else {
-            dcq[0] = dcq[1] = dcq[2] = dcq[3] = mv.dc;
-        }
-    }
-    int fx = 0, fy = 0;
-    bool soft_x = false, soft_y = false;
-    int f0 = 0, f1 = 0, f2 = 0, f3 = 0, sf = 0, af = 0;
-    bool chroma_frac = false;
-    if (subpel_luma) {
-        bool large = abs(mvx) >= 8 || abs(mvy) >= 8;
-        fx = mvx & 3;
-        fy = mvy & 3;
-        soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
-        soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
-    } else if (c != 0 && !intra) {
-        int hb = 2 + sh, vb = 2 + sv, hf = 1 << hb, vf = 1 << vb;
-        int dx = mvx & (hf - 1), dy = mvy & (vf - 1);
-        chroma_frac = (dx | dy) != 0;
-        f0 = (hf - dx) * (vf - dy);
-        f1 = dx * (vf - dy);
-        f2 = (hf - dx) * dy;
-        f3 = dx * dy;
-        sf = hb + vb;
-        af = 1 << (sf - 1);
-    }
-    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
-        int m = idx % bw, n = idx / bw;
-        const uint8_t *r = rbase + (ptrdiff_t) n * rp.stride + m;
-        int pv;
-        if (intra) {
-            int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
-            bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
-            pv = fill ? (dcq[k] & 0xff) : r[0];
-        } else if (subpel_luma) {
-            pv = clamp_u8(luma_subpel_px(r, rp.stride, fx, fy, soft_x, soft_y));
-        } else if (chroma_frac) {
-            pv = (f0 * r[0] + f1 * r[1] + f2 * r[rp.stride] + f3 * r[rp.stride + 1] + af) >> sf;
-            pv &= 0xff;
-        } else {
-            pv = r[0];
-        }
-        ptrdiff_t o = (ptrdiff_t) (y + n) * dp.stride + (x + m);
-        ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
-        if (MODE == MC_SUBTRACT) {
-            dp.data[o] = (uint8_t) pv;
-            sp.data[so] = residual_px(sp.data[so], pv, flags, c, p.lossless);
-        } else {
-            dp.data[o] = recon_px(sp.data[so], pv, flags, p.lossless);
-        }
-    }
+    int c = blockIdx.z % 3;
+    predict_block<MODE>(jb.mvs, jb.p, jb.ref.p[c], jb.pred.p[c], jb.res.p[c], blockIdx.x, blockIdx.y, c, L);
 }
 
 __global__ __launch_bounds__(256) void k_reconstruct_b(const McJob *__restrict__ tab)
