@@ -273,19 +273,20 @@ __global__ __launch_bounds__(256) void k_reconstruct(const DSV_MV *__restrict__ 
 
 // ---- 4x4 edge smoothing primitives (bmc.c:53-191) ------------------------------------------
 
+// Evaluated without branches: the six range tests are combined bitwise and the four outputs are always
+// formed; callers select between old and new samples.  The wave executes every path of divergent code anyway,
+// so predication costs nothing here and removes ~a thousand exec-mask branches per cell.
 __device__ __forceinline__ bool smooth6(int e2, int e1, int e0, int i0, int i1, int i2, int t, int o[4])
 {
     int avg = (5 * (e0 + i0) + 3 * (e1 + i1) + 8) >> 4;
-    if (abs(e0 - avg) < t && abs(i0 - avg) < t && abs(e1 - avg) < t && abs(i1 - avg) < t && abs(e2 - avg) < t &&
-        abs(i2 - avg) < t) {
-        int a5 = avg * 5;
-        o[0] = (3 * (avg + e1) + 2 * e2 + 4) >> 3;
-        o[1] = (a5 + 2 * e1 + e2 + 4) >> 3;
-        o[2] = avg;
-        o[3] = (a5 + 2 * i1 + i2 + 4) >> 3;
-        return true;
-    }
-    return false;
+    bool ok = (abs(e0 - avg) < t) & (abs(i0 - avg) < t) & (abs(e1 - avg) < t) & (abs(i1 - avg) < t) & (abs(e2 - avg) < t) &
+              (abs(i2 - avg) < t);
+    int a5 = avg * 5;
+    o[0] = (3 * (avg + e1) + 2 * e2 + 4) >> 3;
+    o[1] = (a5 + 2 * e1 + e2 + 4) >> 3;
+    o[2] = avg;
+    o[3] = (a5 + 2 * i1 + i2 + 4) >> 3;
+    return ok;
 }
 
 // ---- the filters of one 4x4 cell, evaluated in registers ---------------------------------------
@@ -295,27 +296,52 @@ __device__ __forceinline__ bool smooth6(int e2, int e1, int e0, int i0, int i1, 
 // y - 3 + r): rows 3..6 hold 12 columns, rows 0..2 and 7..10 hold only the cell's own columns 4..7.
 // None of these bytes is written by another cell of the same sweep front (cells (i-2, j+1) and
 // (i+2, j-1) reach at most column x-5 / row y-1 of our rows), so whole-dword stores are safe.
+// where a Tile's pixels live: the plane in global memory ...
+struct GlobalView {
+    static constexpr bool kStoreAll = false; // write back modified rows only
+    DPlane dp;
+    __device__ __forceinline__ uint32_t ld(int row, int col) const { return *(const uint32_t *) (dp.data + (ptrdiff_t) row * dp.stride + col); }
+    __device__ __forceinline__ void st(int row, int col, uint32_t v) const { *(uint32_t *) (dp.data + (ptrdiff_t) row * dp.stride + col) = v; }
+};
+// ... or the LDS ring of a plane-resident sweep (ring_sweep below): one 64-byte ring per pixel row holding a
+// sliding 64-column window.  Rows outside the plane are never filtered (the filters skip y < 4 and
+// y > h - 4), so their loads are clamped and their stores dropped.
+struct RingView {
+    static constexpr bool kStoreAll = true; // LDS: cheaper to write the whole cross back than to branch per row
+    uint8_t *ring;
+    int h;
+    __device__ __forceinline__ uint32_t ld(int row, int col) const
+    {
+        row = row < 0 ? 0 : (row >= h ? h - 1 : row);
+        return *(const uint32_t *) (ring + row * 64 + (col & 63));
+    }
+    __device__ __forceinline__ void st(int row, int col, uint32_t v) const
+    {
+        if (row >= 0 && row < h) {
+            *(uint32_t *) (ring + row * 64 + (col & 63)) = v;
+        }
+    }
+};
+
 struct Tile {
     int t[11][12];
     unsigned dirty; // bit r: row r modified
 
-    __device__ __forceinline__ void load(const DPlane &dp, int x, int y)
+    template <class V> __device__ __forceinline__ void load(const V &view, int x, int y)
     {
-        const uint8_t *base = dp.data + (ptrdiff_t) (y - 3) * dp.stride + (x - 4);
 #pragma unroll
         for (int r = 0; r < 11; r++) {
-            const uint32_t *row = (const uint32_t *) (base + (ptrdiff_t) r * dp.stride);
             if (r >= 3 && r <= 6) {
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    uint32_t v = row[d];
+                    uint32_t v = view.ld(y - 3 + r, x - 4 + 4 * d);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         t[r][4 * d + k] = (int) ((v >> (8 * k)) & 0xffu);
                     }
                 }
             } else {
-                uint32_t v = row[1];
+                uint32_t v = view.ld(y - 3 + r, x);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     t[r][4 + k] = (int) ((v >> (8 * k)) & 0xffu);
@@ -325,26 +351,25 @@ struct Tile {
         dirty = 0;
     }
 
-    __device__ __forceinline__ void store(const DPlane &dp, int x, int y) const
+    template <class V> __device__ __forceinline__ void store(const V &view, int x, int y) const
     {
-        if (!dirty) {
+        if (!V::kStoreAll && !dirty) {
             return;
         }
-        uint8_t *base = dp.data + (ptrdiff_t) (y - 3) * dp.stride + (x - 4);
 #pragma unroll
         for (int r = 0; r < 11; r++) {
-            if (!(dirty & (1u << r))) {
+            if (!V::kStoreAll && !(dirty & (1u << r))) {
                 continue;
             }
-            uint32_t *row = (uint32_t *) (base + (ptrdiff_t) r * dp.stride);
             if (r >= 3 && r <= 6) {
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    row[d] = (uint32_t) t[r][4 * d] | ((uint32_t) t[r][4 * d + 1] << 8) | ((uint32_t) t[r][4 * d + 2] << 16) |
-                             ((uint32_t) t[r][4 * d + 3] << 24);
+                    view.st(y - 3 + r, x - 4 + 4 * d,
+                            (uint32_t) t[r][4 * d] | ((uint32_t) t[r][4 * d + 1] << 8) | ((uint32_t) t[r][4 * d + 2] << 16) |
+                                ((uint32_t) t[r][4 * d + 3] << 24));
                 }
             } else {
-                row[1] = (uint32_t) t[r][4] | ((uint32_t) t[r][5] << 8) | ((uint32_t) t[r][6] << 16) | ((uint32_t) t[r][7] << 24);
+                view.st(y - 3 + r, x, (uint32_t) t[r][4] | ((uint32_t) t[r][5] << 8) | ((uint32_t) t[r][6] << 16) | ((uint32_t) t[r][7] << 24));
             }
         }
     }
@@ -353,33 +378,27 @@ struct Tile {
 // one 11-sample line through the cell: l[3] is the cell's first sample (bmc.c:71-191)
 __device__ __forceinline__ bool line_filter(int (&l)[11], bool in_edge, int tE, int tM)
 {
-    int o[4];
-    bool hit = false;
-    if (smooth6(l[0], l[1], l[2], l[3], l[4], l[5], tE, o)) {
-        l[1] = o[0] & 0xff;
-        l[3] = o[2] & 0xff;
-        l[2] = o[1] & 0xff;
-        l[4] = o[3] & 0xff;
-        hit = true;
-    }
-    if (in_edge && smooth6(l[10], l[9], l[8], l[7], l[6], l[5], tM, o)) {
-        l[7] = o[2] & 0xff;
-        l[9] = o[0] & 0xff;
-        l[6] = o[3] & 0xff;
-        l[8] = o[1] & 0xff;
-        hit = true;
-    }
-    return hit;
+    int o[4], p[4];
+    bool h1 = smooth6(l[0], l[1], l[2], l[3], l[4], l[5], tE, o);
+    bool h2 = in_edge & smooth6(l[10], l[9], l[8], l[7], l[6], l[5], tM, p); // reads l[5..10] only: untouched by the first half
+    l[1] = h1 ? (o[0] & 0xff) : l[1];
+    l[2] = h1 ? (o[1] & 0xff) : l[2];
+    l[3] = h1 ? (o[2] & 0xff) : l[3];
+    l[4] = h1 ? (o[3] & 0xff) : l[4];
+    l[6] = h2 ? (p[3] & 0xff) : l[6];
+    l[7] = h2 ? (p[2] & 0xff) : l[7];
+    l[8] = h2 ? (p[1] & 0xff) : l[8];
+    l[9] = h2 ? (p[0] & 0xff) : l[9];
+    return h1 | h2;
 }
 
-__device__ __forceinline__ void hfilter(Tile &T, const DPlane &dp, int x, bool edge, int tE, int tM)
+// `on` = false turns the pass into a no-op (thresholds 0: no range test can pass)
+__device__ __forceinline__ void hfilter(Tile &T, const DPlane &dp, int x, bool edge, int tE, int tM, bool on = true)
 {
-    if (x < 4 || x > dp.w - 4 || (edge && tE <= 0) || tM <= 0) {
-        return;
-    }
-    if (!edge) {
-        tE = tM;
-    }
+    on = on & !(x < 4 || x > dp.w - 4 || (edge && tE <= 0) || tM <= 0);
+    tE = edge ? tE : tM;
+    tE = on ? tE : 0;
+    tM = on ? tM : 0;
     bool in_edge = x < dp.w - 8;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
@@ -388,24 +407,21 @@ __device__ __forceinline__ void hfilter(Tile &T, const DPlane &dp, int x, bool e
         for (int k = 0; k < 11; k++) {
             l[k] = T.t[3 + n][1 + k];
         }
-        if (line_filter(l, in_edge, tE, tM)) {
+        bool hit = line_filter(l, in_edge, tE, tM);
 #pragma unroll
-            for (int k = 1; k < 10; k++) {
-                T.t[3 + n][1 + k] = l[k];
-            }
-            T.dirty |= 1u << (3 + n);
+        for (int k = 1; k < 10; k++) {
+            T.t[3 + n][1 + k] = l[k];
         }
+        T.dirty |= hit ? (1u << (3 + n)) : 0u;
     }
 }
 
-__device__ __forceinline__ void vfilter(Tile &T, const DPlane &dp, int y, bool edge, int tE, int tM)
+__device__ __forceinline__ void vfilter(Tile &T, const DPlane &dp, int y, bool edge, int tE, int tM, bool on = true)
 {
-    if (y < 4 || y > dp.h - 4 || (edge && tE <= 0) || tM <= 0) {
-        return;
-    }
-    if (!edge) {
-        tE = tM;
-    }
+    on = on & !(y < 4 || y > dp.h - 4 || (edge && tE <= 0) || tM <= 0);
+    tE = edge ? tE : tM;
+    tE = on ? tE : 0;
+    tM = on ? tM : 0;
     bool in_edge = y < dp.h - 8;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
@@ -414,13 +430,12 @@ __device__ __forceinline__ void vfilter(Tile &T, const DPlane &dp, int y, bool e
         for (int k = 0; k < 11; k++) {
             l[k] = T.t[k][4 + n];
         }
-        if (line_filter(l, in_edge, tE, tM)) {
+        bool hit = line_filter(l, in_edge, tE, tM);
 #pragma unroll
-            for (int k = 1; k < 10; k++) {
-                T.t[k][4 + n] = l[k];
-            }
-            T.dirty |= 0x3deu; // rows 1..4 and 6..9
+        for (int k = 1; k < 10; k++) {
+            T.t[k][4 + n] = l[k];
         }
+        T.dirty |= hit ? 0x3deu : 0u; // rows 1..4 and 6..9
     }
 }
 
@@ -654,133 +669,177 @@ __device__ __forceinline__ void neighbordif2(const DSV_MV *v, int nbh, int x, in
     dy = abs(tx - cx) + abs(ty - cy);
 }
 
-// ---- one cell of each filter (oracle/orc_bmc.c: intra_cell, luma_cell, chroma_block) ----------
+// explicit global-memory accesses: a generic pointer would compile to FLAT instructions, which count against the
+// LDS counter as well and so make every LDS wait of the sweep wait for global memory
+typedef const __attribute__((address_space(1))) uint32_t *gu32_t;
+typedef __attribute__((address_space(1))) uint32_t *gu32w_t;
 
-__device__ void intra_cell(const DPlane &dp, const FilterParams &f, const uint8_t *bd, int i, int j, int nsbx, int nsby)
+// what a luma cell needs of the motion field: its block's record and the left / top neighbours' vectors
+struct CellRec {
+    uint32_t all, flags, submask; // this block: packed {x, y}, flags, sub-block intra mask
+    uint32_t l_all, l_flags, t_all, t_flags;
+};
+
+__device__ __forceinline__ CellRec fetch_cell_rec(const DSV_MV *vecs, int nbh, int fx, int fy)
 {
-    int x = i * 4, y = j * 4;
-    if (y + 4 >= dp.h || x + 4 >= dp.w) {
+    gu32_t c = (gu32_t) &vecs[fx + fy * nbh];
+    CellRec r;
+    r.all = c[0];
+    r.flags = c[1];
+    r.submask = c[3] & 0xffu;
+    r.l_all = r.l_flags = r.t_all = r.t_flags = 0;
+    if (fx > 0) {
+        r.l_all = c[-4];
+        r.l_flags = c[-3];
+    }
+    if (fy > 0) {
+        r.t_all = c[-4 * nbh];
+        r.t_flags = c[-4 * nbh + 1];
+    }
+    return r;
+}
+
+__device__ __forceinline__ int mvx_of(uint32_t all) { return (int) (int16_t) (all & 0xffffu); }
+__device__ __forceinline__ int mvy_of(uint32_t all) { return (int) (int16_t) (all >> 16); }
+
+__device__ __forceinline__ void neighbordif2(const CellRec &r, int fx, int fy, int &dx, int &dy) // dsv.c:403
+{
+    int cx = mvx_of(r.all), cy = mvy_of(r.all), lx = cx, ly = cy, tx = cx, ty = cy;
+    if (abs(cx) < 2 && abs(cy) < 2) {
+        dx = dy = 0;
         return;
     }
-    int flags = bd[(i * f.nbh / nsbx) + (j * f.nbv / nsby) * f.nbh];
-    if (flags & DSV_IS_RINGING) {
+    if (fx > 0 && r.l_all && !(r.l_flags & (1u << DSV_MV_BIT_SKIP))) {
+        lx = mvx_of(r.l_all);
+        ly = mvy_of(r.l_all);
+    }
+    if (fy > 0 && r.t_all && !(r.t_flags & (1u << DSV_MV_BIT_SKIP))) {
+        tx = mvx_of(r.t_all);
+        ty = mvy_of(r.t_all);
+    }
+    dx = abs(lx - cx) + abs(ly - cy);
+    dy = abs(tx - cx) + abs(ty - cy);
+}
+
+// ---- one cell of each filter (oracle/orc_bmc.c: intra_cell, luma_cell, chroma_block) ----------
+
+template <class V>
+__device__ void intra_cell(const V &view, const DPlane &dp, const FilterParams &f, const uint8_t *bd, int i, int j, int nsbx, int nsby)
+{
+    int x = i * 4, y = j * 4;
+    bool live = !(y + 4 >= dp.h || x + 4 >= dp.w);
+    int flags = live ? bd[(i * f.nbh / nsbx) + (j * f.nbv / nsby) * f.nbh] : DSV_IS_RINGING;
+    live = live & !(flags & DSV_IS_RINGING);
+    if (!__any(live)) { // nothing to do for the whole wavefront
         return;
     }
     Tile T;
-    T.load(dp, x, y);
+    T.load(view, x, y);
     int sh, sv, shl, svl;
     artf(T, sh, sv, shl, svl);
     int mx = max(sh, sv);
-    if (!(mx < 256 && mx > 8)) {
-        return;
-    }
+    live = live & (mx < 256 && mx > 8);
     int tt = 32;
-    if (flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE)) {
-        tt = (int) dsff(T);
-        if (flags & DSV_IS_STABLE) {
-            tt = tt * 5 >> 2;
-        }
-    } else {
-        tt >>= 2;
+    {
+        int td = (int) dsff(T);
+        td = (flags & DSV_IS_STABLE) ? (td * 5 >> 2) : td;
+        tt = (flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE)) ? td : (tt >> 2);
     }
     tt = tt * 2 / 3;
     tt = (tt * f.q) >> 12;
     tt = clampi(tt, 0, f.fthresh);
-    hfilter(T, dp, x, false, tt, tt);
-    vfilter(T, dp, y, false, tt, tt);
+    hfilter(T, dp, x, false, tt, tt, live);
+    vfilter(T, dp, y, false, tt, tt, live);
     tt = sh > sv ? (3 * sh + sv) : (3 * sv + sh);
     tt = curve_tex(tt);
     tt = 16 + ((tt + 2) >> 2);
     tt = (tt * f.q) >> 12;
     tt = clampi(tt, 0, f.fthresh);
-    hfilter(T, dp, x, false, tt, tt);
-    vfilter(T, dp, y, false, tt, tt);
-    T.store(dp, x, y);
+    hfilter(T, dp, x, false, tt, tt, live);
+    vfilter(T, dp, y, false, tt, tt, live);
+    T.store(view, x, y);
 }
 
-__device__ void luma_cell(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j, int nsbx, int nsby)
+template <class V>
+__device__ void luma_cell_rec(const V &view, const DPlane &dp, const FilterParams &f, const CellRec &rec, int fx, int fy, int i, int j)
 {
     int x = i * 4, y = j * 4;
-    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby;
-    const DSV_MV *mv = &vecs[fx + fy * f.nbh];
-    uint32_t flags = mv->flags;
-    if (y + 4 >= dp.h || (flags & (1u << DSV_MV_BIT_SKIP)) || x + 4 >= dp.w) {
-        return;
-    }
+    uint32_t flags = rec.flags;
+    bool live = !(y + 4 >= dp.h || (flags & (1u << DSV_MV_BIT_SKIP)) || x + 4 >= dp.w);
     bool edgeh = (x % f.blk_w) == 0, edgehs = (x % (f.blk_w / 2)) == 0;
     bool edgev = (y % f.blk_h) == 0, edgevs = (y % (f.blk_h / 2)) == 0;
-    int mvx = mv->u.mv.x, mvy = mv->u.mv.y;
+    int mvx = mvx_of(rec.all), mvy = mvy_of(rec.all);
     int amx = abs(mvx), amy = abs(mvy);
-    if (flags & (1u << DSV_MV_BIT_INTRA)) {
-        int tH = clampi((64 * f.q) >> 12, 2, 32), tL = clampi((32 * f.q) >> 12, 2, 32);
-        bool eh = edgeh, ev = edgev;
-        if (mv->submask != DSV_MASK_ALL_INTRA) {
-            eh |= edgehs;
-            ev |= edgevs;
-        }
-        Tile T;
-        T.load(dp, x, y);
-        hfilter(T, dp, x, eh, tH, tL);
-        vfilter(T, dp, y, ev, tH, tL);
-        T.store(dp, x, y);
-        return;
-    }
+    bool intra = (flags & (1u << DSV_MV_BIT_INTRA)) != 0;
     int ndx = 0, ndy = 0;
-    bool filt = false;
     if (f.do_filter) {
-        neighbordif2(vecs, f.nbh, fx, fy, ndx, ndy);
-        filt = ndx || ndy;
+        neighbordif2(rec, fx, fy, ndx, ndy);
     }
-    bool sharp = f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8;
-    if (!filt && !sharp) {
+    bool filt = !intra && (ndx || ndy);
+    bool sharp = !intra && f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8;
+    live = live & (intra | filt | sharp);
+    if (!__any(live)) { // nothing to do for the whole wavefront
         return;
     }
     Tile T;
-    T.load(dp, x, y);
-    if (filt) {
+    T.load(view, x, y);
+    // the two passes and their thresholds, by block type (bmc.c:527-596)
+    bool h_on, v_on, eh, ev;
+    int hE, hM, vE, vM;
+    {
+        // intra block
+        int tH = clampi((64 * f.q) >> 12, 2, 32), tL = clampi((32 * f.q) >> 12, 2, 32);
+        bool part = rec.submask != DSV_MASK_ALL_INTRA;
+        bool ieh = edgeh | (part & edgehs), iev = edgev | (part & edgevs);
+        // inter block with a motion discontinuity
+        bool eprm = (flags & (1u << DSV_MV_BIT_EPRM)) != 0;
+        int tndc = (ndx + ndy + 1) >> 1;
+        int sh, sv, shl, svl, tt;
+        artf(T, sh, sv, shl, svl);
+        int n_dx = ndx, n_dy = ndy;
+        bool mixed = sh < 2 * sv && sv < 2 * sh;
         {
-            bool eprm = flags & (1u << DSV_MV_BIT_EPRM);
-            bool eh = edgeh || eprm, ev = edgev || eprm;
-            int tndc = (ndx + ndy + 1) >> 1;
-            int sh, sv, shl, svl, tt;
-            artf(T, sh, sv, shl, svl);
-            if (sh < 2 * sv && sv < 2 * sh) {
-                if (ndx < amx) {
-                    ndx >>= 1;
-                }
-                if (ndy < amy) {
-                    ndy >>= 1;
-                }
-                shl = shl > 128 ? 0 : 128 - shl;
-                svl = svl > 128 ? 0 : 128 - svl;
-                int ix = min(amx, 32), iy = min(amy, 32);
-                tt = ((sh * (32 - iy) + shl * iy) + 16) >> 5;
-                tt += ((sv * (32 - ix) + svl * ix) + 16) >> 5;
-                tt = (tt + 1) >> 1;
-                if (ndx < amy && ndy < amx) {
-                    tt = 0;
-                }
-            } else {
-                tt = (sh + sv + 1) >> 1;
-            }
-            tt = (tt * tndc + 4) >> 3;
-            tt = (min(tt, f.fthresh) * f.q) >> 12;
-            int addx = (min(ndy, f.fthresh) * f.q) >> 12;
-            int addy = (min(ndx, f.fthresh) * f.q) >> 12;
-            if (sh > 2 * sv || amy > 2 * amx) {
-                vfilter(T, dp, y, ev, tt + addy, tt);
-            } else if (sv > 2 * sh || amx > 2 * amy) {
-                hfilter(T, dp, x, eh, tt + addx, tt);
-            } else {
-                hfilter(T, dp, x, eh, tt + addx, tt);
-                vfilter(T, dp, y, ev, tt + addy, tt);
-            }
+            int mdx = ndx < amx ? ndx >> 1 : ndx, mdy = ndy < amy ? ndy >> 1 : ndy;
+            int shl2 = shl > 128 ? 0 : 128 - shl, svl2 = svl > 128 ? 0 : 128 - svl;
+            int ix = min(amx, 32), iy = min(amy, 32);
+            int tm = ((sh * (32 - iy) + shl2 * iy) + 16) >> 5;
+            tm += ((sv * (32 - ix) + svl2 * ix) + 16) >> 5;
+            tm = (tm + 1) >> 1;
+            tm = (mdx < amy && mdy < amx) ? 0 : tm;
+            tt = mixed ? tm : ((sh + sv + 1) >> 1);
+            n_dx = mixed ? mdx : ndx;
+            n_dy = mixed ? mdy : ndy;
+        }
+        tt = (tt * tndc + 4) >> 3;
+        tt = (min(tt, f.fthresh) * f.q) >> 12;
+        int addx = (min(n_dy, f.fthresh) * f.q) >> 12;
+        int addy = (min(n_dx, f.fthresh) * f.q) >> 12;
+        bool v_only = sh > 2 * sv || amy > 2 * amx;
+        bool h_only = !v_only && (sv > 2 * sh || amx > 2 * amy);
+        h_on = live & (intra | (filt & !v_only));
+        v_on = live & (intra | (filt & !h_only));
+        eh = intra ? ieh : (edgeh | eprm);
+        ev = intra ? iev : (edgev | eprm);
+        hE = intra ? tH : tt + addx;
+        hM = intra ? tL : tt;
+        vE = intra ? tH : tt + addy;
+        vM = intra ? tL : tt;
+    }
+    hfilter(T, dp, x, eh, hE, hM, h_on);
+    vfilter(T, dp, y, ev, vE, vM, v_on);
+    if (__any(live & sharp)) {
+        if (live & sharp) {
+            degrad(T);
         }
     }
-    if (sharp) {
-        degrad(T);
-    }
-    T.store(dp, x, y);
+    T.store(view, x, y);
+}
+
+template <class V>
+__device__ void luma_cell(const V &view, const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j, int nsbx, int nsby)
+{
+    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby;
+    luma_cell_rec(view, dp, f, fetch_cell_rec(vecs, f.nbh, fx, fy), fx, fy, i, j);
 }
 
 __device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j)
@@ -830,6 +889,76 @@ template <class Body> __device__ __forceinline__ void sweep_fronts(int nx, int n
     }
 }
 
+// ---- plane-resident sweep: the same fronts, but the pixels a front can touch live in LDS -----------------
+// Every pixel row owns a 64-byte ring holding columns [4*ic - 12, 4*ic + 52) of that row, where ic = t - 2j
+// is the cell column its cell row j is at on front t.  Cell (ic, j) touches its own rows at columns
+// 4ic-4 .. 4ic+7 and the rows of cell rows j-1 / j+1 at columns 4ic .. 4ic+3, i.e. (seen from those
+// rows, which are two cells ahead / behind) their columns 4ic'-8 .. 4ic'-5 and 4ic'+8 .. 4ic'+11: all inside the
+// window.  Per front a row fetches the 4 columns entering its window (registers now, LDS next front,
+// first needed nine fronts later), and retires the 4 columns leaving it to global memory; nothing on
+// the dependent path of a front goes to global memory.  Thread = cell row mod blockDim (the band of
+// rows that are active on a front is at most (nsbx + 14) / 2 + 1 rows wide).
+__device__ __forceinline__ bool ring_eligible(const DPlane &dp, int nthreads, size_t lds_bytes)
+{
+    return (dp.w & 3) == 0 && (dp.h & 3) == 0 && dp.w >= 64 && (size_t) dp.h * 64 <= lds_bytes && (dp.w / 4 + 14) / 2 + 1 <= nthreads;
+}
+
+// cell(ic, j) filters one cell; ahead(ic, j) is told which cell this thread will filter four fronts later so
+// that it can fetch that cell's side information off the dependent path
+template <class CellFn, class AheadFn>
+__device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead)
+{
+    const int nsbx = dp.w / 4, nsby = dp.h / 4;
+    const int tid = (int) threadIdx.x, nthr = (int) blockDim.x;
+    const int t_last = (nsbx + 2) + 2 * (nsby - 1);
+    uint32_t pend[4] = {0, 0, 0, 0};
+    int pend_row = -1, pend_col = 0;
+    for (int t = -12; t <= t_last; t++) {
+        // the rows in flight: -12 <= ic <= nsbx + 2
+        int jlo = t - (nsbx + 2) > 0 ? (t - (nsbx + 2) + 1) >> 1 : 0;
+        int jhi = (t + 12) >> 1;
+        jhi = jhi < nsby - 1 ? jhi : nsby - 1;
+        int j = jlo + ((tid - jlo) % nthr + nthr) % nthr;
+        bool active = j <= jhi;
+        int ic = t - 2 * j;
+        if (pend_row >= 0) { // columns fetched on the previous front enter the window
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                *(uint32_t *) (ring + (pend_row + r) * 64 + (pend_col & 63)) = pend[r];
+            }
+            pend_row = -1;
+        }
+        if (active) {
+            int g = 4 * ic + 48;
+            if (g >= 0 && g < dp.w) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pend[r] = *(gu32_t) (dp.data + (ptrdiff_t) (4 * j + r) * dp.stride + g);
+                }
+                pend_row = 4 * j;
+                pend_col = g;
+            }
+            if (ic >= 0 && ic < nsbx) {
+                cell(ic, j);
+            }
+            if (ic + 4 >= 0 && ic + 4 < nsbx) { // one block (four cells) of lead: a global fetch has that long to arrive
+                ahead(ic + 4, j);
+            }
+            g = 4 * ic - 12;
+            if (g >= 0 && g < dp.w) { // these columns are final: no later cell reaches them
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    *(gu32w_t) (dp.data + (ptrdiff_t) (4 * j + r) * dp.stride + g) = *(const uint32_t *) (ring + (4 * j + r) * 64 + (g & 63));
+                }
+            }
+        }
+        // fronts hand over through LDS only: wait for this wave's LDS traffic and meet the others, but leave
+        // the column fetches and retirements in flight (__syncthreads() would drain them every front)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __syncthreads();
+}
+
 // grid = 3 workgroups: luma filter, U chroma filter, V chroma filter
 __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict__ vecs, FilterParams f, Planes3 pl)
 {
@@ -840,15 +969,16 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
     }
     if (c == 0) {
         int nsbx = dp.w / 4, nsby = dp.h / 4;
-        sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(dp, f, vecs, i, j, nsbx, nsby); });
+        sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
     } else {
         sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
     }
 }
 
 // stream-batched filters: grid = (3 planes, n jobs) / (n jobs)
-__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab)
+__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
+    extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.y];
     int c = blockIdx.x;
     const DPlane dp = jb.res.p[c];
@@ -859,26 +989,56 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
     }
     if (c == 0) {
         int nsbx = dp.w / 4, nsby = dp.h / 4;
-        sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(dp, f, vecs, i, j, nsbx, nsby); });
+        if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
+            RingView view{dyn_lds, dp.h};
+            // the block record of the cell at hand and, fetched one front early, of the next one
+            CellRec cur = {}, nxt = {};
+            int cur_key = -1, nxt_key = -1;
+            ring_sweep(
+                dp, dyn_lds,
+                [&](int i, int j) {
+                    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby, key = fx + fy * f.nbh;
+                    if (key != cur_key) {
+                        cur = key == nxt_key ? nxt : fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        cur_key = key;
+                    }
+                    luma_cell_rec(view, dp, f, cur, fx, fy, i, j);
+                },
+                [&](int i, int j) {
+                    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby, key = fx + fy * f.nbh;
+                    if (key != cur_key && key != nxt_key) {
+                        nxt = fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        nxt_key = key;
+                    }
+                });
+        } else {
+            sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
+        }
     } else {
         sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
     }
 }
 
-__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab)
+__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
+    extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
     const DPlane dp = jb.res.p[0];
     const FilterParams f = jb.f;
     const uint8_t *bd = jb.bd;
     int nsbx = dp.w / 4, nsby = dp.h / 4;
-    sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(dp, f, bd, i, j, nsbx, nsby); });
+    if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
+        RingView view{dyn_lds, dp.h};
+        ring_sweep(dp, dyn_lds, [&](int i, int j) { intra_cell(view, dp, f, bd, i, j, nsbx, nsby); }, [](int, int) {});
+    } else {
+        sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
+    }
 }
 
 __global__ __launch_bounds__(256) void k_intra_filter(const uint8_t *__restrict__ bd, FilterParams f, DPlane dp)
 {
     int nsbx = dp.w / 4, nsby = dp.h / 4;
-    sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(dp, f, bd, i, j, nsbx, nsby); });
+    sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
 }
 
 // decoder-side sharpening (dsv_post_process, bmc.c:340): every 4x4 cell is independent
@@ -975,6 +1135,20 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
     HIPCHK(hipGetLastError());
 }
 
+// dynamic LDS of the plane-resident luma sweep: one 64-byte ring per pixel row (0 = use the global-memory sweep)
+static unsigned ring_lds_bytes(int luma_h)
+{
+    static int on = getenv("DSV2_FILTER_RING") ? atoi(getenv("DSV2_FILTER_RING")) : 1;
+    static bool raised = false;
+    if (!raised) { // more than the default 64 KB of dynamic LDS has to be asked for (gfx950 has 160 KB per CU)
+        HIPCHK(hipFuncSetAttribute((const void *) k_inter_filters_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_intra_filter_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        raised = true;
+    }
+    size_t b = (size_t) luma_h * 64;
+    return (on && b <= 150 * 1024) ? (unsigned) b : 0u;
+}
+
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
 void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
 {
@@ -983,31 +1157,31 @@ void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nb
     }
 }
 
-void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter)
+void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_h)
 {
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_b, dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), 0, s, d_tab);
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
         }
     }
 }
 
 // decoder: d_pred jobs {ref, pred = output picture, res = residual}; d_filt jobs {res = output picture}
-void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter)
+void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_h)
 {
     if (n > 0) {
         DSV2_LAUNCH((k_predict_b<MC_RECONSTRUCT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), 0, s, d_filt);
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
         }
     }
 }
 
-void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n)
+void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
     }
 }
 
