@@ -60,7 +60,7 @@ def parse():
                                                       "on a box with fewer GPUs than ranks, together with DSV2_FORCE_DEVICE)")
     ap.add_argument("--no-profile", action="store_true", help="skip the extra stage-timing pass that feeds the roofline object")
     ap.add_argument("--profile-steps", type=int, default=6)
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "6")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "4")),
                     help="batch mode: split the streams into this many lockstep groups, one host thread + HIP stream each")
     ap.add_argument("--mode", choices=["batch", "threads"], default=os.environ.get("DSV2_BENCH_MODE", "batch"),
                     help="batch: lockstep dsv2hip_enc_batch over all streams; threads: one host thread + HIP stream per stream")
