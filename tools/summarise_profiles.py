@@ -69,4 +69,9 @@ json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_w2", "streams_per_gpu": 
 dec = [l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")]
 if dec:
     json.dump(json.loads(dec[-1]), open(os.path.join(dst, prefix + "_decode.json"), "w"), indent=1)
+# the bench line was taken before these PMC passes: complete its roofline object with their figure
+if bench.get("roofline") and bench["roofline"].get("traffic") is None:
+    bench["roofline"]["traffic"] = round(bytes_per_launch)
+    bench["roofline"]["traffic_source"] = "profiles/%s_pmc_hme.txt, same round and configuration" % prefix
+    json.dump(bench, open(os.path.join(dst, prefix + "_bench.json"), "w"), indent=1)
 print("wrote", prefix, "summaries; traffic per launch %.2f MB" % (bytes_per_launch / 1e6))
