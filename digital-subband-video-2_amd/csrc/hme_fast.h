@@ -787,7 +787,9 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
     }
 }
 
-__device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx, int gy, FastLds &S)
+// FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away
+template <bool FULL>
+__device__ __forceinline__ void hme_block_fast_t(const HmeDev &c, int level, int i, int j, int gx, int gy, FastLds &S)
 {
     const int rectx[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1};
     const int recty[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};
@@ -804,7 +806,7 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
     const int bx = (i * y_w) >> level, by = (j * y_h) >> level;
     const int bw = min(src.w - bx, y_w), bh = min(src.h - by, y_h);
     const int qw = bw >> 1, qh = bh >> 1;
-    const bool act = qi < qw && qj < qh;
+    const bool act = FULL ? true : (qi < qw && qj < qh);
     const uint8_t *sblk = at(src, bx, by);
     const Quad a = ldq(sblk, src.stride, qi, qj, act);
 
@@ -1089,4 +1091,15 @@ __device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx,
     }
     hme_block_fast_l0(c, i, j, S, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
                       avg_src, psy);
+}
+
+__device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx, int gy, FastLds &S)
+{
+    const DPlane &src = c.src[level];
+    int bx = (i * 16) >> level, by = (j * 16) >> level;
+    if (src.w - bx >= 16 && src.h - by >= 16) {
+        hme_block_fast_t<true>(c, level, i, j, gx, gy, S);
+    } else {
+        hme_block_fast_t<false>(c, level, i, j, gx, gy, S);
+    }
 }
