@@ -16,6 +16,7 @@
 //     form a wavefront that is processed concurrently; one workgroup per plane sweeps the fronts
 //     with a workgroup barrier between them (the plane stays in L2 / the CU's L1).
 #include "dev.h"
+#include "blockstat.h"
 #include "bmc.h"
 #include "hme.h"
 
@@ -228,31 +229,225 @@ __global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs,
     predict_block<MODE>(mvs, p, refp.p[c], predp.p[c], resp.p[c], blockIdx.x, blockIdx.y, c, L);
 }
 
-// stream-batched form: gridDim.z = 3 * n, job = blockIdx.z / 3, plane = blockIdx.z % 3
-template <int MODE>
-__global__ __launch_bounds__(256) void k_predict_b(const McJob *__restrict__ tab)
+// ---- lockstep-batch forms: one WAVEFRONT per block (all three planes), four pixels per lane ---------------------
+// grid = (ceil(nblocks_h / 4), nblocks_v, n streams), 256 threads = 4 wavefronts = 4 horizontally adjacent blocks.
+// Pixels move as aligned dwords (block origins and widths are multiples of 4); the reference window of a
+// fractional luma vector is staged per wavefront in LDS and filtered in two passes like predict_block().
+struct __attribute__((packed)) U32u {
+    uint32_t v;
+};
+
+struct WaveLds {
+    uint8_t win[35 * 36];
+    int16_t hz[35 * 32];
+};
+
+__device__ __forceinline__ void wave_lds_sync()
 {
-    __shared__ PredLds L;
-    const McJob &jb = tab[blockIdx.z / 3];
-    int c = blockIdx.z % 3;
-    predict_block<MODE>(jb.mvs, jb.p, jb.ref.p[c], jb.pred.p[c], jb.res.p[c], blockIdx.x, blockIdx.y, c, L);
+    // one wavefront runs in lockstep: its LDS writes only have to land before the reads that follow
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void k_reconstruct_b(const McJob *__restrict__ tab)
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+    v = fold_xor<32>(v);
+    v = fold_xor<16>(v);
+    v = fold_xor<8>(v);
+    v = fold_xor<4>(v);
+    v = fold_xor<2>(v);
+    v = fold_xor<1>(v);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int i, int j, WaveLds &L)
+{
+    const int lane = threadIdx.x & 63;
+    const MCParams p = jb.p;
+    const DSV_MV mv = jb.mvs[i + j * p.nbh];
+    const int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
+    const uint32_t flags = mv.flags;
+    const bool intra = flags & (1u << DSV_MV_BIT_INTRA);
+    const bool skip = flags & (1u << DSV_MV_BIT_SKIP), eprm = flags & (1u << DSV_MV_BIT_EPRM);
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
+        const int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+        const DPlane rp = jb.ref.p[c], dp = jb.pred.p[c], sp = jb.res.p[c];
+        const int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
+        const int x = i * bw, y = j * bh;
+        int px = x + sar(mvx, 2 + sh), py = y + sar(mvy, 2 + sv);
+        const int sbw = bw >> 1, sbh = bh >> 1;
+        const bool subpel_luma = (c == 0) && !intra && ((mvx | mvy) & 3);
+        px = clampi(subpel_luma ? px - 1 : px, -kBorder, limx);
+        py = clampi(subpel_luma ? py - 1 : py, -kBorder, limy);
+        const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
+        const int ngroups = (bw * bh) >> 2, gw = bw >> 2; // groups of 4 pixels, gw per row
+        int dcq[4] = {0, 0, 0, 0};
+        if (intra) {
+            if (!(c == 0 && mv.dc)) { // quadrant means of the reference block (bmc.c:845-900)
+                int part[4] = {0, 0, 0, 0};
+                for (int g = lane; g < ngroups; g += 64) {
+                    int m = (g % gw) * 4, n = g / gw;
+                    uint32_t v = ((const U32u *) (rbase + (ptrdiff_t) n * rp.stride + m))->v;
+                    int s4 = (int) ((v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + (v >> 24));
+                    int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+                    if (sbw >= 4) { // the four pixels share a quadrant
+                        part[k] += s4;
+                    } else {        // 4-pixel-wide chroma block: two pixels per quadrant column
+                        part[k & 2] += (int) ((v & 0xff) + ((v >> 8) & 0xff));
+                        part[(k & 2) | 1] += (int) (((v >> 16) & 0xff) + (v >> 24));
+                    }
+                }
+                int q0 = wave_sum_i(part[0]), q1 = wave_sum_i(part[1]), q2 = wave_sum_i(part[2]), q3 = wave_sum_i(part[3]);
+                if (mv.submask == DSV_MASK_ALL_INTRA) {
+                    dcq[0] = dcq[1] = dcq[2] = dcq[3] = (q0 + q1 + q2 + q3) / (bw * bh); // bmc.c:857
+                } else {
+                    dcq[0] = q0 / (sbw * sbh); // bmc.c:884
+                    dcq[1] = q1 / (sbw * sbh);
+                    dcq[2] = q2 / (sbw * sbh);
+                    dcq[3] = q3 / (sbw * sbh);
+                }
+            } else {
+                dcq[0] = dcq[1] = dcq[2] = dcq[3] = mv.dc; // transmitted DC, luma only (bmc.c:854,881)
+            }
+        }
+        int fx = 0, fy = 0;
+        bool soft_x = false, soft_y = false;
+        int f0 = 0, f1 = 0, f2 = 0, f3 = 0, sf = 0, af = 0;
+        bool chroma_frac = false;
+        if (subpel_luma) {
+            bool large = abs(mvx) >= 8 || abs(mvy) >= 8; // bmc.c:674-679
+            fx = mvx & 3;
+            fy = mvy & 3;
+            soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
+            soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
+            const int ww = bw + 3, wh = bh + 3;
+            wave_lds_sync(); // the previous block's readers are done
+            for (int idx = lane; idx < ww * wh; idx += 64) {
+                int r = idx / ww, cc = idx % ww;
+                L.win[r * 36 + cc] = rbase[(ptrdiff_t) r * rp.stride + cc];
+            }
+            wave_lds_sync();
+            for (int idx = lane; idx < wh * bw; idx += 64) {
+                int r = idx / bw, m = idx % bw;
+                const uint8_t *q = &L.win[r * 36 + m];
+                int a = q[0], b = q[1], cc = q[2], d = q[3];
+                L.hz[r * 32 + m] = (int16_t) qp_blend(hp_tap(a, b, cc, d, soft_x), b, cc, fx);
+            }
+            wave_lds_sync();
+        } else if (c != 0 && !intra) {
+            int hb = 2 + sh, vb = 2 + sv, hf = 1 << hb, vf = 1 << vb; // bmc.c:778-798
+            int dx = mvx & (hf - 1), dy = mvy & (vf - 1);
+            chroma_frac = (dx | dy) != 0;
+            f0 = (hf - dx) * (vf - dy);
+            f1 = dx * (vf - dy);
+            f2 = (hf - dx) * dy;
+            f3 = dx * dy;
+            sf = hb + vb;
+            af = 1 << (sf - 1);
+        }
+        const bool noxmit = c == 0 ? (flags & (1u << DSV_MV_BIT_NOXMITY)) : (flags & (1u << DSV_MV_BIT_NOXMITC));
+        for (int g = lane; g < ngroups; g += 64) {
+            int m = (g % gw) * 4, n = g / gw;
+            const uint8_t *r = rbase + (ptrdiff_t) n * rp.stride + m;
+            int pv[4];
+            if (intra) {
+                uint32_t v = ((const U32u *) r)->v;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    int k = ((m + k4) >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+                    bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
+                    pv[k4] = fill ? (dcq[k] & 0xff) : (int) ((v >> (8 * k4)) & 0xff);
+                }
+            } else if (subpel_luma) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const int16_t *t = &L.hz[n * 32 + m + k4];
+                    pv[k4] = clamp_u8(qp_blend(hp_tap(t[0], t[32], t[64], t[96], soft_y), t[32], t[64], fy));
+                }
+            } else if (chroma_frac) {
+                const uint8_t *r2 = r + rp.stride;
+                int a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
+                int b0 = r2[0], b1 = r2[1], b2 = r2[2], b3 = r2[3], b4 = r2[4];
+                pv[0] = ((f0 * a0 + f1 * a1 + f2 * b0 + f3 * b1 + af) >> sf) & 0xff;
+                pv[1] = ((f0 * a1 + f1 * a2 + f2 * b1 + f3 * b2 + af) >> sf) & 0xff;
+                pv[2] = ((f0 * a2 + f1 * a3 + f2 * b2 + f3 * b3 + af) >> sf) & 0xff;
+                pv[3] = ((f0 * a3 + f1 * a4 + f2 * b3 + f3 * b4 + af) >> sf) & 0xff;
+            } else {
+                uint32_t v = ((const U32u *) r)->v;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    pv[k4] = (int) ((v >> (8 * k4)) & 0xff);
+                }
+            }
+            uint32_t *dpx = (uint32_t *) (dp.data + (ptrdiff_t) (y + n) * dp.stride + (x + m));
+            uint32_t *spx = (uint32_t *) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
+            uint32_t sv4 = *spx, out = 0;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++) {
+                int s1 = (int) ((sv4 >> (8 * k4)) & 0xff), o;
+                if (MODE == MC_SUBTRACT) { // residual_px (bmc.c:1015-1050)
+                    if (p.lossless) {
+                        o = (s1 - pv[k4] + 128) & 0xff;
+                    } else if (!intra && (skip || noxmit)) {
+                        o = 128;
+                    } else {
+                        o = eprm ? clamp_u8((s1 - pv[k4] + 256) >> 1) : clamp_u8(s1 - pv[k4] + 128);
+                    }
+                } else { // recon_px (bmc.c:953-983)
+                    bool plain = !eprm || (!intra && skip);
+                    o = p.lossless ? ((pv[k4] + s1 - 128) & 0xff) : (plain ? clamp_u8(pv[k4] + s1 - 128) : clamp_u8(pv[k4] + (s1 - 128) * 2));
+                }
+                out |= (uint32_t) o << (8 * k4);
+            }
+            if (MODE == MC_SUBTRACT) {
+                *dpx = (uint32_t) pv[0] | ((uint32_t) pv[1] << 8) | ((uint32_t) pv[2] << 16) | ((uint32_t) pv[3] << 24);
+                *spx = out;
+            } else {
+                *dpx = out;
+            }
+        }
+    }
+}
+
+template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab)
+{
+    __shared__ WaveLds L[4];
+    const McJob &jb = tab[blockIdx.z];
+    int w = threadIdx.x >> 6;
+    int i = (int) blockIdx.x * 4 + w, j = blockIdx.y;
+    if (i < jb.p.nbh) {
+        predict_block_wave<MODE>(jb, i, j, L[w]);
+    }
+}
+
+// res <- recon(pred, res) over the block grid of every plane: grid = (x groups, rows, 3 n), one dword per thread
+__global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__ tab)
 {
     const McJob &jb = tab[blockIdx.z / 3];
     const MCParams p = jb.p;
-    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z % 3;
+    int c = blockIdx.z % 3;
     int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
     int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
-    const DPlane dp = jb.pred.p[c], sp = jb.res.p[c];
-    uint32_t flags = jb.mvs[i + j * p.nbh].flags;
-    int x = i * bw, y = j * bh;
-    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
-        int m = idx % bw, n = idx / bw;
-        ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
-        sp.data[so] = recon_px(sp.data[so], dp.data[(ptrdiff_t) (y + n) * dp.stride + (x + m)], flags, p.lossless);
+    int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.nbh * bw || y >= p.nbv * bh) {
+        return;
     }
+    const DPlane dp = jb.pred.p[c], sp = jb.res.p[c];
+    uint32_t flags = jb.mvs[(x / bw) + (y / bh) * p.nbh].flags;
+    bool plain = !(flags & (1u << DSV_MV_BIT_EPRM)) || (!(flags & (1u << DSV_MV_BIT_INTRA)) && (flags & (1u << DSV_MV_BIT_SKIP)));
+    uint32_t *spx = (uint32_t *) (sp.data + (ptrdiff_t) y * sp.stride + x);
+    uint32_t rv4 = *spx, pv4 = *(const uint32_t *) (dp.data + (ptrdiff_t) y * dp.stride + x), out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int rv = (int) ((rv4 >> (8 * k)) & 0xff), pv = (int) ((pv4 >> (8 * k)) & 0xff);
+        int o = p.lossless ? ((pv + rv - 128) & 0xff) : (plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2));
+        out |= (uint32_t) o << (8 * k);
+    }
+    *spx = out;
 }
 
 // encoder-side reconstruction in place: res <- recon(pred, res)   (dsv_add_res, bmc.c:1082)
@@ -1153,14 +1348,14 @@ static unsigned ring_lds_bytes(int luma_h)
 void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
 {
     if (n > 0) {
-        DSV2_LAUNCH((k_predict_b<MC_SUBTRACT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH((k_predict_w<MC_SUBTRACT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_tab);
     }
 }
 
-void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_h)
+void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_h, int blk_w, int blk_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH(k_reconstruct_b, dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 4 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
             DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
         }
@@ -1171,7 +1366,7 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
 void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH((k_predict_b<MC_RECONSTRUCT>), dim3(nbh, nbv, 3 * n), dim3(256), 0, s, d_pred);
+        DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
             DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
         }

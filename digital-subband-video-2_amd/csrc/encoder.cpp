@@ -1493,7 +1493,7 @@ void enc_batch(Job *jobs, int n)
     prof.end(bs, ST_INV_SBT, n);
     prof.begin(bs, ST_RECON_FILTER);
     intra_filter_batch(bs, sc.d_mc + n, nI, dv0.h);
-    mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter, dv0.h);
+    mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter, dv0.h, dv0.blk_w, dv0.blk_h);
     prof.end(bs, ST_RECON_FILTER, nP + nI);
     prof.begin(bs, ST_EXTEND);
     extend_planes(bs, d_rext_y, n_rext, dv0.pics[0].recon.p[0].w, dv0.pics[0].recon.p[0].h);
