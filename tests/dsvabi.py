@@ -179,6 +179,14 @@ def load_ref():
 
 
 def load_hip():
+    # A process that also uses torch on the GPU must let torch bring up its (bundled) HIP runtime first: initialising
+    # it after this library has loaded the system one fails with "No HIP GPUs are available".
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return bind_codec_api(load(HIP_SO))
 
 

@@ -99,3 +99,46 @@ def test_dec_batch_444_lossless_and_single_call_agree():
     for s in range(2):
         check(want[s], got[s])
         check(want[s], single[s])
+
+
+def test_lossless_round_trip_1080p_through_both_batch_engines():
+    """Size-independent property at the full BASELINE picture size: lossless (-qp=100) batch encode followed by
+    batch decode returns the input pictures bit for bit (no reference needed)."""
+    import torch
+    from codec_run import configure_encoder
+    hip = A.load_hip()
+    bind(hip)
+    hip.dsv2hip_enc_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(A.BUF), C.POINTER(C.c_int)]
+    hip.dsv2hip_enc_batch.restype = C.c_int
+    pkg = load_pkg()
+    w, h, ns, nf = 1920, 1080, 2, 3
+    vids = [pkg.synth.SynthVideo(w, h, "420", seed=40 + s) for s in range(ns)]
+    frames = [[v.frame_bytes(t) for t in range(nf)] for v in vids]
+    meta = A.mk_meta(w, h, A.SUBSAMP_420)
+    encs = [A.ENCODER() for _ in range(ns)]
+    for e in encs:
+        configure_encoder(hip, e, meta, qp=100, gop=48)
+    encp = (C.POINTER(A.ENCODER) * ns)(*[C.pointer(e) for e in encs])
+    bufs = (A.BUF * (4 * ns))()
+    nbufs = (C.c_int * ns)()
+    streams = [[] for _ in range(ns)]
+    for t in range(nf):
+        dev = [torch.from_numpy(np.frombuffer(frames[s][t], dtype=np.uint8).copy()).cuda() for s in range(ns)]
+        torch.cuda.synchronize()
+        ptrs = (C.c_void_p * ns)(*[d.data_ptr() for d in dev])
+        assert hip.dsv2hip_enc_batch(ns, encp, ptrs, bufs, nbufs) == 0
+        for s in range(ns):
+            for i in range(nbufs[s]):
+                b = bufs[4 * s + i]
+                streams[s].append(bytes(C.string_at(b.data, b.len)))
+                hip.dsv_buf_free(C.byref(b))
+    for e in encs:
+        hip.dsv_enc_free(C.byref(e))
+    got = batch_decode(hip, streams)
+    for s in range(ns):
+        assert len(got[s]) == nf
+        for t, (fn, y, u, v) in enumerate(got[s]):
+            raw = np.frombuffer(frames[s][t], dtype=np.uint8)
+            assert np.array_equal(y.ravel(), raw[:w * h])
+            assert np.array_equal(u.ravel(), raw[w * h:w * h + w * h // 4])
+            assert np.array_equal(v.ravel(), raw[w * h + w * h // 4:])
