@@ -1054,6 +1054,7 @@ void phase_h1b(Job &jb)
         im->pkt.assign((size_t) upper, 0);
     }
     jb.bs = BitWriter{im->pkt.data(), 0};
+    jb.bs.wide = true; // the packet scratch is sized for the worst case, far beyond any write
     BitWriter &bs = jb.bs;
     put_packet_hdr(bs, DSV_PT_PIC | (p->is_ref << 1) | p->has_ref);
     bs.align();
@@ -1147,6 +1148,7 @@ void phase_h2(Job &jb)
 
 struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, printed every 16 steps
     bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+    int every = on && atoi(getenv("DSV2_BATCH_TRACE")) == 2 ? 1 : 16; // =2: print every step
     double acc[10] = {0};
     int steps = 0;
     std::chrono::steady_clock::time_point t0;
@@ -1160,9 +1162,9 @@ struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, 
     }
     void done(int n)
     {
-        if (!on || ++steps % 16) return;
+        if (!on || ++steps % every) return;
         fprintf(stderr, "[batch n=%d] ms/step: p0 %.2f | g1 enqueue %.2f wait %.2f | h1 %.2f | g2 enqueue %.2f wait %.2f | syms %.2f | h2 %.2f\n", n,
-                acc[0] / 16, acc[1] / 16, acc[2] / 16, acc[3] / 16, acc[4] / 16, acc[5] / 16, acc[6] / 16, acc[7] / 16);
+                acc[0] / every, acc[1] / every, acc[2] / every, acc[3] / every, acc[4] / every, acc[5] / every, acc[6] / every, acc[7] / every);
         for (double &a : acc) a = 0;
     }
 };
@@ -1437,7 +1439,7 @@ void enc_batch(Job *jobs, int n)
         }
         h_comp[i] = dv.comp.job(dv.qv, dv.qv_off[3]);
         h_comp[i].total = sc.d_totals + i;
-        dv.ensure_host_syms(dv.qv_off[3] / 8); // usual symbol counts fit; a larger frame falls back to a copy
+        dv.ensure_host_syms(dv.qv_off[3] / 8); // P pictures fit; the first intra picture grows it (one fallback copy)
         h_comp[i].host_pos = dv.h_pos;
         h_comp[i].host_val = dv.h_val;
         h_comp[i].host_cap = (int) dv.h_sym_cap;
@@ -1512,6 +1514,9 @@ void enc_batch(Job *jobs, int n)
             dv.h_ll[c] = sc.h_ll[3 * ti + c];
         }
         if ((size_t) jb.nsym > dv.h_sym_cap) { // rare: more symbols than the pinned mirror held
+            if (getenv("DSV2_BATCH_TRACE")) {
+                fprintf(stderr, "[batch] stream %d: %d symbols > pinned mirror of %zu, copying\n", k, jb.nsym, dv.h_sym_cap);
+            }
             dv.ensure_host_syms((size_t) jb.nsym);
             HIPCHK(hipMemcpyAsync(dv.h_pos, dv.comp.d_pos, (size_t) jb.nsym * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
             HIPCHK(hipMemcpyAsync(dv.h_val, dv.comp.d_val, (size_t) jb.nsym * sizeof(int32_t), hipMemcpyDeviceToHost, bs));

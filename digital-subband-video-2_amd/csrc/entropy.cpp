@@ -12,6 +12,16 @@ namespace dsv2 {
 
 void BitWriter::put_bits(unsigned n, unsigned v)
 {
+    if (wide) { // n <= 32: OR the field into the big-endian 64-bit window that starts at the current byte
+        unsigned sh = pos & 7;
+        uint64_t x = (uint64_t) (n < 32 ? v & ((1u << n) - 1) : v) << (64 - n - sh);
+        uint64_t cur;
+        memcpy(&cur, start + (pos >> 3), 8);
+        cur |= __builtin_bswap64(x);
+        memcpy(start + (pos >> 3), &cur, 8);
+        pos += n;
+        return;
+    }
     while (n > 0) {
         unsigned room = 8 - (pos & 7);
         unsigned take = n < room ? n : room;
@@ -22,15 +32,30 @@ void BitWriter::put_bits(unsigned n, unsigned v)
     }
 }
 
+// bit i of a 16-bit value moves to bit 2i
+static inline unsigned spread16(unsigned x)
+{
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// interleaved exp-Golomb (bs.c:132): for each bit of v+1 below its leading one a 0 followed by that bit, then a 1.
+// The pairs are built with a bit spread and written with one or two put_bits calls instead of bit by bit.
 void BitWriter::put_ueg(unsigned v)
 {
     v++;
     int nb = 31 - __builtin_clz(v);
-    for (int i = nb - 1; i >= 0; i--) {
-        pos++; // a zero bit
-        put_bit((v >> i) & 1);
+    unsigned low = v & ((1u << nb) - 1);
+    if (nb <= 15) {
+        put_bits((unsigned) (2 * nb + 1), (spread16(low) << 1) | 1u);
+        return;
     }
-    put_bit(1);
+    int hi = nb - 15; // the upper `hi` pairs first, then the lower 15 pairs and the terminator
+    put_bits((unsigned) (2 * hi), spread16(low >> 15));
+    put_bits(31, (spread16(low & 0x7fffu) << 1) | 1u);
 }
 
 void BitWriter::put_seg(int v)
@@ -63,10 +88,7 @@ void BitWriter::put_nrice(int v, int *rk, int damp)
         (*rk)--;
     }
     pos += qq; // qq zero bits
-    put_bit(1);
-    if (k) {
-        put_bits(k, u & ((1u << k) - 1));
-    }
+    put_bits(k + 1, (1u << k) | (u & ((1u << k) - 1))); // the terminating 1 and the k remainder bits
 }
 
 void BitWriter::concat(const uint8_t *data, int len)

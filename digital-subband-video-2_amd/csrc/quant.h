@@ -78,6 +78,7 @@ void dequant_jobs(hipStream_t s, const DequantJob *d_jobs, int n, const int max_
 struct BitWriter { // MSB-first, buffer must be zero-filled (bs.c:143)
     uint8_t *start;
     unsigned pos;
+    bool wide = false; // the buffer has >= 8 bytes of slack behind every write: put_bits may use 64-bit stores
     void align() { pos = (pos + 7) & ~7u; }
     unsigned byte_pos() const { return pos >> 3; }
     void put_bit(int v)
