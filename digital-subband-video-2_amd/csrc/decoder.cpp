@@ -117,6 +117,7 @@ BitReader take_sub(BitReader &br, const uint8_t *base)
     unsigned len = br.get_ueg();
     br.align();
     BitReader sub{base + br.byte_pos(), 0};
+    sub.wide = br.wide;
     br.pos += len * 8;
     return sub;
 }
@@ -280,7 +281,13 @@ void dec_parse(DecJob &jb)
     DSV_DECODER *d = jb.d;
     DSV_BUF *buffer = jb.buf;
     *jb.fn = (DSV_FNUM) -1;
-    BitReader br{buffer->data, 0};
+    // parse from a private copy with zeroed slack behind it, so that codes can be read through a 64-bit window
+    static thread_local std::vector<uint8_t> copy;
+    copy.assign(buffer->data, buffer->data + buffer->len);
+    copy.resize((size_t) buffer->len + 16, 0);
+    const uint8_t *pkt = copy.data();
+    BitReader br{pkt, 0};
+    br.wide = true;
     int type = read_packet_hdr(br);
     if (type == -1) {
         jb.ret = DSV_DEC_ERROR;
@@ -354,12 +361,12 @@ void dec_parse(DecJob &jb)
     br.align();
 
     im->blockdata.assign(nb, 0);
-    read_stability(im, br, buffer->data, jb.has_ref, stats);
+    read_stability(im, br, pkt, jb.has_ref, stats);
     if (jb.has_ref) {
         im->mvs.assign(nb, DSV_MV{});
-        read_motion(im, br, buffer->data, stats);
+        read_motion(im, br, pkt, stats);
     } else {
-        read_intra_meta(im, br, buffer->data, stats);
+        read_intra_meta(im, br, pkt, stats);
     }
     br.align();
 

@@ -99,8 +99,24 @@ void BitWriter::concat(const uint8_t *data, int len)
     }
 }
 
+// bit 2i of a 32-bit value moves to bit i (inverse of spread16)
+static inline unsigned compress16(unsigned x)
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+
 unsigned BitReader::get_bits(unsigned n)
 {
+    if (wide && n <= 32) {
+        unsigned out = n ? (unsigned) (window() >> (64 - n)) : 0u;
+        pos += n;
+        return out;
+    }
     unsigned out = 0;
     while (n > 0) {
         unsigned room = 8 - (pos & 7);
@@ -115,6 +131,20 @@ unsigned BitReader::get_bits(unsigned n)
 
 unsigned BitReader::get_ueg()
 {
+    if (wide) {
+        // pairs (0, b) ... closed by a 1 in a pair-start position: find that 1 among the even offsets
+        uint64_t w = window();
+        uint64_t starts = w & 0xaaaaaaaaaaaaaa00ull; // pair starts within the 56 bits that are certainly valid
+        if (starts) {
+            int lz = __builtin_clzll(starts); // = 2 * nb
+            int nb = lz >> 1;
+            if (nb <= 16) {
+                unsigned low = nb ? compress16((unsigned) (w >> (64 - lz))) : 0u; // value bits sit at the odd offsets
+                pos += (unsigned) lz + 1;
+                return ((1u << nb) | low) - 1;
+            }
+        }
+    }
     unsigned v = 1;
     while (!get_bit()) {
         v = (v << 1) | get_bit();
@@ -144,9 +174,18 @@ int BitReader::get_nrice(int *rk, int damp)
 {
     int k = *rk >> damp;
     unsigned qq = 0;
+    if (wide) {
+        uint64_t w = window() & 0xffffffffffffff00ull;
+        if (w) { // the unary part ends inside the window
+            qq = (unsigned) __builtin_clzll(w);
+            pos += qq + 1;
+            goto have_q;
+        }
+    }
     while (!get_bit()) {
         qq++;
     }
+have_q:
     if (qq) {
         (*rk)++;
     } else if (*rk > 0) {
@@ -245,8 +284,8 @@ int entropy_decode_plane(BitReader &br, int32_t *LL, uint32_t *pos, int32_t *val
     uint32_t cur = 0;
     uint32_t total = (uint32_t) g.base[10];
     bool truncated = false;
+    uint32_t run = runs > 0 ? br.get_ueg() : 0; // every run is parsed once: the look-ahead below becomes the next run
     while (runs-- > 0) {
-        uint32_t run = br.get_ueg();
         uint64_t p = (uint64_t) cur + run;
         if (p >= total) {
             break; // the run walks off the plane: nothing further is placed (hzcc.c:481-581 with run never reaching 0)
@@ -259,9 +298,8 @@ int entropy_decode_plane(BitReader &br, int32_t *LL, uint32_t *pos, int32_t *val
         // the reference reads the next run before its overrun check (hzcc.c:525-529), so a symbol whose
         // successor's run crosses the plane-length limit is dropped together with everything after it
         if (runs > 0) {
-            BitReader peek = br;
-            peek.get_ueg();
-            if (peek.byte_pos() >= limit) {
+            run = br.get_ueg();
+            if (br.byte_pos() >= limit) {
                 truncated = true;
             }
         } else if (br.byte_pos() >= limit) {

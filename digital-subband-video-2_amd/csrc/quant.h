@@ -99,6 +99,14 @@ struct BitWriter { // MSB-first, buffer must be zero-filled (bs.c:143)
 struct BitReader {
     const uint8_t *start;
     unsigned pos;
+    bool wide = false; // >= 8 readable bytes behind every position that is read: codes are parsed from a 64-bit window
+    // the next 57+ bits, left-aligned (wide mode only)
+    uint64_t window() const
+    {
+        uint64_t w;
+        __builtin_memcpy(&w, start + (pos >> 3), 8);
+        return __builtin_bswap64(w) << (pos & 7);
+    }
     void align() { pos = (pos + 7) & ~7u; }
     unsigned byte_pos() const { return pos >> 3; }
     unsigned get_bit()
