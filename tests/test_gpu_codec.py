@@ -61,3 +61,38 @@ def test_encode_decode_bit_exact(name, w, h, subsamp, n, cfg):
             src = np.frombuffer(frames[t], dtype=np.uint8)
             assert np.array_equal(y.ravel(), src[:w * h]), "lossless luma frame %d" % t
             assert np.array_equal(u.ravel(), src[w * h:w * h + cw * ch])
+
+
+def test_frame_callback_sees_reference_pictures():
+    """DSV_ENCODER.frame_callback(meta, orig, recon) (dsv_encoder.h:170, called at dsv_encoder.c:1299): same
+    source and reconstructed pictures as the reference hands out, frame by frame."""
+    import ctypes as C
+    ref, hip = A.load_ref(), A.load_hip()
+    w, h = 352, 288
+    frames = synth_frames(w, h, A.SUBSAMP_420, 5, seed=9)
+    CB = C.CFUNCTYPE(None, C.POINTER(A.META), C.POINTER(A.FRAME), C.POINTER(A.FRAME))
+
+    def run(lib):
+        seen = []
+
+        def cb(meta, orig, recon):
+            rec = []
+            for fp in (orig, recon):
+                f = fp.contents
+                for c in range(3):
+                    p = f.planes[c]
+                    a = np.ctypeslib.as_array(p.data, shape=(p.h * p.stride,))
+                    rec.append(a.reshape(-1, p.stride)[:p.h, :p.w].copy())
+            seen.append(rec)
+
+        keep = CB(cb)
+        pk, _ = encode_stream(lib, frames, w, h, A.SUBSAMP_420, qp=60, gop=3, frame_callback=C.cast(keep, C.c_void_p))
+        return pk, seen
+
+    pk_r, seen_r = run(ref)
+    pk_h, seen_h = run(hip)
+    assert pk_r == pk_h
+    assert len(seen_r) == len(seen_h) == len(frames)
+    for a, b in zip(seen_r, seen_h):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
