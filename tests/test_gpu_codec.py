@@ -96,3 +96,77 @@ def test_frame_callback_sees_reference_pictures():
     for a, b in zip(seen_r, seen_h):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+OPTION_CASES = [
+    dict(do_psy=0),
+    dict(do_psy=0x0f),
+    dict(do_scd=0),
+    dict(do_inter_filter=0),
+    dict(do_inter_filter=1, do_intra_filter=0),
+    dict(skip_block_thresh=-1),
+    dict(skip_block_thresh=8),
+    dict(block_size_override_x=1, block_size_override_y=1),   # 32x32 blocks on a small picture
+    dict(variable_i_interval=1, gop=4),
+    dict(do_temporal_aq=0, do_dark_intra_boost=0),
+    dict(pyramid_levels=3),
+    dict(scene_change_pct=20, intra_pct_thresh=30),
+]
+
+
+@pytest.mark.parametrize("opts", OPTION_CASES, ids=[",".join("%s=%s" % kv for kv in o.items()) for o in OPTION_CASES])
+def test_encoder_option_matrix(opts):
+    """Public DSV_ENCODER switches (dsv_encoder.h:68-188) away from their defaults: same packets as the reference."""
+    ref, hip = A.load_ref(), A.load_hip()
+    w, h = 352, 288
+    frames = synth_frames(w, h, A.SUBSAMP_420, 6, seed=31)
+    # a scene cut in the middle so that the scene-change / intra-refresh switches matter
+    frames[4] = bytes(255 - b for b in frames[4])
+    cfg = dict(qp=55, gop=12)
+    cfg.update(opts)
+    pk_r, st_r = encode_stream(ref, frames, w, h, A.SUBSAMP_420, **cfg)
+    pk_h, st_h = encode_stream(hip, frames, w, h, A.SUBSAMP_420, **cfg)
+    assert pk_r == pk_h
+    assert st_r == st_h
+
+
+@pytest.mark.parametrize("sharpen,fps", [(0, (30, 1)), (1, (25, 1)), (1, (60000, 1001))])
+def test_metadata_variants_and_forced_metadata(sharpen, fps):
+    """Stream metadata other than the defaults (no inter sharpening, other frame rates -> other refresh interval),
+    dsv_enc_force_metadata() mid-stream, and dsv_get_metadata() on the decoder side."""
+    import ctypes as C
+    ref, hip = A.load_ref(), A.load_hip()
+    w, h = 352, 288
+    frames = synth_frames(w, h, A.SUBSAMP_420, 5, seed=17)
+
+    def run(lib):
+        meta = A.mk_meta(w, h, A.SUBSAMP_420, fps=fps, inter_sharpen=sharpen)
+        enc = A.ENCODER()
+        from codec_run import configure_encoder
+        configure_encoder(lib, enc, meta, qp=60, gop=-1)
+        packets, bufs, keep = [], (A.BUF * 4)(), []
+        for t, fb in enumerate(frames):
+            if t == 3:
+                lib.dsv_enc_force_metadata(C.byref(enc))
+            arr = np.frombuffer(fb, dtype=np.uint8).copy()
+            keep.append(arr)
+            fr = lib.dsv_load_planar_frame(A.SUBSAMP_420, arr.ctypes.data, w, h)
+            n = lib.dsv_enc(C.byref(enc), fr, bufs)
+            for i in range(n):
+                packets.append(bytes(C.string_at(bufs[i].data, bufs[i].len)))
+                lib.dsv_buf_free(C.byref(bufs[i]))
+        lib.dsv_enc_free(C.byref(enc))
+        return packets
+
+    pk_r, pk_h = run(ref), run(hip)
+    assert pk_r == pk_h
+    # decoder side: metadata as parsed
+    dec = A.DECODER()
+    buf = A.BUF()
+    hip.dsv_mk_buf(C.byref(buf), len(pk_h[0]) + 64)
+    C.memmove(buf.data, pk_h[0], len(pk_h[0]))
+    fp, fn = C.POINTER(A.FRAME)(), C.c_uint32(0)
+    assert hip.dsv_dec(C.byref(dec), C.byref(buf), C.byref(fp), C.byref(fn)) == A.DEC_GOT_META
+    m = hip.dsv_get_metadata(C.byref(dec)).contents
+    assert (m.width, m.height, m.subsamp, m.fps_num, m.fps_den, m.inter_sharpen) == (w, h, A.SUBSAMP_420, fps[0], fps[1], sharpen)
+    hip.dsv_dec_free(C.byref(dec))
