@@ -36,6 +36,89 @@ struct HmeDev {
     int *host_counters; // optional pinned host copy of counters[0..7]
 };
 
+// What the blocks of ONE level need, copied out of the job table once per row as wave-uniform scalars: the table
+// sits in global memory, and after every hand-off fence its fields would otherwise be reloaded (vector loads, in
+// front of each block).  Same member names as HmeDev; src[] / ref[] / ogr[] answer for this level and for
+// level 0, mvf[] for this level and its parent; the chroma planes are picked by select, not by indexing.
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    unsigned long long v = (unsigned long long) p;
+    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    return (T *) (((unsigned long long) hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ DPlane uni(const DPlane &p) { return DPlane{uni_ptr(p.data), uni(p.stride), uni(p.w), uni(p.h)}; }
+
+struct HmeCtx {
+    struct Planes {
+        DPlane lvl, zero;
+        __device__ __forceinline__ DPlane operator[](int l) const
+        {
+            bool z = l == 0; // by value, field by field: a reference to either member would force the struct into memory
+            return DPlane{z ? zero.data : lvl.data, z ? zero.stride : lvl.stride, z ? zero.w : lvl.w, z ? zero.h : lvl.h};
+        }
+    };
+    struct Pair { // two planes, selected per lane
+        DPlane p0, p1;
+        __device__ __forceinline__ DPlane operator[](int k) const
+        {
+            return DPlane{k ? p1.data : p0.data, k ? p1.stride : p0.stride, k ? p1.w : p0.w, k ? p1.h : p0.h};
+        }
+    };
+    struct Fields {
+        DSV_MV *cur, *parent;
+        int level;
+        __device__ __forceinline__ DSV_MV *operator[](int l) const { return l == level ? cur : parent; }
+    };
+    AnalysisParams a;
+    int effort, lossless, quant, skip_block_thresh, pyr_levels, psyscale;
+    Planes src, ref, ogr;
+    Pair srcc, refc;
+    Fields mvf;
+    const DSV_MV *ref_mvf;
+    int *counters;
+    DSV_MV *host_mvs;
+};
+
+__device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
+{
+    HmeCtx c;
+    c.a.width = uni(d.a.width);
+    c.a.height = uni(d.a.height);
+    c.a.blk_w = uni(d.a.blk_w);
+    c.a.blk_h = uni(d.a.blk_h);
+    c.a.nbh = uni(d.a.nbh);
+    c.a.nbv = uni(d.a.nbv);
+    c.a.hshift = uni(d.a.hshift);
+    c.a.vshift = uni(d.a.vshift);
+    c.a.do_psy = uni(d.a.do_psy);
+    c.a.scale = uni(d.a.scale);
+    c.effort = uni(d.effort);
+    c.lossless = uni(d.lossless);
+    c.quant = uni(d.quant);
+    c.skip_block_thresh = uni(d.skip_block_thresh);
+    c.pyr_levels = uni(d.pyr_levels);
+    c.psyscale = uni(d.psyscale);
+    c.src.lvl = uni(d.src[level]);
+    c.ref.lvl = uni(d.ref[level]);
+    c.ogr.lvl = uni(d.ogr[level]);
+    c.src.zero = uni(d.src[0]);
+    c.ref.zero = uni(d.ref[0]);
+    c.ogr.zero = uni(d.ogr[0]);
+    c.srcc.p0 = uni(d.srcc[0]);
+    c.srcc.p1 = uni(d.srcc[1]);
+    c.refc.p0 = uni(d.refc[0]);
+    c.refc.p1 = uni(d.refc[1]);
+    c.mvf.cur = uni_ptr(d.mvf[level]);
+    c.mvf.parent = level < d.pyr_levels ? uni_ptr(d.mvf[level + 1]) : nullptr;
+    c.mvf.level = level;
+    c.ref_mvf = uni_ptr(d.ref_mvf);
+    c.counters = uni_ptr(d.counters);
+    c.host_mvs = uni_ptr(d.host_mvs);
+    return c;
+}
+
 struct Psy {
     int err_weight, tex_weight, avg_weight;
 };
@@ -154,7 +237,7 @@ __device__ __forceinline__ void st_mv(DSV_MV *out, const DSV_MV &mv)
 }
 
 // level-0 result: device field + (when asked for) the host's pinned copy, so no read-back copy is needed
-__device__ __forceinline__ void st_mv_final(const HmeDev &c, DSV_MV *out, const DSV_MV &mv)
+template <class Ctx> __device__ __forceinline__ void st_mv_final(const Ctx &c, DSV_MV *out, const DSV_MV &mv)
 {
     st_mv(out, mv);
     if (c.host_mvs) {
@@ -1105,9 +1188,10 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
 template <bool FAST_ONLY>
 __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int nbx, int nby, int allow_fast, FastLds &S)
 {
-    int gx = c.counters[4], gy = c.counters[5];
-    unsigned *progress = (unsigned *) c.counters + kHmeProgress;
+    int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
+    unsigned *progress = (unsigned *) uni_ptr(c.counters) + kHmeProgress;
     int j = bj << level;
+    const HmeCtx x = make_ctx(c, level);
     for (int bi = 0; bi < nbx; bi++) {
         if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
             return;
@@ -1119,7 +1203,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
         if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast(c, level, i, j, gx, gy, S);
+            hme_block_fast(x, level, i, j, gx, gy, S);
         } else {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
         }

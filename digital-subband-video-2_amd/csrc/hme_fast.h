@@ -326,7 +326,8 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
 }
 
 // sub-pel search around full-pel vector (fpelx, fpely): hme.c:1051
-__device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
+template <class Ctx>
+__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
                                      int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy)
 {
     const DPlane &src = c.src[0], &ref = c.ref[0];
@@ -421,7 +422,8 @@ __device__ unsigned subpixel_me_fast(const HmeDev &c, FastLds &S, const CostCtx 
 }
 
 // level-0 tail of hme_block_fast: sub-pel refinement + mode decision (hme.c:1598-1821)
-__device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
+template <class Ctx>
+__device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
                                   unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy)
 {
@@ -788,8 +790,8 @@ __device__ void hme_block_fast_l0(const HmeDev &c, int i, int j, FastLds &S, DSV
 }
 
 // FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away
-template <bool FULL>
-__device__ __forceinline__ void hme_block_fast_t(const HmeDev &c, int level, int i, int j, int gx, int gy, FastLds &S)
+template <bool FULL, class Ctx>
+__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S)
 {
     const int rectx[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1};
     const int recty[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};
@@ -852,7 +854,7 @@ __device__ __forceinline__ void hme_block_fast_t(const HmeDev &c, int level, int
     bool exist = lane == 0;
     int cxv = 0, cyv = 0;
     if (parent != nullptr) {
-        const int ptx[9] = {0, -2, 2, 0, 0, -2, 2, 2, -2}, pty[9] = {0, 0, 0, -2, 2, -2, 2, -2, 2};
+        static constexpr int ptx[9] = {0, -2, 2, 0, 0, -2, 2, 2, -2}, pty[9] = {0, 0, 0, -2, 2, -2, 2, -2, 2};
         unsigned parent_mask = ~(((unsigned) step << 1) - 1);
         int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
         bool pvalid = false;
@@ -1093,7 +1095,8 @@ __device__ __forceinline__ void hme_block_fast_t(const HmeDev &c, int level, int
                       avg_src, psy);
 }
 
-__device__ void hme_block_fast(const HmeDev &c, int level, int i, int j, int gx, int gy, FastLds &S)
+template <class Ctx>
+__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S)
 {
     const DPlane &src = c.src[level];
     int bx = (i * 16) >> level, by = (j * 16) >> level;
