@@ -400,6 +400,21 @@ __device__ void build_hpel(SubpelLds &s, const uint8_t *r, int rs)
     __syncthreads();
 }
 
+// the same with the sub-sample phase given as a wave-uniform value (bit 0: X odd, bit 1: Y odd): one scalar branch
+// instead of four masked paths
+__device__ __forceinline__ int qsample_ph(const uint8_t *h, int X, int Y, int phase)
+{
+    const uint8_t *p = h + (Y >> 1) * 34 + (X >> 1);
+    if (phase == 0) {
+        return p[0];
+    } else if (phase == 1) {
+        return AVG2(p[0], p[1]);
+    } else if (phase == 2) {
+        return AVG2(p[0], p[34]);
+    }
+    return (p[0] + p[1] + p[34] + p[35] + 2) >> 2;
+}
+
 __device__ __forceinline__ int qsample(const uint8_t *h, int X, int Y) // hme.c:815
 {
     const uint8_t *p = h + (Y >> 1) * 34 + (X >> 1);
