@@ -1207,10 +1207,20 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
     unsigned *progress = (unsigned *) uni_ptr(c.counters) + kHmeProgress;
     int j = bj << level;
     const HmeCtx x = make_ctx(c, level);
+#ifdef DSV2_HME_PROF
+    if ((threadIdx.x & 63) == 0) {
+        S.prof_on = level == 0;
+        for (int k = 0; k < 10; k++) {
+            S.prof_acc[k] = 0;
+        }
+        S.prof_t = __builtin_amdgcn_s_memtime();
+    }
+#endif
     for (int bi = 0; bi < nbx; bi++) {
         if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
             return;
         }
+        HME_MARK(S, 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // no neighbour load may move above the poll
         if (allow_fast & 2) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1230,7 +1240,15 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         if ((threadIdx.x & 63) == 0) {
             __hip_atomic_store(&progress[bj], (unsigned) bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        HME_MARK(S, 9);
     }
+#ifdef DSV2_HME_PROF
+    if ((threadIdx.x & 63) == 0 && S.prof_on) {
+        for (int k = 0; k < 10; k++) {
+            atomicAdd(&g_hme_prof[k], S.prof_acc[k]);
+        }
+    }
+#endif
     // arrival of this row; its vectors and counter updates were drained above
     int done = 0;
     if ((threadIdx.x & 63) == 0) {
@@ -1527,3 +1545,12 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
 }
 
 } // namespace dsv2
+
+#ifdef DSV2_HME_PROF
+// debugging build only: cumulative phase clocks of the level-0 search (see HME_MARK)
+extern "C" void dsv2hip_debug_hme_prof(unsigned long long out[16])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dsv2::g_hme_prof), 16 * sizeof(unsigned long long)));
+}
+#endif

@@ -175,7 +175,29 @@ struct FastLds {
     int hist[16];
     int cx[64], cy[64];
     SubpelLds sp;
+#ifdef DSV2_HME_PROF
+    unsigned long long prof_t, prof_acc[10];
+    int prof_on;
+#endif
 };
+
+// phase clock of a debugging build (-DDSV2_HME_PROF): shader-clock ticks per phase of the level-0 search,
+// summed over all wavefronts into g_hme_prof[]
+#ifdef DSV2_HME_PROF
+__device__ unsigned long long g_hme_prof[16];
+#define HME_MARK(S, k)                                                                                                \
+    do {                                                                                                              \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                        \
+        if ((threadIdx.x & 63) == 0 && (S).prof_on) {                                                                 \
+            (S).prof_acc[k] += t_ - (S).prof_t;                                                                       \
+            (S).prof_t = t_;                                                                                          \
+        }                                                                                                             \
+    } while (0)
+#else
+#define HME_MARK(S, k)                                                                                                \
+    do {                                                                                                              \
+    } while (0)
+#endif
 
 // sums needed by block_detail (hme.c:546) from a register-resident block: pixel sum and the
 // horizontal / vertical first-difference sums; partials only, the caller reduces them
@@ -460,6 +482,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
         ratio = (best << 5) / (best_fp + !best_fp);
     }
 
+    HME_MARK(S, 5);
     // ---- operands of the mode decision, one load round ----
     const int cbx = i * 8, cby = j * 8;                     // 4:2:0, 16x16 blocks
     const int cbmx = cbx + sarx(fpelx, 1), cbmy = cby + sarx(fpely, 1);
@@ -642,6 +665,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
                 mv.flags |= 1u << DSV_MV_BIT_SIMCMPLX;
             }
         }
+        HME_MARK(S, 6);
         // ---- test_subblock_intra_y (hme.c:891), all four sub-blocks evaluated together ----
         {
             const DSV_MV *refmv = c.ref_mvf ? &c.ref_mvf[i + j * nxb] : nullptr;
@@ -716,6 +740,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
                 }
             }
         }
+        HME_MARK(S, 7);
         // ---- test_subblock_intra_c (hme.c:987) ----
         if (c.effort >= 6) {
             unsigned detail_c = (unsigned) div_nn(ipolvar, bw * bh);
@@ -774,6 +799,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     if (mv.flags & ((1u << DSV_MV_BIT_INTRA) | (1u << DSV_MV_BIT_EPRM))) {
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
+    HME_MARK(S, 8);
     if (lane == 0) {
         st_mv_final(c, out, mv);
         if (is_intra) {
@@ -813,6 +839,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     const bool act = FULL ? true : (qi < qw && qj < qh);
     const uint8_t *sblk = at(src, bx, by);
     const Quad a = ldq(sblk, src.stride, qi, qj, act);
+    const Quad o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act); // for the "good enough" test far below: same load round
 
     int motion_bias = y_w * y_h;
     unsigned var_src = 0, avg_src = 0;
@@ -849,31 +876,71 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         }
     }
 
+    HME_MARK(S, 1);
     // ---- candidate gathering: lane p owns canonical list position p (hme.c:1443-1528) ----
     //  0 zero | 1 parent inlier average | 2 predictor (level 0) | 3 left 4 top 5 top-left |
     //  6..14 temporal | 15 global | 16..24 parent inliers
     int lax = 0, lay = 0;
     bool exist = lane == 0;
     int cxv = 0, cyv = 0;
-    if (parent != nullptr) {
-        static constexpr int ptx[9] = {0, -2, 2, 0, 0, -2, 2, 2, -2}, pty[9] = {0, 0, 0, -2, 2, -2, 2, -2, 2};
-        unsigned parent_mask = ~(((unsigned) step << 1) - 1);
-        int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
-        bool pvalid = false;
-        int pvx = 0, pvy = 0;
-        if (lane >= 16 && lane < 25) {
-            int m = lane - 16;
-            int x = pi + ptx[m] * step, y = pj + pty[m] * step;
-            if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
-                const DSV_MV *pm = &parent[x + y * nxb];
-                pvx = pm->u.mv.x;
-                pvy = pm->u.mv.y;
-                pvalid = true;
+    // ONE load round for every vector the list and the cost predictor read: lanes 3..5 fetch the same-level
+    // neighbours (left, top, top-left; coherent loads, the row above may be on another XCD), lanes 6..14 the
+    // co-located vectors of the previous frame, lanes 16..24 the parent level's.  Lanes without a vector
+    // load this block's own entry and ignore it.
+    bool nb_ok = false, pvalid = false, tvalid = false;
+    MvHead nbv;
+    int pvx = 0, pvy = 0;
+    {
+        const bool need_i = lane != 4, need_j = lane != 3;
+        nb_ok = lane >= 3 && lane <= 5 && (!need_i || i > 0) && (!need_j || j > 0);
+        const DSV_MV *np = nb_ok ? &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb] : out;
+        const DSV_MV *op = out;
+        if (parent != nullptr) {
+            static constexpr int ptx[9] = {0, -2, 2, 0, 0, -2, 2, 2, -2}, pty[9] = {0, 0, 0, -2, 2, -2, 2, -2, 2};
+            unsigned parent_mask = ~(((unsigned) step << 1) - 1);
+            int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
+            if (lane >= 16 && lane < 25) {
+                int m = lane - 16;
+                int x = pi + ptx[m] * step, y = pj + pty[m] * step;
+                if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
+                    op = &parent[x + y * nxb];
+                    pvalid = true;
+                }
+            } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
+                int k = lane - 6;
+                int rx = i + rectx[k] * step, ry = j + recty[k] * step;
+                if (rx >= 0 && ry >= 0 && rx < nxb && ry < nyb) {
+                    op = &c.ref_mvf[rx + ry * nxb];
+                    tvalid = true;
+                }
             }
+        }
+        nbv = ld_mv_head(np);
+        uint32_t ov = *(const uint32_t *) op;
+        pvx = (int) (int16_t) (ov & 0xffffu);
+        pvy = (int) (int16_t) (ov >> 16);
+    }
+    // dsv_movec_pred (dsv.c:375) of this block: at level 0 its operands are the three neighbours just loaded;
+    // at the coarser levels it reads entries between the level's grid points, which are never written (zero)
+    CostCtx cc;
+    cc.px = cc.py = 0;
+    if (level == 0) {
+        int v0 = __builtin_amdgcn_readlane((int) nbv.all, 3), v1 = __builtin_amdgcn_readlane((int) nbv.all, 4),
+            v2 = __builtin_amdgcn_readlane((int) nbv.all, 5);
+        v0 = i > 0 ? v0 : 0;
+        v1 = j > 0 ? v1 : 0;
+        v2 = i > 0 && j > 0 ? v2 : 0;
+        cc.px = pred1((int) (int16_t) (v0 & 0xffff), (int) (int16_t) (v1 & 0xffff), (int) (int16_t) (v2 & 0xffff));
+        cc.py = pred1(v0 >> 16, v1 >> 16, v2 >> 16);
+    }
+    if (parent != nullptr) {
+        if (!pvalid) {
+            pvx = tvalid ? pvx : 0;
+            pvy = tvalid ? pvy : 0;
         }
         int npar = __popcll(__ballot(pvalid));
         if (npar) {
-            int v2[2] = {pvx, pvy};
+            int v2[2] = {pvalid ? pvx : 0, pvalid ? pvy : 0};
             int r = reduceN<2>(v2);
             lax = bcastN<2>(r, 0) / npar;
             lay = bcastN<2>(r, 1) / npar;
@@ -896,28 +963,17 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
                 cxv = qp2fp((int16_t) (lax * 4));
                 cyv = qp2fp((int16_t) (lay * 4));
             } else if (lane == 2 && level == 0) {
-                int px, py;
-                movec_pred(mvf, nxb, i, j, px, py);
                 exist = true;
-                cxv = qp2fp((int16_t) px);
-                cyv = qp2fp((int16_t) py);
-            } else if (lane >= 3 && lane <= 5) {
-                bool need_i = lane != 4, need_j = lane != 3;
-                if ((!need_i || i > 0) && (!need_j || j > 0)) {
-                    MvHead m = ld_mv_head(&mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb]);
-                    exist = true;
-                    cxv = qp2fp(m.x);
-                    cyv = qp2fp(m.y);
-                }
-            } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
-                int k = lane - 6;
-                int rx = i + rectx[k] * step, ry = j + recty[k] * step;
-                if (rx >= 0 && ry >= 0 && rx < nxb && ry < nyb) {
-                    const DSV_MV *m = &c.ref_mvf[rx + ry * nxb];
-                    exist = true;
-                    cxv = qp2fp(m->u.mv.x);
-                    cyv = qp2fp(m->u.mv.y);
-                }
+                cxv = qp2fp((int16_t) cc.px);
+                cyv = qp2fp((int16_t) cc.py);
+            } else if (nb_ok) {
+                exist = true;
+                cxv = qp2fp(nbv.x);
+                cyv = qp2fp(nbv.y);
+            } else if (tvalid) {
+                exist = true;
+                cxv = qp2fp(pvx);
+                cyv = qp2fp(pvy);
             } else if (lane == 15) {
                 exist = true;
                 cxv = qp2fp((int16_t) (gx * 4));
@@ -963,10 +1019,9 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         }
         __syncthreads();
     }
-    CostCtx cc;
-    movec_pred(mvf, nxb, i, j, cc.px, cc.py);
     cc.q = c.quant;
     cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
+    HME_MARK(S, 2);
 
     // ---- best candidate (hme.c:1530-1557): lane k scores candidate k ----
     int dx, dy;
@@ -1004,8 +1059,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
     {
-        Quad o = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
-        unsigned zoscore = metric_return(wave_sum(act ? qmetric(a, o, psy) : 0u), bw, bh);
+        unsigned zoscore = metric_return(wave_sum(act ? qmetric(a, o_zero, psy) : 0u), bw, bh);
         if (abs(dx) <= 1 && abs(dy) <= 1) {
             qthresh *= 2;
         }
@@ -1015,6 +1069,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
             good_enough = true;
         }
     }
+    HME_MARK(S, 3);
     // ---- refinement (hme.c:1300): each round scores the full 3x3 neighbourhood at once ----
     if (!good_enough) {
         unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
@@ -1085,6 +1140,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
             }
         }
     }
+    HME_MARK(S, 4);
     mv.u.mv.x = (int16_t) (dx * step);
     mv.u.mv.y = (int16_t) (dy * step);
     if (level != 0) {

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Phase clocks of the level-0 motion search (debugging build: make -C digital-subband-video-2_amd/csrc prof).  Runs bench.py's loop in-process, then prints the share of each phase."""
+import ctypes
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF_SO = os.path.join(ROOT, "digital-subband-video-2_amd", "libdsv2hip_prof.so")
+os.environ["DSV2HIP_LIB"] = PROF_SO
+import bench  # noqa: E402
+
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-profile"] + sys.argv[1:]
+bench.main()
+lib = ctypes.CDLL(PROF_SO)
+out = (ctypes.c_ulonglong * 16)()
+lib.dsv2hip_debug_hme_prof(out)
+names = ["wait row above", "source analysis", "candidate gather", "candidate score + good-enough", "refinement",
+         "sub-pel", "mode decision A", "intra sub-block luma", "intra sub-block chroma + rest", "store + publish"]
+tot = float(sum(out[:10])) or 1.0
+for k, nm in enumerate(names):
+    print(f"{k} {nm:34s} {out[k] / tot * 100:6.2f} %  {out[k] / 1e9:9.3f} Gticks", file=sys.stderr)
+print(f"total {tot / 1e9:.3f} Gticks", file=sys.stderr)
