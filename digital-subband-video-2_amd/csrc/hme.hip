@@ -368,17 +368,40 @@ __device__ int find_inliers(const Vec2 *list, Vec2 *out, int n, int &ax, int &ay
 __device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t) (v > 255 ? 255 : (v < 0 ? 0 : v)); }
 
 struct SubpelLds {
-    uint8_t win[20 * 20]; // reference window rows/cols -1..18 around the 17x17 area
+    alignas(4) uint8_t win[20 * 20]; // reference window rows/cols -1..18 around the 17x17 area
     uint8_t h[34 * 34];   // half-pel image
 };
 
-// cooperative construction of the 34x34 half-pel image (hme.c:787); r = top-left full-pel sample
-__device__ void build_hpel(SubpelLds &s, const uint8_t *r, int rs)
+// the 20x20 reference window of a sub-pel search as 100 row dwords: lane L holds dwords L and L + 64
+struct HpelWin {
+    uint32_t d0, d1;
+};
+struct __attribute__((packed)) U32u { // possibly unaligned 32-bit load (one global_load_dword)
+    uint32_t v;
+};
+
+// r = full-pel sample at window position (1, 1); both loads are issued together with the caller's other loads
+__device__ __forceinline__ HpelWin load_hpel_window(const uint8_t *r, int rs)
+{
+    typedef const __attribute__((address_space(1))) uint8_t *gb_t;
+    typedef const __attribute__((address_space(1))) U32u *gu32_t;
+    const int lane = threadIdx.x & 63;
+    gb_t g = (gb_t) r - rs - 1;
+    const int k0 = lane, k1 = lane + 64 < 100 ? lane + 64 : 0;
+    HpelWin w;
+    w.d0 = ((gu32_t) (g + (k0 / 5) * rs + (k0 % 5) * 4))->v;
+    w.d1 = ((gu32_t) (g + (k1 / 5) * rs + (k1 % 5) * 4))->v;
+    return w;
+}
+
+// cooperative construction of the 34x34 half-pel image (hme.c:787) from the loaded window
+__device__ __forceinline__ void build_hpel(SubpelLds &s, const HpelWin &w)
 {
     int lane = threadIdx.x & 63;
-    for (int idx = lane; idx < 400; idx += 64) {
-        int x = idx % 20, y = idx / 20;
-        s.win[idx] = r[(ptrdiff_t) (y - 1) * rs + (x - 1)];
+    uint32_t *win32 = (uint32_t *) s.win;
+    win32[lane] = w.d0;
+    if (lane + 64 < 100) {
+        win32[lane + 64] = w.d1;
     }
     __syncthreads();
     for (int idx = lane; idx < 289; idx += 64) {
@@ -400,8 +423,6 @@ __device__ void build_hpel(SubpelLds &s, const uint8_t *r, int rs)
     __syncthreads();
 }
 
-// the same with the sub-sample phase given as a wave-uniform value (bit 0: X odd, bit 1: Y odd): one scalar branch
-// instead of four masked paths
 __device__ __forceinline__ int qsample_ph(const uint8_t *h, int X, int Y, int phase)
 {
     const uint8_t *p = h + (Y >> 1) * 34 + (X >> 1);
@@ -457,7 +478,7 @@ __device__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, const CostCtx &
     best = best * (unsigned) area_ratio >> 3;
     int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
     const uint8_t *srcw = at(src, xx, yy);
-    build_hpel(lds, at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
+    build_hpel(lds, load_hpel_window(at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride));
 
     int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
     unsigned ms1 = quad[1], ms2 = quad[3];

@@ -36,16 +36,45 @@ struct __attribute__((packed)) U16u { // possibly unaligned 16-bit load (one glo
 typedef const __attribute__((address_space(1))) uint8_t *gbytes_t;
 typedef const __attribute__((address_space(1))) U16u *gu16_t;
 
+// Branch-free on purpose: a load inside a conditional block ends that block with a wait for it, which turns
+// a batch of independent loads into as many memory round trips.  Lanes outside the block read its first quad.
 __device__ __forceinline__ Quad ldq(const uint8_t *blk, int stride, int qi, int qj, bool act)
 {
-    Quad q = {0};
-    if (act) {
-        gbytes_t g = (gbytes_t) blk;
-        unsigned off = (unsigned) ((2 * qj) * stride + 2 * qi);
-        uint32_t top = ((gu16_t) (g + off))->v, bot = ((gu16_t) (g + off + (unsigned) stride))->v;
-        q.w = top | (bot << 16);
-    }
+    gbytes_t g = (gbytes_t) blk;
+    unsigned off = act ? (unsigned) ((2 * qj) * stride + 2 * qi) : 0u;
+    uint32_t top = ((gu16_t) (g + off))->v, bot = ((gu16_t) (g + off + (unsigned) stride))->v;
+    Quad q;
+    q.w = act ? (top | (bot << 16)) : 0u;
     return q;
+}
+
+// the same in two steps, for call sites that fence a group of loads off from their first use with
+// __builtin_amdgcn_sched_barrier (the scheduler otherwise pairs each load with its wait)
+struct QuadRaw {
+    uint32_t top, bot;
+};
+__device__ __forceinline__ QuadRaw ldq_raw(const uint8_t *blk, int stride, int qi, int qj, bool act)
+{
+    gbytes_t g = (gbytes_t) blk;
+    unsigned off = act ? (unsigned) ((2 * qj) * stride + 2 * qi) : 0u;
+    QuadRaw r;
+    r.top = ((gu16_t) (g + off))->v;
+    r.bot = ((gu16_t) (g + off + (unsigned) stride))->v;
+    return r;
+}
+__device__ __forceinline__ Quad ldq_finish(const QuadRaw &r, bool act)
+{
+    Quad q;
+    q.w = act ? (r.top | (r.bot << 16)) : 0u;
+    return q;
+}
+
+// one pixel, same rules
+__device__ __forceinline__ int ldpx(const uint8_t *p, int off, bool act)
+{
+    gbytes_t g = (gbytes_t) p;
+    int v = g[act ? off : 0];
+    return act ? v : 0;
 }
 
 __device__ __forceinline__ Quad mkq(int s1, int s2, int s3, int s4)
@@ -315,17 +344,29 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
 // scores up to 16 displacement vectors held in LDS (s.cx/cy[first .. first+cnt)) against the
 // register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
 // first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
+template <int NT>
 __device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
                                             const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
 {
+    // all loads first, back to back (one memory round trip); a vector that may not be read is replaced by
+    // the zero vector, whose block always lies inside the frame
+    Quad b[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
+        int dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]), dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
+        ok[t] = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
+        b[t] = ldq(at(ref, bx + (ok[t] ? dx : 0), by + (ok[t] ? dy : 0)), ref.stride, qi, qj, act);
+    }
     int v[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) {
-        // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
-        int dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]), dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
-        bool ok = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
-        Quad b = ldq(at(ref, bx + dx, by + dy), ref.stride, qi, qj, act && ok);
-        v[t] = (act && ok) ? (int) (level > 1 ? qsse(a, b) : qmetric(a, b, psy)) : 0;
+        v[t] = 0;
+        if (t < NT && ok[t]) { // wave-uniform: the arithmetic of an absent vector is skipped, its (dummy) load was not
+            int m = (int) (level > 1 ? qsse(a, b[t]) : qmetric(a, b[t], psy));
+            v[t] = act ? m : 0;
+        }
     }
     int r = reduceN<16>(v);
     return (unsigned) bcastL<16>(r, threadIdx.x & 15);
@@ -361,19 +402,26 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     unsigned yarea = (unsigned) (bw * bh);
     const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
     int v4[4];
+    QuadRaw b4[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        Quad b = ldq(at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, qi, qj, act);
-        v4[n] = act ? (int) qsse(a, b) : 0;
+        b4[n] = ldq_raw(at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, qi, qj, act);
+    }
+    int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
+    QuadRaw awr = ldq_raw(at(src, xx, yy), src.stride, qi, qj, true); // the centred 16x16 source window
+    HpelWin hw = load_hpel_window(at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
+    __builtin_amdgcn_sched_barrier(0); // all twelve loads are in flight before the first is waited for
+    Quad aw = ldq_finish(awr, true);
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        v4[n] = act ? (int) qsse(a, ldq_finish(b4[n], act)) : 0;
     }
     int r4 = reduceN<4>(v4);
     unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
              quad3 = (unsigned) bcastN<4>(r4, 3);
     int area_ratio = (int) div_nn(8u * 256u, yarea), iarea_ratio = (int) (8 * yarea / 256);
     best = best * (unsigned) area_ratio >> 3;
-    int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
-    Quad aw = ldq(at(src, xx, yy), src.stride, qi, qj, true); // the centred 16x16 source window
-    build_hpel(S.sp, at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
+    build_hpel(S.sp, hw);
 
     int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
     unsigned ms1 = quad1, ms2 = quad3;
@@ -492,13 +540,10 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     const Quad r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
     const Quad o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
     const Quad rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
-    int us = 0, vs = 0, um = 0, vm = 0;
-    if (actc) {
-        us = *at(c.srcc[0], cbx + cxp, cby + cyp);
-        vs = *at(c.srcc[1], cbx + cxp, cby + cyp);
-        um = *at(c.refc[0], cbmx + cxp, cbmy + cyp);
-        vm = *at(c.refc[1], cbmx + cxp, cbmy + cyp);
-    }
+    const int us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
+    const int vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
+    const int um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
+    const int vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
     // chroma quads for the sub-block metrics: lanes 0..15 U, 16..31 V
     const int cpl = (lane >> 4) & 1, cqi = lane & 3, cqj = (lane >> 2) & 3;
     const bool actq = lane < 32 && cqi < (cbw >> 1) && cqj < (cbh >> 1);
@@ -817,12 +862,17 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     }
 }
 
+
+// the 3x3 offset tables of the search, entry k in {-1, 0, 1}: arithmetic on a packed constant (a lane-indexed
+// constant array would be fetched from memory, one round trip per lookup)
+__device__ __forceinline__ int tab9(unsigned packed, int k) { return (int) ((packed >> (2 * k)) & 3u) - 1; }
+constexpr unsigned kRectX = 0x22149u, kRectY = 0x28095u; // rect[]: {0,1,-1,0,0,-1,1,-1,1} / {0,0,0,1,-1,-1,-1,1,1} (hme.c:1304)
+constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {0,-1,1,0,0,-1,1,1,-1} / {0,0,0,-1,1,-1,1,-1,1} (hme.c:1468)
+
 // FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away
 template <bool FULL, class Ctx>
 __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S)
 {
-    const int rectx[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1};
-    const int recty[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};
     const int lane = threadIdx.x & 63;
     const int qi = lane & 7, qj = lane >> 3;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
@@ -896,27 +946,30 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         const DSV_MV *np = nb_ok ? &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb] : out;
         const DSV_MV *op = out;
         if (parent != nullptr) {
-            static constexpr int ptx[9] = {0, -2, 2, 0, 0, -2, 2, 2, -2}, pty[9] = {0, 0, 0, -2, 2, -2, 2, -2, 2};
             unsigned parent_mask = ~(((unsigned) step << 1) - 1);
             int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
             if (lane >= 16 && lane < 25) {
                 int m = lane - 16;
-                int x = pi + ptx[m] * step, y = pj + pty[m] * step;
+                int x = pi + 2 * tab9(kParX, m) * step, y = pj + 2 * tab9(kParY, m) * step;
                 if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
                     op = &parent[x + y * nxb];
                     pvalid = true;
                 }
             } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
                 int k = lane - 6;
-                int rx = i + rectx[k] * step, ry = j + recty[k] * step;
+                int rx = i + tab9(kRectX, k) * step, ry = j + tab9(kRectY, k) * step;
                 if (rx >= 0 && ry >= 0 && rx < nxb && ry < nyb) {
                     op = &c.ref_mvf[rx + ry * nxb];
                     tvalid = true;
                 }
             }
         }
-        nbv = ld_mv_head(np);
-        uint32_t ov = *(const uint32_t *) op;
+        typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
+        uint32_t ov = *(gu32p_t) op;
+        nbv.all = __hip_atomic_load((gu32p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // {x, y} is all a candidate needs
+        nbv.x = (int) (int16_t) (nbv.all & 0xffffu);
+        nbv.y = (int) (int16_t) (nbv.all >> 16);
+        nbv.flags = 0;
         pvx = (int) (int16_t) (ov & 0xffffu);
         pvy = (int) (int16_t) (ov >> 16);
     }
@@ -1029,7 +1082,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     {
         unsigned raw = 0;
         for (int first = 0; first < n; first += 16) {
-            unsigned r = score16(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
             if (lane >= first && lane < first + 16) {
                 raw = r;
             }
@@ -1078,12 +1131,12 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
             again = false;
             __syncthreads();
             if (lane < 16) {
-                S.cx[lane] = dx + (lane < 9 ? rectx[lane] : 0);
-                S.cy[lane] = dy + (lane < 9 ? recty[lane] : 0);
+                S.cx[lane] = dx + (lane < 9 ? tab9(kRectX, lane) : 0);
+                S.cy[lane] = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
             }
             __syncthreads();
-            unsigned raw = score16(S, 0, 9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
-            int tx = dx + rectx[lane < 9 ? lane : 0], ty = dy + recty[lane < 9 ? lane : 0];
+            unsigned raw = score16<9>(S, 0, 9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
             bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
             if (level <= 1) {
                 raw = metric_return(raw, bw, bh);
@@ -1096,7 +1149,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
                     continue;
                 }
                 unsigned sk = (unsigned) __builtin_amdgcn_readlane((int) raw, k);
-                int tvx = cdx + rectx[k], tvy = cdy + recty[k];
+                int tvx = cdx + tab9(kRectX, k), tvy = cdy + tab9(kRectY, k);
                 if (k == 1) {
                     metr0 = sk;
                 } else if (k == 2) {
