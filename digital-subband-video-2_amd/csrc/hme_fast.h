@@ -493,11 +493,38 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     return best * (unsigned) iarea_ratio >> 3;
 }
 
+// what the candidate load round already fetched and the level-0 tail needs again (wave-uniform)
+struct NbPre {
+    uint32_t l_all, l_flags, t_all, t_flags; // left / top neighbour of the same level: {x, y}, flags
+    uint32_t colo;                           // co-located vector of the previous frame
+    bool colo_ok;
+};
+
+// neighbour difference of the current block (vector cx,cy not yet stored) -- dsv.c:403
+__device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, int cx, int cy, int &dx, int &dy)
+{
+    int lx = cx, ly = cy, tx = cx, ty = cy;
+    if (abs(cx) < 2 && abs(cy) < 2) {
+        dx = dy = 0;
+        return;
+    }
+    if (x > 0 && p.l_all && !(p.l_flags & (1u << DSV_MV_BIT_SKIP))) {
+        lx = (int) (int16_t) (p.l_all & 0xffffu);
+        ly = (int) (int16_t) (p.l_all >> 16);
+    }
+    if (y > 0 && p.t_all && !(p.t_flags & (1u << DSV_MV_BIT_SKIP))) {
+        tx = (int) (int16_t) (p.t_all & 0xffffu);
+        ty = (int) (int16_t) (p.t_all >> 16);
+    }
+    dx = abs(lx - cx) + abs(ly - cy);
+    dy = abs(tx - cx) + abs(ty - cy);
+}
+
 // level-0 tail of hme_block_fast: sub-pel refinement + mode decision (hme.c:1598-1821)
 template <class Ctx>
 __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
-                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy)
+                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre)
 {
     const int lane = threadIdx.x & 63;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
@@ -641,7 +668,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     int neidif;
     {
         int na, nb_;
-        neighbordif2_cur(mvf, nxb, i, j, mv.u.mv.x, mv.u.mv.y, na, nb_);
+        neighbordif2_pre(pre, i, j, mv.u.mv.x, mv.u.mv.y, na, nb_);
         neidif = (na + nb_) / 3;
     }
     unsigned skipt = ((unsigned) c.quant * (unsigned) c.quant) >> 19;
@@ -713,8 +740,15 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
         HME_MARK(S, 6);
         // ---- test_subblock_intra_y (hme.c:891), all four sub-blocks evaluated together ----
         {
-            const DSV_MV *refmv = c.ref_mvf ? &c.ref_mvf[i + j * nxb] : nullptr;
-            int rx = __builtin_amdgcn_readfirstlane(refmv ? refmv->u.mv.x : mv.u.mv.x), ry = __builtin_amdgcn_readfirstlane(refmv ? refmv->u.mv.y : mv.u.mv.y);
+            int rx = mv.u.mv.x, ry = mv.u.mv.y;
+            if (c.ref_mvf != nullptr) {
+                uint32_t colo = pre.colo;
+                if (!pre.colo_ok) { // no coarser level (one-level pyramid): the candidate round did not fetch it
+                    colo = (uint32_t) __builtin_amdgcn_readfirstlane((int) *(const uint32_t *) &c.ref_mvf[i + j * nxb]);
+                }
+                rx = (int) (int16_t) (colo & 0xffffu);
+                ry = (int) (int16_t) (colo >> 16);
+            }
             int sbw = bw / 2, sbh = bh / 2;
             bool run = !(mv.u.all && neidif < 3 && abs(rx - mv.u.mv.x) < 3 && abs(ry - mv.u.mv.y) < 3) && sbw != 0 && sbh != 0;
             if (run) {
@@ -939,6 +973,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     // load this block's own entry and ignore it.
     bool nb_ok = false, pvalid = false, tvalid = false;
     MvHead nbv;
+    uint32_t ov;
     int pvx = 0, pvy = 0;
     {
         const bool need_i = lane != 4, need_j = lane != 3;
@@ -965,11 +1000,13 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
             }
         }
         typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
-        uint32_t ov = *(gu32p_t) op;
-        nbv.all = __hip_atomic_load((gu32p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // {x, y} is all a candidate needs
+        typedef const __attribute__((address_space(1))) unsigned long long *gu64p_t;
+        ov = *(gu32p_t) op;
+        unsigned long long head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nbv.all = (uint32_t) head;
+        nbv.flags = (uint32_t) (head >> 32);
         nbv.x = (int) (int16_t) (nbv.all & 0xffffu);
         nbv.y = (int) (int16_t) (nbv.all >> 16);
-        nbv.flags = 0;
         pvx = (int) (int16_t) (ov & 0xffffu);
         pvy = (int) (int16_t) (ov >> 16);
     }
@@ -1202,8 +1239,15 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         }
         return;
     }
+    NbPre pre;
+    pre.l_all = (uint32_t) __builtin_amdgcn_readlane((int) nbv.all, 3);
+    pre.l_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 3);
+    pre.t_all = (uint32_t) __builtin_amdgcn_readlane((int) nbv.all, 4);
+    pre.t_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 4);
+    pre.colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
+    pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
     hme_block_fast_l0(c, i, j, S, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
-                      avg_src, psy);
+                      avg_src, psy, pre);
 }
 
 template <class Ctx>
