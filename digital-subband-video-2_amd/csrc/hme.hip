@@ -1231,7 +1231,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
 #ifdef DSV2_HME_PROF
     if ((threadIdx.x & 63) == 0) {
         S.prof_on = level == 0;
-        for (int k = 0; k < 10; k++) {
+        for (int k = 0; k < 16; k++) {
             S.prof_acc[k] = 0;
         }
         S.prof_t = __builtin_amdgcn_s_memtime();
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
     }
 #ifdef DSV2_HME_PROF
     if ((threadIdx.x & 63) == 0 && S.prof_on) {
-        for (int k = 0; k < 10; k++) {
+        for (int k = 0; k < 16; k++) {
             atomicAdd(&g_hme_prof[k], S.prof_acc[k]);
         }
     }

@@ -205,7 +205,7 @@ struct FastLds {
     int cx[64], cy[64];
     SubpelLds sp;
 #ifdef DSV2_HME_PROF
-    unsigned long long prof_t, prof_acc[10];
+    unsigned long long prof_t, prof_acc[16];
     int prof_on;
 #endif
 };
@@ -222,8 +222,17 @@ __device__ unsigned long long g_hme_prof[16];
             (S).prof_t = t_;                                                                                          \
         }                                                                                                             \
     } while (0)
+#define HME_COUNT(S, k, n)                                                                                            \
+    do {                                                                                                              \
+        if ((threadIdx.x & 63) == 0 && (S).prof_on) {                                                                 \
+            (S).prof_acc[k] += (unsigned long long) (n);                                                              \
+        }                                                                                                             \
+    } while (0)
 #else
 #define HME_MARK(S, k)                                                                                                \
+    do {                                                                                                              \
+    } while (0)
+#define HME_COUNT(S, k, n)                                                                                            \
     do {                                                                                                              \
     } while (0)
 #endif
@@ -359,17 +368,18 @@ __device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt
         ok[t] = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
         b[t] = ldq(at(ref, bx + (ok[t] ? dx : 0), by + (ok[t] ? dy : 0)), ref.stride, qi, qj, act);
     }
-    int v[16];
+    constexpr int NR = NT <= 4 ? 4 : (NT <= 8 ? 8 : 16); // width of the joint reduction
+    int v[NR];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < NR; t++) {
         v[t] = 0;
         if (t < NT && ok[t]) { // wave-uniform: the arithmetic of an absent vector is skipped, its (dummy) load was not
             int m = (int) (level > 1 ? qsse(a, b[t]) : qmetric(a, b[t], psy));
             v[t] = act ? m : 0;
         }
     }
-    int r = reduceN<16>(v);
-    return (unsigned) bcastL<16>(r, threadIdx.x & 15);
+    int r = reduceN<NR>(v);
+    return (unsigned) bcastL<NR>(r, threadIdx.x & (NR - 1));
 }
 
 // psy accumulator of one 2x2 quad pair for the three predictions compared by err_intra (hme.c:839)
@@ -399,6 +409,7 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     if (best == 0) {
         return best;
     }
+    HME_COUNT(S, 13, 1);
     unsigned yarea = (unsigned) (bw * bh);
     const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
     int v4[4];
@@ -1113,15 +1124,23 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
     HME_MARK(S, 2);
 
+    HME_COUNT(S, 10, 1);
+    HME_COUNT(S, 14, n);
     // ---- best candidate (hme.c:1530-1557): lane k scores candidate k ----
     int dx, dy;
     unsigned best, score_zero;
     {
         unsigned raw = 0;
-        for (int first = 0; first < n; first += 16) {
-            unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
-            if (lane >= first && lane < first + 16) {
-                raw = r;
+        if (n <= 4) { // the usual case after de-duplication
+            raw = score16<4>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+        } else if (n <= 8) {
+            raw = score16<8>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+        } else {
+            for (int first = 0; first < n; first += 16) {
+                unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+                if (lane >= first && lane < first + 16) {
+                    raw = r;
+                }
             }
         }
         int mx = S.cx[lane], my = S.cy[lane];
@@ -1164,8 +1183,10 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     if (!good_enough) {
         unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
         bool again = true;
+        HME_COUNT(S, 11, 1);
         while (again && !good_enough) {
             again = false;
+            HME_COUNT(S, 12, 1);
             __syncthreads();
             if (lane < 16) {
                 S.cx[lane] = dx + (lane < 9 ? tab9(kRectX, lane) : 0);
