@@ -461,13 +461,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restric
     }
 }
 
+// The tile's symbols are first packed in LDS, then written out as one contiguous run: every store instruction of
+// a wavefront covers 256 consecutive bytes (the host mirror is written across PCIe, where scattered 4-byte
+// stores cost a transaction each).
 __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ tab, CompactJob one)
 {
     __shared__ int wsum[4];
+    __shared__ uint32_t spos[kTile];
+    __shared__ int32_t sval[kTile];
     const CompactJob &J = tab ? tab[blockIdx.y] : one;
     const int32_t *qv = J.qv;
     int n = J.n;
-    const int *tile_base = J.tile_base;
     uint32_t *out_pos = J.pos;
     int32_t *out_val = J.val;
     uint32_t *host_pos = J.host_pos;
@@ -488,20 +492,29 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
         wsum[wv] = inc;
     }
     __syncthreads();
-    int o = tile_base[blockIdx.x] + inc - cnt;
+    int o = inc - cnt;
     for (int k = 0; k < wv; k++) {
         o += wsum[k];
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (vals[j] != 0) {
-            out_pos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
-            out_val[o] = vals[j];
-            if (o < host_cap) {
-                host_pos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
-                host_val[o] = vals[j];
-            }
+            spos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
+            sval[o] = vals[j];
             o++;
+        }
+    }
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int tb = J.tile_base[blockIdx.x];
+    __syncthreads();
+    for (int k = threadIdx.x; k < total; k += 256) {
+        uint32_t p = spos[k];
+        int32_t v = sval[k];
+        out_pos[tb + k] = p;
+        out_val[tb + k] = v;
+        if (tb + k < host_cap) {
+            host_pos[tb + k] = p;
+            host_val[tb + k] = v;
         }
     }
 }
