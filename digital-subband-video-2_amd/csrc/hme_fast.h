@@ -398,12 +398,35 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
     isrc = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - dc) << (psy.avg_weight + 1));
 }
 
-// sub-pel search around full-pel vector (fpelx, fpely): hme.c:1051
+// everything a sub-pel search reads from memory: the four neighbouring full-pel blocks, the centred source
+// window and the 20x20 reference window -- twelve loads, one round trip; issued by the search itself or, for
+// the first search (around the parent average, known long before it runs), ahead of candidate scoring
+struct SubpelLoads {
+    QuadRaw b4[4];
+    QuadRaw awr;
+    HpelWin hw;
+};
 template <class Ctx>
-__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
-                                     int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy)
+__device__ __forceinline__ SubpelLoads subpel_issue_loads(const Ctx &c, int fpelx, int fpely, int bx, int by, int bw, int bh, int qi, int qj, bool act)
 {
     const DPlane &src = c.src[0], &ref = c.ref[0];
+    const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
+    SubpelLoads L;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        L.b4[n] = ldq_raw(at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, qi, qj, act);
+    }
+    int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
+    L.awr = ldq_raw(at(src, xx, yy), src.stride, qi, qj, true); // the centred 16x16 source window
+    L.hw = load_hpel_window(at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
+    return L;
+}
+
+// sub-pel search around full-pel vector (fpelx, fpely): hme.c:1051
+template <bool PRELOADED, class Ctx>
+__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
+                                     int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy, const SubpelLoads &pre)
+{
     const int lane = threadIdx.x & 63;
     sub_x = sub_y = 0;
     if (best == 0) {
@@ -411,21 +434,19 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     }
     HME_COUNT(S, 13, 1);
     unsigned yarea = (unsigned) (bw * bh);
-    const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
     int v4[4];
-    QuadRaw b4[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        b4[n] = ldq_raw(at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, qi, qj, act);
+    SubpelLoads L;
+    if constexpr (PRELOADED) {
+        L = pre;
+    } else {
+        L = subpel_issue_loads(c, fpelx, fpely, bx, by, bw, bh, qi, qj, act);
     }
-    int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
-    QuadRaw awr = ldq_raw(at(src, xx, yy), src.stride, qi, qj, true); // the centred 16x16 source window
-    HpelWin hw = load_hpel_window(at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride);
     __builtin_amdgcn_sched_barrier(0); // all twelve loads are in flight before the first is waited for
-    Quad aw = ldq_finish(awr, true);
+    Quad aw = ldq_finish(L.awr, true);
+    const HpelWin &hw = L.hw;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        v4[n] = act ? (int) qsse(a, ldq_finish(b4[n], act)) : 0;
+        v4[n] = act ? (int) qsse(a, ldq_finish(L.b4[n], act)) : 0;
     }
     int r4 = reduceN<4>(v4);
     unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
@@ -535,7 +556,7 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
 template <class Ctx>
 __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
-                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre)
+                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, const SubpelLoads &sp_pre)
 {
     const int lane = threadIdx.x & 63;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
@@ -550,7 +571,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     unsigned best_fp = best;
     if (c.effort >= 4) {
         if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
-            best = subpixel_me_fast(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+            best = subpixel_me_fast<false>(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
             if (sx || sy) {
                 fpelx = lax;
                 fpely = lay;
@@ -558,7 +579,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
             }
         }
         if (!found_sub && !good_enough && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
-            best = subpixel_me_fast(c, S, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+            best = subpixel_me_fast<false>(c, S, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
         }
     }
     mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
@@ -936,48 +957,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     const Quad a = ldq(sblk, src.stride, qi, qj, act);
     const Quad o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act); // for the "good enough" test far below: same load round
 
-    int motion_bias = y_w * y_h;
-    unsigned var_src = 0, avg_src = 0;
-    Psy psy = {2, 1, 0};
-    if (level <= 1) {
-        int ps, ph, pv;
-        quad_grad_partials(a, act, qi, qj, 0, 0, ps, ph, pv);
-        int v4[4] = {ps, ph, pv, 0};
-        int r = reduceN<4>(v4);
-        int sum = bcastN<4>(r, 0);
-        unsigned sh = (unsigned) bcastN<4>(r, 1), sv = (unsigned) bcastN<4>(r, 2);
-        int mean = div_nn(sum, bw * bh);
-        avg_src = (unsigned) mean;
-        int var = wave_sum(quad_absdev(a, act, mean)) >> 1;
-        int tex = (int) (max(sh, sv) - (unsigned) var);
-        var_src = (unsigned) (var + max(tex, 0));
-        int tvar = (int) (var_src + SQR(var_src >> 10));
-        tvar = div_nn(8 * tvar * c.quant >> 9, bw * bh);
-        if (tvar) {
-            int hvar = src_hist_var(a, act, sum, bw, bh, S.hist);
-            int qtex = src_quant_tex(a, act, qi, qj, qw, bw, bh);
-            int npeaks = src_peaks(a, act, (int) avg_src, S.hist);
-            motion_bias += tvar * (hvar - qtex) * npeaks;
-        }
-        motion_bias = max(motion_bias, 0) / (2 + (abs(gx) + abs(gy)));
-        if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
-            psy = Psy{2, 1, 2};
-            motion_bias = 0;
-        } else {
-            psy = Psy{1, 2, 1};
-        }
-        if (var_src > (unsigned) (24 * bw * bh)) {
-            psy.avg_weight = 0;
-        }
-    }
-
-    HME_MARK(S, 1);
-    // ---- candidate gathering: lane p owns canonical list position p (hme.c:1443-1528) ----
-    //  0 zero | 1 parent inlier average | 2 predictor (level 0) | 3 left 4 top 5 top-left |
-    //  6..14 temporal | 15 global | 16..24 parent inliers
-    int lax = 0, lay = 0;
-    bool exist = lane == 0;
-    int cxv = 0, cyv = 0;
+    // (issued here, ahead of the source analysis, so that its latency is covered by that arithmetic)
     // ONE load round for every vector the list and the cost predictor read: lanes 3..5 fetch the same-level
     // neighbours (left, top, top-left; coherent loads, the row above may be on another XCD), lanes 6..14 the
     // co-located vectors of the previous frame, lanes 16..24 the parent level's.  Lanes without a vector
@@ -1021,6 +1001,48 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         pvx = (int) (int16_t) (ov & 0xffffu);
         pvy = (int) (int16_t) (ov >> 16);
     }
+    int motion_bias = y_w * y_h;
+    unsigned var_src = 0, avg_src = 0;
+    Psy psy = {2, 1, 0};
+    if (level <= 1) {
+        int ps, ph, pv;
+        quad_grad_partials(a, act, qi, qj, 0, 0, ps, ph, pv);
+        int v4[4] = {ps, ph, pv, 0};
+        int r = reduceN<4>(v4);
+        int sum = bcastN<4>(r, 0);
+        unsigned sh = (unsigned) bcastN<4>(r, 1), sv = (unsigned) bcastN<4>(r, 2);
+        int mean = div_nn(sum, bw * bh);
+        avg_src = (unsigned) mean;
+        int var = wave_sum(quad_absdev(a, act, mean)) >> 1;
+        int tex = (int) (max(sh, sv) - (unsigned) var);
+        var_src = (unsigned) (var + max(tex, 0));
+        int tvar = (int) (var_src + SQR(var_src >> 10));
+        tvar = div_nn(8 * tvar * c.quant >> 9, bw * bh);
+        if (tvar) {
+            int hvar = src_hist_var(a, act, sum, bw, bh, S.hist);
+            int qtex = src_quant_tex(a, act, qi, qj, qw, bw, bh);
+            int npeaks = src_peaks(a, act, (int) avg_src, S.hist);
+            motion_bias += tvar * (hvar - qtex) * npeaks;
+        }
+        motion_bias = max(motion_bias, 0) / (2 + (abs(gx) + abs(gy)));
+        if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
+            psy = Psy{2, 1, 2};
+            motion_bias = 0;
+        } else {
+            psy = Psy{1, 2, 1};
+        }
+        if (var_src > (unsigned) (24 * bw * bh)) {
+            psy.avg_weight = 0;
+        }
+    }
+
+    HME_MARK(S, 1);
+    // ---- candidate gathering: lane p owns canonical list position p (hme.c:1443-1528) ----
+    //  0 zero | 1 parent inlier average | 2 predictor (level 0) | 3 left 4 top 5 top-left |
+    //  6..14 temporal | 15 global | 16..24 parent inliers
+    int lax = 0, lay = 0;
+    bool exist = lane == 0;
+    int cxv = 0, cyv = 0;
     // dsv_movec_pred (dsv.c:375) of this block: at level 0 its operands are the three neighbours just loaded;
     // at the coarser levels it reads entries between the level's grid points, which are never written (zero)
     CostCtx cc;
@@ -1122,6 +1144,13 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     }
     cc.q = c.quant;
     cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
+    // loads of the first sub-pel search (around the parent average; hme_block_fast_l0 runs it under this same
+    // condition): in flight from here on, under candidate scoring and refinement
+    SubpelLoads sp_pre;
+    constexpr bool kPrefetchSubpel = false; // costs ~14 VGPRs: see DESIGN 5.2 (register footprint vs co-resident kernels)
+    if (kPrefetchSubpel && level == 0 && c.effort >= 4 && !invalid_block(ref, bx + lax, by + lay, bw, bh, 4)) {
+        sp_pre = subpel_issue_loads(c, lax, lay, bx, by, bw, bh, qi, qj, act);
+    }
     HME_MARK(S, 2);
 
     HME_COUNT(S, 10, 1);
@@ -1268,7 +1297,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     pre.colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
     pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
     hme_block_fast_l0(c, i, j, S, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
-                      avg_src, psy, pre);
+                      avg_src, psy, pre, sp_pre);
 }
 
 template <class Ctx>
