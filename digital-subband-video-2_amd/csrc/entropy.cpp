@@ -223,6 +223,56 @@ int RleReader::get()
     return nz == 0;
 }
 
+// MSB-first bit accumulator over a zero-filled buffer: same bytes as BitWriter, without touching memory per code
+struct AccWriter {
+    uint8_t *p;
+    uint64_t acc = 0;
+    unsigned n = 0; // pending bits, in the low end of acc (< 32 between calls)
+    explicit AccWriter(uint8_t *at) : p(at) {}
+    inline void put(unsigned nb, unsigned v) // nb <= 32, v < 2^nb
+    {
+        acc = (acc << nb) | v;
+        n += nb;
+        if (n >= 32) {
+            n -= 32;
+            uint32_t w = __builtin_bswap32((uint32_t) (acc >> n));
+            memcpy(p, &w, 4);
+            p += 4;
+        }
+    }
+    inline void zeros(unsigned q)
+    {
+        while (q > 32) {
+            put(32, 0);
+            q -= 32;
+        }
+        put(q, 0);
+    }
+    inline void ueg(unsigned v) // bs.c:132, see BitWriter::put_ueg
+    {
+        v++;
+        int nb = 31 - __builtin_clz(v);
+        unsigned low = v & ((1u << nb) - 1);
+        if (nb <= 15) {
+            put((unsigned) (2 * nb + 1), (spread16(low) << 1) | 1u);
+            return;
+        }
+        put((unsigned) (2 * (nb - 15)), spread16(low >> 15));
+        put(31, (spread16(low & 0x7fffu) << 1) | 1u);
+    }
+    inline uint8_t *finish() // pads with zero bits to the next byte boundary
+    {
+        if (n) {
+            uint32_t w = __builtin_bswap32((uint32_t) ((acc & ((1ull << n) - 1)) << (32 - n)));
+            unsigned bytes = (n + 7) / 8;
+            memcpy(p, &w, bytes);
+            p += bytes;
+            n = 0;
+        }
+        return p;
+    }
+};
+
 void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const int32_t *val, int n, const ScanGeom &g)
 {
     bw.align();
@@ -236,18 +286,58 @@ void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const 
 
     int vk = 0, seg = 0;
     uint32_t prev_end = 0; // scan position following the previous nonzero
-    for (int i = 0; i < n; i++) {
-        uint32_t p = pos[i];
-        while (p >= (uint32_t) g.base[seg + 1]) {
-            seg++;
+    if (bw.wide) {
+        // the symbol loop proper: codes are gathered in a register and leave it 32 bits at a time (the generic writer
+        // read-modify-writes memory twice per symbol); starts and ends on a byte boundary like the code below
+        AccWriter aw(bw.start + (bw.pos >> 3));
+        for (int i = 0; i < n; i++) {
+            uint32_t p = pos[i];
+            while (p >= (uint32_t) g.base[seg + 1]) {
+                seg++;
+            }
+            aw.ueg(p - prev_end);
+            int v = val[i];
+            if (seg == 0) { // NEG (bs.c:206)
+                unsigned a = (unsigned) (v < 0 ? -v : v);
+                aw.ueg(a - 1);
+                if (a) {
+                    aw.put(1, v < 0);
+                }
+            } else { // adaptive Rice (bs.c:237)
+                int damp = 3 + (seg - 1) / 3;
+                unsigned u = ((unsigned) (2 * v) ^ (v < 0 ? ~0u : 0u)) - 1;
+                unsigned k = (unsigned) (vk >> damp), qq = u >> k;
+                if (qq) {
+                    vk++;
+                } else if (vk > 0) {
+                    vk--;
+                }
+                aw.zeros(qq);
+                if (k < 32) {
+                    aw.put(k + 1, (1u << k) | (u & ((1u << k) - 1)));
+                } else {
+                    aw.put(1, 1);
+                    aw.put(32, u);
+                    aw.put(k - 32, 0);
+                }
+            }
+            prev_end = p + 1;
         }
-        bw.put_ueg(p - prev_end);
-        if (seg == 0) {
-            bw.put_neg(val[i]);
-        } else {
-            bw.put_nrice(val[i], &vk, 3 + (seg - 1) / 3);
+        bw.pos = (unsigned) (aw.finish() - bw.start) * 8;
+    } else {
+        for (int i = 0; i < n; i++) {
+            uint32_t p = pos[i];
+            while (p >= (uint32_t) g.base[seg + 1]) {
+                seg++;
+            }
+            bw.put_ueg(p - prev_end);
+            if (seg == 0) {
+                bw.put_neg(val[i]);
+            } else {
+                bw.put_nrice(val[i], &vk, 3 + (seg - 1) / 3);
+            }
+            prev_end = p + 1;
         }
-        prev_end = p + 1;
     }
     bw.align();
     unsigned after = bw.pos;
