@@ -209,7 +209,11 @@ def main():
 
     run_phase(0, Wm)                      # warm-up: first I frame + a few P frames, allocations, clocks
     hip.dsv2hip_prof_enable(0)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = run_phase(Wm, total)        # timed: exactly K steps
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
 
     # stage profile: a few more steps of the SAME configuration with HIP-event stage timing on (not timed)
     stage_ms, stage_launches, stage_units, prof_steps = None, None, None, 0
@@ -264,7 +268,7 @@ def main():
         "dtype": "u8/int32",
         "data": "synthetic",
         "config": {"workload": "1920x1080 4:2:0 -qp=60 -gop=48 effort=10 CRF, %d closed-GOP streams per GPU" % S,
-                   "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mode": args.mode, "groups": G, "mpix_per_s": round(fps * N_PIX / 1e6, 1),
+                   "streams_per_gpu": S, "frames_per_step_per_gpu": S, "mode": args.mode, "groups": G, "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2), "mpix_per_s": round(fps * N_PIX / 1e6, 1),
                    "stream_bytes_total": total_bytes, "host_cpus": ncpu},
     }
     if stage_ms is not None and prof_steps:

@@ -573,7 +573,7 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     }
     copy_linear_batch(bs, d_out, n, dv0.pics[0].recon.bytes);
     t_dec_clock.lap(2);
-    HIPCHK(hipStreamSynchronize(bs));
+    stream_wait(bs);
     t_dec_clock.lap(3);
 
     // phase C: the pictures are already in their output frames

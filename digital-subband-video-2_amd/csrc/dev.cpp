@@ -1,6 +1,9 @@
 // dev.cpp -- device memory, frame transfer and error plumbing for libdsv2hip.
 #include "dev.h"
 
+#include <sys/prctl.h>
+#include <time.h>
+
 #include <mutex>
 
 namespace dsv2 {
@@ -70,6 +73,38 @@ void dev_zero(void *p, size_t bytes)
 {
     HIPCHK(hipMemset(p, 0, bytes));
     HIPCHK(hipStreamSynchronize(nullptr));
+}
+
+// Host wait for a stream to drain WITHOUT occupying a core: the runtime's waits (hipStreamSynchronize, and
+// hipEventSynchronize even on an event created for blocking synchronisation) poll, so a waiting thread shows
+// ~100 % CPU.  The host threads of the lockstep groups wait most of the time, and host CPU time is the scarce
+// resource once the kernels are fast (a container's CPU quota is shared with the entropy back end).  Here the
+// thread sleeps between completion queries; the added latency is bounded by the sleep (tens of microseconds
+// against waits of several milliseconds).  DSV2_SPIN_WAIT=1 restores the runtime's polling wait.
+void stream_wait(hipStream_t s)
+{
+    static const bool spin = getenv("DSV2_SPIN_WAIT") && atoi(getenv("DSV2_SPIN_WAIT")) != 0;
+    if (spin) {
+        HIPCHK(hipStreamSynchronize(s));
+        return;
+    }
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) {
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        prctl(PR_SET_TIMERSLACK, 2000ul, 0, 0, 0); // the default slack of 50 us would triple every short sleep
+    }
+    HIPCHK(hipEventRecord(ev, s));
+    for (unsigned tries = 0;; tries++) {
+        hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) {
+            return;
+        }
+        if (e != hipErrorNotReady) {
+            HIPCHK(e);
+        }
+        timespec ts = {0, tries < 8 ? 15000 : 40000};
+        nanosleep(&ts, nullptr);
+    }
 }
 
 void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-113, always bordered

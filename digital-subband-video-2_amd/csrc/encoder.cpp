@@ -1322,7 +1322,7 @@ void enc_batch(Job *jobs, int n)
         prof.end(bs, ST_HME, (int) pjobs.size(), nfronts); // launches = the per-level search kernels
     }
     t_clock.lap(1);
-    HIPCHK(hipStreamSynchronize(bs));
+    stream_wait(bs);
     t_clock.lap(2);
     for (int k = 0; k < n; k++) {
         if (jobs[k].frame) {
@@ -1351,7 +1351,7 @@ void enc_batch(Job *jobs, int n)
         if (n_late) {
             sc.tabs.upload(bs);
             intra_analysis_batch(bs, d_late, n_late, analysis_params(dv0, jobs[0].d.params.do_psy));
-            HIPCHK(hipStreamSynchronize(bs));
+            stream_wait(bs);
         }
     }
     parallel_for(n, [&](int k) { phase_h1b(jobs[k]); });
@@ -1502,7 +1502,7 @@ void enc_batch(Job *jobs, int n)
     extend_planes(bs, d_rext_c, 2 * n_rext, dv0.pics[0].recon.p[1].w, dv0.pics[0].recon.p[1].h);
     prof.end(bs, ST_EXTEND, n_rext);
     t_clock.lap(4);
-    HIPCHK(hipStreamSynchronize(bs));
+    stream_wait(bs);
     t_clock.lap(5);
     bool late_copy = false;
     for (int k = 0; k < n; k++) {
@@ -1524,7 +1524,7 @@ void enc_batch(Job *jobs, int n)
         }
     }
     if (late_copy) {
-        HIPCHK(hipStreamSynchronize(bs));
+        stream_wait(bs);
     }
     t_clock.lap(6);
     prof.collect();
@@ -1538,7 +1538,7 @@ void enc_batch(Job *jobs, int n)
             DSV_FRAME *orig = dsv_mk_frame(dv.format, dv.w, dv.h, 1), *rec = dsv_mk_frame(dv.format, dv.w, dv.h, 1);
             dframe_download_full(&cur.src, orig, bs);
             dframe_download_full(&cur.recon, rec, bs);
-            HIPCHK(hipStreamSynchronize(bs));
+            stream_wait(bs);
             jb.enc->frame_callback(&jb.enc->vidmeta, orig, rec);
             dsv_frame_ref_dec(orig);
             dsv_frame_ref_dec(rec);
