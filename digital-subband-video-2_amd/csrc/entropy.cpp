@@ -223,55 +223,50 @@ int RleReader::get()
     return nz == 0;
 }
 
-// MSB-first bit accumulator over a zero-filled buffer: same bytes as BitWriter, without touching memory per code
+// MSB-first bit accumulator over a zero-filled buffer with >= 8 bytes of slack: same bytes as BitWriter, without a
+// memory read-modify-write per code and without a data-dependent branch per code.  The pending bits sit left-aligned
+// in `acc`; every put stores the whole 8-byte window at the write pointer and advances by the completed bytes.
 struct AccWriter {
     uint8_t *p;
     uint64_t acc = 0;
-    unsigned n = 0; // pending bits, in the low end of acc (< 32 between calls)
+    unsigned n = 0; // pending bits (< 8 between calls)
     explicit AccWriter(uint8_t *at) : p(at) {}
-    inline void put(unsigned nb, unsigned v) // nb <= 32, v < 2^nb
+    inline void put(unsigned len, uint64_t code) // 1 <= len <= 56, code < 2^len
     {
-        acc = (acc << nb) | v;
-        n += nb;
-        if (n >= 32) {
-            n -= 32;
-            uint32_t w = __builtin_bswap32((uint32_t) (acc >> n));
-            memcpy(p, &w, 4);
-            p += 4;
-        }
+        acc |= code << (64 - n - len);
+        n += len;
+        uint64_t be = __builtin_bswap64(acc);
+        memcpy(p, &be, 8);
+        p += n >> 3;
+        acc <<= n & ~7u;
+        n &= 7;
     }
     inline void zeros(unsigned q)
     {
-        while (q > 32) {
-            put(32, 0);
-            q -= 32;
+        while (q > 56) {
+            put(56, 0);
+            q -= 56;
         }
-        put(q, 0);
-    }
-    inline void ueg(unsigned v) // bs.c:132, see BitWriter::put_ueg
-    {
-        v++;
-        int nb = 31 - __builtin_clz(v);
-        unsigned low = v & ((1u << nb) - 1);
-        if (nb <= 15) {
-            put((unsigned) (2 * nb + 1), (spread16(low) << 1) | 1u);
-            return;
+        if (q) {
+            put(q, 0);
         }
-        put((unsigned) (2 * (nb - 15)), spread16(low >> 15));
-        put(31, (spread16(low & 0x7fffu) << 1) | 1u);
     }
-    inline uint8_t *finish() // pads with zero bits to the next byte boundary
-    {
-        if (n) {
-            uint32_t w = __builtin_bswap32((uint32_t) ((acc & ((1ull << n) - 1)) << (32 - n)));
-            unsigned bytes = (n + 7) / 8;
-            memcpy(p, &w, bytes);
-            p += bytes;
-            n = 0;
-        }
-        return p;
-    }
+    inline uint8_t *finish() { return p + (n ? 1 : 0); } // the partial byte is already in place, zero padded
 };
+
+// interleaved exp-Golomb code of v (bs.c:132) as (bits, length); length <= 63
+static inline void ueg_code(unsigned v, uint64_t &code, unsigned &len)
+{
+    v++;
+    int nb = 31 - __builtin_clz(v);
+    unsigned low = v & ((1u << nb) - 1);
+    len = (unsigned) (2 * nb + 1);
+    if (__builtin_expect(nb <= 15, 1)) {
+        code = ((uint64_t) spread16(low) << 1) | 1u;
+    } else {
+        code = ((uint64_t) spread16(low >> 15) << 31) | ((uint64_t) spread16(low & 0x7fffu) << 1) | 1u;
+    }
+}
 
 void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const int32_t *val, int n, const ScanGeom &g)
 {
@@ -295,33 +290,45 @@ void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const 
             while (p >= (uint32_t) g.base[seg + 1]) {
                 seg++;
             }
-            aw.ueg(p - prev_end);
+            uint64_t rc, vc;
+            unsigned rl, vl;
+            ueg_code(p - prev_end, rc, rl);
+            prev_end = p + 1;
             int v = val[i];
+            unsigned lead = 0; // zero bits in front of the value code
             if (seg == 0) { // NEG (bs.c:206)
                 unsigned a = (unsigned) (v < 0 ? -v : v);
-                aw.ueg(a - 1);
+                ueg_code(a - 1, vc, vl);
                 if (a) {
-                    aw.put(1, v < 0);
+                    vc = (vc << 1) | (unsigned) (v < 0);
+                    vl++;
                 }
             } else { // adaptive Rice (bs.c:237)
                 int damp = 3 + (seg - 1) / 3;
                 unsigned u = ((unsigned) (2 * v) ^ (v < 0 ? ~0u : 0u)) - 1;
-                unsigned k = (unsigned) (vk >> damp), qq = u >> k;
-                if (qq) {
-                    vk++;
-                } else if (vk > 0) {
-                    vk--;
-                }
-                aw.zeros(qq);
-                if (k < 32) {
-                    aw.put(k + 1, (1u << k) | (u & ((1u << k) - 1)));
+                unsigned k = (unsigned) (vk >> damp);
+                lead = k < 32 ? u >> k : 0;
+                vk += lead ? 1 : (vk > 0 ? -1 : 0);
+                vc = (1ull << k) | (k < 32 ? (u & ((1u << k) - 1)) : u);
+                vl = k + 1;
+            }
+            if (__builtin_expect(rl + lead + vl <= 56, 1)) {
+                aw.put(rl + lead + vl, (rc << (lead + vl)) | vc); // run code, `lead` zeros, value code: one store
+            } else {
+                if (rl > 56) {
+                    aw.put(rl - 32, rc >> 32);
+                    aw.put(32, rc & 0xffffffffu);
                 } else {
-                    aw.put(1, 1);
-                    aw.put(32, u);
-                    aw.put(k - 32, 0);
+                    aw.put(rl, rc);
+                }
+                aw.zeros(lead);
+                if (vl > 56) {
+                    aw.put(vl - 32, vc >> 32);
+                    aw.put(32, vc & 0xffffffffu);
+                } else {
+                    aw.put(vl, vc);
                 }
             }
-            prev_end = p + 1;
         }
         bw.pos = (unsigned) (aw.finish() - bw.start) * 8;
     } else {
