@@ -254,9 +254,30 @@ struct AccWriter {
     inline uint8_t *finish() { return p + (n ? 1 : 0); } // the partial byte is already in place, zero padded
 };
 
+// codes of the small values, which are nearly all of them: entry v = (code << 8) | length
+struct UegTable {
+    uint32_t e[256];
+    UegTable()
+    {
+        for (unsigned v = 0; v < 256; v++) {
+            unsigned x = v + 1;
+            int nb = 31 - __builtin_clz(x);
+            unsigned low = x & ((1u << nb) - 1);
+            e[v] = (((spread16(low) << 1) | 1u) << 8) | (unsigned) (2 * nb + 1);
+        }
+    }
+};
+static const UegTable g_ueg;
+
 // interleaved exp-Golomb code of v (bs.c:132) as (bits, length); length <= 63
 static inline void ueg_code(unsigned v, uint64_t &code, unsigned &len)
 {
+    if (__builtin_expect(v < 256, 1)) {
+        uint32_t e = g_ueg.e[v];
+        code = e >> 8;
+        len = e & 0xffu;
+        return;
+    }
     v++;
     int nb = 31 - __builtin_clz(v);
     unsigned low = v & ((1u << nb) - 1);
@@ -285,10 +306,16 @@ void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const 
         // the symbol loop proper: codes are gathered in a register and leave it 32 bits at a time (the generic writer
         // read-modify-writes memory twice per symbol); starts and ends on a byte boundary like the code below
         AccWriter aw(bw.start + (bw.pos >> 3));
+        uint32_t seg_end = (uint32_t) g.base[1];
+        int damp = 3;
         for (int i = 0; i < n; i++) {
             uint32_t p = pos[i];
-            while (p >= (uint32_t) g.base[seg + 1]) {
-                seg++;
+            if (__builtin_expect(p >= seg_end, 0)) {
+                while (p >= (uint32_t) g.base[seg + 1]) {
+                    seg++;
+                }
+                seg_end = (uint32_t) g.base[seg + 1];
+                damp = 3 + (seg - 1) / 3;
             }
             uint64_t rc, vc;
             unsigned rl, vl;
@@ -304,7 +331,6 @@ void entropy_encode_plane(BitWriter &bw, int32_t LL, const uint32_t *pos, const 
                     vl++;
                 }
             } else { // adaptive Rice (bs.c:237)
-                int damp = 3 + (seg - 1) / 3;
                 unsigned u = ((unsigned) (2 * v) ^ (v < 0 ? ~0u : 0u)) - 1;
                 unsigned k = (unsigned) (vk >> damp);
                 lead = k < 32 ? u >> k : 0;
