@@ -238,7 +238,7 @@ struct __attribute__((packed)) U32u {
 };
 
 struct WaveLds {
-    uint8_t win[35 * 36];
+    alignas(4) uint8_t win[35 * 36];
     int16_t hz[35 * 32];
 };
 
@@ -325,10 +325,30 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
             soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
             soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
             const int ww = bw + 3, wh = bh + 3;
+            // the (bw+3) x (bh+3) window as row dwords, all loads of a lane issued before the first is used (a load in
+            // a loop body is followed by its wait: one memory round trip per iteration)
+            typedef const __attribute__((address_space(1))) uint8_t *gb_t;
+            typedef const __attribute__((address_space(1))) U32u *gu32_t;
+            const int ndw = (ww + 3) >> 2, total = wh * ndw;
+            gb_t gbase = (gb_t) rbase;
+            uint32_t *win32 = (uint32_t *) L.win;
             wave_lds_sync(); // the previous block's readers are done
-            for (int idx = lane; idx < ww * wh; idx += 64) {
-                int r = idx / ww, cc = idx % ww;
-                L.win[r * 36 + cc] = rbase[(ptrdiff_t) r * rp.stride + cc];
+            if (total <= 128) { // 16-pixel blocks: 19 rows of 5 dwords
+                const int k0 = lane, k1 = lane + 64 < total ? lane + 64 : 0;
+                const int r0 = k0 / ndw, c0 = k0 % ndw, r1 = k1 / ndw, c1 = k1 % ndw;
+                uint32_t d0 = ((gu32_t) (gbase + (ptrdiff_t) r0 * rp.stride + 4 * c0))->v;
+                uint32_t d1 = ((gu32_t) (gbase + (ptrdiff_t) r1 * rp.stride + 4 * c1))->v;
+                if (k0 < total) {
+                    win32[r0 * 9 + c0] = d0;
+                }
+                if (lane + 64 < total) {
+                    win32[r1 * 9 + c1] = d1;
+                }
+            } else {
+                for (int idx = lane; idx < total; idx += 64) {
+                    int r = idx / ndw, cc = idx % ndw;
+                    win32[r * 9 + cc] = ((gu32_t) (gbase + (ptrdiff_t) r * rp.stride + 4 * cc))->v;
+                }
             }
             wave_lds_sync();
             for (int idx = lane; idx < wh * bw; idx += 64) {
@@ -350,12 +370,17 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
             af = 1 << (sf - 1);
         }
         const bool noxmit = c == 0 ? (flags & (1u << DSV_MV_BIT_NOXMITY)) : (flags & (1u << DSV_MV_BIT_NOXMITC));
+        typedef const __attribute__((address_space(1))) uint8_t *gbr_t;
+        typedef const __attribute__((address_space(1))) U32u *gur_t;
+        typedef __attribute__((address_space(1))) uint32_t *gw32_t;
         for (int g = lane; g < ngroups; g += 64) {
             int m = (g % gw) * 4, n = g / gw;
-            const uint8_t *r = rbase + (ptrdiff_t) n * rp.stride + m;
+            gbr_t r = (gbr_t) rbase + (ptrdiff_t) n * rp.stride + m;
+            // every load of the group up front (explicit global accesses), so that they share one round trip
+            const uint32_t sv4 = *(gw32_t) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
             int pv[4];
             if (intra) {
-                uint32_t v = ((const U32u *) r)->v;
+                uint32_t v = ((gur_t) r)->v;
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {
                     int k = ((m + k4) >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
@@ -369,23 +394,25 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
                     pv[k4] = clamp_u8(qp_blend(hp_tap(t[0], t[32], t[64], t[96], soft_y), t[32], t[64], fy));
                 }
             } else if (chroma_frac) {
-                const uint8_t *r2 = r + rp.stride;
-                int a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
-                int b0 = r2[0], b1 = r2[1], b2 = r2[2], b3 = r2[3], b4 = r2[4];
+                gbr_t r2 = r + rp.stride;
+                const uint32_t va = ((gur_t) r)->v, vb = ((gur_t) r2)->v; // five pixels of two rows: a dword and a byte each
+                const int a4 = r[4], b4 = r2[4];
+                int a0 = va & 0xff, a1 = (va >> 8) & 0xff, a2 = (va >> 16) & 0xff, a3 = va >> 24;
+                int b0 = vb & 0xff, b1 = (vb >> 8) & 0xff, b2 = (vb >> 16) & 0xff, b3 = vb >> 24;
                 pv[0] = ((f0 * a0 + f1 * a1 + f2 * b0 + f3 * b1 + af) >> sf) & 0xff;
                 pv[1] = ((f0 * a1 + f1 * a2 + f2 * b1 + f3 * b2 + af) >> sf) & 0xff;
                 pv[2] = ((f0 * a2 + f1 * a3 + f2 * b2 + f3 * b3 + af) >> sf) & 0xff;
                 pv[3] = ((f0 * a3 + f1 * a4 + f2 * b3 + f3 * b4 + af) >> sf) & 0xff;
             } else {
-                uint32_t v = ((const U32u *) r)->v;
+                uint32_t v = ((gur_t) r)->v;
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {
                     pv[k4] = (int) ((v >> (8 * k4)) & 0xff);
                 }
             }
-            uint32_t *dpx = (uint32_t *) (dp.data + (ptrdiff_t) (y + n) * dp.stride + (x + m));
-            uint32_t *spx = (uint32_t *) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
-            uint32_t sv4 = *spx, out = 0;
+            gw32_t dpx = (gw32_t) (dp.data + (ptrdiff_t) (y + n) * dp.stride + (x + m));
+            gw32_t spx = (gw32_t) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
+            uint32_t out = 0;
 #pragma unroll
             for (int k4 = 0; k4 < 4; k4++) {
                 int s1 = (int) ((sv4 >> (8 * k4)) & 0xff), o;
