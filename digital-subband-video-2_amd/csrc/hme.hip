@@ -100,16 +100,18 @@ __device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
     c.skip_block_thresh = uni(d.skip_block_thresh);
     c.pyr_levels = uni(d.pyr_levels);
     c.psyscale = uni(d.psyscale);
+    // the source, reference and original-reference pyramids have one geometry per level, and so have the four
+    // chroma planes (hme_run_batch checks it): only the data pointers differ, the rest shares scalar registers
     c.src.lvl = uni(d.src[level]);
-    c.ref.lvl = uni(d.ref[level]);
-    c.ogr.lvl = uni(d.ogr[level]);
+    c.ref.lvl = DPlane{uni_ptr(d.ref[level].data), c.src.lvl.stride, c.src.lvl.w, c.src.lvl.h};
+    c.ogr.lvl = DPlane{uni_ptr(d.ogr[level].data), c.src.lvl.stride, c.src.lvl.w, c.src.lvl.h};
     c.src.zero = uni(d.src[0]);
-    c.ref.zero = uni(d.ref[0]);
-    c.ogr.zero = uni(d.ogr[0]);
+    c.ref.zero = DPlane{uni_ptr(d.ref[0].data), c.src.zero.stride, c.src.zero.w, c.src.zero.h};
+    c.ogr.zero = DPlane{uni_ptr(d.ogr[0].data), c.src.zero.stride, c.src.zero.w, c.src.zero.h};
     c.srcc.p0 = uni(d.srcc[0]);
-    c.srcc.p1 = uni(d.srcc[1]);
-    c.refc.p0 = uni(d.refc[0]);
-    c.refc.p1 = uni(d.refc[1]);
+    c.srcc.p1 = DPlane{uni_ptr(d.srcc[1].data), c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
+    c.refc.p0 = DPlane{uni_ptr(d.refc[0].data), c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
+    c.refc.p1 = DPlane{uni_ptr(d.refc[1].data), c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
     c.mvf.cur = uni_ptr(d.mvf[level]);
     c.mvf.parent = level < d.pyr_levels ? uni_ptr(d.mvf[level + 1]) : nullptr;
     c.mvf.level = level;
@@ -1302,6 +1304,19 @@ HME_ROWS_B(4)
 static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 4;
 static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 3;
 
+// make_ctx() keeps ONE geometry per level for the source / reference / original-reference luma planes and one for
+// the four chroma planes; frames made by dframe_alloc() always satisfy this, anything else takes the general routine
+static bool same_geom(const DPlane &a, const DPlane &b) { return a.stride == b.stride && a.w == b.w && a.h == b.h; }
+static bool uniform_geometry(const HmeFrames &f, int pyr_levels)
+{
+    for (int l = 0; l <= pyr_levels; l++) {
+        if (!same_geom(f.src[l], f.ref[l]) || !same_geom(f.src[l], f.ogr[l])) {
+            return false;
+        }
+    }
+    return same_geom(f.srcc[0], f.srcc[1]) && same_geom(f.srcc[0], f.refc[0]) && same_geom(f.srcc[0], f.refc[1]);
+}
+
 // host mirror of fast_path_ok() over a whole level
 static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level)
 {
@@ -1478,6 +1493,12 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     const HmeDev *tab = (const HmeDev *) d_table;
     const HmeParams &g = hp[0];
     int nlaunch = 0;
+    int fast = g_hme_fast;
+    for (int k = 0; k < n; k++) {
+        if (!uniform_geometry(f[k], g.pyr_levels)) {
+            fast &= ~1;
+        }
+    }
     int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
     if (g_hme_rows) { // one clear for all levels; each level's last row then re-arms the hand-off words itself
         DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n, g.pyr_levels + 1), dim3(256), 0, s, tab, -1, nwords, 1);
@@ -1490,11 +1511,11 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         }
         if (g_hme_rows) {
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
-            if ((g_hme_fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
+            if ((fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
                 int w = g_hme_waves_fast;
                 kern = w >= 4 ? k_hme_rows_b_fast_w4 : w == 3 ? k_hme_rows_b_fast_w3 : w == 2 ? k_hme_rows_b_fast_w2 : k_hme_rows_b_fast_w1;
             }
-            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
+            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
             for (int t = 0; t <= nbx + nby - 2; t++) {
@@ -1547,7 +1568,7 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
         int nbx = (hp.a.nbh + step - 1) / step, nby = (hp.a.nbv + step - 1) / step;
         HIPCHK(hipMemsetAsync(f.mvf[level], 0, nb * sizeof(DSV_MV), s));
         if (g_hme_rows) {
-            DSV2_LAUNCH(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, (g_hme_fast & 1) | (g_hme_fence << 1));
+            DSV2_LAUNCH(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, ((uniform_geometry(f, hp.pyr_levels) ? g_hme_fast : 0) & 1) | (g_hme_fence << 1));
             nlaunch++;
         } else {
             for (int t = 0; t <= nbx + nby - 2; t++) {
