@@ -1283,7 +1283,12 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
     }
 }
 
-// occupancy variants (waves per SIMD) of the batched kernel; DSV2_HME_WAVES picks one
+// occupancy variants of the batched kernel: amdgpu_waves_per_eu(W, W) both budgets the registers and CAPS the
+// wavefronts of this kernel per SIMD at W (the register allocation is padded accordingly).  The cap matters when
+// several lockstep groups share the GPU: the search is latency-bound and long-lived, and whatever register file it
+// does not hold is where the other groups' streaming kernels run meanwhile.  Measured at 384 streams in 4 groups
+// (fast-path kernel, 121 VGPRs): W = 1: 4 440, W = 2: 4 990, W = 3: 4 690, W = 4: 4 380 frames/s -- although
+// one group alone is fastest at W = 3 or 4.  DSV2_HME_WAVES / DSV2_HME_WAVES_FAST pick the variants.
 #define HME_ROWS_B(W)                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_w##W(                  \
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
@@ -1301,8 +1306,8 @@ HME_ROWS_B(1)
 HME_ROWS_B(2)
 HME_ROWS_B(3)
 HME_ROWS_B(4)
-static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 4;
-static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 3;
+static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 2;
+static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
 
 // make_ctx() keeps ONE geometry per level for the source / reference / original-reference luma planes and one for
 // the four chroma planes; frames made by dframe_alloc() always satisfy this, anything else takes the general routine

@@ -398,6 +398,8 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
     isrc = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - dc) << (psy.avg_weight + 1));
 }
 
+constexpr bool kPrefetchSubpelFirst = false; // (measured: no gain once the loads of a phase were batched; costs 12 VGPRs) the first search's loads are issued ahead of candidate scoring (hme_block_fast_t)
+
 // everything a sub-pel search reads from memory: the four neighbouring full-pel blocks, the centred source
 // window and the 20x20 reference window -- twelve loads, one round trip; issued by the search itself or, for
 // the first search (around the parent average, known long before it runs), ahead of candidate scoring
@@ -571,7 +573,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     unsigned best_fp = best;
     if (c.effort >= 4) {
         if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
-            best = subpixel_me_fast<false>(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
+            best = subpixel_me_fast<kPrefetchSubpelFirst>(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
             if (sx || sy) {
                 fpelx = lax;
                 fpely = lay;
@@ -1147,7 +1149,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     // loads of the first sub-pel search (around the parent average; hme_block_fast_l0 runs it under this same
     // condition): in flight from here on, under candidate scoring and refinement
     SubpelLoads sp_pre;
-    constexpr bool kPrefetchSubpel = false; // costs ~14 VGPRs: see DESIGN 5.2 (register footprint vs co-resident kernels)
+    constexpr bool kPrefetchSubpel = kPrefetchSubpelFirst; // costs ~14 VGPRs: see DESIGN 5.2 (register footprint vs co-resident kernels)
     if (kPrefetchSubpel && level == 0 && c.effort >= 4 && !invalid_block(ref, bx + lax, by + lay, bw, bh, 4)) {
         sp_pre = subpel_issue_loads(c, lax, lay, bx, by, bw, bh, qi, qj, act);
     }
