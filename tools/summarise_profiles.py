@@ -62,7 +62,7 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
         nl += len(fv)
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
     f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
-json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_w3", "streams_per_gpu": traced["config"]["streams_per_gpu"],
+json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
            "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
