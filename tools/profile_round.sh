@@ -21,5 +21,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
     cp $out/pmc_$c/*/*_counter_collection.csv $out/pmc_$c.csv
     rm -rf $out/pmc_$c
 done
-python3 tools/bench_decode.py --streams 256 --groups 1 > $out/decode.json 2> $out/decode.err
+python3 tools/bench_decode.py --streams 256 --groups 4 > $out/decode.json 2> $out/decode.err
 ls -la $out
