@@ -1308,6 +1308,7 @@ HME_ROWS_B(3)
 HME_ROWS_B(4)
 static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 2;
 static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
+static int g_hme_waves_fast_lx = getenv("DSV2_HME_WAVES_FAST_LX") ? atoi(getenv("DSV2_HME_WAVES_FAST_LX")) : g_hme_waves_fast; // levels > 0
 
 // make_ctx() keeps ONE geometry per level for the source / reference / original-reference luma planes and one for
 // the four chroma planes; frames made by dframe_alloc() always satisfy this, anything else takes the general routine
@@ -1517,7 +1518,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         if (g_hme_rows) {
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
             if ((fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
-                int w = g_hme_waves_fast;
+                int w = level == 0 ? g_hme_waves_fast : g_hme_waves_fast_lx;
                 kern = w >= 4 ? k_hme_rows_b_fast_w4 : w == 3 ? k_hme_rows_b_fast_w3 : w == 2 ? k_hme_rows_b_fast_w2 : k_hme_rows_b_fast_w1;
             }
             DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1));
