@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(const DSV_MV *__restrict__ 
 __device__ __forceinline__ bool smooth6(int e2, int e1, int e0, int i0, int i1, int i2, int t, int o[4])
 {
     int avg = (5 * (e0 + i0) + 3 * (e1 + i1) + 8) >> 4;
-    bool ok = (abs(e0 - avg) < t) & (abs(i0 - avg) < t) & (abs(e1 - avg) < t) & (abs(i1 - avg) < t) & (abs(e2 - avg) < t) &
-              (abs(i2 - avg) < t);
+    bool ok = ((int) (abs(e0 - avg) < t) & (int) (abs(i0 - avg) < t) & (int) (abs(e1 - avg) < t) & (int) (abs(i1 - avg) < t) &
+               (int) (abs(e2 - avg) < t) & (int) (abs(i2 - avg) < t)) != 0; // bitwise on purpose: no short-circuit branches
     int a5 = avg * 5;
     o[0] = (3 * (avg + e1) + 2 * e2 + 4) >> 3;
     o[1] = (a5 + 2 * e1 + e2 + 4) >> 3;

@@ -103,6 +103,8 @@ struct PlaneJob {
     int q;             // frame quantiser
     int qll;           // LL step size
     int qp[3][3];      // detail step sizes [level][subband - 1]
+    int *tile_count;   // quantiser: per-1024-position nonzero counts of the stream's symbol list, or null (counted later)
+    unsigned qv_base;  // scan position of this plane's first value within that list
 };
 
 // --- subband transform (sbt.hip) ------------------------------------------------

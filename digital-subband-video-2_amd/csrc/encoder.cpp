@@ -1170,6 +1170,9 @@ struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, 
 };
 thread_local PhaseClock t_clock;
 
+// the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
+static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV2_FUSED_COUNT")) == 0);
+
 void enc_batch(Job *jobs, int n)
 {
     bind_device();
@@ -1434,6 +1437,8 @@ void enc_batch(Job *jobs, int n)
             }
             pj.bd = d_bd;
             pj.qv = dv.qv + dv.qv_off[c];
+            pj.tile_count = kFusedCount ? dv.comp.tile_count : nullptr;
+            pj.qv_base = (unsigned) dv.qv_off[c];
             pj.mvs = cur.d_final_mvs;
             quant_steps(&pj, dv.quant_cfg(c, p->has_ref, p->lossless, p->do_psy, nullptr), jb.d.quant);
         }
@@ -1484,7 +1489,7 @@ void enc_batch(Job *jobs, int n)
         quant_jobs(bs, d_py + sl.first, sl.count, dv0.quant_cfg(0, sl.isP, sl.lossless, do_psy, nullptr));
         quant_jobs(bs, d_pc + 2 * sl.first, 2 * sl.count, dv0.quant_cfg(1, sl.isP, sl.lossless, do_psy, nullptr));
     }
-    compact_jobs(bs, d_comp, n, dv0.qv_off[3]);
+    compact_jobs(bs, d_comp, n, dv0.qv_off[3], kFusedCount);
     HIPCHK(hipMemcpyAsync(sc.h_totals, sc.d_totals, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, bs));
     prof.end(bs, ST_QUANT, n);
     prof.begin(bs, ST_INV_SBT);

@@ -562,7 +562,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
 {
     const int lane = threadIdx.x & 63;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
-    const DPlane &src = c.src[0], &ref0 = c.ref[0];
+    const DPlane &ref0 = c.ref[0];
     const int qw = bw >> 1, qh = bh >> 1;
     int fpelx = mv.u.mv.x, fpely = mv.u.mv.y, sx = 0, sy = 0;
     bool found_sub = false;

@@ -55,7 +55,7 @@ struct Compactor {
     CompactJob job(const int32_t *qv, size_t n); // this compactor's buffers as a table entry
 };
 // njobs compactions of n values each in one set of launches; each job's count lands in *job.total
-void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n);
+void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n, bool counted = false);
 
 // decoder: scatter + dequantise symbols sorted by scan position into a ZEROED coefficient plane;
 // seg_count = {LL, l0, l1, l2}; LL = the separately transmitted DC, stored to coefs[0]

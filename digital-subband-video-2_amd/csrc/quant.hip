@@ -236,6 +236,28 @@ __device__ __forceinline__ int quant_detail(const QuantCfg &c, const DSV_MV *mvs
 // Kernels work through PlaneJob records (dev.h): tab == nullptr runs the single job `one`,
 // otherwise a grid dimension indexes a device table whose entries share the geometry in `c`.
 
+// Nonzero bookkeeping for the compaction that follows (saves it a pass over the dense values): the wavefront's
+// nonzeros are tallied per 1024-position tile of the stream's symbol list; a wavefront writes consecutive scan
+// positions, so one atomic per wavefront is the rule and a tile boundary inside it the exception.
+__device__ __forceinline__ void count_nonzero(const PlaneJob &J, size_t pos, int v)
+{
+    if (J.tile_count == nullptr) {
+        return;
+    }
+    const bool nz = v != 0;
+    const unsigned tile = (unsigned) ((J.qv_base + pos) >> 10);
+    const unsigned t0 = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
+    const unsigned long long same = __ballot(nz && tile == t0);
+    const unsigned long long active = __ballot(true);
+    const int lane = (int) (threadIdx.x + threadIdx.y * blockDim.x) & 63;
+    if (same && lane == __ffsll((long long) active) - 1) {
+        atomicAdd(&J.tile_count[t0], __popcll(same));
+    }
+    if (nz && tile != t0) {
+        atomicAdd(&J.tile_count[tile], 1);
+    }
+}
+
 // LL region: hzcc.c:308-328
 __global__ __launch_bounds__(256) void k_quant_ll(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, int sw, int sh)
 {
@@ -258,6 +280,7 @@ __global__ __launch_bounds__(256) void k_quant_ll(const PlaneJob *__restrict__ t
         }
     }
     J.qv[(size_t) y * sw + x] = v;
+    count_nonzero(J, (size_t) y * sw + x, v);
 }
 
 __device__ __forceinline__ void quant_cell(const PlaneJob &J, const QuantCfg &c, const LevelArgs &a, int si, int x, int y)
@@ -276,6 +299,7 @@ __device__ __forceinline__ void quant_cell(const PlaneJob &J, const QuantCfg &c,
         *cell = v ? dequant_D(v, (unsigned) tmq) : 0;
     }
     J.qv[a.base[si] + (size_t) y * a.sw + x] = v;
+    count_nonzero(J, a.base[si] + (size_t) y * a.sw + x, v);
 }
 
 __device__ __forceinline__ bool is_dependent(const LevelArgs &a, int s, int x, int y)
@@ -421,7 +445,7 @@ __global__ __launch_bounds__(256) void k_count(const CompactJob *__restrict__ ta
 }
 
 // exclusive scan of up to 1024*ntile_per_thread tile counts by one workgroup; also emits the total
-__global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restrict__ tab, CompactJob one)
+__global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restrict__ tab, CompactJob one, int reset)
 {
     __shared__ int wsum[16];
     const CompactJob &J = tab ? tab[blockIdx.y] : one;
@@ -437,6 +461,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restric
     for (int start = 0; start < ntiles; start += 1024) {
         int i = start + threadIdx.x;
         int v = i < ntiles ? tile_count[i] : 0;
+        if (reset && i < ntiles) {
+            J.tile_count[i] = 0; // the quantiser of the next frame accumulates into it
+        }
         int inc = wave_incl_scan(v, lane);
         if (lane == 63) {
             wsum[wv] = inc;
@@ -527,6 +554,7 @@ void Compactor::ensure(size_t n)
     release();
     size_t ntiles = (n + kTile - 1) / kTile;
     HIPCHK(hipMalloc((void **) &tile_count, ntiles * sizeof(int)));
+    dev_zero(tile_count, ntiles * sizeof(int));
     HIPCHK(hipMalloc((void **) &tile_base, ntiles * sizeof(int)));
     HIPCHK(hipMalloc((void **) &d_total, sizeof(int)));
     HIPCHK(hipMalloc((void **) &d_pos, n * sizeof(uint32_t)));
@@ -560,20 +588,22 @@ void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
     CompactJob one = job(qv, n);
     int ntiles = (int) ((n + kTile - 1) / kTile);
     DSV2_LAUNCH(k_count, dim3(ntiles), dim3(256), 0, s, nullptr, one);
-    DSV2_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, s, nullptr, one);
+    DSV2_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, s, nullptr, one, 1); // counts always left at zero
     DSV2_LAUNCH(k_scatter, dim3(ntiles), dim3(256), 0, s, nullptr, one);
     HIPCHK(hipMemcpyAsync(h_total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
 }
 
-void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n)
+void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n, bool counted)
 {
     if (njobs <= 0) {
         return;
     }
     int ntiles = (int) ((n + kTile - 1) / kTile);
-    DSV2_LAUNCH(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
-    DSV2_LAUNCH(k_scan_tiles, dim3(1, njobs), dim3(1024), 0, s, d_jobs, CompactJob{});
+    if (!counted) { // else the quantiser tallied the tiles while writing the values (count_nonzero)
+        DSV2_LAUNCH(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
+    }
+    DSV2_LAUNCH(k_scan_tiles, dim3(1, njobs), dim3(1024), 0, s, d_jobs, CompactJob{}, counted ? 1 : 0);
     DSV2_LAUNCH(k_scatter, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     HIPCHK(hipGetLastError());
 }
