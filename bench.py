@@ -78,7 +78,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     # host phases run on a worker pool inside the library: share the box's cores between the ranks
-    os.environ.setdefault("DSV2_HOST_THREADS", str(min(128, max(16, (os.cpu_count() or 16) // max(1, world)))))
+    os.environ.setdefault("DSV2_HOST_THREADS", str(min(48, max(16, (os.cpu_count() or 16) // max(1, world)))))
     local = int(os.environ.get("DSV2_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     dist = None
     if world > 1:

@@ -89,7 +89,7 @@ class WorkerPool {
     WorkerPool()
     {
         unsigned hw = std::thread::hardware_concurrency();
-        unsigned nthreads = hw ? (hw > 128 ? 128 : hw) : 8;
+        unsigned nthreads = hw ? (hw > 48 ? 48 : hw) : 8; // more only adds wake-ups: the per-stream tasks are short (measured 32 ... 128)
         if (const char *e = getenv("DSV2_HOST_THREADS")) {
             nthreads = (unsigned) atoi(e);
         }
