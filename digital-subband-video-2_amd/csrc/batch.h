@@ -91,7 +91,8 @@ class WorkerPool {
         unsigned hw = std::thread::hardware_concurrency();
         unsigned nthreads = hw ? (hw > 48 ? 48 : hw) : 8; // more only adds wake-ups: the per-stream tasks are short (measured 32 ... 128)
         if (const char *e = getenv("DSV2_HOST_THREADS")) {
-            nthreads = (unsigned) atoi(e);
+            int v = atoi(e);
+            nthreads = (unsigned) (v < 1 ? 1 : (v > 256 ? 256 : v)); // 1 = the calling thread does all the work
         }
         for (unsigned i = 0; i + 1 < nthreads; i++) {
             std::thread([this] { loop(); }).detach();

@@ -116,9 +116,13 @@ BitReader take_sub(BitReader &br, const uint8_t *base)
     br.align();
     unsigned len = br.get_ueg();
     br.align();
+    if (br.pos > br.limit) {
+        br.seek(br.pos);
+    }
     BitReader sub{base + br.byte_pos(), 0};
     sub.wide = br.wide;
-    br.pos += len * 8;
+    sub.limit = br.limit - br.pos; // a sub-stream may be read up to the end of the packet, as in the reference
+    br.seek((uint64_t) br.pos + (uint64_t) len * 8);
     return sub;
 }
 
@@ -283,11 +287,16 @@ void dec_parse(DecJob &jb)
     *jb.fn = (DSV_FNUM) -1;
     // parse from a private copy with zeroed slack behind it, so that codes can be read through a 64-bit window
     static thread_local std::vector<uint8_t> copy;
+    if (buffer->len > (1u << 28)) { // (bit positions are 32-bit)
+        jb.ret = DSV_DEC_ERROR;
+        return;
+    }
     copy.assign(buffer->data, buffer->data + buffer->len);
-    copy.resize((size_t) buffer->len + 16, 0);
+    copy.resize((size_t) buffer->len + 64, 0);
     const uint8_t *pkt = copy.data();
     BitReader br{pkt, 0};
     br.wide = true;
+    br.limit = (buffer->len + 8) * 8; // reads stop here; the copy is zero for 56 more bytes (see BitReader)
     int type = read_packet_hdr(br);
     if (type == -1) {
         jb.ret = DSV_DEC_ERROR;
@@ -319,6 +328,18 @@ void dec_parse(DecJob &jb)
     if (blk_w < 16 || blk_h < 16 || blk_w > 32 || blk_h > 32) {
         jb.ret = DSV_DEC_ERROR;
         return;
+    }
+    // the metadata is untrusted: only geometries the device pipeline can allocate and run are accepted (the reference
+    // would pass anything on to calloc); a hostile packet must come back as an error, not take the process down
+    {
+        const int ss = meta->subsamp;
+        const bool known = ss == DSV_SUBSAMP_444 || ss == DSV_SUBSAMP_422 || ss == DSV_SUBSAMP_420 || ss == DSV_SUBSAMP_411 ||
+                           ss == DSV_SUBSAMP_410 || ss == DSV_SUBSAMP_UYVY;
+        if (!known || meta->width < 16 || meta->height < 16 || meta->width > 16384 || meta->height > 16384 || (meta->width & 1) ||
+            (meta->height & 1)) {
+            jb.ret = DSV_DEC_ERROR;
+            return;
+        }
     }
     bind_device();
     DecImpl *im = (DecImpl *) d->ref;

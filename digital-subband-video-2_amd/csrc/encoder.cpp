@@ -39,6 +39,12 @@ struct EncImpl {
     bool have_ref = false; // pics[cur ^ 1] holds a usable reference
     std::vector<DSV_MV> mvs; // host copy of the current motion field
     std::vector<DSV_MV> intramv;
+    // pictures handed over in HOST memory (dsv2hip_enc_batch_host): two packed planar staging pictures in HBM;
+    // the one not being ingested receives the next step's upload on the group's copy stream meanwhile
+    uint8_t *d_stage[2] = {nullptr, nullptr};
+    int stage_cur = 0;
+    const void *staged_src = nullptr; // host picture whose upload into d_stage[stage_cur ^ 1] is in flight / done
+    hipEvent_t staged_ev = nullptr;   // ... and the event (of the uploading group) that marks its completion
 };
 
 inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -867,6 +873,8 @@ struct Job {
     EncImpl *im;
     DSV_FRAME *frame;          // host picture (dsv_enc) ...
     const uint8_t *dev_planar; // ... or packed planar picture already in HBM
+    const uint8_t *host_planar; // ... or packed planar picture in host memory, uploaded by the batch engine (pinned: asynchronously)
+    const uint8_t *host_next;   // the picture this stream will bring to the NEXT step: uploaded under this step's kernels
     DSV_BUF *bufs;
     int nbuf;
     FrameCtl d;
@@ -897,6 +905,16 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
     }
     int32_t *h_ll = nullptr, *d_ll = nullptr; // [3 * n] DC coefficients
     int *h_totals = nullptr, *d_totals = nullptr; // [n] symbol counts
+    // uploads of the NEXT step's host pictures run on a stream of their own, under this step's kernels
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    void ensure_copy_stream()
+    {
+        if (!copy_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&copy_done, hipEventDisableTiming));
+        }
+    }
     TableArena tabs;
     int cap = 0;
     void ensure(int n)
@@ -1007,7 +1025,9 @@ void phase_h1a(Job &jb)
     if (jb.ran_hme) {
         im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
         if (dv.h_counters[7]) {
-            fatal("motion estimation row pipeline timed out", __FILE__, __LINE__);
+            fatal(dv.h_counters[7] == 1 ? "motion estimation row pipeline timed out (a row waited > 4 s for the row above; DSV2_HME_ROWS=0 selects the launch-per-front form)"
+                                        : "motion estimation did not deliver its counters (search incomplete)",
+                  __FILE__, __LINE__);
         }
         int nintra = dv.h_counters[0], ndiff = dv.h_counters[1], eligible = dv.h_counters[2]; // hme.c:1825-1832, 2015
         unsigned total_err = (unsigned) dv.h_counters[3];
@@ -1223,6 +1243,56 @@ void enc_batch(Job *jobs, int n)
     const PlaneOutJob *d_small;
     PlaneOutJob *h_small = sc.tabs.take<PlaneOutJob>((size_t) n, &d_small);
     int n_ing = 0, n_pyr = 0, n_intra = 0;
+    {
+        // pictures that arrive in host memory: this step's either came up during the previous step (prefetched
+        // through host_next) or is uploaded now; the next step's goes up on the copy stream under this step's kernels
+        const DFrame &f0 = dv0.pics[0].src;
+        const size_t pbytes = (size_t) f0.p[0].w * f0.p[0].h + (size_t) f0.p[1].w * f0.p[1].h + (size_t) f0.p[2].w * f0.p[2].h;
+        hipEvent_t waited[4] = {nullptr, nullptr, nullptr, nullptr};
+        int nwaited = 0;
+        bool any_next = false;
+        for (int k = 0; k < n; k++) {
+            Job &jb = jobs[k];
+            EncImpl *im = jb.im;
+            if (!jb.host_planar) {
+                continue;
+            }
+            if (!im->d_stage[0]) {
+                HIPCHK(hipMalloc((void **) &im->d_stage[0], pbytes));
+                HIPCHK(hipMalloc((void **) &im->d_stage[1], pbytes));
+            }
+            if (im->staged_src == (const void *) jb.host_planar) {
+                im->stage_cur ^= 1;
+                bool seen = false;
+                for (int e = 0; e < nwaited; e++) {
+                    seen = seen || waited[e] == im->staged_ev;
+                }
+                if (!seen) {
+                    HIPCHK(hipStreamWaitEvent(bs, im->staged_ev, 0));
+                    if (nwaited < 4) {
+                        waited[nwaited++] = im->staged_ev;
+                    }
+                }
+            } else {
+                HIPCHK(hipMemcpyAsync(im->d_stage[im->stage_cur], jb.host_planar, pbytes, hipMemcpyHostToDevice, bs));
+            }
+            im->staged_src = nullptr;
+            jb.dev_planar = im->d_stage[im->stage_cur];
+        }
+        for (int k = 0; k < n; k++) {
+            Job &jb = jobs[k];
+            if (jb.host_planar && jb.host_next) {
+                sc.ensure_copy_stream();
+                HIPCHK(hipMemcpyAsync(jb.im->d_stage[jb.im->stage_cur ^ 1], jb.host_next, pbytes, hipMemcpyHostToDevice, sc.copy_stream));
+                jb.im->staged_src = jb.host_next;
+                jb.im->staged_ev = sc.copy_done;
+                any_next = true;
+            }
+        }
+        if (any_next) {
+            HIPCHK(hipEventRecord(sc.copy_done, sc.copy_stream));
+        }
+    }
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
@@ -1305,6 +1375,7 @@ void enc_batch(Job *jobs, int n)
             f.counters = dv.d_counters;
             f.host_mvs = dv.h_mvs; // the search itself delivers its results to the host
             f.host_counters = dv.h_counters;
+            dv.h_counters[7] = -1; // overwritten with 0 by the search's last row (1: a row timed out); -1 left = it never finished
             HmeParams h;
             h.a = analysis_params(dv, jb.d.params.do_psy);
             h.effort = jb.d.params.effort;
@@ -1618,6 +1689,13 @@ void dsv_enc_free(DSV_ENCODER *enc)
         if (im->ready) {
             im->dev.destroy();
         }
+        for (int i = 0; i < 2; i++) {
+            if (im->d_stage[i]) {
+                HIPCHK(hipDeviceSynchronize()); // an upload into it may still be in flight on a copy stream
+                HIPCHK(hipFree(im->d_stage[i]));
+                im->d_stage[i] = nullptr;
+            }
+        }
         delete im;
         enc->ref = NULL;
     }
@@ -1697,6 +1775,52 @@ int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, 
         nbufs[k] = jobs[(size_t) k].nbuf;
     }
     return 0;
+}
+
+/* the same with the pictures in HOST memory (packed planar Y, U, V).  host_planar[k]: stream k's picture of this
+ * step; host_next (may be NULL, entries may be NULL): the picture stream k will bring to the NEXT call -- it is
+ * uploaded on a copy stream while this step's kernels run, and the next call finds it in HBM when it passes the same
+ * pointer as host_planar[k] (the bytes must stay unchanged until then).  Memory from dsv2hip_host_alloc is pinned,
+ * which makes the uploads asynchronous; any other host memory works, synchronously. */
+int dsv2hip_enc_batch_host(int n, DSV_ENCODER **encs, const void *const *host_planar, const void *const *host_next, DSV_BUF *bufs, int *nbufs)
+{
+    if (n <= 0 || !encs || !host_planar || !bufs || !nbufs) {
+        return -1;
+    }
+    std::vector<Job> jobs((size_t) n);
+    for (int k = 0; k < n; k++) {
+        if (!host_planar[k]) {
+            return -1;
+        }
+        memset(&jobs[(size_t) k], 0, sizeof(Job));
+        jobs[(size_t) k].enc = encs[k];
+        jobs[(size_t) k].host_planar = (const uint8_t *) host_planar[k];
+        jobs[(size_t) k].host_next = host_next ? (const uint8_t *) host_next[k] : nullptr;
+        jobs[(size_t) k].bufs = bufs + 4 * k;
+    }
+    enc_batch(jobs.data(), n);
+    for (int k = 0; k < n; k++) {
+        nbufs[k] = jobs[(size_t) k].nbuf;
+    }
+    return 0;
+}
+
+/* pinned host memory for pictures handed to dsv2hip_enc_batch_host */
+void *dsv2hip_host_alloc(size_t bytes)
+{
+    bind_device();
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        return nullptr;
+    }
+    return p;
+}
+
+void dsv2hip_host_free(void *p)
+{
+    if (p) {
+        HIPCHK(hipHostFree(p));
+    }
 }
 
 } // extern "C"

@@ -112,6 +112,9 @@ static inline unsigned compress16(unsigned x)
 
 unsigned BitReader::get_bits(unsigned n)
 {
+    if (past_end()) {
+        return 0;
+    }
     if (wide && n <= 32) {
         unsigned out = n ? (unsigned) (window() >> (64 - n)) : 0u;
         pos += n;
@@ -119,6 +122,9 @@ unsigned BitReader::get_bits(unsigned n)
     }
     unsigned out = 0;
     while (n > 0) {
+        if (past_end()) {
+            return out << n;
+        }
         unsigned room = 8 - (pos & 7);
         unsigned take = n < room ? n : room;
         unsigned chunk = (start[pos >> 3] >> (room - take)) & ((1u << take) - 1);
@@ -131,6 +137,9 @@ unsigned BitReader::get_bits(unsigned n)
 
 unsigned BitReader::get_ueg()
 {
+    if (past_end()) {
+        return 0;
+    }
     if (wide) {
         // pairs (0, b) ... closed by a 1 in a pair-start position: find that 1 among the even offsets
         uint64_t w = window();
@@ -174,6 +183,12 @@ int BitReader::get_nrice(int *rk, int damp)
 {
     int k = *rk >> damp;
     unsigned qq = 0;
+    if (past_end()) {
+        return 0;
+    }
+    if (k > 31) {
+        k = 31; // (only reachable on damaged input: keeps the shifts below defined)
+    }
     if (wide) {
         uint64_t w = window() & 0xffffffffffffff00ull;
         if (w) { // the unary part ends inside the window
@@ -445,7 +460,7 @@ int entropy_decode_plane(BitReader &br, int32_t *LL, uint32_t *pos, int32_t *val
     } else {
         ok = 0;
     }
-    br.pos = (start + plen) * 8;
+    br.seek(((uint64_t) start + plen) * 8);
     return ok;
 }
 

@@ -1241,6 +1241,11 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
 #endif
     for (int bi = 0; bi < nbx; bi++) {
         if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
+            // the row above never got there (or another row gave up): tell the host directly -- the level's
+            // epilogue, which normally delivers the counters, will not run because this row does not arrive
+            if (c.host_counters && (threadIdx.x & 63) == 0) {
+                __hip_atomic_store(&c.host_counters[kHmeErrWord], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return;
         }
         HME_MARK(S, 0);

@@ -100,6 +100,28 @@ struct BitReader {
     const uint8_t *start;
     unsigned pos;
     bool wide = false; // >= 8 readable bytes behind every position that is read: codes are parsed from a 64-bit window
+    // Untrusted input: no code is parsed from a position at or beyond `limit` (bits) -- such reads return a value that
+    // ends every parsing loop and raise `overrun`.  A parse call advances by < 128 bits, so with the buffer readable
+    // (zero-filled) for 32 bytes past limit/8 no read leaves it.  The default (no limit) is for trusted buffers.
+    unsigned limit = 0xffffffffu;
+    bool overrun = false;
+    bool past_end()
+    {
+        if (pos >= limit) {
+            overrun = true;
+            return true;
+        }
+        return false;
+    }
+    // move to an absolute bit position taken from the stream (sub-stream and plane lengths): clamped to the limit
+    void seek(uint64_t bitpos)
+    {
+        if (bitpos > limit) {
+            overrun = true;
+            bitpos = limit;
+        }
+        pos = (unsigned) bitpos;
+    }
     // the next 57+ bits, left-aligned (wide mode only)
     uint64_t window() const
     {
@@ -111,6 +133,9 @@ struct BitReader {
     unsigned byte_pos() const { return pos >> 3; }
     unsigned get_bit()
     {
+        if (past_end()) {
+            return 1; // closes every unary / exp-Golomb loop
+        }
         unsigned b = (start[pos >> 3] >> (7 - (pos & 7))) & 1;
         pos++;
         return b;

@@ -372,6 +372,16 @@ int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *
  * kernels (motion-estimation fronts, MC, in-loop filters) are launched once for all streams.  bufs has
  * 4 slots per stream; nbufs[k] = packets of stream k.  Output is identical to n separate dsv_enc calls. */
 int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, DSV_BUF *bufs, int *nbufs);
+/* the same step with the pictures in HOST memory, as dsv_enc (dsv_encoder.c:1430) receives them: host_planar[k] is
+ * stream k's packed planar picture of this step.  host_next (NULL, or NULL entries, allowed) names the picture each
+ * stream will bring to the NEXT call: it is uploaded on a copy stream under this step's kernels, and the next call
+ * finds it in HBM when it passes the same pointer as host_planar[k] (the bytes must not change in between).  With
+ * pictures in pinned memory (dsv2hip_host_alloc) every upload is asynchronous.  This is the entry point bench.py
+ * times: the host-to-device transfer of every frame is inside the measured region. */
+int dsv2hip_enc_batch_host(int n, DSV_ENCODER **encs, const void *const *host_planar, const void *const *host_next,
+                           DSV_BUF *bufs, int *nbufs);
+void *dsv2hip_host_alloc(size_t bytes); /* pinned host memory (NULL on failure) */
+void dsv2hip_host_free(void *p);
 /* lockstep decode over n independent decoder instances: packet bufs[k] goes to decs[k]; ret[k], out[k]
  * and fn[k] are exactly what dsv_dec(decs[k], &bufs[k], &out[k], &fn[k]) would have produced (packets are
  * consumed the same way).  All pictures of a step run through one set of kernel launches. */
