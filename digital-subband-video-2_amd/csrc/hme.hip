@@ -425,6 +425,30 @@ __device__ __forceinline__ void build_hpel(SubpelLds &s, const HpelWin &w)
     __syncthreads();
 }
 
+// the same from a 20x20 area that already sits in LDS with row pitch PITCH (w = its first sample): the staged
+// search window is filtered in place, nothing is copied
+template <int PITCH> __device__ __forceinline__ void build_hpel_at(SubpelLds &s, const uint8_t *w)
+{
+    int lane = threadIdx.x & 63;
+    for (int idx = lane; idx < 289; idx += 64) {
+        int i = idx % 17, j = idx / 17;
+        const uint8_t *p = &w[(j + 1) * PITCH + (i + 1)];
+        int hz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *q = p + (k - 1) * PITCH;
+            hz[k] = HPF_ME(q[-1], q[0], q[1], q[2]);
+        }
+        int c = HPF_ME(hz[0], hz[1], hz[2], hz[3]);
+        uint8_t *o = &s.h[(2 * j) * 34 + 2 * i];
+        o[0] = p[0];
+        o[1] = clamp_u8((hz[1] + 4) >> 3);
+        o[34] = clamp_u8((HPF_ME(p[-PITCH], p[0], p[PITCH], p[2 * PITCH]) + 4) >> 3);
+        o[35] = clamp_u8((c + 32) >> 6);
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ int qsample_ph(const uint8_t *h, int X, int Y, int phase)
 {
     const uint8_t *p = h + (Y >> 1) * 34 + (X >> 1);
@@ -1128,7 +1152,8 @@ __global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, in
     int gx = c.counters[4], gy = c.counters[5];
     int i = bi << level, j = bj << level;
     if (allow_fast && fast_path_ok(c, level, i, j)) {
-        hme_block_fast(c, level, i, j, gx, gy, S);
+        int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
+        hme_block_fast(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
         hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
     }
@@ -1148,7 +1173,8 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
     int gx = c.counters[4], gy = c.counters[5];
     int i = bi << level, j = bj << level;
     if (allow_fast && fast_path_ok(c, level, i, j)) {
-        hme_block_fast(c, level, i, j, gx, gy, S);
+        int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
+        hme_block_fast(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
         hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
     }
@@ -1239,6 +1265,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         S.prof_t = __builtin_amdgcn_s_memtime();
     }
 #endif
+    int pcx = 0, pcy = 0; // where the previous block of this row ended up: centre of the next block's LDS windows
     for (int bi = 0; bi < nbx; bi++) {
         if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
             // the row above never got there (or another row gave up): tell the host directly -- the level's
@@ -1256,9 +1283,10 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
         if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast(x, level, i, j, gx, gy, S);
+            hme_block_fast(x, level, i, j, gx, gy, S, pcx, pcy);
         } else {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
+            pcx = pcy = 0;
         }
         if (allow_fast & 4) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -200,10 +200,88 @@ __device__ __forceinline__ unsigned div_nn(unsigned n, unsigned d)
     return n / d;
 }
 
+// ---- search windows staged in LDS ------------------------------------------------------------------
+// Every block starts with ONE round of memory traffic: its source quads, its neighbours' vectors and -- by
+// LDS-DMA (global_load_lds: no registers, the data lands in LDS while the source analysis runs) -- the part of
+// the reference picture the search is going to look at: a 48x48 luma window centred on where the block to the
+// left ended up, and at level 0 a 28x28 window of the original reference and two 16x16 chroma windows for the
+// mode decision.  Candidate scoring, every refinement round, the sub-pel search (whose 20x20 filter window and
+// four neighbour blocks are read in place) and the mode-decision operands then come out of LDS (~100 clocks)
+// instead of L2 / HBM (~2 500 clocks under load per dependent round, five to seven rounds per block before).
+// A vector that leaves the window -- a wave-uniform test per phase -- takes that phase's original global path.
+// Window rows are stored as loaded: whole dwords starting at the dword that holds the window's first pixel.
+constexpr int kWinW = 48, kWinH = 48, kWinPitch = 52, kWinMargin = 16; // luma reference window, 13 dwords a row
+constexpr int kOgrW = 28, kOgrPitch = 32, kOgrMargin = 6;               // original-reference window (level 0)
+constexpr int kCwW = 16, kCwPitch = 20, kCwMargin = 4;                  // chroma reference windows (level 0)
+
+struct WinLds {
+    alignas(16) uint32_t ref[kWinH * kWinPitch / 4];
+    uint32_t ogr[kOgrW * kOgrPitch / 4];
+    uint32_t chr[2][kCwW * kCwPitch / 4];
+    uint32_t csrc[2][16]; // the block's 8x8 source chroma samples (U, V): 8 rows of 2 dwords
+};
+
+// what the windows hold, in plane coordinates (wave-uniform)
+struct Win {
+    int rx, ry; // first pixel of the luma reference window (kWinW x kWinH pixels are guaranteed from here)
+    int ox, oy; // ... of the original-reference window (kOgrW x kOgrW)
+    int cx, cy; // ... of the chroma windows (kCwW x kCwW)
+    bool on;
+};
+
+// ROWS x (PITCH / 4) dwords from `src` (address of the first, 4-byte aligned, dword) into `lds`, row by row.  One
+// instruction moves RPI whole rows (RPI * PITCH / 4 <= 64 lanes), so a lane's offset from the instruction's
+// wave-uniform base is the same in every step: one offset register for the whole window, scalar base arithmetic.
+template <int ROWS, int PITCH, int RPI> __device__ __forceinline__ void win_issue(uint32_t *lds, const uint8_t *src, int stride)
+{
+    typedef __attribute__((address_space(3))) uint32_t *lds_t;
+    typedef const __attribute__((address_space(1))) uint8_t *g_t;
+    const int lane = threadIdx.x & 63;
+    constexpr int PDW = PITCH / 4;
+    static_assert(RPI * PDW <= 64, "win_issue: rows per instruction do not fit a wavefront");
+    const int r = lane / PDW, col = lane - r * PDW;
+    const unsigned voff = (unsigned) (r * stride + col * 4);
+#pragma unroll
+    for (int k = 0; k * RPI < ROWS; k++) {
+        const int rows = ROWS - k * RPI < RPI ? ROWS - k * RPI : RPI;
+        if (lane < rows * PDW) {
+            g_t base = (g_t) src + (size_t) (k * RPI) * (size_t) (unsigned) stride;
+            __builtin_amdgcn_global_load_lds(base + voff, (lds_t) (lds + k * RPI * PDW), 4, 0, 0);
+        }
+    }
+}
+
+// the window's first pixel for a 16-pixel block at `b` displaced by `c`, kept inside the padded plane [-32, dim + 32)
+__device__ __forceinline__ int win_origin(int b, int c, int margin, int span, int dim)
+{
+    return min(max(b + c - margin, -kBorder), dim + kBorder - span);
+}
+
+// is the `bs`-pixel block at plane position p (+ margins before / after) inside a window of `span` pixels starting at w0?
+__device__ __forceinline__ bool win_has(int w0, int span, int p, int bs, int before, int after)
+{
+    return p - before >= w0 && p + bs + after <= w0 + span;
+}
+
+struct __attribute__((packed)) U16l { // possibly unaligned 16-bit LDS read
+    uint16_t v;
+};
+
+// quad (qi, qj) of the block whose first pixel sits `offx` bytes into row `offy` of a window with row pitch PITCH
+template <int PITCH> __device__ __forceinline__ Quad winq(const uint32_t *win, int offx, int offy, int qi, int qj, bool act)
+{
+    const uint8_t *p = (const uint8_t *) win + (offy + 2 * qj) * PITCH + offx + 2 * qi;
+    uint32_t top = ((const U16l *) p)->v, bot = ((const U16l *) (p + PITCH))->v;
+    Quad q;
+    q.w = act ? (top | (bot << 16)) : 0u;
+    return q;
+}
+
 struct FastLds {
     int hist[16];
     int cx[64], cy[64];
     SubpelLds sp;
+    WinLds win;
 #ifdef DSV2_HME_PROF
     unsigned long long prof_t, prof_acc[16];
     int prof_on;
@@ -354,19 +432,34 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
 // register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
 // first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
 template <int NT>
-__device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
+__device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
                                             const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
 {
-    // all loads first, back to back (one memory round trip); a vector that may not be read is replaced by
-    // the zero vector, whose block always lies inside the frame
+    // all loads first, back to back (one round trip); a vector that may not be read is replaced by a safe one
     Quad b[NT];
     bool ok[NT];
+    int dxs[NT], dys[NT];
+    bool allin = w.on;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
         int dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]), dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
         ok[t] = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
-        b[t] = ldq(at(ref, bx + (ok[t] ? dx : 0), by + (ok[t] ? dy : 0)), ref.stride, qi, qj, act);
+        dxs[t] = dx;
+        dys[t] = dy;
+        allin = allin && (!ok[t] || (win_has(w.rx, kWinW, bx + dx, 16, 0, 0) && win_has(w.ry, kWinH, by + dy, 16, 0, 0)));
+    }
+    if (allin) { // every vector of the round points into the staged window
+        const int rxa = w.rx & ~3;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            b[t] = winq<kWinPitch>(s.win.ref, ok[t] ? bx + dxs[t] - rxa : 0, ok[t] ? by + dys[t] - w.ry : 0, qi, qj, act);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; t++) { // the zero vector's block always lies inside the frame
+            b[t] = ldq(at(ref, bx + (ok[t] ? dxs[t] : 0), by + (ok[t] ? dys[t] : 0)), ref.stride, qi, qj, act);
+        }
     }
     constexpr int NR = NT <= 4 ? 4 : (NT <= 8 ? 8 : 16); // width of the joint reduction
     int v[NR];
@@ -398,6 +491,15 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
     isrc = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - dc) << (psy.avg_weight + 1));
 }
 
+// Measured on MI355X (tools/ab_hme.sh, 1080p, 384 streams / 4 groups, and 128 streams / 1 group): with the windows
+// 4 841 / 2 369 frames/s, without 5 015 / 2 511; phase clocks per block 60 200 vs 54 830.  The search is bound by
+// instruction issue, not by memory round trips: a quad out of the byte-addressed LDS window costs more instructions
+// (unaligned 16-bit reads split into byte reads + packing) than the two global_load_ushort it replaces, and the 21
+// LDS-DMA instructions per block are issue slots too.  Kept as a build option (make winlds); off by default.
+#ifndef DSV2_HME_WIN
+#define DSV2_HME_WIN 0
+#endif
+constexpr bool kUseWin = DSV2_HME_WIN != 0; // stage the search windows in LDS (false: every phase reads global memory, the round-1 form)
 constexpr bool kPrefetchSubpelFirst = false; // (measured: no gain once the loads of a phase were batched; costs 12 VGPRs) the first search's loads are issued ahead of candidate scoring (hme_block_fast_t)
 
 // everything a sub-pel search reads from memory: the four neighbouring full-pel blocks, the centred source
@@ -426,7 +528,7 @@ __device__ __forceinline__ SubpelLoads subpel_issue_loads(const Ctx &c, int fpel
 
 // sub-pel search around full-pel vector (fpelx, fpely): hme.c:1051
 template <bool PRELOADED, class Ctx>
-__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
+__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const Win &W, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
                                      int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy, const SubpelLoads &pre)
 {
     const int lane = threadIdx.x & 63;
@@ -437,25 +539,51 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     HME_COUNT(S, 13, 1);
     unsigned yarea = (unsigned) (bw * bh);
     int v4[4];
-    SubpelLoads L;
-    if constexpr (PRELOADED) {
-        L = pre;
-    } else {
-        L = subpel_issue_loads(c, fpelx, fpely, bx, by, bw, bh, qi, qj, act);
-    }
-    __builtin_amdgcn_sched_barrier(0); // all twelve loads are in flight before the first is waited for
-    Quad aw = ldq_finish(L.awr, true);
-    const HpelWin &hw = L.hw;
+    Quad aw;
+    // whole blocks whose filter window (fpel - 2 ... fpel + 17 both ways, which also holds the four neighbour blocks)
+    // lies inside the staged reference window read everything from LDS; for a whole block the centred 16x16
+    // source window is the block itself
+    const bool inwin = W.on && bw == 16 && bh == 16 && win_has(W.rx, kWinW, bx + fpelx, 16, 2, 2) && win_has(W.ry, kWinH, by + fpely, 16, 2, 2);
+    const int wox = bx + fpelx - (W.rx & ~3), woy = by + fpely - W.ry; // the block at the full-pel vector, in window coordinates
+    if (inwin) {
+        const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
+        aw = a;
 #pragma unroll
-    for (int n = 0; n < 4; n++) {
-        v4[n] = act ? (int) qsse(a, ldq_finish(L.b4[n], act)) : 0;
+        for (int n = 0; n < 4; n++) {
+            v4[n] = (int) qsse(a, winq<kWinPitch>(S.win.ref, wox + dxs[n], woy + dys[n], qi, qj, true));
+        }
+    } else {
+        SubpelLoads L;
+        if constexpr (PRELOADED) {
+            L = pre;
+        } else {
+            L = subpel_issue_loads(c, fpelx, fpely, bx, by, bw, bh, qi, qj, act);
+        }
+        __builtin_amdgcn_sched_barrier(0); // all twelve loads are in flight before the first is waited for
+        aw = ldq_finish(L.awr, true);
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            v4[n] = act ? (int) qsse(a, ldq_finish(L.b4[n], act)) : 0;
+        }
+        // park the 20x20 window in LDS now: the registers that hold it are free during the reduction below
+        int lane_ = threadIdx.x & 63;
+        uint32_t *win32 = (uint32_t *) S.sp.win;
+        win32[lane_] = L.hw.d0;
+        if (lane_ + 64 < 100) {
+            win32[lane_ + 64] = L.hw.d1;
+        }
     }
     int r4 = reduceN<4>(v4);
     unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
              quad3 = (unsigned) bcastN<4>(r4, 3);
     int area_ratio = (int) div_nn(8u * 256u, yarea), iarea_ratio = (int) (8 * yarea / 256);
     best = best * (unsigned) area_ratio >> 3;
-    build_hpel(S.sp, hw);
+    if (inwin) {
+        build_hpel_at<kWinPitch>(S.sp, (const uint8_t *) S.win.ref + (woy - 2) * kWinPitch + (wox - 2)); // the 20x20 area starts at fpel - 2 (hme.c:1108, :794)
+    } else {
+        __syncthreads();
+        build_hpel_at<20>(S.sp, S.sp.win);
+    }
 
     int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
     unsigned ms1 = quad1, ms2 = quad3;
@@ -556,7 +684,7 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
 
 // level-0 tail of hme_block_fast: sub-pel refinement + mode decision (hme.c:1598-1821)
 template <class Ctx>
-__device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
+__device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, const Win &W, int &pcx, int &pcy, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
                                   unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, const SubpelLoads &sp_pre)
 {
@@ -573,7 +701,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     unsigned best_fp = best;
     if (c.effort >= 4) {
         if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
-            best = subpixel_me_fast<kPrefetchSubpelFirst>(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
+            best = subpixel_me_fast<kPrefetchSubpelFirst>(c, S, W, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
             if (sx || sy) {
                 fpelx = lax;
                 fpely = lay;
@@ -581,7 +709,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
             }
         }
         if (!found_sub && !good_enough && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
-            best = subpixel_me_fast<false>(c, S, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
+            best = subpixel_me_fast<false>(c, S, W, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
         }
     }
     mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
@@ -598,19 +726,44 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     const int cbw = bw >> 1, cbh = bh >> 1;
     const int cxp = lane & 7, cyp = lane >> 3;              // chroma pixel owned by this lane
     const bool actc = cxp < cbw && cyp < cbh;
-    const Quad r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
-    const Quad o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
-    const Quad rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
-    const int us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
-    const int vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
-    const int um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
-    const int vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
     // chroma quads for the sub-block metrics: lanes 0..15 U, 16..31 V
     const int cpl = (lane >> 4) & 1, cqi = lane & 3, cqj = (lane >> 2) & 3;
     const bool actq = lane < 32 && cqi < (cbw >> 1) && cqj < (cbh >> 1);
-    const Quad cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
-    const Quad cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
-    const Quad cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
+    Quad r, o, rz, cs, cz, cm;
+    int us, vs, um, vm;
+    // every operand sits in a staged window when the final vector stayed near the left neighbour's (the usual case)
+    const bool mwin = W.on && win_has(W.rx, kWinW, bx + fpelx, 16, 0, 0) && win_has(W.ry, kWinH, by + fpely, 16, 0, 0) &&
+                      win_has(W.rx, kWinW, bx, 16, 0, 0) && win_has(W.ry, kWinH, by, 16, 0, 0) &&
+                      win_has(W.ox, kOgrW, bx + fpelx, 16, 0, 0) && win_has(W.oy, kOgrW, by + fpely, 16, 0, 0) &&
+                      win_has(W.cx, kCwW, cbmx, 8, 0, 0) && win_has(W.cy, kCwW, cbmy, 8, 0, 0) && win_has(W.cx, kCwW, cbx, 8, 0, 0) &&
+                      win_has(W.cy, kCwW, cby, 8, 0, 0);
+    if (mwin) {
+        const int rxa = W.rx & ~3, oxa = W.ox & ~3, cxa = W.cx & ~3;
+        r = winq<kWinPitch>(S.win.ref, bx + fpelx - rxa, by + fpely - W.ry, qi, qj, act);
+        rz = winq<kWinPitch>(S.win.ref, bx - rxa, by - W.ry, qi, qj, act);
+        o = winq<kOgrPitch>(S.win.ogr, bx + fpelx - oxa, by + fpely - W.oy, qi, qj, act);
+        const uint8_t *su = (const uint8_t *) S.win.csrc[0], *sv = (const uint8_t *) S.win.csrc[1];
+        us = actc ? su[cyp * 8 + cxp] : 0;
+        vs = actc ? sv[cyp * 8 + cxp] : 0;
+        const uint8_t *wu = (const uint8_t *) S.win.chr[0], *wv = (const uint8_t *) S.win.chr[1];
+        const int mo = (cbmy - W.cy + cyp) * kCwPitch + (cbmx - cxa + cxp);
+        um = actc ? wu[mo] : 0;
+        vm = actc ? wv[mo] : 0;
+        cs = winq<8>(S.win.csrc[cpl], 0, 0, cqi, cqj, actq);
+        cz = winq<kCwPitch>(S.win.chr[cpl], cbx - cxa, cby - W.cy, cqi, cqj, actq);
+        cm = winq<kCwPitch>(S.win.chr[cpl], cbmx - cxa, cbmy - W.cy, cqi, cqj, actq);
+    } else {
+        r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
+        o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
+        rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
+        us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
+        vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
+        um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
+        vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
+        cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
+        cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
+        cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
+    }
     const int kq = (qi >= (qw >> 1) ? 1 : 0) | (qj >= (qh >> 1) ? 2 : 0);         // luma quadrant of this lane's quad
     const int kc = (cqi >= (cbw >> 2) ? 1 : 0) | (cqj >= (cbh >> 2) ? 2 : 0);      // chroma quadrant of this lane's chroma quad
     const int kp = (cxp >= (cbw >> 1) ? 1 : 0) | (cyp >= (cbh >> 1) ? 2 : 0);      // chroma quadrant of this lane's chroma pixel
@@ -913,6 +1066,8 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
     HME_MARK(S, 8);
+    pcx = sarx((int) mv.u.mv.x, 2);
+    pcy = sarx((int) mv.u.mv.y, 2);
     if (lane == 0) {
         st_mv_final(c, out, mv);
         if (is_intra) {
@@ -938,8 +1093,10 @@ constexpr unsigned kRectX = 0x22149u, kRectY = 0x28095u; // rect[]: {0,1,-1,0,0,
 constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {0,-1,1,0,0,-1,1,1,-1} / {0,0,0,-1,1,-1,1,-1,1} (hme.c:1468)
 
 // FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away
+// (pcx, pcy): in -- where the block to the left ended up (full-pel, this level's pixels), the centre of the staged
+// windows; out -- the same for this block
 template <bool FULL, class Ctx>
-__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S)
+__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
 {
     const int lane = threadIdx.x & 63;
     const int qi = lane & 7, qj = lane >> 3;
@@ -958,6 +1115,31 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     const uint8_t *sblk = at(src, bx, by);
     const Quad a = ldq(sblk, src.stride, qi, qj, act);
     const Quad o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act); // for the "good enough" test far below: same load round
+    // the same round also stages the search windows in LDS (LDS-DMA, no registers: see WinLds)
+    Win W;
+    W.on = kUseWin;
+    W.rx = W.ry = W.ox = W.oy = W.cx = W.cy = 0;
+    if (kUseWin) {
+        W.rx = win_origin(bx, pcx, kWinMargin, kWinW, src.w);
+        W.ry = win_origin(by, pcy, kWinMargin, kWinH, src.h);
+        win_issue<kWinH, kWinPitch, 4>(S.win.ref, at(ref, W.rx & ~3, W.ry), ref.stride);
+        if (level == 0) {
+            W.ox = win_origin(bx, pcx, kOgrMargin, kOgrW, src.w);
+            W.oy = win_origin(by, pcy, kOgrMargin, kOgrW, src.h);
+            win_issue<kOgrW, kOgrPitch, 8>(S.win.ogr, at(ogr, W.ox & ~3, W.oy), ogr.stride);
+            const DPlane cu = c.refc[0], cv = c.refc[1];
+            W.cx = win_origin(i * 8, sarx(pcx, 1), kCwMargin, kCwW, cu.w);
+            W.cy = win_origin(j * 8, sarx(pcy, 1), kCwMargin, kCwW, cu.h);
+            win_issue<kCwW, kCwPitch, 12>(S.win.chr[0], at(cu, W.cx & ~3, W.cy), cu.stride);
+            win_issue<kCwW, kCwPitch, 12>(S.win.chr[1], at(cv, W.cx & ~3, W.cy), cv.stride);
+            if (lane < 32) { // the block's own chroma samples: 8 rows x 2 dwords of U (lanes 0..15) and V (16..31)
+                typedef __attribute__((address_space(3))) uint32_t *lds_t;
+                typedef const __attribute__((address_space(1))) uint8_t *g_t;
+                const DPlane sp = c.srcc[(lane >> 4) & 1];
+                __builtin_amdgcn_global_load_lds((g_t) at(sp, i * 8, j * 8) + ((lane & 15) >> 1) * sp.stride + (lane & 1) * 4, (lds_t) &S.win.csrc[0][0], 4, 0, 0);
+            }
+        }
+    }
 
     // (issued here, ahead of the source analysis, so that its latency is covered by that arithmetic)
     // ONE load round for every vector the list and the cost predictor read: lanes 3..5 fetch the same-level
@@ -1154,6 +1336,11 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         sp_pre = subpel_issue_loads(c, lax, lay, bx, by, bw, bh, qi, qj, act);
     }
     HME_MARK(S, 2);
+    if (kUseWin) {
+        // the staged windows are read from here on: the LDS-DMA transfers issued at the top of the block must have
+        // landed (the compiler does not order LDS reads behind them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     HME_COUNT(S, 10, 1);
     HME_COUNT(S, 14, n);
@@ -1163,12 +1350,12 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     {
         unsigned raw = 0;
         if (n <= 4) { // the usual case after de-duplication
-            raw = score16<4>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            raw = score16<4>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
         } else if (n <= 8) {
-            raw = score16<8>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            raw = score16<8>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
         } else {
             for (int first = 0; first < n; first += 16) {
-                unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+                unsigned r = score16<16>(S, W, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
                 if (lane >= first && lane < first + 16) {
                     raw = r;
                 }
@@ -1224,7 +1411,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
                 S.cy[lane] = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
             }
             __syncthreads();
-            unsigned raw = score16<9>(S, 0, 9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            unsigned raw = score16<9>(S, W, 0, 9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
             int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
             bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
             if (level <= 1) {
@@ -1286,6 +1473,8 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     mv.u.mv.x = (int16_t) (dx * step);
     mv.u.mv.y = (int16_t) (dy * step);
     if (level != 0) {
+        pcx = dx;
+        pcy = dy;
         if (lane == 0) {
             st_mv(out, mv);
         }
@@ -1298,18 +1487,18 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     pre.t_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 4);
     pre.colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
     pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
-    hme_block_fast_l0(c, i, j, S, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
+    hme_block_fast_l0(c, i, j, S, W, pcx, pcy, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
                       avg_src, psy, pre, sp_pre);
 }
 
 template <class Ctx>
-__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S)
+__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
 {
     const DPlane &src = c.src[level];
     int bx = (i * 16) >> level, by = (j * 16) >> level;
     if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_fast_t<true>(c, level, i, j, gx, gy, S);
+        hme_block_fast_t<true>(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
-        hme_block_fast_t<false>(c, level, i, j, gx, gy, S);
+        hme_block_fast_t<false>(c, level, i, j, gx, gy, S, pcx, pcy);
     }
 }

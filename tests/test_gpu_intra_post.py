@@ -30,7 +30,7 @@ def test_intra_analysis_matches_reference(w, h, subsamp, do_psy):
 
 
 @pytest.mark.parametrize("w,h", [(352, 288), (354, 290), (1000, 562), (1280, 720), (1920, 1080), (960, 540)])
-@pytest.mark.parametrize("kind", ["synthetic", "random", "smooth"])
+@pytest.mark.parametrize("kind", ["synthetic", "random", "ramp"])
 def test_post_process_matches_reference(w, h, kind):
     ref, hip = A.load_ref(), A.load_hip()
     ref.dsv_post_process.argtypes = [C.POINTER(A.PLANE)]
@@ -40,10 +40,10 @@ def test_post_process_matches_reference(w, h, kind):
         w, h = w & ~1, h & ~1
     elif kind == "random":
         a = rand_frame(A.SUBSAMP_420, w, h, seed=11)
-    else:  # gentle gradients: the de-gradient sharpen acts on these
+    else:  # ramps that cross histogram buckets inside every 4x4 cell: the de-gradient blend acts on all of them
         a = A.HostFrame(A.SUBSAMP_420, w, h)
         yy, xx = np.mgrid[0:h, 0:w]
-        a.plane(0)[:, :] = ((xx * 3 + yy * 2) // 7 % 256).astype(np.uint8)
+        a.plane(0)[:, :] = ((xx * 9 + yy * 5) % 256).astype(np.uint8)
     b = A.HostFrame(A.SUBSAMP_420, w, h)
     for c in range(3):
         b.full[c][:, :] = a.full[c]

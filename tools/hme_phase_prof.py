@@ -11,7 +11,7 @@ PROF_SO = os.path.join(ROOT, "digital-subband-video-2_amd", "libdsv2hip_prof.so"
 os.environ["DSV2HIP_LIB"] = PROF_SO
 import bench  # noqa: E402
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--no-profile"] + sys.argv[1:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-profile", "--no-extras"] + sys.argv[1:]
 bench.main()
 lib = ctypes.CDLL(PROF_SO)
 out = (ctypes.c_ulonglong * 16)()
