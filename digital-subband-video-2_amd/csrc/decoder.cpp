@@ -27,6 +27,7 @@ struct DecImpl {
     std::vector<uint8_t> blockdata;
     std::vector<uint32_t> pos;
     std::vector<int32_t> val;
+    bool out420p = false; // deliver every picture as 4:2:0 (the CLI's -out420p, util.c:79-153, done by the GPU on the way out)
 };
 
 inline int sar(int v, int s) { return v < 0 ? ~(~v >> s) : v >> s; }
@@ -417,7 +418,7 @@ void dec_parse(DecJob &jb)
         jb.ret = DSV_DEC_ERROR; /* reference frame not found (dsv_decoder.c:535) */
         return;
     }
-    jb.of = mk_frame_pinned(meta->subsamp, meta->width, meta->height);
+    jb.of = mk_frame_pinned(im->out420p ? DSV_SUBSAMP_420 : meta->subsamp, meta->width, meta->height);
     jb.pic = true;
 }
 
@@ -479,7 +480,9 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     }
     const CopyJob *d_zfail;
     CopyJob *h_zfail = sc.tabs.take<CopyJob>(3 * (size_t) n, &d_zfail);
-    int nP = 0, nI = 0, nIf = 0, n_ext = 0, n_zfail = 0;
+    const To420Job *d_to420;
+    To420Job *h_to420 = sc.tabs.take<To420Job>(3 * (size_t) n, &d_to420);
+    int nP = 0, nI = 0, nIf = 0, n_ext = 0, n_zfail = 0, n_out = 0, n_to420 = 0;
     size_t max_plane_bytes = 0;
     bool any_filter = false;
     size_t max_coef_bytes = 0;
@@ -572,7 +575,17 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
             }
             n_ext++;
         }
-        h_out[i] = CopyJob{cur.recon.alloc, jb.of->alloc, cur.recon.bytes};
+        if (im->out420p && dv.format != DSV_SUBSAMP_420) {
+            // converted on the way out (dsv_main.c:1030-1048): luma copied, chroma through the reference's pair averages
+            const int hs = DSV_FORMAT_H_SHIFT(dv.format), vs = DSV_FORMAT_V_SHIFT(dv.format);
+            const int mode = (hs == 0 && vs == 0) ? 1 : (hs == 1 && vs == 0) ? 2 : (hs == 2 && vs == 0) ? 3 : 4;
+            for (int c = 0; c < 3; c++) {
+                const DSV_PLANE &op = jb.of->planes[c];
+                h_to420[n_to420++] = To420Job{cur.recon.p[c], DPlane{op.data, op.stride, op.w, op.h}, c ? mode : 0};
+            }
+        } else {
+            h_out[n_out++] = CopyJob{cur.recon.alloc, jb.of->alloc, cur.recon.bytes};
+        }
     }
 
     HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, total, hipMemcpyHostToDevice, bs));
@@ -592,7 +605,8 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
         copy_planes_batch(bs, d_icopy[c], nI, pl.w, pl.h);
         extend_planes(bs, d_ext[c], n_ext, pl.w, pl.h);
     }
-    copy_linear_batch(bs, d_out, n, dv0.pics[0].recon.bytes);
+    copy_linear_batch(bs, d_out, n_out, dv0.pics[0].recon.bytes);
+    to420_batch(bs, d_to420, n_to420, dv0.w, dv0.h);
     t_dec_clock.lap(2);
     stream_wait(bs);
     t_dec_clock.lap(3);
@@ -672,6 +686,20 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn) // d
     jb.fn = fn;
     dec_batch(&jb, 1);
     return jb.ret;
+}
+
+/* every picture this decoder returns from now on is converted to 4:2:0 by the GPU while it is written to the output
+ * frame -- what the reference CLI's -out420p does on the host afterwards (dsv_main.c:1030-1048, util.c:79-153) */
+int dsv2hip_dec_set_out420p(DSV_DECODER *d, int on)
+{
+    if (!d) {
+        return -1;
+    }
+    if (!d->ref) {
+        d->ref = new DecImpl();
+    }
+    ((DecImpl *) d->ref)->out420p = on != 0;
+    return 0;
 }
 
 // lockstep decode: packet bufs[k] on decoder decs[k]; ret[k], out[k], fn[k] are what dsv_dec would return

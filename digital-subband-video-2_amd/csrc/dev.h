@@ -143,6 +143,12 @@ struct PlaneOutJob {
     DPlane src;
     uint8_t *dst; // pinned host memory, w * h bytes
 };
+struct To420Job { // one plane of a decoded picture on its way into a 4:2:0 output frame (frame.hip: k_to420)
+    DPlane src, dst;
+    int mode; // 0 copy, 1 from 4:4:4, 2 from 4:2:2, 3 from 4:1:1, 4 from "4:1:0"
+};
+void to420_batch(hipStream_t s, const To420Job *d_jobs, int n, int max_w, int max_h);
+void ingest_uyvy_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int h); // src = interleaved UYVY rows
 void planes_to_host_batch(hipStream_t s, const PlaneOutJob *d_jobs, int n, int h);
 void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int max_h);
 void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h);

@@ -45,6 +45,7 @@ struct EncImpl {
     int stage_cur = 0;
     const void *staged_src = nullptr; // host picture whose upload into d_stage[stage_cur ^ 1] is in flight / done
     hipEvent_t staged_ev = nullptr;   // ... and the event (of the uploading group) that marks its completion
+    bool input_uyvy = false;          // packed pictures arrive as interleaved UYVY rows (de-interleaved by the ingest kernel)
 };
 
 inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -1226,8 +1227,9 @@ void enc_batch(Job *jobs, int n)
     std::vector<HmeFrames> hf;
     std::vector<HmeParams> hp;
     std::vector<int> pjobs;
-    const IngestJob *d_ing;
-    IngestJob *h_ing = sc.tabs.take<IngestJob>((size_t) n, &d_ing);
+    const IngestJob *d_ing, *d_ingu;
+    IngestJob *h_ing = sc.tabs.take<IngestJob>((size_t) n, &d_ing), *h_ingu = sc.tabs.take<IngestJob>((size_t) n, &d_ingu);
+    int n_ingu = 0;
     const DPlane *d_ext_y, *d_ext_c;
     DPlane *h_ext_y = sc.tabs.take<DPlane>((size_t) n, &d_ext_y), *h_ext_c = sc.tabs.take<DPlane>(2 * (size_t) n, &d_ext_c);
     const PlanePair *d_pair[DSV_MAX_PYRAMID_LEVELS];
@@ -1303,11 +1305,11 @@ void enc_batch(Job *jobs, int n)
         if (jb.frame) {
             dframe_upload(&cur.src, jb.frame, bs);
         } else {
-            h_ing[n_ing].src = jb.dev_planar;
+            IngestJob &ij = jb.im->input_uyvy ? h_ingu[n_ingu++] : h_ing[n_ing++];
+            ij.src = jb.dev_planar;
             for (int c = 0; c < 3; c++) {
-                h_ing[n_ing].dst[c] = cur.src.p[c];
+                ij.dst[c] = cur.src.p[c];
             }
-            n_ing++;
         }
         h_ext_y[k] = cur.src.p[0];
         h_ext_c[2 * k] = cur.src.p[1];
@@ -1340,6 +1342,7 @@ void enc_batch(Job *jobs, int n)
     {
         const DFrame &f0 = dv0.pics[0].src;
         ingest_batch(bs, d_ing, n_ing, f0.p[0].w, f0.p[0].h + f0.p[1].h + f0.p[2].h);
+        ingest_uyvy_batch(bs, d_ingu, n_ingu, f0.p[0].w, f0.p[0].h);
         extend_planes(bs, d_ext_y, n, f0.p[0].w, f0.p[0].h);
         extend_planes(bs, d_ext_c, 2 * n, f0.p[1].w, f0.p[1].h);
         for (int l = 0; l < L; l++) {
@@ -1802,6 +1805,24 @@ int dsv2hip_enc_batch_host(int n, DSV_ENCODER **encs, const void *const *host_pl
     for (int k = 0; k < n; k++) {
         nbufs[k] = jobs[(size_t) k].nbuf;
     }
+    return 0;
+}
+
+/* packed pictures handed to this encoder (dsv2hip_enc_device_frame / _batch / _batch_host) are interleaved UYVY 4:2:2
+ * rows instead of planar: the de-interleave of dsv_yuv_read (dsv.c:177-205) moves into the ingest kernel.  The
+ * stream's metadata must say DSV_SUBSAMP_UYVY (or 4:2:2: same plane geometry). */
+int dsv2hip_enc_set_uyvy_input(DSV_ENCODER *enc, int on)
+{
+    if (!enc) {
+        return -1;
+    }
+    if (DSV_FORMAT_H_SHIFT(enc->vidmeta.subsamp) != 1 || DSV_FORMAT_V_SHIFT(enc->vidmeta.subsamp) != 0 || (enc->vidmeta.width & 1)) {
+        return -1;
+    }
+    if (!enc->ref) {
+        enc->ref = new EncImpl();
+    }
+    ((EncImpl *) enc->ref)->input_uyvy = on != 0;
     return 0;
 }
 

@@ -263,6 +263,72 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestJob *__restrict__ ta
     }
 }
 
+// interleaved UYVY 4:2:2 picture (rows of 2 * w bytes: U0 Y0 V0 Y1 ...) -> the three padded planes; the
+// de-interleave of dsv_yuv_read (dsv.c:177-205) done while the picture is ingested.  One thread per 4 luma pixels
+// (8 source bytes -> 4 Y, 2 U, 2 V).
+__global__ __launch_bounds__(256) void k_ingest_uyvy(const IngestJob *__restrict__ tab)
+{
+    const IngestJob &j = tab[blockIdx.z];
+    const int y = blockIdx.y, w = j.dst[0].w;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (y >= j.dst[0].h || x >= w) {
+        return;
+    }
+    const uint8_t *s = j.src + (size_t) y * (size_t) (2 * w) + (size_t) 2 * x;
+    uint8_t *dy = j.dst[0].data + (size_t) y * j.dst[0].stride + x;
+    uint8_t *du = j.dst[1].data + (size_t) y * j.dst[1].stride + (x >> 1);
+    uint8_t *dv = j.dst[2].data + (size_t) y * j.dst[2].stride + (x >> 1);
+    if (x + 4 <= w && (((uintptr_t) s) & 7) == 0) {
+        uint2 q = *(const uint2 *) s; // U0 Y0 V0 Y1 | U1 Y2 V1 Y3
+        uint32_t yy = ((q.x >> 8) & 0xffu) | ((q.x >> 16) & 0xff00u) | ((q.y << 8) & 0xff0000u) | (q.y & 0xff000000u);
+        *(uint32_t *) dy = yy; // x is a multiple of 4 and the plane origin is 16-byte aligned
+        *(uint16_t *) du = (uint16_t) ((q.x & 0xffu) | ((q.y & 0xffu) << 8));
+        *(uint16_t *) dv = (uint16_t) (((q.x >> 16) & 0xffu) | (((q.y >> 16) & 0xffu) << 8));
+    } else {
+        for (int i = 0; i < 4 && x + i < w; i += 2) { // (w is even for this format)
+            du[i >> 1] = s[2 * i];
+            dy[i] = s[2 * i + 1];
+            dv[i >> 1] = s[2 * i + 2];
+            dy[i + 1] = s[2 * i + 3];
+        }
+    }
+}
+
+// ---- decoder egress: chroma planes of a decoded picture converted to 4:2:0 -----------------------------------
+// util.c:79-153 of the reference CLI (-out420p): 4:4:4 -> 4:2:2 -> 4:2:0 (two rounded pair averages, the second
+// operand clamped at the plane edge), 4:2:2 -> 4:2:0, 4:1:1 -> 4:2:0, 4:1:0 -> 4:2:0; one thread per output sample,
+// both steps of the 4:4:4 chain fused (the intermediate 4:2:2 sample is recomputed, never stored).
+__device__ __forceinline__ int px(const DPlane &p, int x, int y) { return p.data[(size_t) y * p.stride + x]; }
+
+__global__ __launch_bounds__(256) void k_to420(const To420Job *__restrict__ tab)
+{
+    const To420Job &j = tab[blockIdx.z];
+    const DPlane &s = j.src, &d = j.dst;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= d.w || y >= d.h) {
+        return;
+    }
+    int v;
+    if (j.mode == 0) { // luma (and chroma that is 4:2:0 already): copy
+        v = px(s, x, y);
+    } else if (j.mode == 1) { // 4:4:4: conv444to422 then conv422to420
+        int x0 = 2 * x, x1 = x0 < s.w - 1 ? x0 + 1 : s.w - 1;
+        int y0 = 2 * y, y1 = y0 < s.h - 1 ? y0 + 1 : s.h - 1;
+        int a = (px(s, x0, y0) + px(s, x1, y0) + 1) >> 1, b = (px(s, x0, y1) + px(s, x1, y1) + 1) >> 1;
+        v = (a + b + 1) >> 1;
+    } else if (j.mode == 2) { // 4:2:2: conv422to420
+        int y0 = 2 * y, y1 = y0 < s.h - 1 ? y0 + 1 : s.h - 1;
+        v = (px(s, x, y0) + px(s, x, y1) + 1) >> 1;
+    } else if (j.mode == 3) { // 4:1:1: conv411to420
+        int y0 = 2 * y, y1 = y0 < s.h - 1 ? y0 + 1 : s.h - 1;
+        int sx = min(x >> 1, s.w - 1);
+        v = (px(s, sx, y0) + px(s, sx, y1) + 1) >> 1;
+    } else { // "4:1:0": conv410to420
+        v = px(s, min(x >> 1, s.w - 1), min(y >> 1, s.h - 1));
+    }
+    d.data[(size_t) y * d.stride + x] = (uint8_t) v;
+}
+
 // small planes (the coarsest pyramid level) packed row after row into pinned host memory
 __global__ __launch_bounds__(64) void k_plane_to_host(const PlaneOutJob *__restrict__ tab)
 {
@@ -289,6 +355,22 @@ void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int tota
         return;
     }
     DSV2_LAUNCH(k_ingest, dim3((w + 1023) / 1024, total_rows, n), dim3(256), 0, s, d_jobs);
+}
+
+void ingest_uyvy_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int h)
+{
+    if (n <= 0) {
+        return;
+    }
+    DSV2_LAUNCH(k_ingest_uyvy, dim3((w + 1023) / 1024, h, n), dim3(256), 0, s, d_jobs);
+}
+
+void to420_batch(hipStream_t s, const To420Job *d_jobs, int n, int max_w, int max_h)
+{
+    if (n <= 0) {
+        return;
+    }
+    DSV2_LAUNCH(k_to420, dim3((max_w + 255) / 256, max_h, n), dim3(256), 0, s, d_jobs);
 }
 
 } // namespace dsv2

@@ -380,6 +380,14 @@ int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, 
  * times: the host-to-device transfer of every frame is inside the measured region. */
 int dsv2hip_enc_batch_host(int n, DSV_ENCODER **encs, const void *const *host_planar, const void *const *host_next,
                            DSV_BUF *bufs, int *nbufs);
+/* frame ingest / egress on the GPU.  (a) Packed pictures given to this encoder are interleaved UYVY
+ * 4:2:2 rows: the de-interleave that dsv_yuv_read does on the host (dsv.c:177-205) happens in the ingest kernel;
+ * the metadata must say DSV_SUBSAMP_UYVY or DSV_SUBSAMP_422.  (b) Every picture this decoder returns is delivered
+ * as 4:2:0: the chroma conversions of the reference CLI's -out420p (util.c:79-153: conv444to422 + conv422to420,
+ * conv422to420, conv411to420, conv410to420; dsv_main.c:1030-1048) run on the GPU as the picture is written to the
+ * output frame.  Both return 0, or -1 when the stream's format does not allow it. */
+int dsv2hip_enc_set_uyvy_input(DSV_ENCODER *enc, int on);
+int dsv2hip_dec_set_out420p(DSV_DECODER *dec, int on);
 void *dsv2hip_host_alloc(size_t bytes); /* pinned host memory (NULL on failure) */
 void dsv2hip_host_free(void *p);
 /* lockstep decode over n independent decoder instances: packet bufs[k] goes to decs[k]; ret[k], out[k]

@@ -18,6 +18,8 @@ def cli_equivalent_cfg(flags):
         k, v = f.lstrip("-").split("=")
         if k == "noeos":
             eos = not int(v)
+        elif k == "kbps":
+            cfg["bitrate"] = int(v) * 1024  # dsv_main.c:77 to_bps
         else:
             cfg[k] = int(v)
     return cfg, eos

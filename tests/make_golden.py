@@ -23,6 +23,14 @@ CONFIGS = [
     dict(name="c4_1080p_444_lossless", w=1920, h=1080, fmt="444", seed=4, n=2, flags=["-qp=100", "-gop=60"]),
     dict(name="c5_1080p_segment", w=1920, h=1080, fmt="420", seed=5, n=3, flags=["-qp=60", "-gop=48", "-noeos=1"]),
     dict(name="x_cif_ip_long", w=352, h=288, fmt="420", seed=6, n=30, flags=["-qp=55", "-gop=12"]),
+    # long enough to cross a GOP boundary (periodic intra picture, stability refresh dsv_encoder.c:798-872, 1247-1271)
+    dict(name="c2_720p_gop_cross", w=1280, h=720, fmt="420", seed=12, n=100, flags=["-qp=60", "-gop=48", "-effort=10"]),
+    dict(name="c3_1080p_gop60_cross", w=1920, h=1080, fmt="420", seed=13, n=62, flags=["-qp=60", "-gop=60"]),
+    # rate control by byte feedback and the low-effort paths at 720p
+    dict(name="x_720p_abr", w=1280, h=720, fmt="420", seed=14, n=24, flags=["-qp=50", "-gop=12", "-rc_mode=1", "-kbps=3000"]),
+    dict(name="x_720p_effort3", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=3"]),
+    dict(name="x_720p_effort5", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=5"]),
+    dict(name="x_720p_effort7", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=7"]),
 ]
 
 
