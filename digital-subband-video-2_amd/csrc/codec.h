@@ -8,6 +8,7 @@
 #include "dev.h"
 #include "hme.h"
 #include "quant.h"
+#include "entropy_gpu.h"
 
 namespace dsv2 {
 
@@ -60,6 +61,7 @@ struct CodecDev {
     SbtScratch scratch;        // luma (and, one plane at a time, any plane of the single-stream calls)
     SbtScratch scratch_uv[2];  // chroma planes of the table-driven encoder path, where U and V share a launch
     Compactor comp;
+    EntBuffers ent;            // plane sections of the packet assembled on the GPU (encoder, batch engine)
     uint8_t *d_blockdata = nullptr;
     DSV_MV *d_mvs_stage = nullptr; // analysis output / upload staging
     DSV_MV *d_mvf[DSV_MAX_PYRAMID_LEVELS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -256,6 +256,7 @@ void CodecDev::destroy()
     scratch_uv[0].release();
     scratch_uv[1].release();
     comp.release();
+    ent.release();
     HIPCHK(hipFree(d_blockdata));
     HIPCHK(hipFree(d_mvs_stage));
     for (int l = 0; l <= DSV_MAX_PYRAMID_LEVELS; l++) {

@@ -45,6 +45,7 @@ struct EncImpl {
     int stage_cur = 0;
     const void *staged_src = nullptr; // host picture whose upload into d_stage[stage_cur ^ 1] is in flight / done
     hipEvent_t staged_ev = nullptr;   // ... and the event (of the uploading group) that marks its completion
+    std::vector<uint8_t> big_bytes;   // plane sections of a picture too large for the pinned mirror of the GPU entropy coder
     bool input_uyvy = false;          // packed pictures arrive as interleaved UYVY rows (de-interleaved by the ingest kernel)
 };
 
@@ -882,6 +883,8 @@ struct Job {
     DSV_BUF out;
     BitWriter bs;
     int gop_start, forced_intra, ran_hme, inter_filter, nsym;
+    const uint8_t *gpu_bytes; // the three plane sections as assembled by the GPU (entropy_gpu.hip), or null: the host codes them
+    unsigned gpu_plane_bytes[3];
     DSV_FNUM prev_I;
     int stats[ST_MAX];
 };
@@ -1133,15 +1136,25 @@ void phase_h2(Job &jb)
     CodecDev &dv = im->dev;
     BitWriter &bs = jb.bs;
     bs.align();
-    int at = 0;
-    for (int c = 0; c < 3; c++) {
-        uint32_t lo = (uint32_t) dv.qv_off[c], hi = (uint32_t) dv.qv_off[c + 1];
-        int begin = at;
-        while (at < jb.nsym && dv.h_pos[at] < hi) {
-            dv.h_pos[at] -= lo;
-            at++;
+    if (jb.gpu_bytes) { // the sections arrive finished: byte-aligned, length field, DC, count, codes, 0x55 (hzcc.c:586-613)
+        const uint8_t *src = jb.gpu_bytes;
+        for (int c = 0; c < 3; c++) {
+            bs.align();
+            memcpy(bs.start + bs.byte_pos(), src, jb.gpu_plane_bytes[c]);
+            bs.pos += 8u * jb.gpu_plane_bytes[c];
+            src += jb.gpu_plane_bytes[c];
         }
-        entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
+    } else {
+        int at = 0;
+        for (int c = 0; c < 3; c++) {
+            uint32_t lo = (uint32_t) dv.qv_off[c], hi = (uint32_t) dv.qv_off[c + 1];
+            int begin = at;
+            while (at < jb.nsym && dv.h_pos[at] < hi) {
+                dv.h_pos[at] -= lo;
+                at++;
+            }
+            entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
+        }
     }
     bs.align();
     {
@@ -1191,6 +1204,9 @@ struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, 
 };
 thread_local PhaseClock t_clock;
 
+// the plane sections of the packet are assembled on the GPU (DSV2_GPU_ENTROPY=0: the host codes them from the symbol list)
+static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV2_GPU_ENTROPY")) == 0);
+static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") && atoi(getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK")) != 0; // (tests)
 // the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
 static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV2_FUSED_COUNT")) == 0);
 
@@ -1449,6 +1465,8 @@ void enc_batch(Job *jobs, int n)
     PlaneJob *h_py = sc.tabs.take<PlaneJob>((size_t) n, &d_py), *h_pc = sc.tabs.take<PlaneJob>(2 * (size_t) n, &d_pc);
     const CompactJob *d_comp;
     CompactJob *h_comp = sc.tabs.take<CompactJob>((size_t) n, &d_comp);
+    const EntJob *d_ent;
+    EntJob *h_ent = sc.tabs.take<EntJob>((size_t) n, &d_ent);
     const DPlane *d_rext_y, *d_rext_c;
     DPlane *h_rext_y = sc.tabs.take<DPlane>((size_t) n, &d_rext_y), *h_rext_c = sc.tabs.take<DPlane>(2 * (size_t) n, &d_rext_c);
     // host -> device hand-over of what H1 decided: per stream the transmitted motion field and the
@@ -1518,10 +1536,17 @@ void enc_batch(Job *jobs, int n)
         }
         h_comp[i] = dv.comp.job(dv.qv, dv.qv_off[3]);
         h_comp[i].total = sc.d_totals + i;
-        dv.ensure_host_syms(dv.qv_off[3] / 8); // P pictures fit; the first intra picture grows it (one fallback copy)
-        h_comp[i].host_pos = dv.h_pos;
-        h_comp[i].host_val = dv.h_val;
-        h_comp[i].host_cap = (int) dv.h_sym_cap;
+        if (kGpuEntropy) {
+            // the symbols stay in HBM; what comes back is the finished plane sections (pinned mirror: 1 MB, far above
+            // any 1080p picture at sane quality -- larger ones are fetched by a copy)
+            dv.ent.ensure(dv.qv_off[3], 4u << 20, 1u << 20);
+            h_ent[i] = dv.ent.job(dv.comp.d_pos, dv.comp.d_val, sc.d_totals + i, sc.d_ll + 3 * i);
+        } else {
+            dv.ensure_host_syms(dv.qv_off[3] / 8); // P pictures fit; the first intra picture grows it (one fallback copy)
+            h_comp[i].host_pos = dv.h_pos;
+            h_comp[i].host_val = dv.h_val;
+            h_comp[i].host_cap = (int) dv.h_sym_cap;
+        }
         if (jb.enc->frame_callback || (p->is_ref && jb.enc->gop != DSV_GOP_INTRA)) {
             h_rext_y[n_rext] = cur.recon.p[0];
             h_rext_c[2 * n_rext] = cur.recon.p[1];
@@ -1565,6 +1590,9 @@ void enc_batch(Job *jobs, int n)
     }
     compact_jobs(bs, d_comp, n, dv0.qv_off[3], kFusedCount);
     HIPCHK(hipMemcpyAsync(sc.h_totals, sc.d_totals, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, bs));
+    if (kGpuEntropy) {
+        entropy_gpu_jobs(bs, d_ent, n, ent_geom(dv0.qv_off, dv0.scan), 192);
+    }
     prof.end(bs, ST_QUANT, n);
     prof.begin(bs, ST_INV_SBT);
     for (const Slice &sl : slices) {
@@ -1592,7 +1620,31 @@ void enc_batch(Job *jobs, int n)
         for (int c = 0; c < 3; c++) {
             dv.h_ll[c] = sc.h_ll[3 * ti + c];
         }
-        if ((size_t) jb.nsym > dv.h_sym_cap) { // rare: more symbols than the pinned mirror held
+        jb.gpu_bytes = nullptr;
+        bool need_syms = !kGpuEntropy;
+        if (kGpuEntropy) {
+            const int *info = dv.ent.host_info;
+            if ((info[0] & ENT_FALLBACK_MASK) || kEntForceFallback) {
+                need_syms = true; // (state outside the tabulated range / no room: code this picture on the host)
+                if (getenv("DSV2_BATCH_TRACE")) {
+                    fprintf(stderr, "[batch] stream %d: GPU entropy coder fell back (flags %d)\n", k, info[0]);
+                }
+            } else {
+                for (int c = 0; c < 3; c++) {
+                    jb.gpu_plane_bytes[c] = (unsigned) info[ENT_INFO_PBYTES + c];
+                }
+                if (info[0] & ENT_NOT_MIRRORED) { // finished, but larger than the pinned mirror
+                    jb.im->big_bytes.resize((size_t) info[ENT_INFO_TOTAL]);
+                    HIPCHK(hipMemcpyAsync(jb.im->big_bytes.data(), dv.ent.out, (size_t) info[ENT_INFO_TOTAL], hipMemcpyDeviceToHost, bs));
+                    late_copy = true;
+                    jb.gpu_bytes = jb.im->big_bytes.data();
+                } else {
+                    jb.gpu_bytes = dv.ent.host_out;
+                }
+            }
+        }
+        // the symbols are needed on the host: copied when the mirror did not hold them (always so with the GPU coder on)
+        if (need_syms && jb.nsym > 0 && (kGpuEntropy || (size_t) jb.nsym > dv.h_sym_cap)) {
             if (getenv("DSV2_BATCH_TRACE")) {
                 fprintf(stderr, "[batch] stream %d: %d symbols > pinned mirror of %zu, copying\n", k, jb.nsym, dv.h_sym_cap);
             }

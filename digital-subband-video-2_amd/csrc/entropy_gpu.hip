@@ -1,0 +1,525 @@
+// entropy_gpu.hip -- the symbol-stream half of hzcc_enc (reference src/hzcc.c:230-447, :586-613) and the bit codes
+// of src/bs.c (UEG :132, SEG :175, NEG :206, adaptive Rice :237) as kernels: the picture packet's three plane
+// sections are assembled on the GPU and only their bytes cross PCIe (50 KB per 1080p P picture instead of 1.4 MB of
+// symbols; 345 KB instead of 10.5 MB for an intra picture), and the host's per-symbol loop disappears.
+//
+// What is sequential in the reference is ONE integer per plane: the adaptive Rice state `vk` (bs.c:237-251:
+// k = vk >> damp codes the value, then vk moves up by one if the unary part was non-empty, else down by one,
+// floored at 0).  Everything else -- run lengths, code words, code lengths -- is a pure function of a symbol, its
+// predecessor's position and the vk it meets.  The state is made parallel exactly, with no speculation:
+//
+//   1 k_ent_planes   per stream: where each plane's symbols start in the compacted (position, value) list
+//   2 k_ent_tables   per chunk of 1024 symbols: the chunk's TRANSFER FUNCTION vk_in -> vk_out as a 256-entry table,
+//                    by walking all 256 start states through the chunk at once (one lane per state; a state's step
+//                    only needs bitlen(u) of the symbol, staged in LDS)
+//   3 k_ent_chain    per plane: vk at the start of every chunk by following the tables (one lookup per chunk)
+//   4 k_ent_ks       per chunk: one lane walks the chunk from its now known start state: k of every symbol and the
+//                    chunk's total code length
+//   5 k_ent_layout   per stream: exclusive scan of the chunk lengths, byte layout of the three plane sections
+//   6 k_ent_zero / k_ent_emit   every symbol ORs its code words into the (zeroed) output at its bit offset
+//   7 k_ent_out      the finished bytes and their sizes to pinned host memory
+//
+// A state beyond 255 (k >= 32 at damp 3, never seen on real pictures) or a plane that outgrows its buffer raises a
+// flag; the host then codes that picture from the symbol list as before (entropy.cpp) -- same bytes either way.
+#include "entropy_gpu.h"
+
+namespace dsv2 {
+
+namespace {
+
+constexpr int kStates = 256;
+
+// info words (device and, mirrored, pinned host)
+enum { EI_FLAGS = 0, EI_PSTART = 1 /* 1..3 */, EI_N = 4, EI_PBYTES = 5 /* 5..7 */, EI_TOTAL = 8, EI_NCH = 9 /* 9..11 */, EI_SYMBIT = 12 /* 12..14 */ };
+
+__device__ __forceinline__ uint64_t spread32(uint32_t x) // bit i -> bit 2i
+{
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
+// interleaved exp-Golomb (bs.c:132): for every bit of v + 1 below its leading one a 0 followed by that bit, then a 1
+__device__ __forceinline__ void ueg_code(uint32_t v, uint64_t &code, int &len)
+{
+    uint32_t x = v + 1u;
+    int nb = 31 - __clz((int) x);
+    uint32_t low = nb ? (x & (0xffffffffu >> (32 - nb))) : 0u;
+    code = (spread32(low) << 1) | 1ull;
+    len = 2 * nb + 1;
+}
+
+__device__ __forceinline__ int ueg_len(uint32_t v) { return 2 * (31 - __clz((int) (v + 1u))) + 1; }
+
+__device__ __forceinline__ int seg_of(const EntGeom &g, int c, uint32_t p)
+{
+    int seg = 0;
+#pragma unroll
+    for (int k = 1; k < 10; k++) {
+        seg += p >= (uint32_t) g.base[c][k];
+    }
+    return seg;
+}
+
+__device__ __forceinline__ uint32_t rice_u(int32_t v) { return ((uint32_t) (2 * v) ^ (v < 0 ? ~0u : 0u)) - 1u; }
+__device__ __forceinline__ int bitlen(uint32_t u) { return u ? 32 - __clz((int) u) : 0; }
+
+// the stream's bit `bitpos` is bit 7 - (bitpos & 7) of byte bitpos >> 3: ORs the `len` low bits of `code`, MSB first
+__device__ __forceinline__ void put_code(uint32_t *out32, uint32_t bitpos, uint64_t code, int len)
+{
+    uint64_t c64 = code << (64 - len);
+    uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    uint64_t hi = c64 >> sh;
+    uint32_t w0 = (uint32_t) (hi >> 32), w1 = (uint32_t) hi, w2 = sh ? (uint32_t) ((c64 << (64 - sh)) >> 32) : 0u;
+    if (w0) {
+        atomicOr(&out32[w], __builtin_bswap32(w0));
+    }
+    if (w1) {
+        atomicOr(&out32[w + 1], __builtin_bswap32(w1));
+    }
+    if (w2) {
+        atomicOr(&out32[w + 2], __builtin_bswap32(w2));
+    }
+}
+
+__device__ __forceinline__ int wave_incl_scan_u(unsigned v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = (unsigned) __shfl_up((int) v, d, 64);
+        if (lane >= d) {
+            v += t;
+        }
+    }
+    return (int) v;
+}
+
+// ---- 1 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ent_planes(const EntJob *__restrict__ tab, EntGeom g)
+{
+    const EntJob &J = tab[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int N = *J.total;
+    int res = 0;
+    if (lane == 1 || lane == 2) { // first symbol whose position lies in plane `lane`
+        uint32_t key = (uint32_t) g.qv_off[lane];
+        int lo = 0, hi = N;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (J.pos[mid] < key) {
+                lo = mid + 1;
+            } else {
+                hi = mid;
+            }
+        }
+        res = lo;
+    }
+    int p1 = __shfl(res, 1, 64), p2 = __shfl(res, 2, 64);
+    if (lane == 0) {
+        int *I = J.info;
+        I[EI_FLAGS] = 0;
+        I[EI_PSTART + 0] = 0;
+        I[EI_PSTART + 1] = p1;
+        I[EI_PSTART + 2] = p2;
+        I[EI_N] = N;
+        I[EI_NCH + 0] = (p1 + kEntChunk - 1) / kEntChunk;
+        I[EI_NCH + 1] = (p2 - p1 + kEntChunk - 1) / kEntChunk;
+        I[EI_NCH + 2] = (N - p2 + kEntChunk - 1) / kEntChunk;
+    }
+}
+
+struct PlaneSpan {
+    int first, end, nch, cbase; // symbols [first, end) of the plane, its chunk count and first chunk slot
+};
+__device__ __forceinline__ PlaneSpan plane_span(const int *I, int c)
+{
+    PlaneSpan s;
+    s.first = I[EI_PSTART + c];
+    s.end = c == 2 ? I[EI_N] : I[EI_PSTART + c + 1];
+    s.nch = I[EI_NCH + c];
+    s.cbase = (c > 0 ? I[EI_NCH] : 0) + (c > 1 ? I[EI_NCH + 1] : 0);
+    return s;
+}
+
+// ---- 2 ----------------------------------------------------------------------------------------------------
+// per symbol one byte in LDS: 0xff = coded without the adaptive state (LL region), else bitlen(u) | (damp - 3) << 6
+__global__ __launch_bounds__(kStates) void k_ent_tables(const EntJob *__restrict__ tab, EntGeom g)
+{
+    __shared__ uint32_t meta32[kEntChunk / 4];
+    uint8_t *meta = (uint8_t *) meta32;
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.z;
+    const PlaneSpan ps = plane_span(J.info, c);
+    const uint32_t off = (uint32_t) g.qv_off[c];
+    for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
+        const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kEntChunk / kStates; j++) {
+            int s = j * kStates + threadIdx.x;
+            uint8_t m = 0xff;
+            if (s < cnt) {
+                int seg = seg_of(g, c, J.pos[first + s] - off);
+                if (seg > 0) {
+                    m = (uint8_t) (bitlen(rice_u(J.val[first + s])) | (((seg - 1) / 3) << 6));
+                }
+            }
+            meta[s] = m;
+        }
+        __syncthreads();
+        int vk = threadIdx.x;
+        const int cnt4 = (cnt + 3) >> 2;
+        for (int q = 0; q < cnt4; q++) {
+            uint32_t m4 = meta32[q]; // same word for every lane: an LDS broadcast
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t m = (m4 >> (8 * b)) & 0xffu;
+                if (m != 0xffu) { // (symbols past cnt hold 0xff too)
+                    int k = vk >> (3 + (int) (m >> 6));
+                    vk = (int) (m & 63u) > k ? vk + 1 : max(vk - 1, 0);
+                }
+            }
+        }
+        J.tables[(size_t) (ps.cbase + lc) * kStates + threadIdx.x] = (uint16_t) vk;
+    }
+}
+
+// ---- 3 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab)
+{
+    const EntJob &J = tab[blockIdx.x];
+    const int c = threadIdx.x;
+    if (c >= 3) {
+        return;
+    }
+    const PlaneSpan ps = plane_span(J.info, c);
+    int vk = 0;
+    bool ovf = false;
+    for (int lc = 0; lc < ps.nch; lc++) {
+        J.chunk_vk[ps.cbase + lc] = (uint16_t) vk;
+        vk = J.tables[(size_t) (ps.cbase + lc) * kStates + vk];
+        if (vk >= kStates) {
+            ovf = true;
+            vk = kStates - 1;
+        }
+    }
+    if (ovf) {
+        atomicOr(&J.info[EI_FLAGS], 1);
+    }
+}
+
+// ---- 4 ----------------------------------------------------------------------------------------------------
+// one lane per chunk: the Rice parameter every symbol is coded with, and the chunk's total code length
+__global__ __launch_bounds__(64) void k_ent_ks(const EntJob *__restrict__ tab, EntGeom g)
+{
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.z;
+    const PlaneSpan ps = plane_span(J.info, c);
+    const uint32_t off = (uint32_t) g.qv_off[c];
+    for (int lc = blockIdx.x * 64 + threadIdx.x; lc < ps.nch; lc += gridDim.x * 64) {
+        const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
+        int vk = J.chunk_vk[ps.cbase + lc];
+        uint32_t prev_end = first > ps.first ? J.pos[first - 1] - off + 1u : 0u;
+        unsigned long long bits = 0;
+        for (int s = 0; s < cnt; s++) {
+            uint32_t p = J.pos[first + s] - off;
+            int32_t v = J.val[first + s];
+            int seg = seg_of(g, c, p);
+            int len = ueg_len(p - prev_end);
+            prev_end = p + 1u;
+            int kk = 0;
+            if (seg == 0) {
+                uint32_t a = (uint32_t) (v < 0 ? -v : v);
+                len += ueg_len(a - 1u) + 1;
+            } else {
+                uint32_t u = rice_u(v);
+                int damp = 3 + (seg - 1) / 3;
+                kk = vk >> damp;
+                uint32_t lead = kk < 32 ? u >> kk : 0u;
+                vk += lead ? 1 : (vk > 0 ? -1 : 0);
+                bits += lead;
+                len += kk + 1;
+            }
+            bits += (unsigned) len;
+            J.ksym[first + s] = (uint8_t) kk;
+        }
+        if (bits >= (1ull << 24)) { // 16 Kbit per symbol on average: not a picture (and keeps the 32-bit scans below exact)
+            atomicOr(&J.info[EI_FLAGS], 4);
+            bits = 0;
+        }
+        J.chunk_bits[ps.cbase + lc] = (uint32_t) bits;
+    }
+}
+
+// ---- 5 ----------------------------------------------------------------------------------------------------
+// byte layout of one plane section (hzcc.c:586-613): 32-bit length | SEG(DC) | pad | 24-bit count | codes | pad | 0x55
+__global__ __launch_bounds__(64) void k_ent_layout(const EntJob *__restrict__ tab)
+{
+    const EntJob &J = tab[blockIdx.x];
+    const int lane = threadIdx.x;
+    int *I = J.info;
+    unsigned long long byte_at = 0; // start of the current plane section
+    bool too_big = false;
+    for (int c = 0; c < 3; c++) {
+        const PlaneSpan ps = plane_span(I, c);
+        int32_t ll = J.ll[c];
+        uint32_t a = (uint32_t) (ll < 0 ? -ll : ll);
+        int lseg = ueg_len(a) + (a ? 1 : 0);
+        unsigned long long sym_byte = byte_at + 4 + (unsigned) ((lseg + 7) >> 3) + 3;
+        unsigned long long carry = sym_byte * 8;
+        for (int base = 0; base < ps.nch; base += 64) {
+            int lc = base + lane;
+            unsigned v = lc < ps.nch ? J.chunk_bits[ps.cbase + lc] : 0u;
+            // (64-bit running offset, 32-bit partial sums: a chunk holds < 2^24 bits, see k_ent_ks)
+            unsigned inc = (unsigned) wave_incl_scan_u(v, lane);
+            unsigned long long o = carry + inc - v;
+            if (lc < ps.nch) {
+                if (o >= (1ull << 32)) {
+                    too_big = true;
+                    o = 0;
+                }
+                J.chunk_off[ps.cbase + lc] = (uint32_t) o;
+            }
+            carry += (unsigned long long) __shfl((int) inc, 63, 64);
+        }
+        unsigned long long end_byte = (carry + 7) >> 3; // the 0x55 goes here
+        if (lane == 0) {
+            I[EI_SYMBIT + c] = (int) (unsigned) (sym_byte & 0xffffffffull);
+            I[EI_PBYTES + c] = (int) (unsigned) ((end_byte + 1 - byte_at) & 0xffffffffull);
+        }
+        byte_at = end_byte + 1;
+    }
+    if (byte_at + 16 > J.out_cap || too_big) {
+        too_big = true;
+    }
+    if (lane == 0) {
+        I[EI_TOTAL] = too_big ? 0 : (int) byte_at;
+        if (too_big) {
+            atomicOr(&I[EI_FLAGS], 2);
+        }
+    }
+}
+
+// ---- 6 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ent_zero(const EntJob *__restrict__ tab)
+{
+    const EntJob &J = tab[blockIdx.y];
+    const unsigned words = ((unsigned) J.info[EI_TOTAL] + 16u + 3u) >> 2;
+    uint32_t *o = (uint32_t *) J.out;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) {
+        o[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g)
+{
+    __shared__ unsigned wsum[4];
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.z;
+    const int *I = J.info;
+    if (I[EI_FLAGS] & ENT_FALLBACK_MASK) { // the host codes this picture itself
+        return;
+    }
+    const PlaneSpan ps = plane_span(I, c);
+    const uint32_t off = (uint32_t) g.qv_off[c];
+    uint32_t *out32 = (uint32_t *) J.out;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // the section's fixed fields
+        unsigned sec_bytes = (unsigned) I[EI_PBYTES + c];
+        unsigned sym_byte = (unsigned) I[EI_SYMBIT + c];
+        int32_t ll = J.ll[c];
+        uint32_t a = (uint32_t) (ll < 0 ? -ll : ll);
+        uint64_t code;
+        int len;
+        ueg_code(a, code, len);
+        if (a) {
+            code = (code << 1) | (uint64_t) (ll < 0);
+            len++;
+        }
+        // section start = symbol start - 3 (count) - SEG bytes - 4 (length)
+        unsigned sec_start = sym_byte - 3u - (unsigned) ((len + 7) >> 3) - 4u;
+        put_code(out32, sec_start * 8u, (uint64_t) (sec_bytes - 4u), 32);
+        put_code(out32, (sec_start + 4u) * 8u, code, len);
+        put_code(out32, (sym_byte - 3u) * 8u, (uint64_t) (unsigned) (ps.end - ps.first), 24);
+        put_code(out32, (sec_start + sec_bytes - 1u) * 8u, 0x55ull, 8);
+    }
+    for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
+        const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
+        // four consecutive symbols per thread
+        uint64_t rc[4], vc[4];
+        int rl[4], vl[4];
+        unsigned lead[4], tot = 0;
+        const int s0 = threadIdx.x * 4;
+        uint32_t prev_end = 0;
+        if (s0 < cnt) {
+            int i0 = first + s0;
+            prev_end = i0 > ps.first ? J.pos[i0 - 1] - off + 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            rl[j] = vl[j] = 0;
+            lead[j] = 0;
+            rc[j] = vc[j] = 0;
+            if (s0 + j < cnt) {
+                uint32_t p = J.pos[first + s0 + j] - off;
+                int32_t v = J.val[first + s0 + j];
+                int seg = seg_of(g, c, p);
+                ueg_code(p - prev_end, rc[j], rl[j]);
+                prev_end = p + 1u;
+                if (seg == 0) { // NEG (bs.c:206)
+                    uint32_t a = (uint32_t) (v < 0 ? -v : v);
+                    ueg_code(a - 1u, vc[j], vl[j]);
+                    vc[j] = (vc[j] << 1) | (uint64_t) (v < 0);
+                    vl[j]++;
+                } else { // adaptive Rice (bs.c:237) with the parameter found by k_ent_ks
+                    uint32_t u = rice_u(v);
+                    int kk = J.ksym[first + s0 + j];
+                    lead[j] = kk < 32 ? u >> kk : 0u;
+                    vc[j] = (1ull << kk) | (kk < 32 ? (uint64_t) (u & (uint32_t) ((1ull << kk) - 1ull)) : (uint64_t) u);
+                    vl[j] = kk + 1;
+                }
+                tot += (unsigned) rl[j] + lead[j] + (unsigned) vl[j];
+            }
+        }
+        __syncthreads();
+        unsigned inc = (unsigned) wave_incl_scan_u(tot, lane);
+        if (lane == 63) {
+            wsum[wv] = inc;
+        }
+        __syncthreads();
+        unsigned o = inc - tot;
+        for (int k = 0; k < wv; k++) {
+            o += wsum[k];
+        }
+        uint32_t bit = J.chunk_off[ps.cbase + lc] + o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (s0 + j < cnt) {
+                put_code(out32, bit, rc[j], rl[j]);
+                bit += (uint32_t) rl[j] + lead[j];
+                put_code(out32, bit, vc[j], vl[j]);
+                bit += (uint32_t) vl[j];
+            }
+        }
+    }
+}
+
+// ---- 7 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ent_out(const EntJob *__restrict__ tab)
+{
+    const EntJob &J = tab[blockIdx.y];
+    const int *I = J.info;
+    unsigned total = (unsigned) I[EI_TOTAL];
+    int flags = I[EI_FLAGS];
+    if (total > J.host_cap) {
+        flags |= 8; // finished on the device, but larger than the pinned mirror: the host fetches it with a copy
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+        J.host_info[threadIdx.x] = threadIdx.x == EI_FLAGS ? flags : I[threadIdx.x];
+    }
+    if (flags & 15) {
+        return;
+    }
+    const uint4 *src = (const uint4 *) J.out;
+    uint4 *dst = (uint4 *) J.host_out;
+    const unsigned n16 = (total + 15u) >> 4;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) {
+        dst[i] = src[i];
+    }
+}
+
+} // namespace
+
+EntGeom ent_geom(const size_t qv_off[4], const ScanGeom scan[3])
+{
+    EntGeom g;
+    for (int c = 0; c < 4; c++) {
+        g.qv_off[c] = (int) qv_off[c];
+    }
+    for (int c = 0; c < 3; c++) {
+        for (int k = 0; k < 11; k++) {
+            g.base[c][k] = scan[c].base[k];
+        }
+    }
+    return g;
+}
+
+void EntBuffers::ensure(size_t nsym_cap, uint32_t out_bytes, uint32_t host_bytes)
+{
+    if (tables) {
+        return;
+    }
+    size_t nch = (nsym_cap + kEntChunk - 1) / kEntChunk + 3;
+    HIPCHK(hipMalloc((void **) &tables, nch * kStates * sizeof(uint16_t)));
+    HIPCHK(hipMalloc((void **) &chunk_vk, nch * sizeof(uint16_t)));
+    HIPCHK(hipMalloc((void **) &chunk_bits, nch * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &chunk_off, nch * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &ksym, nsym_cap));
+    out_cap = (out_bytes + 15u) & ~15u;
+    HIPCHK(hipMalloc((void **) &out, out_cap + 64));
+    HIPCHK(hipMalloc((void **) &info, 16 * sizeof(int)));
+    host_cap = (host_bytes + 15u) & ~15u;
+    HIPCHK(hipHostMalloc((void **) &host_out, host_cap, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &host_info, 16 * sizeof(int), hipHostMallocDefault));
+}
+
+void EntBuffers::release()
+{
+    if (!tables) {
+        return;
+    }
+    HIPCHK(hipFree(tables));
+    HIPCHK(hipFree(chunk_vk));
+    HIPCHK(hipFree(chunk_bits));
+    HIPCHK(hipFree(chunk_off));
+    HIPCHK(hipFree(ksym));
+    HIPCHK(hipFree(out));
+    HIPCHK(hipFree(info));
+    HIPCHK(hipHostFree(host_out));
+    HIPCHK(hipHostFree(host_info));
+    tables = nullptr;
+}
+
+EntJob EntBuffers::job(const uint32_t *pos, const int32_t *val, const int *total, const int32_t *ll) const
+{
+    EntJob j;
+    j.pos = pos;
+    j.val = val;
+    j.total = total;
+    j.ll = ll;
+    j.tables = tables;
+    j.chunk_vk = chunk_vk;
+    j.chunk_bits = chunk_bits;
+    j.chunk_off = chunk_off;
+    j.ksym = ksym;
+    j.out = out;
+    j.out_cap = out_cap;
+    j.info = info;
+    j.host_out = host_out;
+    j.host_info = host_info;
+    j.host_cap = host_cap;
+    return j;
+}
+
+void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom &g, int chunk_slots)
+{
+    if (n <= 0) {
+        return;
+    }
+    const int slots = chunk_slots < 1 ? 1 : chunk_slots;
+    DSV2_LAUNCH(k_ent_planes, dim3(n), dim3(64), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_tables, dim3(slots, n, 3), dim3(kStates), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_chain, dim3(n), dim3(64), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ent_ks, dim3((slots + 63) / 64, n, 3), dim3(64), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_out, dim3(8, n), dim3(256), 0, s, d_jobs);
+    HIPCHK(hipGetLastError());
+}
+
+} // namespace dsv2
