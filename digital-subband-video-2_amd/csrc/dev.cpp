@@ -102,7 +102,9 @@ void stream_wait(hipStream_t s)
         if (e != hipErrorNotReady) {
             HIPCHK(e);
         }
-        timespec ts = {0, tries < 8 ? 15000 : 40000};
+        // short waits are answered quickly, long ones (tens of milliseconds of kernels) are polled sparsely: every
+        // wake-up costs several microseconds of host CPU, and the host is shared by every rank of the node
+        timespec ts = {0, tries < 8 ? 15000 : (tries < 64 ? 40000 : 120000)};
         nanosleep(&ts, nullptr);
     }
 }

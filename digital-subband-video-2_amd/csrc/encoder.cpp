@@ -573,6 +573,23 @@ void gather_stats(DSV_ENCODER *enc, const FrameCtl *d, const DSV_MV *mvs, const 
     }
 }
 
+// Zero-filled scratch for the bit writers of the per-block side information (bs.c:143: the writers skip zero bits).  The
+// sub-streams are sized for the worst case (32 bytes a block) but a frame writes a few hundred bytes of each: the
+// buffers live per worker thread and only what a frame wrote is cleared again (a fresh zero-filled vector per
+// sub-stream was 1.6 MB of memset per 1080p frame -- most of a host core at 5 000 frames/s).
+struct ZeroScratch {
+    std::vector<uint8_t> mem;
+    uint8_t *get(size_t bytes)
+    {
+        if (mem.size() < bytes) {
+            mem.assign(bytes, 0);
+        }
+        return mem.data();
+    }
+    void clear(size_t used) { memset(mem.data(), 0, std::min(used + 16, mem.size())); }
+};
+thread_local ZeroScratch t_side[6];
+
 void append_sub(BitWriter &bs, const uint8_t *data, int bytes)
 {
     bs.put_ueg((unsigned) bytes);
@@ -584,9 +601,9 @@ void encode_stable_blocks(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DS
                           const int *stats) // dsv_encoder.c:797
 {
     int nblk = d->params.nblocks_h * d->params.nblocks_v;
-    std::vector<uint8_t> buf((size_t) nblk * 32, 0);
+    uint8_t *buf = t_side[5].get((size_t) nblk * 32);
     RleWriter rle;
-    rle.bw = BitWriter{buf.data(), 0};
+    rle.bw = BitWriter{buf, 0};
     if (enc->refresh_ctr >= enc->stable_refresh) {
         enc->refresh_ctr = 0;
         memset(enc->stability, 0, sizeof(*enc->stability) * (size_t) nblk);
@@ -630,7 +647,8 @@ void encode_stable_blocks(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DS
     }
     bs.align();
     int bytes = rle.finish();
-    append_sub(bs, buf.data(), bytes);
+    append_sub(bs, buf, bytes);
+    t_side[5].clear((size_t) bytes);
 }
 
 void encode_motion(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DSV_MV *mvs, const int *stats) // dsv_encoder.c:692
@@ -638,14 +656,14 @@ void encode_motion(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DSV_MV *m
     const DSV_PARAMS *p = &d->params;
     int nblk = p->nblocks_h * p->nblocks_v;
     size_t ub = (size_t) nblk * 32;
-    std::vector<uint8_t> bufs[5];
-    for (auto &b : bufs) {
-        b.assign(ub, 0);
+    uint8_t *bufs[5];
+    for (int k = 0; k < 5; k++) {
+        bufs[k] = t_side[k].get(ub);
     }
     RleWriter mode_rle, eprm_rle;
-    mode_rle.bw = BitWriter{bufs[0].data(), 0};
-    eprm_rle.bw = BitWriter{bufs[4].data(), 0};
-    BitWriter mvx{bufs[1].data(), 0}, mvy{bufs[2].data(), 0}, sbim{bufs[3].data(), 0};
+    mode_rle.bw = BitWriter{bufs[0], 0};
+    eprm_rle.bw = BitWriter{bufs[4], 0};
+    BitWriter mvx{bufs[1], 0}, mvy{bufs[2], 0}, sbim{bufs[3], 0};
 
     for (int j = 0; j < p->nblocks_v; j++) {
         for (int i = 0; i < p->nblocks_h; i++) {
@@ -704,17 +722,18 @@ void encode_motion(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DSV_MV *m
             w.align();
             bytes = (int) w.byte_pos();
         }
-        append_sub(bs, bufs[s].data(), bytes);
+        append_sub(bs, bufs[s], bytes);
+        t_side[s].clear((size_t) bytes);
     }
 }
 
 void encode_intra_meta(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, const DSV_MV *intramv, const int *stats) // :886
 {
     int nblk = d->params.nblocks_h * d->params.nblocks_v;
-    std::vector<uint8_t> br((size_t) nblk * 32, 0), bm((size_t) nblk * 32, 0);
+    uint8_t *br = t_side[0].get((size_t) nblk * 32), *bm = t_side[1].get((size_t) nblk * 32);
     RleWriter rr, rm;
-    rr.bw = BitWriter{br.data(), 0};
-    rm.bw = BitWriter{bm.data(), 0};
+    rr.bw = BitWriter{br, 0};
+    rm.bw = BitWriter{bm, 0};
     for (int i = 0; i < nblk; i++) {
         int ring = mvflag(intramv[i], DSV_MV_BIT_RINGING), maintain = mvflag(intramv[i], DSV_MV_BIT_MAINTAIN);
         enc->blockdata[i] |= (uint8_t) (ring << 3);
@@ -724,10 +743,12 @@ void encode_intra_meta(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, const
     }
     bs.align();
     int bytes = rr.finish();
-    append_sub(bs, br.data(), bytes);
+    append_sub(bs, br, bytes);
+    t_side[0].clear((size_t) bytes);
     bs.align();
     bytes = rm.finish();
-    append_sub(bs, bm.data(), bytes);
+    append_sub(bs, bm, bytes);
+    t_side[1].clear((size_t) bytes);
 }
 
 // ---- device pipeline pieces -----------------------------------------------------------------
@@ -912,6 +933,32 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
     // uploads of the NEXT step's host pictures run on a stream of their own, under this step's kernels
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
+    // side streams of a step: work that does not depend on the main chain runs beside it (the plane sections are
+    // assembled while the inverse transform / reconstruction / in-loop filters run; the intra pictures' filter sweeps
+    // beside the inter pictures')
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork[2], ev_join[2];
+    void ensure_aux()
+    {
+        if (!aux[0]) {
+            for (int i = 0; i < 2; i++) {
+                HIPCHK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ev_fork[i], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+            }
+        }
+    }
+    // the rest of `side` happens after everything enqueued on `main` so far
+    void fork(hipStream_t main, int i)
+    {
+        HIPCHK(hipEventRecord(ev_fork[i], main));
+        HIPCHK(hipStreamWaitEvent(aux[i], ev_fork[i], 0));
+    }
+    void join(hipStream_t main, int i)
+    {
+        HIPCHK(hipEventRecord(ev_join[i], aux[i]));
+        HIPCHK(hipStreamWaitEvent(main, ev_join[i], 0));
+    }
     void ensure_copy_stream()
     {
         if (!copy_stream) {
@@ -1206,6 +1253,7 @@ thread_local PhaseClock t_clock;
 
 // the plane sections of the packet are assembled on the GPU (DSV2_GPU_ENTROPY=0: the host codes them from the symbol list)
 static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV2_GPU_ENTROPY")) == 0);
+static const int kAuxStreams = getenv("DSV2_AUX_STREAMS") ? atoi(getenv("DSV2_AUX_STREAMS")) : 0; // side streams within a step: bit 0 entropy coder, bit 1 intra filter (0: one chain)
 static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") && atoi(getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK")) != 0; // (tests)
 // the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
 static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV2_FUSED_COUNT")) == 0);
@@ -1591,7 +1639,13 @@ void enc_batch(Job *jobs, int n)
     compact_jobs(bs, d_comp, n, dv0.qv_off[3], kFusedCount);
     HIPCHK(hipMemcpyAsync(sc.h_totals, sc.d_totals, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, bs));
     if (kGpuEntropy) {
-        entropy_gpu_jobs(bs, d_ent, n, ent_geom(dv0.qv_off, dv0.scan), 192);
+        if (kAuxStreams & 1) {
+            sc.ensure_aux();
+            sc.fork(bs, 0);
+            entropy_gpu_jobs(sc.aux[0], d_ent, n, ent_geom(dv0.qv_off, dv0.scan), 192);
+        } else {
+            entropy_gpu_jobs(bs, d_ent, n, ent_geom(dv0.qv_off, dv0.scan), 192);
+        }
     }
     prof.end(bs, ST_QUANT, n);
     prof.begin(bs, ST_INV_SBT);
@@ -1601,13 +1655,26 @@ void enc_batch(Job *jobs, int n)
     }
     prof.end(bs, ST_INV_SBT, n);
     prof.begin(bs, ST_RECON_FILTER);
-    intra_filter_batch(bs, sc.d_mc + n, nI, dv0.h);
+    const bool side_intra = (kAuxStreams & 2) && nI > 0 && nP > 0; // two latency-bound sweeps over disjoint pictures: side by side
+    if (side_intra) {
+        sc.ensure_aux();
+        sc.fork(bs, 1);
+        intra_filter_batch(sc.aux[1], sc.d_mc + n, nI, dv0.h);
+    } else {
+        intra_filter_batch(bs, sc.d_mc + n, nI, dv0.h);
+    }
     mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter, dv0.h, dv0.blk_w, dv0.blk_h);
+    if (side_intra) {
+        sc.join(bs, 1);
+    }
     prof.end(bs, ST_RECON_FILTER, nP + nI);
     prof.begin(bs, ST_EXTEND);
     extend_planes(bs, d_rext_y, n_rext, dv0.pics[0].recon.p[0].w, dv0.pics[0].recon.p[0].h);
     extend_planes(bs, d_rext_c, 2 * n_rext, dv0.pics[0].recon.p[1].w, dv0.pics[0].recon.p[1].h);
     prof.end(bs, ST_EXTEND, n_rext);
+    if (kGpuEntropy && (kAuxStreams & 1)) {
+        sc.join(bs, 0);
+    }
     t_clock.lap(4);
     stream_wait(bs);
     t_clock.lap(5);

@@ -13,8 +13,8 @@
 //                    by walking all 256 start states through the chunk at once (one lane per state; a state's step
 //                    only needs bitlen(u) of the symbol, staged in LDS)
 //   3 k_ent_chain    per plane: vk at the start of every chunk by following the tables (one lookup per chunk)
-//   4 k_ent_ks       per chunk: one lane walks the chunk from its now known start state: k of every symbol and the
-//                    chunk's total code length
+//   4 k_ent_ks       per chunk: one lane walks the chunk (staged in LDS) from its now known start state: k of every
+//                    symbol and the chunk's total code length
 //   5 k_ent_layout   per stream: exclusive scan of the chunk lengths, byte layout of the three plane sections
 //   6 k_ent_zero / k_ent_emit   every symbol ORs its code words into the (zeroed) output at its bit offset
 //   7 k_ent_out      the finished bytes and their sizes to pinned host memory
@@ -213,45 +213,92 @@ __global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab
 }
 
 // ---- 4 ----------------------------------------------------------------------------------------------------
-// one lane per chunk: the Rice parameter every symbol is coded with, and the chunk's total code length
-__global__ __launch_bounds__(64) void k_ent_ks(const EntJob *__restrict__ tab, EntGeom g)
+// per chunk: the Rice parameter every symbol is coded with, and the chunk's total code length.  The chunk is staged in
+// LDS by the whole workgroup (code lengths that do not depend on the state are summed in parallel); ONE lane then
+// walks the adaptive state through it out of LDS (~60 clocks a symbol instead of a dependent global load each).
+__global__ __launch_bounds__(256) void k_ent_ks(const EntJob *__restrict__ tab, EntGeom g)
 {
+    __shared__ uint32_t su[kEntChunk];        // Rice-mapped value of every symbol
+    __shared__ uint8_t sm[kEntChunk];         // 0xff: not Rice coded; else damp - 3
+    __shared__ uint8_t sk[kEntChunk];         // the parameter found for it
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned long long dyn_bits;
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
     const uint32_t off = (uint32_t) g.qv_off[c];
-    for (int lc = blockIdx.x * 64 + threadIdx.x; lc < ps.nch; lc += gridDim.x * 64) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
         const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
-        int vk = J.chunk_vk[ps.cbase + lc];
-        uint32_t prev_end = first > ps.first ? J.pos[first - 1] - off + 1u : 0u;
-        unsigned long long bits = 0;
-        for (int s = 0; s < cnt; s++) {
-            uint32_t p = J.pos[first + s] - off;
-            int32_t v = J.val[first + s];
-            int seg = seg_of(g, c, p);
-            int len = ueg_len(p - prev_end);
-            prev_end = p + 1u;
-            int kk = 0;
-            if (seg == 0) {
-                uint32_t a = (uint32_t) (v < 0 ? -v : v);
-                len += ueg_len(a - 1u) + 1;
-            } else {
-                uint32_t u = rice_u(v);
-                int damp = 3 + (seg - 1) / 3;
-                kk = vk >> damp;
-                uint32_t lead = kk < 32 ? u >> kk : 0u;
-                vk += lead ? 1 : (vk > 0 ? -1 : 0);
-                bits += lead;
-                len += kk + 1;
+        __syncthreads();
+        // four consecutive symbols per thread: run code + state-free value code lengths
+        unsigned stat = 0;
+        const int s0 = threadIdx.x * 4;
+        uint32_t prev_end = 0;
+        if (s0 < cnt) {
+            int i0 = first + s0;
+            prev_end = i0 > ps.first ? J.pos[i0 - 1] - off + 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint8_t m = 0xff;
+            uint32_t u = 0;
+            if (s0 + j < cnt) {
+                uint32_t p = J.pos[first + s0 + j] - off;
+                int32_t v = J.val[first + s0 + j];
+                int seg = seg_of(g, c, p);
+                stat += (unsigned) ueg_len(p - prev_end);
+                prev_end = p + 1u;
+                if (seg == 0) {
+                    uint32_t a = (uint32_t) (v < 0 ? -v : v);
+                    stat += (unsigned) ueg_len(a - 1u) + 1u;
+                } else {
+                    u = rice_u(v);
+                    m = (uint8_t) ((seg - 1) / 3);
+                }
             }
-            bits += (unsigned) len;
-            J.ksym[first + s] = (uint8_t) kk;
+            su[s0 + j] = u;
+            sm[s0 + j] = m;
+            sk[s0 + j] = 0;
         }
-        if (bits >= (1ull << 24)) { // 16 Kbit per symbol on average: not a picture (and keeps the 32-bit scans below exact)
-            atomicOr(&J.info[EI_FLAGS], 4);
-            bits = 0;
+        unsigned inc = (unsigned) wave_incl_scan_u(stat, lane);
+        if (lane == 63) {
+            wsum[wv] = inc;
         }
-        J.chunk_bits[ps.cbase + lc] = (uint32_t) bits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int vk = J.chunk_vk[ps.cbase + lc];
+            unsigned long long bits = 0;
+            for (int s = 0; s < cnt; s++) {
+                unsigned m = sm[s];
+                if (m != 0xffu) {
+                    uint32_t u = su[s];
+                    int kk = vk >> (3 + (int) m);
+                    uint32_t lead = kk < 32 ? u >> kk : 0u;
+                    vk += lead ? 1 : (vk > 0 ? -1 : 0);
+                    bits += (unsigned long long) lead + (unsigned) (kk + 1);
+                    sk[s] = (uint8_t) kk;
+                }
+            }
+            dyn_bits = bits;
+        }
+        __syncthreads();
+        if (s0 < cnt) { // (chunks start at multiples of 1024 symbols of a plane; the plane's first symbol is not aligned)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (s0 + j < cnt) {
+                    J.ksym[first + s0 + j] = sk[s0 + j];
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            unsigned long long bits = dyn_bits + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (bits >= (1ull << 24)) { // 16 Kbit per symbol on average: not a picture (and keeps the 32-bit scans below exact)
+                atomicOr(&J.info[EI_FLAGS], 4);
+                bits = 0;
+            }
+            J.chunk_bits[ps.cbase + lc] = (uint32_t) bits;
+        }
     }
 }
 
@@ -514,7 +561,7 @@ void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom 
     DSV2_LAUNCH(k_ent_planes, dim3(n), dim3(64), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_tables, dim3(slots, n, 3), dim3(kStates), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_chain, dim3(n), dim3(64), 0, s, d_jobs);
-    DSV2_LAUNCH(k_ent_ks, dim3((slots + 63) / 64, n, 3), dim3(64), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);

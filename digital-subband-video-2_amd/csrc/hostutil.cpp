@@ -23,6 +23,9 @@ std::unordered_map<void *, size_t> g_pool_live;                 // block -> size
 std::unordered_map<size_t, std::vector<void *>> g_pool_idle;    // size -> idle blocks
 size_t g_pool_idle_count = 0;
 constexpr size_t kPoolMax = 2048;
+// blocks currently handed out: dsv_free() consults the pool (mutex + hash lookup) only while there are any, so that the
+// encoder's many ordinary frees (packet buffers on the hot path) never touch the lock
+std::atomic<size_t> g_pool_live_count{0};
 } // namespace
 
 void *pinned_pool_take(size_t bytes)
@@ -35,6 +38,7 @@ void *pinned_pool_take(size_t bytes)
             it->second.pop_back();
             g_pool_idle_count--;
             g_pool_live[p] = bytes;
+            g_pool_live_count++;
             return p;
         }
     }
@@ -42,11 +46,15 @@ void *pinned_pool_take(size_t bytes)
     HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_pool_live[p] = bytes;
+    g_pool_live_count++;
     return p;
 }
 
 bool pinned_pool_release(void *p)
 {
+    if (g_pool_live_count.load(std::memory_order_acquire) == 0) {
+        return false; // (a block of the pool is only ever released by its holder, after the take that counted it)
+    }
     size_t bytes;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -56,6 +64,7 @@ bool pinned_pool_release(void *p)
         }
         bytes = it->second;
         g_pool_live.erase(it);
+        g_pool_live_count--;
         if (g_pool_idle_count < kPoolMax) {
             g_pool_idle[bytes].push_back(p);
             g_pool_idle_count++;
