@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, in
     int i = bi << level, j = bj << level;
     if (allow_fast && fast_path_ok(c, level, i, j)) {
         int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
-        hme_block_fast(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
         hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
     }
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
     int i = bi << level, j = bj << level;
     if (allow_fast && fast_path_ok(c, level, i, j)) {
         int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
-        hme_block_fast(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
         hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
     }
@@ -1249,9 +1249,12 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
     }
 }
 
-template <bool FAST_ONLY>
-__device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int nbx, int nby, int allow_fast, FastLds &S)
+// LV: 0 / 1 = the launch is known to be level 0 / a coarser level (fast-only kernels: the other half of the block routine
+// is not compiled in), -1 = any level
+template <bool FAST_ONLY, int LV = -1>
+__device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, int allow_fast, FastLds &S)
 {
+    const int level = LV == 0 ? 0 : level_rt;
     int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
     unsigned *progress = (unsigned *) uni_ptr(c.counters) + kHmeProgress;
     int j = bj << level;
@@ -1283,8 +1286,8 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
         if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast(x, level, i, j, gx, gy, S, pcx, pcy);
-        } else {
+            hme_block_fast<LV>(x, level, i, j, gx, gy, S, pcx, pcy);
+        } else if constexpr (!FAST_ONLY) {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
             pcx = pcy = 0;
         }
@@ -1329,11 +1332,17 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level, int 
         __shared__ FastLds S;                                                                                            \
         hme_row<false>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                                    \
     }                                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_w##W(             \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_w##W(          \
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row<true>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                                    \
+        hme_row<true, 0>(tab[blockIdx.x], (int) blockIdx.y, 0, nbx, (int) gridDim.y, allow_fast, S);                     \
+    }                                                                                                                    \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_w##W(          \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        hme_row<true, 1>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                 \
     }
 HME_ROWS_B(1)
 HME_ROWS_B(2)
@@ -1552,7 +1561,11 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
             if ((fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
                 int w = level == 0 ? g_hme_waves_fast : g_hme_waves_fast_lx;
-                kern = w >= 4 ? k_hme_rows_b_fast_w4 : w == 3 ? k_hme_rows_b_fast_w3 : w == 2 ? k_hme_rows_b_fast_w2 : k_hme_rows_b_fast_w1;
+                if (level == 0) {
+                    kern = w >= 4 ? k_hme_rows_b_fast_l0_w4 : w == 3 ? k_hme_rows_b_fast_l0_w3 : w == 2 ? k_hme_rows_b_fast_l0_w2 : k_hme_rows_b_fast_l0_w1;
+                } else {
+                    kern = w >= 4 ? k_hme_rows_b_fast_lx_w4 : w == 3 ? k_hme_rows_b_fast_lx_w3 : w == 2 ? k_hme_rows_b_fast_lx_w2 : k_hme_rows_b_fast_lx_w1;
+                }
             }
             DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1));
             nlaunch++;

@@ -1095,9 +1095,12 @@ constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {
 // FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away
 // (pcx, pcy): in -- where the block to the left ended up (full-pel, this level's pixels), the centre of the staged
 // windows; out -- the same for this block
-template <bool FULL, class Ctx>
-__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
+// LV: what is known about the level at compile time -- 0: it is level 0; 1: it is a coarser level (the sub-pel search and
+// the mode decision are not even compiled in: a third of the registers); -1: decided at run time
+template <bool FULL, int LV, class Ctx>
+__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
 {
+    const int level = LV == 0 ? 0 : level_rt;
     const int lane = threadIdx.x & 63;
     const int qi = lane & 7, qj = lane >> 3;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
@@ -1472,7 +1475,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     HME_MARK(S, 4);
     mv.u.mv.x = (int16_t) (dx * step);
     mv.u.mv.y = (int16_t) (dy * step);
-    if (level != 0) {
+    if (LV > 0 || level != 0) {
         pcx = dx;
         pcy = dy;
         if (lane == 0) {
@@ -1480,6 +1483,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
         }
         return;
     }
+    if constexpr (LV <= 0) {
     NbPre pre;
     pre.l_all = (uint32_t) __builtin_amdgcn_readlane((int) nbv.all, 3);
     pre.l_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 3);
@@ -1489,16 +1493,18 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level, int i,
     pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
     hme_block_fast_l0(c, i, j, S, W, pcx, pcy, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
                       avg_src, psy, pre, sp_pre);
+    }
 }
 
-template <class Ctx>
-__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
+template <int LV, class Ctx>
+__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
 {
+    const int level = LV == 0 ? 0 : level_rt;
     const DPlane &src = c.src[level];
     int bx = (i * 16) >> level, by = (j * 16) >> level;
     if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_fast_t<true>(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast_t<true, LV>(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
-        hme_block_fast_t<false>(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast_t<false, LV>(c, level, i, j, gx, gy, S, pcx, pcy);
     }
 }

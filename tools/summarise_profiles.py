@@ -22,7 +22,7 @@ traced = json.loads([l for l in open(os.path.join(src, "bench_traced.json")) if 
 rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
-    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (MI355X, %d streams / %d groups)\n"
+    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras   (MI355X, %d streams / %d groups)\n"
             % (traced["config"]["streams_per_gpu"], traced["config"]["groups"]))
     f.write("bench line under the profiler: %.1f frames/s, %.2f ms/step; sum of kernel durations %.1f ms\n"
             % (traced["value"], traced["ms_per_step"], total / 1e6))
@@ -36,8 +36,8 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
     f.write("\nk_hme_rows_b_*: %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event stage span / launches: %.1f us\n"
             % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
-    f.write("(all k_hme_rows_b_* variants: the fast-path kernel on the fine levels, the general one on the coarsest; the bench span also "
-            "holds one clear launch)\n")
+    f.write("(all k_hme_rows_b_* variants: k_hme_rows_b_fast_l0_* on level 0, k_hme_rows_b_fast_lx_* on the coarser levels whose blocks all "
+            "qualify, the general kernel on the coarsest; the bench span also holds one clear launch)\n")
 
 # PMC: per-launch HBM-side bytes of the dominant kernel
 agg = {}
@@ -51,7 +51,7 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
     f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows_b_fast -- python3 bench.py "
             "--steps 6 --warmup 3\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
             "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width); only the launches of the "
-            "fast-path kernel (levels 0-2 at 1080p) are listed\n\n")
+            "fast-path kernels (k_hme_rows_b_fast_l0_* / _lx_*, levels 0-4 at 1080p) are listed\n\n")
     f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
     tot_f = tot_w = nl = 0
     for g in sorted(agg["FETCH_SIZE"]):
@@ -62,13 +62,14 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
         nl += len(fv)
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
     f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
-json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
+json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_l0_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
            "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-dec = [l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")]
-if dec:
-    json.dump(json.loads(dec[-1]), open(os.path.join(dst, prefix + "_decode.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "decode.json")):  # (since round 2 the decode leg is part of the bench line itself)
+    dec = [l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")]
+    if dec:
+        json.dump(json.loads(dec[-1]), open(os.path.join(dst, prefix + "_decode.json"), "w"), indent=1)
 # the bench line was taken before these PMC passes: complete its roofline object with their figure
 if bench.get("roofline") and bench["roofline"].get("traffic") is None:
     bench["roofline"]["traffic"] = round(bytes_per_launch)
