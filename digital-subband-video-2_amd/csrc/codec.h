@@ -31,7 +31,7 @@ struct PlaneSyms { // host view of one plane's entropy input
 };
 
 // ---- optional stage timing with HIP events on the codec's own stream (bench.py roofline) ----
-enum Stage { ST_INGEST = 0, ST_HME, ST_PREDICT, ST_FWD_SBT, ST_QUANT, ST_INV_SBT, ST_RECON_FILTER, ST_EXTEND, ST_COUNT };
+enum Stage { ST_INGEST = 0, ST_HME, ST_PREDICT, ST_FWD_SBT, ST_QUANT, ST_INV_SBT, ST_RECON_FILTER, ST_EXTEND, ST_HME_L0 /* the level-0 search launch alone (inside ST_HME) */, ST_COUNT };
 
 struct StageProf {
     bool created = false;

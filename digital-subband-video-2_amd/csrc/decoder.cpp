@@ -325,11 +325,12 @@ void dec_parse(DecJob &jb)
     br.align();
     jb.fno = br.get_bits(32);
     br.align();
-    int blk_w = 16 << br.get_ueg(), blk_h = 16 << br.get_ueg();
-    if (blk_w < 16 || blk_h < 16 || blk_w > 32 || blk_h > 32) {
+    unsigned ew = br.get_ueg(), eh = br.get_ueg(); // log2 of the block size - 4: 0 or 1 (checked before it becomes a shift count)
+    if (ew > 1 || eh > 1 || br.overrun) {
         jb.ret = DSV_DEC_ERROR;
         return;
     }
+    int blk_w = 16 << ew, blk_h = 16 << eh;
     // the metadata is untrusted: only geometries the device pipeline can allocate and run are accepted (the reference
     // would pass anything on to calloc); a hostile packet must come back as an error, not take the process down
     {

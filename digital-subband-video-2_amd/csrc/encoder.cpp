@@ -1459,7 +1459,7 @@ void enc_batch(Job *jobs, int n)
     prof.end(bs, ST_INGEST, n);
     if (!pjobs.empty()) {
         prof.begin(bs, ST_HME);
-        int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme);
+        int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof);
         prof.end(bs, ST_HME, (int) pjobs.size(), nfronts); // launches = the per-level search kernels
     }
     t_clock.lap(1);

@@ -48,7 +48,9 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns 
 
 // lockstep variant for n streams of identical geometry; h_table (pinned) / d_table hold hme_table_bytes(n)
 size_t hme_table_bytes(int n);
-int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table);
+struct StageProf;
+// prof (optional): HIP events around the level-0 launch alone (stage ST_HME_L0), for the roofline of the dominant kernel
+int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof = nullptr);
 
 struct CodecDev;
 struct PicSet;

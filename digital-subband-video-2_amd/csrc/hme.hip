@@ -1528,7 +1528,7 @@ static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
 size_t hme_table_bytes(int n) { return (size_t) n * sizeof(HmeDev); }
 
 // n independent streams of identical geometry in lockstep: every front is ONE launch for all of them
-int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table)
+int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof)
 {
     if (n <= 0) {
         return 0;
@@ -1567,7 +1567,13 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
                     kern = w >= 4 ? k_hme_rows_b_fast_lx_w4 : w == 3 ? k_hme_rows_b_fast_lx_w3 : w == 2 ? k_hme_rows_b_fast_lx_w2 : k_hme_rows_b_fast_lx_w1;
                 }
             }
+            if (prof && level == 0) {
+                prof->begin(s, ST_HME_L0);
+            }
             DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1));
+            if (prof && level == 0) {
+                prof->end(s, ST_HME_L0, n, 1);
+            }
             nlaunch++;
         } else {
             for (int t = 0; t <= nbx + nby - 2; t++) {

@@ -395,8 +395,9 @@ void dsv2hip_host_free(void *p);
  * consumed the same way).  All pictures of a step run through one set of kernel launches. */
 int dsv2hip_dec_batch(int n, DSV_DECODER **decs, DSV_BUF *bufs, DSV_FRAME **out, DSV_FNUM *fn, int *ret);
 /* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
- * off at any time (resets the totals).  dsv2hip_prof_read fills 8 entries (ingest+pyramid, HME,
- * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend): milliseconds of stage span,
+ * off at any time (resets the totals).  dsv2hip_prof_read fills 9 entries (ingest+pyramid, HME,
+ * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend, and -- inside HME -- the level-0
+ * search launch alone, the dominant kernel): milliseconds of stage span,
  * kernel launches, and *frames = steps folded in; dsv2hip_prof_read_units: stream-frames each
  * stage processed (what the algorithmic byte counts of DESIGN.md are multiplied by). */
 void dsv2hip_prof_enable(int on);

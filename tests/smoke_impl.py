@@ -35,3 +35,46 @@ def run():
             hip.dsv_fwd_sbt(frame.plane_ptr(plane), C.byref(cs), C.byref(fm))
             assert np.array_equal(want, got), "smoke: fwd sbt mismatch plane %d isP %d" % (plane, isP)
     print("smoke ok")
+    run_codec()
+
+
+def run_codec():
+    """two CIF streams, 4 frames each, through the lockstep batch engine with host pictures (upload, every kernel group,
+    GPU entropy coder) against the real reference where oracle/_ref travelled with the repo"""
+    import os
+    from codec_run import configure_encoder, encode_stream
+    from conftest import load_pkg
+    hip = A.load_hip()
+    hip.dsv2hip_enc_batch_host.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(A.BUF),
+                                           C.POINTER(C.c_int)]
+    w, h, n, S = 352, 288, 4, 2
+    vids = [load_pkg().synth.SynthVideo(w, h, "420", seed=70 + s) for s in range(S)]
+    frames = [[np.frombuffer(v.frame_bytes(t), dtype=np.uint8).copy() for t in range(n)] for v in vids]
+    meta = A.mk_meta(w, h, A.SUBSAMP_420)
+    encs = [A.ENCODER() for _ in range(S)]
+    for e in encs:
+        configure_encoder(hip, e, meta, qp=60, gop=48)
+    gp = (C.POINTER(A.ENCODER) * S)(*[C.pointer(e) for e in encs])
+    gb = (A.BUF * (4 * S))()
+    gn = (C.c_int * S)()
+    got = [b"" for _ in range(S)]
+    for t in range(n):
+        cur = (C.c_void_p * S)(*[frames[s][t].ctypes.data for s in range(S)])
+        nxt = (C.c_void_p * S)(*[(frames[s][t + 1].ctypes.data if t + 1 < n else None) for s in range(S)])
+        assert hip.dsv2hip_enc_batch_host(S, gp, cur, nxt, gb, gn) == 0
+        for s in range(S):
+            for i in range(gn[s]):
+                b = gb[4 * s + i]
+                got[s] += C.string_at(b.data, b.len)
+                hip.dsv_buf_free(C.byref(b))
+    for e in encs:
+        hip.dsv_enc_free(C.byref(e))
+    if os.path.exists(A.REF_SO):
+        ref = A.load_ref()
+        for s in range(S):
+            want, _ = encode_stream(ref, [f.tobytes() for f in frames[s]], w, h, A.SUBSAMP_420, eos=False, qp=60, gop=48)
+            assert got[s] == b"".join(want), "smoke: stream %d differs from the reference" % s
+        print("smoke codec ok (vs reference)")
+    else:
+        assert all(len(g) > 1000 for g in got)
+        print("smoke codec ran (oracle/_ref absent: not compared)")

@@ -66,3 +66,76 @@ def test_damaged_plane_data(seed):
         if pw is not None:
             for c in range(3):
                 assert np.array_equal(pw[c], pg[c])
+
+
+def _feed(hip, dec, pk):
+    buf = A.BUF()
+    hip.dsv_mk_buf(C.byref(buf), len(pk))  # exactly as long as the packet: nothing readable behind it
+    C.memmove(buf.data, pk, len(pk))
+    fp = C.POINTER(A.FRAME)()
+    fn = C.c_uint32(0)
+    code = hip.dsv_dec(C.byref(dec), C.byref(buf), C.byref(fp), C.byref(fn))
+    if code == A.DEC_OK and fp:
+        hip.dsv_frame_ref_dec(fp)
+    return code
+
+
+def _ueg(v):
+    """bit string of the interleaved exp-Golomb code (bs.c:132)"""
+    v += 1
+    nb = v.bit_length() - 1
+    return "".join("0" + str((v >> i) & 1) for i in range(nb - 1, -1, -1)) + "1"
+
+
+def _meta_packet(fields):
+    bits = "".join(_ueg(f) for f in fields) + "0"
+    bits += "0" * (-len(bits) % 8)
+    body = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+    return b"DSV2" + bytes([8, 0x00]) + bytes(8) + body
+
+
+def test_hostile_packets_return_errors_not_crashes():
+    """The product only (the reference reads out of bounds on such input): truncated packets, absurd sub-stream and
+    plane lengths, metadata the device pipeline cannot allocate -- every call returns a decoder code, the process
+    survives and a clean stream decodes correctly afterwards on the same library."""
+    ref, hip = A.load_ref(), A.load_hip()
+    pkg = load_pkg()
+    w, h = 352, 288
+    v = pkg.synth.SynthVideo(w, h, "420", seed=12)
+    frames = [v.frame_bytes(t) for t in range(3)]
+    packets, _ = encode_stream(ref, frames, w, h, A.SUBSAMP_420, eos=False, qp=60, gop=48)
+    meta, pic_i, pic_p = packets[0], packets[1], packets[2]
+    rng = np.random.default_rng(5)
+    codes = set()
+    # (1) truncation at every kind of place
+    for pk in (pic_i, pic_p):
+        for cut in [15, 18, 20, 24, 30, 40, 64, 100, 200, len(pk) // 3, len(pk) // 2, len(pk) - 1]:
+            dec = A.DECODER()
+            assert _feed(hip, dec, meta) == A.DEC_GOT_META
+            if pk is pic_p:
+                assert _feed(hip, dec, pic_i) == A.DEC_OK
+            codes.add(_feed(hip, dec, pk[:cut]))
+            hip.dsv_dec_free(C.byref(dec))
+    # (2) random garbage behind a valid picture header, and 0xff runs (huge exp-Golomb lengths)
+    for k in range(24):
+        dec = A.DECODER()
+        assert _feed(hip, dec, meta) == A.DEC_GOT_META
+        junk = bytes(rng.integers(0, 256, size=int(rng.integers(1, 4000)), dtype=np.uint8)) if k % 3 else bytes([0]) * 64 + bytes([0xff]) * 64
+        codes.add(_feed(hip, dec, pic_i[:22 + k] + junk))
+        hip.dsv_dec_free(C.byref(dec))
+    # (3) metadata that must be refused: zero / odd / enormous sizes, unknown subsampling
+    for fields in [(0, 288, 5, 30, 1, 1, 1, 1), (352, 0, 5, 30, 1, 1, 1, 1), (353, 288, 5, 30, 1, 1, 1, 1), (1 << 20, 1 << 20, 5, 30, 1, 1, 1, 1),
+                   (352, 288, 3, 30, 1, 1, 1, 1), (352, 288, 0x3f, 30, 1, 1, 1, 1)]:
+        dec = A.DECODER()
+        assert _feed(hip, dec, _meta_packet(fields)) == A.DEC_GOT_META
+        assert _feed(hip, dec, pic_i) == A.DEC_ERROR
+        hip.dsv_dec_free(C.byref(dec))
+    assert codes <= {A.DEC_OK, A.DEC_ERROR}
+    # the library is still healthy
+    from codec_run import decode_stream
+    good = decode_stream(hip, packets)
+    want = decode_stream(ref, packets)
+    assert len(good) == len(want) == 3
+    for a, b in zip(good, want):
+        for c in (1, 2, 3):
+            assert np.array_equal(a[c], b[c])

@@ -4,7 +4,7 @@ set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-timeout 150 rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_hme_rows" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 2 --streams 64 --groups 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
+timeout 150 rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_hme_rows_b_fast_l0" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 2 --streams ${PMC_STREAMS:-64} --groups 1 --no-stagger --no-extras --no-cpu-baseline --no-profile > /dev/null 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, collections, sys
 for d in sorted(glob.glob(f"gpurun_out/pmc_{sys.argv[1]}/*/*_counter_collection.csv")):
@@ -14,9 +14,8 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_{sys.argv[1]}/*/*_counter_collection.
         k = (r["Kernel_Name"][:34], r["Grid_Size"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k] += 1
     for k, v in agg.items():
-        if int(k[1]) < 250000:
-            continue
         nl = n[k] / len(v)
-        print(k, int(nl), {a: round(b / nl / (64 * 8160), 1) for a, b in v.items()})
+        streams = int(k[1]) // (64 * 68)  # grid = streams x 68 block rows x 64 lanes
+        print(k, int(nl), "per block:", {a: round(b / nl / (streams * 8160), 1) for a, b in v.items()})
 PY
 rm -rf gpurun_out/pmc_$tag

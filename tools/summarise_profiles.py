@@ -34,10 +34,9 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     # cross-check of the bench's HIP-event figure for the dominant kernel
     tr = list(csv.DictReader(open(os.path.join(src, "kernel_trace_hme.csv"))))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
-    f.write("\nk_hme_rows_b_*: %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event stage span / launches: %.1f us\n"
-            % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
-    f.write("(all k_hme_rows_b_* variants: k_hme_rows_b_fast_l0_* on level 0, k_hme_rows_b_fast_lx_* on the coarser levels whose blocks all "
-            "qualify, the general kernel on the coarsest; the bench span also holds one clear launch)\n")
+    f.write("\nk_hme_rows_b_fast_l0_w2 (level-0 search, the dominant kernel): %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event span of "
+            "that launch: %.1f us\n" % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
+    f.write("(the trace includes the pre-roll steps, in which a launch serves fewer streams than the 96 of a full step)\n")
 
 # PMC: per-launch HBM-side bytes of the dominant kernel
 agg = {}
@@ -48,10 +47,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         by_grid[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
     agg[c] = by_grid
 with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
-    f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows_b_fast -- python3 bench.py "
-            "--steps 6 --warmup 3\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
+    f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows_b_fast_l0 -- python3 bench.py "
+            "--steps 6 --warmup 3 --no-stagger\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
             "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width); only the launches of the "
-            "fast-path kernels (k_hme_rows_b_fast_l0_* / _lx_*, levels 0-4 at 1080p) are listed\n\n")
+            "level-0 search kernel are listed (96 streams per launch)\n\n")
     f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
     tot_f = tot_w = nl = 0
     for g in sorted(agg["FETCH_SIZE"]):
@@ -62,7 +61,7 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
         nl += len(fv)
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
     f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
-json.dump({"stage": "hme", "kernel": "k_hme_rows_b_fast_l0_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
+json.dump({"stage": "hme_level0", "kernel": "k_hme_rows_b_fast_l0_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
            "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
