@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for exercising the N>1 path "
                                                       "on a box with fewer GPUs than ranks, together with DSV2_FORCE_DEVICE)")
     ap.add_argument("--profile-steps", type=int, default=6)
+    ap.add_argument("--gen-procs", type=int, default=-1,
+                    help="helper processes that generate the synthetic pictures (default: the usable cores, 1 under a profiler: "
+                         "forked children of a process with rocprofv3's tool library loaded can hang at exit)")
     return ap.parse_args()
 
 
@@ -397,7 +400,9 @@ def main():
         specs += [(1280, 720, "420", 101 + k, 24) for k in range(4)]
         specs += [(W_, H_, "444", 201, 12)]
     t_gen = time.perf_counter()
-    vids = gen_videos(specs, max(1, min(8, ncpu // max(1, world))))
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(8, ncpu // max(1, world))))
+    vids = gen_videos(specs, gen_procs)
     t_gen = time.perf_counter() - t_gen
 
     import torch

@@ -4,7 +4,7 @@ set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-timeout 150 rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_hme_rows_b_fast_l0" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 2 --streams ${PMC_STREAMS:-64} --groups 1 --no-stagger --no-extras --no-cpu-baseline --no-profile > /dev/null 2>&1
+timeout 420 rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_hme_rows_b_fast_l0" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 2 --streams ${PMC_STREAMS:-64} --groups 1 --gen-procs 1 --no-stagger --no-extras --no-cpu-baseline --no-profile > /dev/null 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, collections, sys
 for d in sorted(glob.glob(f"gpurun_out/pmc_{sys.argv[1]}/*/*_counter_collection.csv")):
