@@ -606,6 +606,18 @@ def main():
                                            "mpix_per_s": round(f2 / e2 * 1280 * 720 / 1e6, 1), "twin_pairs_equal": p2 - b2, "twin_pairs": p2,
                                            "input": "pinned_host, staggered GOP phases"}
         r2.free()
+        # C3: 1920x1080 4:2:0 -qp=60 -gop=60 (the headline's geometry with the CLI's default GOP)
+        r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:NV], not args.no_stagger)
+        r3.run(r3.R + 4)
+        k3 = 16
+        g3 = r3.step
+        e3 = r3.run(k3)
+        p3, b3 = r3.twins_equal()
+        f3 = r3.frames_in(g3, g3 + k3)
+        cfgs["c3_1080p_420_qp60_gop60"] = {"value": round(f3 / e3, 2), "unit": "frames/s", "streams": S, "steps": k3, "ms_per_step": round(1e3 * e3 / k3, 3),
+                                            "mpix_per_s": round(f3 / e3 * W_ * H_ / 1e6, 1), "twin_pairs_equal": p3 - b3, "twin_pairs": p3,
+                                            "input": "pinned_host, staggered GOP phases"}
+        r3.free()
         # C4: 1920x1080 4:4:4 lossless (-qp=100), every stream from its first (intra) frame; round trip through the decoder
         s4 = min(32, S)
         r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, 2, vids[NV + 4:NV + 5], False)

@@ -425,28 +425,64 @@ __device__ __forceinline__ void build_hpel(SubpelLds &s, const HpelWin &w)
     __syncthreads();
 }
 
-// the same from a 20x20 area that already sits in LDS with row pitch PITCH (w = its first sample): the staged
-// search window is filtered in place, nothing is copied
+struct __attribute__((packed)) U32l { // possibly unaligned 32-bit LDS read (one ds_read_b32)
+    uint32_t v;
+};
+
+// The 34x34 half-pel image (hme.c:787) from a 20x20 area that sits in LDS with row pitch PITCH (w = its first sample;
+// PITCH = 20: the search's own copy, else the staged search window, filtered in place).  Per point one dword per window row
+// (the four taps of a row filter are one unaligned LDS dword) and the 5,5,-1,-1 filter as two dot products.
 template <int PITCH> __device__ __forceinline__ void build_hpel_at(SubpelLds &s, const uint8_t *w)
 {
     int lane = threadIdx.x & 63;
     for (int idx = lane; idx < 289; idx += 64) {
         int i = idx % 17, j = idx / 17;
         const uint8_t *p = &w[(j + 1) * PITCH + (i + 1)];
+        uint32_t D[4]; // row k - 1: samples p[-1], p[0], p[1], p[2] of that row in bytes 0..3
         int hz[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint8_t *q = p + (k - 1) * PITCH;
-            hz[k] = HPF_ME(q[-1], q[0], q[1], q[2]);
+            D[k] = ((const U32l *) (p + (k - 1) * PITCH - 1))->v;
+            hz[k] = (int) __builtin_amdgcn_udot4(D[k], 0x00050500u, 0u, false) - (int) __builtin_amdgcn_udot4(D[k], 0x01000001u, 0u, false);
         }
         int c = HPF_ME(hz[0], hz[1], hz[2], hz[3]);
-        uint8_t *o = &s.h[(2 * j) * 34 + 2 * i];
-        o[0] = p[0];
-        o[1] = clamp_u8((hz[1] + 4) >> 3);
-        o[34] = clamp_u8((HPF_ME(p[-PITCH], p[0], p[PITCH], p[2 * PITCH]) + 4) >> 3);
-        o[35] = clamp_u8((c + 32) >> 6);
+        // the centre column (byte 1 of every row) for the vertical filter
+        int b0 = (int) ((D[0] >> 8) & 0xffu), b1 = (int) ((D[1] >> 8) & 0xffu), b2 = (int) ((D[2] >> 8) & 0xffu), b3 = (int) ((D[3] >> 8) & 0xffu);
+        int vz = HPF_ME(b0, b1, b2, b3);
+        uint32_t o01 = clamp_u8((hz[1] + 4) >> 3), o10 = clamp_u8((vz + 4) >> 3), o11 = clamp_u8((c + 32) >> 6);
+        uint8_t *o = &s.h[(2 * j) * 34 + 2 * i]; // even offset in an array that starts on a 4-byte boundary: aligned 16-bit stores
+        *(uint16_t *) o = (uint16_t) ((uint32_t) b1 | (o01 << 8));
+        *(uint16_t *) (o + 34) = (uint16_t) (o10 | (o11 << 8));
     }
     __syncthreads();
+}
+
+// one source quad's four quarter-pel samples (qi, qj spacing: X, X + 4 / Y, Y + 4 in quarter-pel units = two half-pel
+// samples apart) at quarter-pel phase `ph`, as a packed Quad: two or four unaligned dwords of the half-pel image and
+// byte-lane arithmetic instead of up to 16 byte reads (hme.c:815-835: AVG2 / AVG4 of the neighbouring half-pel samples)
+__device__ __forceinline__ uint32_t qquad_ph(const uint8_t *h, int X, int Y, int ph)
+{
+    const uint8_t *p = h + (Y >> 1) * 34 + (X >> 1);
+    const uint32_t m = 0x00ff00ffu;
+    uint32_t r0 = ((const U32l *) p)->v, r2 = ((const U32l *) (p + 68))->v;
+    uint32_t a, b; // the samples of the quad's upper / lower row in bytes 0 and 2
+    if (ph == 0) {
+        a = r0;
+        b = r2;
+    } else if (ph == 1) {
+        a = ((r0 & m) + ((r0 >> 8) & m) + 0x00010001u) >> 1;
+        b = ((r2 & m) + ((r2 >> 8) & m) + 0x00010001u) >> 1;
+    } else {
+        uint32_t r1 = ((const U32l *) (p + 34))->v, r3 = ((const U32l *) (p + 102))->v;
+        if (ph == 2) {
+            a = ((r0 & m) + (r1 & m) + 0x00010001u) >> 1;
+            b = ((r2 & m) + (r3 & m) + 0x00010001u) >> 1;
+        } else {
+            a = ((r0 & m) + ((r0 >> 8) & m) + (r1 & m) + ((r1 >> 8) & m) + 0x00020002u) >> 2;
+            b = ((r2 & m) + ((r2 >> 8) & m) + (r3 & m) + ((r3 >> 8) & m) + 0x00020002u) >> 2;
+        }
+    }
+    return __builtin_amdgcn_perm(b, a, 0x06040200u); // (a.b0, a.b2, b.b0, b.b2)
 }
 
 __device__ __forceinline__ int qsample_ph(const uint8_t *h, int X, int Y, int phase)

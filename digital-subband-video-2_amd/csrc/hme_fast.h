@@ -620,9 +620,9 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
         int X = 4 + 8 * qi + t0, Y = 4 + 8 * qj + t1;
         // every lane samples at the same quarter-pel phase (its X, Y differ from the probe offset by multiples of 4)
         const int ph = __builtin_amdgcn_readfirstlane((t0 & 1) | ((t1 & 1) << 1));
-        v8[n] = n < 7 ? (int) qmetric(aw, mkq(qsample_ph(S.sp.h, X, Y, ph), qsample_ph(S.sp.h, X + 4, Y, ph), qsample_ph(S.sp.h, X, Y + 4, ph),
-                                                qsample_ph(S.sp.h, X + 4, Y + 4, ph)), psy)
-                      : 0;
+        Quad qs;
+        qs.w = n < 7 ? qquad_ph(S.sp.h, X, Y, ph) : 0u;
+        v8[n] = n < 7 ? (int) qmetric(aw, qs, psy) : 0;
     }
     int r8 = reduceN<8>(v8);
     // lane n finishes probe n: metric_return + vector cost

@@ -34,9 +34,14 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     # cross-check of the bench's HIP-event figure for the dominant kernel
     tr = list(csv.DictReader(open(os.path.join(src, "kernel_trace_hme.csv"))))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
-    f.write("\nk_hme_rows_b_fast_l0_w2 (level-0 search, the dominant kernel): %d launches, mean %.1f us (kernel trace) -- bench.py HIP-event span of "
-            "that launch: %.1f us\n" % (len(durs), sum(durs) / max(1, len(durs)), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
-    f.write("(the trace includes the pre-roll steps, in which a launch serves fewer streams than the 96 of a full step)\n")
+    gmax = max(int(r["Grid_Size_X"]) for r in tr)
+    full = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if int(r["Grid_Size_X"]) >= gmax - 6 * 64]
+    f.write("\nk_hme_rows_b_fast_l0_w2 (level-0 search, the dominant kernel): %d launches, mean %.1f us over all of them (the pre-roll steps "
+            "launch it for fewer streams), mean %.1f us over the %d full-size launches (90-96 inter pictures of a group) -- bench.py HIP-event span of that "
+            "launch in its profiled steps: %.1f us (the event span also holds the wait for a free queue slot between the group's "
+            "launches while the other three groups' kernels are being dispatched)\n"
+            % (len(durs), sum(durs) / max(1, len(durs)), sum(full) / max(1, len(full)), len(full),
+               traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
 
 # PMC: per-launch HBM-side bytes of the dominant kernel
 agg = {}
