@@ -73,25 +73,21 @@ __device__ __forceinline__ int wave_sum(int v)
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) { return (unsigned) wave_sum((int) v); }
 
-__device__ __forceinline__ unsigned isqrt_u32(unsigned n) // hme.c:99
+// floor(sqrt(n)) -- what the bit-by-bit loop of hme.c:99 computes -- from the hardware's float square root plus one
+// exact integer correction step.  (float) n and v_sqrt_f32 are each within a relative 2^-23: the truncated estimate is off
+// by at most one either way for every 32-bit n (root <= 65535, so r * r never overflows).  The loop was ~100 instructions
+// with a data-dependent trip count, and the block metric calls this once per scored vector: a quarter of the search's
+// vector instructions.
+__device__ __forceinline__ unsigned isqrt_u32(unsigned n)
 {
-    if (n == 0) {
-        return 0;
+    unsigned r = (unsigned) __builtin_amdgcn_sqrtf((float) n); // v_sqrt_f32: one instruction, 1 ulp
+    r = r > 65535u ? 65535u : r;
+    if (r * r > n) {
+        r--;
+    } else if (r < 65535u && (r + 1u) * (r + 1u) <= n) {
+        r++;
     }
-    unsigned pos = 1u << 30, res = 0, rem = n;
-    while (pos > rem) {
-        pos >>= 2;
-    }
-    while (pos) {
-        unsigned dif = res + pos;
-        res >>= 1;
-        if (rem >= dif) {
-            rem -= dif;
-            res += pos;
-        }
-        pos >>= 2;
-    }
-    return res;
+    return r;
 }
 
 struct Grad {

@@ -157,7 +157,8 @@ __device__ __forceinline__ unsigned ws_umetr(const uint8_t *a, int as, const uin
 
 __device__ __forceinline__ unsigned metric_return(unsigned acc, int w, int h)
 {
-    return isqrt_u32(acc) * (unsigned) w * (unsigned) h / (unsigned) AVG2(w, h);
+    const unsigned num = isqrt_u32(acc) * (unsigned) w * (unsigned) h, d = (unsigned) AVG2(w, h);
+    return (d & (d - 1u)) == 0u ? num >> (31 - __clz((int) d)) : num / d; // (16 for every whole block: a shift, not a division)
 }
 
 __device__ __forceinline__ unsigned ws_metr(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h, const Psy &psy)

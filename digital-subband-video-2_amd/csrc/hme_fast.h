@@ -431,9 +431,10 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
 // scores up to 16 displacement vectors held in LDS (s.cx/cy[first .. first+cnt)) against the
 // register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
 // first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
-template <int NT>
-__device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
-                                            const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
+// vec(t, dx, dy): the t-th displacement vector of the round, wave-uniform
+template <int NT, class VecFn>
+__device__ __forceinline__ unsigned score_vecs(const FastLds &s, const Win &w, VecFn vec, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
+                                               const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
 {
     // all loads first, back to back (one round trip); a vector that may not be read is replaced by a safe one
     Quad b[NT];
@@ -443,7 +444,8 @@ __device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int 
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
-        int dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]), dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
+        int dx, dy;
+        vec(t, dx, dy);
         ok[t] = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
         dxs[t] = dx;
         dys[t] = dy;
@@ -473,6 +475,20 @@ __device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int 
     }
     int r = reduceN<NR>(v);
     return (unsigned) bcastL<NR>(r, threadIdx.x & (NR - 1));
+}
+
+// the same for vectors held in LDS (s.cx / s.cy [first .. first + cnt)): the candidate list
+template <int NT>
+__device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
+                                            const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
+{
+    return score_vecs<NT>(
+        s, w,
+        [&](int t, int &dx, int &dy) {
+            dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]);
+            dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
+        },
+        cnt, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
 }
 
 // psy accumulator of one 2x2 quad pair for the three predictions compared by err_intra (hme.c:839)
@@ -1297,32 +1313,27 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     }
     cxv = (int) (int16_t) ((int) (int16_t) cxv >> level);
     cyv = (int) (int16_t) ((int) (int16_t) cyv >> level);
-    // order-preserving compaction, then first-occurrence de-duplication (hme.c:1166)
+    // first-occurrence de-duplication (hme.c:1166), then ONE order-preserving compaction into LDS.  The comparison walks the
+    // existing entries with scalar reads of the owning lanes (no LDS round trip per entry).
     int n;
     {
-        unsigned long long em = __ballot(exist);
-        int idx = __popcll(em & ((1ull << lane) - 1));
-        if (exist) {
-            S.cx[idx] = cxv;
-            S.cy[idx] = cyv;
-        }
-        n = __popcll(em);
-        __syncthreads();
-        int mx = lane < n ? S.cx[lane] : 0, my = lane < n ? S.cy[lane] : 0;
+        const unsigned long long em = __ballot(exist);
+        const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16); // both components are int16 by now
         bool dup = false;
-        for (int m = 0; m < n; m++) {
-            int ox = S.cx[m], oy = S.cy[m];
-            dup = dup || (m < lane && ox == mx && oy == my);
+        for (unsigned long long rest = em; rest; rest &= rest - 1) {
+            const int m = __ffsll((long long) rest) - 1;
+            const int km = __builtin_amdgcn_readlane(key, m);
+            dup = dup || (m < lane && km == key);
         }
-        __syncthreads();
-        bool keep = lane < n && !dup;
-        unsigned long long km = __ballot(keep);
-        int nidx = __popcll(km & ((1ull << lane) - 1));
-        if (keep) {
-            S.cx[nidx] = mx;
-            S.cy[nidx] = my;
-        }
+        const bool keep = exist && !dup;
+        const unsigned long long km = __ballot(keep);
+        const int nidx = __popcll(km & ((1ull << lane) - 1));
         n = __popcll(km);
+        __syncthreads(); // (the previous block's readers of S.cx / S.cy are done)
+        if (keep) {
+            S.cx[nidx] = cxv;
+            S.cy[nidx] = cyv;
+        }
         if (lane >= n) { // pad: unused slots hold the zero vector (never selected: masked below)
             S.cx[lane] = 0;
             S.cy[lane] = 0;
@@ -1408,13 +1419,14 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         while (again && !good_enough) {
             again = false;
             HME_COUNT(S, 12, 1);
-            __syncthreads();
-            if (lane < 16) {
-                S.cx[lane] = dx + (lane < 9 ? tab9(kRectX, lane) : 0);
-                S.cy[lane] = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
-            }
-            __syncthreads();
-            unsigned raw = score16<9>(S, W, 0, 9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            const int rdx = dx, rdy = dy;
+            unsigned raw = score_vecs<9>(
+                S, W,
+                [&](int t, int &vx, int &vy) {
+                    vx = rdx + tab9(kRectX, t);
+                    vy = rdy + tab9(kRectY, t);
+                },
+                9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
             int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
             bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
             if (level <= 1) {
