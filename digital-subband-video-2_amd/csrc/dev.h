@@ -156,6 +156,7 @@ void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_b
 void zero_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes); // dst, bytes of each job
 void copy_planes_batch(hipStream_t s, const PlanePair *d_pairs, int n, int w, int h);  // visible pixels, same-size planes
 void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int total_rows);
+void ingest_batch16(hipStream_t s, const IngestJob *d_jobs, int n, int total_rows); // all plane widths % 16 == 0, <= 2048, 16-byte aligned sources
 
 void ensure_device();
 void set_default_device(int ordinal);

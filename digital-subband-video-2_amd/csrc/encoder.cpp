@@ -1405,7 +1405,18 @@ void enc_batch(Job *jobs, int n)
     sc.tabs.upload(bs);
     {
         const DFrame &f0 = dv0.pics[0].src;
-        ingest_batch(bs, d_ing, n_ing, f0.p[0].w, f0.p[0].h + f0.p[1].h + f0.p[2].h);
+        {
+            bool wide = f0.p[0].w <= 2048 && (f0.p[0].w % 16) == 0 && (f0.p[1].w % 16) == 0 && (f0.p[2].w % 16) == 0 &&
+                        (((size_t) f0.p[0].w * f0.p[0].h) % 16) == 0 && (((size_t) f0.p[1].w * f0.p[1].h) % 16) == 0;
+            for (int k = 0; k < n_ing && wide; k++) {
+                wide = ((uintptr_t) h_ing[k].src % 16) == 0;
+            }
+            if (wide) {
+                ingest_batch16(bs, d_ing, n_ing, f0.p[0].h + f0.p[1].h + f0.p[2].h);
+            } else {
+                ingest_batch(bs, d_ing, n_ing, f0.p[0].w, f0.p[0].h + f0.p[1].h + f0.p[2].h);
+            }
+        }
         ingest_uyvy_batch(bs, d_ingu, n_ingu, f0.p[0].w, f0.p[0].h);
         extend_planes(bs, d_ext_y, n, f0.p[0].w, f0.p[0].h);
         extend_planes(bs, d_ext_c, 2 * n, f0.p[1].w, f0.p[1].h);

@@ -263,6 +263,29 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestJob *__restrict__ ta
     }
 }
 
+// the same for pictures whose rows are multiples of 16 bytes in every plane (all the usual sizes): 16 bytes per thread and
+// load, four rows per workgroup -- an eighth of the workgroups and a quarter of the memory instructions of k_ingest
+__global__ __launch_bounds__(128) void k_ingest16(const IngestJob *__restrict__ tab)
+{
+    const IngestJob &j = tab[blockIdx.y];
+    const int x = (int) threadIdx.x * 16;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int y = (int) blockIdx.x * 4 + r;
+        const uint8_t *sp = j.src;
+        int c = 0;
+        while (c < 2 && y >= j.dst[c].h) { // plane of this row
+            sp += (size_t) j.dst[c].w * j.dst[c].h;
+            y -= j.dst[c].h;
+            c++;
+        }
+        const DPlane &pl = j.dst[c];
+        if (y < pl.h && x < pl.w) {
+            *(uint4 *) (pl.data + (size_t) y * pl.stride + x) = *(const uint4 *) (sp + (size_t) y * pl.w + x);
+        }
+    }
+}
+
 // interleaved UYVY 4:2:2 picture (rows of 2 * w bytes: U0 Y0 V0 Y1 ...) -> the three padded planes; the
 // de-interleave of dsv_yuv_read (dsv.c:177-205) done while the picture is ingested.  One thread per 4 luma pixels
 // (8 source bytes -> 4 Y, 2 U, 2 V).
@@ -355,6 +378,15 @@ void ingest_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int tota
         return;
     }
     DSV2_LAUNCH(k_ingest, dim3((w + 1023) / 1024, total_rows, n), dim3(256), 0, s, d_jobs);
+}
+
+// every plane's width a multiple of 16 (and at most 2048), sources 16-byte aligned: the wide form
+void ingest_batch16(hipStream_t s, const IngestJob *d_jobs, int n, int total_rows)
+{
+    if (n <= 0) {
+        return;
+    }
+    DSV2_LAUNCH(k_ingest16, dim3((total_rows + 3) / 4, n), dim3(128), 0, s, d_jobs);
 }
 
 void ingest_uyvy_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int h)
