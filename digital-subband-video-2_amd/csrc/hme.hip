@@ -1218,15 +1218,27 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
 }
 
 // ---- row-pipelined level: ONE launch per pyramid level for all streams --------------------------
-// blockIdx.x = stream, blockIdx.y = block row (workgroups are dispatched row-major ACROSS streams, so
-// by the time row j of any stream gets a slot its row j-1 is well under way and few resident
-// wavefronts sit spinning); one wavefront walks its row left to right.  Block
-// (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and (bi, bj-1), (bi-1, bj-1) of the
-// row above, so a row only ever waits for the progress word of the row above it: a slow block
-// delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front
-// does.  A waiting row depends on a lower workgroup index only, so the lowest unfinished workgroup
-// can always run; every spin is bounded by the wall clock and reports through counters[7].
-constexpr int kHmeErrWord = 7, kHmeProgress = 16;
+// grid = (streams, block rows); one wavefront walks one block row of one stream left to right (which row: see take_ticket
+// below -- tickets run row-major ACROSS streams, so by the time row j of any stream is taken its row j-1 is well under way
+// and few resident wavefronts sit spinning).  Block (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and
+// (bi, bj-1), (bi-1, bj-1) of the row above, so a row only ever waits for the progress word of the row above it: a slow
+// block delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front does.  Every spin
+// is bounded by the wall clock and reports through counters[7] and the host's pinned counter block.
+constexpr int kHmeErrWord = 7, kHmeTicket = 8 /* 8 .. 13: one ticket counter per pyramid level */, kHmeProgress = 16;
+
+// Which row a workgroup works on is NOT its index in the grid: every wavefront takes the next TICKET of its launch from a
+// counter (rows in row-major order across the launch's streams).  A row only ever waits for the row above it, whose
+// ticket is lower, i.e. was taken by a wavefront that is already running: the chain of waits ends at a row 0, which
+// waits for nothing -- progress is guaranteed whatever order the hardware dispatches the workgroups in (HIP promises
+// none), as long as a workgroup, once started, keeps running (no preemption of a launch's resident wavefronts).
+__device__ __forceinline__ int take_ticket(int *counter)
+{
+    int t = 0;
+    if ((threadIdx.x & 63) == 0) {
+        t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __builtin_amdgcn_readfirstlane(t);
+}
 constexpr unsigned long long kHmeSpinLimit = 400000000ull; // 100 MHz ticks = 4 s
 
 __device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned need, int *err)
@@ -1367,19 +1379,22 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row<false>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                                    \
+        const int t_ = take_ticket(&tab[0].counters[kHmeTicket + level]), n_ = (int) gridDim.x;                          \
+        hme_row<false>(tab[t_ % n_], t_ / n_, level, nbx, (int) gridDim.y, allow_fast, S);                               \
     }                                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_w##W(          \
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row<true, 0>(tab[blockIdx.x], (int) blockIdx.y, 0, nbx, (int) gridDim.y, allow_fast, S);                     \
+        const int t_ = take_ticket(&tab[0].counters[kHmeTicket + 0]), n_ = (int) gridDim.x;                              \
+        hme_row<true, 0>(tab[t_ % n_], t_ / n_, 0, nbx, (int) gridDim.y, allow_fast, S);                                 \
     }                                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_w##W(          \
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        hme_row<true, 1>(tab[blockIdx.x], (int) blockIdx.y, level, nbx, (int) gridDim.y, allow_fast, S);                 \
+        const int t_ = take_ticket(&tab[0].counters[kHmeTicket + level]), n_ = (int) gridDim.x;                          \
+        hme_row<true, 1>(tab[t_ % n_], t_ / n_, level, nbx, (int) gridDim.y, allow_fast, S);                             \
     }
 HME_ROWS_B(1)
 HME_ROWS_B(2)
@@ -1421,7 +1436,7 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
 __global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
 {
     __shared__ FastLds S;
-    hme_row<false>(c, (int) blockIdx.x, level, nbx, (int) gridDim.x, allow_fast, S);
+    hme_row<false>(c, take_ticket(&c.counters[kHmeTicket + level]), level, nbx, (int) gridDim.x, allow_fast, S);
 }
 
 // level < 0: blockIdx.z enumerates the levels (row pipeline: one clear for the whole search)
