@@ -2,7 +2,10 @@
 # usage: tools/cpu_quota_probe.sh <bench args...>  -- prints CPU time and CFS throttling of one bench.py run (GPU box)
 s0=$(grep -E "^usage_usec|^nr_throttled|^throttled_usec|^nr_periods" /sys/fs/cgroup/cpu.stat | awk '{print $2}' | tr '\n' ' ')
 t0=$(date +%s.%N)
-python3 bench.py --no-cpu-baseline --no-profile "$@" 2>/dev/null | python3 tools/brief.py "run"
+python3 bench.py --no-cpu-baseline --no-profile --no-extras "$@" 2>/dev/null | python3 -c "
+import json, sys
+d = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('run', d['value'], 'frames/s', d['ms_per_step'], 'ms/step', 'host cores busy', d['config'].get('host_cpu_cores_busy'))"
 t1=$(date +%s.%N)
 s1=$(grep -E "^usage_usec|^nr_throttled|^throttled_usec|^nr_periods" /sys/fs/cgroup/cpu.stat | awk '{print $2}' | tr '\n' ' ')
 python3 - "$s0" "$s1" "$t0" "$t1" <<'PY'
