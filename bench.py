@@ -564,17 +564,22 @@ def main():
             sel.append(s if s < S else 2 * u)
         nfr = [min(NREF_FRAMES, len(run.out[s])) for s in sel]
         jobs = [(W_, H_, "420", 1 + rank * NV + run.video[s], QP, GOP, effort, [run.frame_index(s, t) for t in range(nfr[i])]) for i, s in enumerate(sel)]
-        rw = RefWorkers(jobs)
-        one = rw.go([0], min(24, nfr[0]))[0]             # one reference thread, alone on the box
-        allr = rw.go(list(range(len(sel))), max(nfr))    # all workers at once (each stops at its own frame count)
-        mism = []
-        for i, s in enumerate(sel):
-            want = rw.frames(i)
-            got = [b"".join(fr) for fr in run.out[s][:len(want)]]
-            if want != got:
-                first = next((t for t, (a, b) in enumerate(zip(want, got)) if a != b), min(len(want), len(got)))
-                mism.append((s, first))
-        rw.close()
+        try:
+            rw = RefWorkers(jobs)
+            one = rw.go([0], min(24, nfr[0]))[0]             # one reference thread, alone on the box
+            allr = rw.go(list(range(len(sel))), max(nfr))    # all workers at once (each stops at its own frame count)
+            mism = []
+            for i, s in enumerate(sel):
+                want = rw.frames(i)
+                got = [b"".join(fr) for fr in run.out[s][:len(want)]]
+                if want != got:
+                    first = next((t for t, (a, b) in enumerate(zip(want, got)) if a != b), min(len(want), len(got)))
+                    mism.append((s, first))
+            rw.close()
+        except (OSError, AssertionError, ValueError) as e:  # the reference side failed: say so beside the headline
+            result["parity_checked"]["vs_reference_error"] = repr(e)
+            print(json.dumps(result))
+            sys.exit(5)
         result["parity_checked"].update({"vs_reference_streams": len(sel), "vs_reference_frames_each": nfr, "streams": sel,
                                          "groups_covered": sorted(set(s % G for s in sel)), "mismatches": len(mism)})
         result["cpu_baseline"] = {"value": round(one["frames"] / (one["t1"] - one["t0"]), 3), "unit": "frames/s", "cores": 1, "kind": "reference",
@@ -590,49 +595,61 @@ def main():
             sys.exit(4)
 
     # ---- the decoder on this run's packets, and the other BASELINE.json configurations (N = 1 only) ----
+    # (the headline above is complete: whatever goes wrong below is reported beside it, never instead of it)
     if extras:
-        result["decode"] = decode_leg(hip, A, run, 0, 32, 256, 4)
+        try:
+            result["decode"] = decode_leg(hip, A, run, 0, 32, 256, 4)
+        except Exception as e:  # noqa: BLE001
+            result["decode"] = {"error": repr(e)}
     run.free()
     if extras:
-        cfgs = {}
-        # C2: 1280x720 4:2:0 -qp=60 -gop=48 effort 10
-        r2 = EncodeRun(hip, A, torch, 1280, 720, "420", 60, 48, 10, S, args.groups, vids[NV:NV + 4], not args.no_stagger)
-        r2.run(r2.R + 4)
-        k2 = 24
-        g2 = r2.step
-        e2 = r2.run(k2)
-        p2, b2 = r2.twins_equal()
-        f2 = r2.frames_in(g2, g2 + k2)
-        cfgs["c2_720p_420_qp60_gop48"] = {"value": round(f2 / e2, 2), "unit": "frames/s", "streams": S, "steps": k2, "ms_per_step": round(1e3 * e2 / k2, 3),
-                                           "mpix_per_s": round(f2 / e2 * 1280 * 720 / 1e6, 1), "twin_pairs_equal": p2 - b2, "twin_pairs": p2,
-                                           "input": "pinned_host, staggered GOP phases"}
-        r2.free()
-        # C3: 1920x1080 4:2:0 -qp=60 -gop=60 (the headline's geometry with the CLI's default GOP)
-        r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:NV], not args.no_stagger)
-        r3.run(r3.R + 4)
-        k3 = 16
-        g3 = r3.step
-        e3 = r3.run(k3)
-        p3, b3 = r3.twins_equal()
-        f3 = r3.frames_in(g3, g3 + k3)
-        cfgs["c3_1080p_420_qp60_gop60"] = {"value": round(f3 / e3, 2), "unit": "frames/s", "streams": S, "steps": k3, "ms_per_step": round(1e3 * e3 / k3, 3),
-                                            "mpix_per_s": round(f3 / e3 * W_ * H_ / 1e6, 1), "twin_pairs_equal": p3 - b3, "twin_pairs": p3,
-                                            "input": "pinned_host, staggered GOP phases"}
-        r3.free()
-        # C4: 1920x1080 4:4:4 lossless (-qp=100), every stream from its first (intra) frame; round trip through the decoder
-        s4 = min(32, S)
-        r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, 2, vids[NV + 4:NV + 5], False)
-        r4.run(2)
-        k4 = 8
-        e4 = r4.run(k4)
-        cfgs["c4_1080p_444_lossless"] = {"value": round(s4 * k4 / e4, 2), "unit": "frames/s", "streams": s4, "steps": k4, "ms_per_step": round(1e3 * e4 / k4, 3),
-                                          "mpix_per_s": round(s4 * k4 / e4 * W_ * H_ / 1e6, 1), "frames": "P frames 2..9 of each stream (general ME routine)",
-                                          "round_trip": lossless_round_trip(hip, A, r4, vids[NV + 4])}
-        r4.free()
-        result["configs"] = cfgs
+        try:
+            result["configs"] = other_configs(hip, A, torch, args, vids, NV, S, W_, H_)
+        except Exception as e:  # noqa: BLE001
+            result["configs"] = {"error": repr(e)}
     print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_configs(hip, A, torch, args, vids, NV, S, W_, H_):
+    """the other BASELINE.json configurations, each a short run of the same engine (N = 1 only)"""
+    cfgs = {}
+    # C2: 1280x720 4:2:0 -qp=60 -gop=48 effort 10
+    r2 = EncodeRun(hip, A, torch, 1280, 720, "420", 60, 48, 10, S, args.groups, vids[NV:NV + 4], not args.no_stagger)
+    r2.run(r2.R + 4)
+    k2 = 24
+    g2 = r2.step
+    e2 = r2.run(k2)
+    p2, b2 = r2.twins_equal()
+    f2 = r2.frames_in(g2, g2 + k2)
+    cfgs["c2_720p_420_qp60_gop48"] = {"value": round(f2 / e2, 2), "unit": "frames/s", "streams": S, "steps": k2, "ms_per_step": round(1e3 * e2 / k2, 3),
+                                       "mpix_per_s": round(f2 / e2 * 1280 * 720 / 1e6, 1), "twin_pairs_equal": p2 - b2, "twin_pairs": p2,
+                                       "input": "pinned_host, staggered GOP phases"}
+    r2.free()
+    # C3: 1920x1080 4:2:0 -qp=60 -gop=60 (the headline's geometry with the CLI's default GOP)
+    r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:NV], not args.no_stagger)
+    r3.run(r3.R + 4)
+    k3 = 16
+    g3 = r3.step
+    e3 = r3.run(k3)
+    p3, b3 = r3.twins_equal()
+    f3 = r3.frames_in(g3, g3 + k3)
+    cfgs["c3_1080p_420_qp60_gop60"] = {"value": round(f3 / e3, 2), "unit": "frames/s", "streams": S, "steps": k3, "ms_per_step": round(1e3 * e3 / k3, 3),
+                                        "mpix_per_s": round(f3 / e3 * W_ * H_ / 1e6, 1), "twin_pairs_equal": p3 - b3, "twin_pairs": p3,
+                                        "input": "pinned_host, staggered GOP phases"}
+    r3.free()
+    # C4: 1920x1080 4:4:4 lossless (-qp=100), every stream from its first (intra) frame; round trip through the decoder
+    s4 = min(32, S)
+    r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, 2, vids[NV + 4:NV + 5], False)
+    r4.run(2)
+    k4 = 8
+    e4 = r4.run(k4)
+    cfgs["c4_1080p_444_lossless"] = {"value": round(s4 * k4 / e4, 2), "unit": "frames/s", "streams": s4, "steps": k4, "ms_per_step": round(1e3 * e4 / k4, 3),
+                                      "mpix_per_s": round(s4 * k4 / e4 * W_ * H_ / 1e6, 1), "frames": "P frames 2..9 of each stream (general ME routine)",
+                                      "round_trip": lossless_round_trip(hip, A, r4, vids[NV + 4])}
+    r4.free()
+    return cfgs
 
 
 def lossless_round_trip(hip, A, run, frames):
