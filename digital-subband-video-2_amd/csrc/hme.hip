@@ -1173,7 +1173,7 @@ __device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, 
     if (level == 0) {
         return (bw & 7) == 0 && (bh & 7) == 0;
     }
-    return !(bw & 1) && !(bh & 1);
+    return level > 1 || (!(bw & 1) && !(bh & 1)); // (the squared-error levels take any clipped size)
 }
 
 // one anti-diagonal front of one level: blockIdx.x enumerates the blocks on the front
@@ -1430,7 +1430,7 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
         return false;
     }
     int bw = src.w - lx < 16 ? src.w - lx : 16, bh = src.h - ly < 16 ? src.h - ly : 16;
-    return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (!(bw & 1) && !(bh & 1));
+    return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (level > 1 || (!(bw & 1) && !(bh & 1)));
 }
 
 __global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)

@@ -12,8 +12,8 @@
 //   * candidate bookkeeping (gather, qpel->fpel rounding, level scaling, first-occurrence
 //     de-duplication, cost, arg-min with first-wins ties) is lane-parallel: lane k owns candidate
 //     k; order-preserving compaction uses ballots.
-// Preconditions (else hme_block() is used): 16x16 blocks, 4:2:0, even clipped block size; at
-// level 0 additionally block width/height multiples of 8.
+// Preconditions (else hme_block() is used): 16x16 blocks, 4:2:0; clipped block sizes even at levels 0 and 1 (any size
+// at the squared-error levels above), at level 0 additionally block width/height multiples of 8.
 #pragma once
 
 // a 2x2 pixel quad packed in one register: byte 0 = top-left, 1 = top-right, 2 = bottom-left,
@@ -432,9 +432,11 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
 // register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
 // first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
 // vec(t, dx, dy): the t-th displacement vector of the round, wave-uniform
+// smask: bytes of a quad that belong to the block (all four, except in the half quads of an odd last row / column at the
+// squared-error levels)
 template <int NT, class VecFn>
 __device__ __forceinline__ unsigned score_vecs(const FastLds &s, const Win &w, VecFn vec, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
-                                               const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
+                                               const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
 {
     // all loads first, back to back (one round trip); a vector that may not be read is replaced by a safe one
     Quad b[NT];
@@ -469,6 +471,7 @@ __device__ __forceinline__ unsigned score_vecs(const FastLds &s, const Win &w, V
     for (int t = 0; t < NR; t++) {
         v[t] = 0;
         if (t < NT && ok[t]) { // wave-uniform: the arithmetic of an absent vector is skipped, its (dummy) load was not
+            b[t].w &= smask;
             int m = (int) (level > 1 ? qsse(a, b[t]) : qmetric(a, b[t], psy));
             v[t] = act ? m : 0;
         }
@@ -480,7 +483,7 @@ __device__ __forceinline__ unsigned score_vecs(const FastLds &s, const Win &w, V
 // the same for vectors held in LDS (s.cx / s.cy [first .. first + cnt)): the candidate list
 template <int NT>
 __device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
-                                            const Quad &a, bool act, int qi, int qj, int level, const Psy &psy)
+                                            const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
 {
     return score_vecs<NT>(
         s, w,
@@ -488,7 +491,7 @@ __device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int 
             dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]);
             dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
         },
-        cnt, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+        cnt, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
 }
 
 // psy accumulator of one 2x2 quad pair for the three predictions compared by err_intra (hme.c:839)
@@ -1130,9 +1133,19 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     const int bx = (i * y_w) >> level, by = (j * y_h) >> level;
     const int bw = min(src.w - bx, y_w), bh = min(src.h - by, y_h);
     const int qw = bw >> 1, qh = bh >> 1;
-    const bool act = FULL ? true : (qi < qw && qj < qh);
+    // The psy metric works on whole 2x2 quads and drops an odd last row / column (hme.c:136: loops to h / 2, w / 2); the squared
+    // error of the levels above 1 counts every pixel (hme.c:198).  There an odd row / column is a row / column of HALF quads:
+    // those lanes take part (`act`) with the bytes outside the block masked off in both operands (`smask`).
+    const bool actM = FULL ? true : (qi < qw && qj < qh);
+    bool act = actM;
+    uint32_t smask = 0xffffffffu;
+    if (!FULL && level > 1) {
+        act = qi < ((bw + 1) >> 1) && qj < ((bh + 1) >> 1);
+        smask = (((bw & 1) && qi == qw) ? 0x00ff00ffu : 0xffffffffu) & (((bh & 1) && qj == qh) ? 0x0000ffffu : 0xffffffffu);
+    }
     const uint8_t *sblk = at(src, bx, by);
-    const Quad a = ldq(sblk, src.stride, qi, qj, act);
+    Quad a = ldq(sblk, src.stride, qi, qj, act);
+    a.w &= smask;
     const Quad o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act); // for the "good enough" test far below: same load round
     // the same round also stages the search windows in LDS (LDS-DMA, no registers: see WinLds)
     Win W;
@@ -1364,12 +1377,12 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     {
         unsigned raw = 0;
         if (n <= 4) { // the usual case after de-duplication
-            raw = score16<4>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            raw = score16<4>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
         } else if (n <= 8) {
-            raw = score16<8>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+            raw = score16<8>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
         } else {
             for (int first = 0; first < n; first += 16) {
-                unsigned r = score16<16>(S, W, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+                unsigned r = score16<16>(S, W, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
                 if (lane >= first && lane < first + 16) {
                     raw = r;
                 }
@@ -1400,7 +1413,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
     {
-        unsigned zoscore = metric_return(wave_sum(act ? qmetric(a, o_zero, psy) : 0u), bw, bh);
+        unsigned zoscore = metric_return(wave_sum(actM ? qmetric(a, o_zero, psy) : 0u), bw, bh);
         if (abs(dx) <= 1 && abs(dy) <= 1) {
             qthresh *= 2;
         }
@@ -1426,7 +1439,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
                     vx = rdx + tab9(kRectX, t);
                     vy = rdy + tab9(kRectY, t);
                 },
-                9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy);
+                9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
             int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
             bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
             if (level <= 1) {
