@@ -452,6 +452,21 @@ template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJ
 }
 
 // res <- recon(pred, res) over the block grid of every plane: grid = (x groups, rows, 3 n), one dword per thread
+__device__ __forceinline__ uint32_t recon4(uint32_t rv4, uint32_t pv4, bool plain, int lossless)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int rv = (int) ((rv4 >> (8 * k)) & 0xff), pv = (int) ((pv4 >> (8 * k)) & 0xff);
+        int o = lossless ? ((pv + rv - 128) & 0xff) : (plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2));
+        out |= (uint32_t) o << (8 * k);
+    }
+    return out;
+}
+
+// sixteen pixels of a row per thread (one 16-byte load of the residual and of the prediction, one 16-byte store); a
+// group of four pixels never straddles a block (block widths are multiples of 8 in every plane), so each dword takes the
+// flags of its own block.  Planes come from dframe_alloc: rows and origins are 16-byte aligned.
 __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__ tab)
 {
     const McJob &jb = tab[blockIdx.z / 3];
@@ -459,22 +474,47 @@ __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__
     int c = blockIdx.z % 3;
     int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
     int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
-    int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= p.nbh * bw || y >= p.nbv * bh) {
+    int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int xlim = p.nbh * bw;
+    if (x >= xlim || y >= p.nbv * bh) {
         return;
     }
     const DPlane dp = jb.pred.p[c], sp = jb.res.p[c];
-    uint32_t flags = jb.mvs[(x / bw) + (y / bh) * p.nbh].flags;
-    bool plain = !(flags & (1u << DSV_MV_BIT_EPRM)) || (!(flags & (1u << DSV_MV_BIT_INTRA)) && (flags & (1u << DSV_MV_BIT_SKIP)));
-    uint32_t *spx = (uint32_t *) (sp.data + (ptrdiff_t) y * sp.stride + x);
-    uint32_t rv4 = *spx, pv4 = *(const uint32_t *) (dp.data + (ptrdiff_t) y * dp.stride + x), out = 0;
+    const DSV_MV *row = jb.mvs + (y / bh) * p.nbh;
+    uint8_t *spx = sp.data + (ptrdiff_t) y * sp.stride + x;
+    const uint8_t *dpx = dp.data + (ptrdiff_t) y * dp.stride + x;
+    uint32_t rv[4], pv[4];
+    const bool whole = x + 16 <= xlim;
+    if (whole) {
+        const uint4 r = *(const uint4 *) spx, q = *(const uint4 *) dpx;
+        rv[0] = r.x, rv[1] = r.y, rv[2] = r.z, rv[3] = r.w;
+        pv[0] = q.x, pv[1] = q.y, pv[2] = q.z, pv[3] = q.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int rv = (int) ((rv4 >> (8 * k)) & 0xff), pv = (int) ((pv4 >> (8 * k)) & 0xff);
-        int o = p.lossless ? ((pv + rv - 128) & 0xff) : (plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2));
-        out |= (uint32_t) o << (8 * k);
+        for (int g = 0; g < 4; g++) {
+            bool in = x + 4 * g < xlim;
+            rv[g] = in ? *(const uint32_t *) (spx + 4 * g) : 0u;
+            pv[g] = in ? *(const uint32_t *) (dpx + 4 * g) : 0u;
+        }
     }
-    *spx = out;
+    uint32_t o[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        int bi = min((x + 4 * g) / bw, p.nbh - 1);
+        uint32_t flags = row[bi].flags;
+        bool plain = !(flags & (1u << DSV_MV_BIT_EPRM)) || (!(flags & (1u << DSV_MV_BIT_INTRA)) && (flags & (1u << DSV_MV_BIT_SKIP)));
+        o[g] = recon4(rv[g], pv[g], plain, p.lossless);
+    }
+    if (whole) {
+        *(uint4 *) spx = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (x + 4 * g < xlim) {
+                *(uint32_t *) (spx + 4 * g) = o[g];
+            }
+        }
+    }
 }
 
 // encoder-side reconstruction in place: res <- recon(pred, res)   (dsv_add_res, bmc.c:1082)
@@ -1382,7 +1422,7 @@ void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nb
 void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_h, int blk_w, int blk_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 4 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
+        DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
             DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
         }

@@ -152,6 +152,7 @@ void ingest_uyvy_batch(hipStream_t s, const IngestJob *d_jobs, int n, int w, int
 void planes_to_host_batch(hipStream_t s, const PlaneOutJob *d_jobs, int n, int h);
 void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int max_h);
 void ds2x_planes(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h);
+void ds2x_planes4(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int dst_h); // planes from dframe_alloc: 4 samples per thread
 void copy_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes);
 void zero_linear_batch(hipStream_t s, const CopyJob *d_jobs, int n, size_t max_bytes); // dst, bytes of each job
 void copy_planes_batch(hipStream_t s, const PlanePair *d_pairs, int n, int w, int h);  // visible pixels, same-size planes

@@ -1422,7 +1422,7 @@ void enc_batch(Job *jobs, int n)
         extend_planes(bs, d_ext_c, 2 * n, f0.p[1].w, f0.p[1].h);
         for (int l = 0; l < L; l++) {
             const DPlane &lp = dv0.pics[0].src_pyr[l].p[0];
-            ds2x_planes(bs, d_pair[l], n_pyr, lp.w, lp.h);
+            ds2x_planes4(bs, d_pair[l], n_pyr, lp.w, lp.h); // (picture sets are dframe_alloc'd: aligned)
             extend_planes(bs, d_pext[l], n_pyr, lp.w, lp.h);
         }
         planes_to_host_batch(bs, d_small, n, dv0.pics[0].src_pyr[L - 1].p[0].h);
