@@ -146,45 +146,81 @@ __device__ __forceinline__ PlaneSpan plane_span(const int *I, int c)
 }
 
 // ---- 2 ----------------------------------------------------------------------------------------------------
-// per symbol one byte in LDS: 0xff = coded without the adaptive state (LL region), else bitlen(u) | (damp - 3) << 6
-__global__ __launch_bounds__(kStates) void k_ent_tables(const EntJob *__restrict__ tab, EntGeom g)
+// A Rice-coded symbol moves the state up iff bitlen(u) > (vk >> damp), i.e. iff vk < T with T = bitlen(u) << damp: one
+// threshold per symbol, staged in LDS as a splat pair of 16-bit values.  Every lane walks TWO start states through the
+// chunk in packed 16-bit arithmetic (128 lanes = 256 states; five v_pk instructions a symbol for the pair).  The
+// symbols coded without the state (LL region, seg 0) are a prefix of the plane's list (positions ascend): the walk
+// simply starts behind them.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pk16 pk_step(pk16 vk, uint32_t tm1_splat) // tm1_splat = (T - 1) in both halves
 {
-    __shared__ uint32_t meta32[kEntChunk / 4];
-    uint8_t *meta = (uint8_t *) meta32;
+    pk16 x = __builtin_bit_cast(pk16, tm1_splat) - vk;   // negative: vk >= T, the state moves down
+    pk16 m = x >> (pk16){15, 15};                         // -1 down, 0 up
+    uint32_t step = (__builtin_bit_cast(uint32_t, m) << 1) | 0x00010001u; // -1 / +1 per half (the bit the low half's sign
+                                                                          // shifts into the high half is the one OR'd anyway)
+    vk = vk + __builtin_bit_cast(pk16, step);
+    return __builtin_elementwise_max(vk, (pk16){0, 0});
+}
+
+__device__ __forceinline__ uint32_t rice_threshold(int32_t v, int seg) // T of a symbol of subband index seg >= 1
+{
+    return (uint32_t) bitlen(rice_u(v)) << (3 + (seg - 1) / 3);
+}
+
+__global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__restrict__ tab, EntGeom g)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sT[kEntChunk];
+    __shared__ int s_nskip;
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
     const uint32_t off = (uint32_t) g.qv_off[c];
+    const int tid = threadIdx.x;
     for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
         const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
         __syncthreads();
+        if (tid == 0) {
+            s_nskip = 0;
+        }
+        __syncthreads();
+        int nskip_mine = 0;
 #pragma unroll
-        for (int j = 0; j < kEntChunk / kStates; j++) {
-            int s = j * kStates + threadIdx.x;
-            uint8_t m = 0xff;
+        for (int j = 0; j < kEntChunk / (kStates / 2); j++) {
+            int s = j * (kStates / 2) + tid;
+            uint32_t t = 0;
             if (s < cnt) {
                 int seg = seg_of(g, c, J.pos[first + s] - off);
                 if (seg > 0) {
-                    m = (uint8_t) (bitlen(rice_u(J.val[first + s])) | (((seg - 1) / 3) << 6));
+                    t = rice_threshold(J.val[first + s], seg) - 1u; // T - 1 in -1 .. 1023
+                    t = (t & 0xffffu) | (t << 16);
+                } else {
+                    nskip_mine++;
                 }
             }
-            meta[s] = m;
+            sT[s] = t;
+        }
+        if (nskip_mine) {
+            atomicAdd(&s_nskip, nskip_mine);
         }
         __syncthreads();
-        int vk = threadIdx.x;
-        const int cnt4 = (cnt + 3) >> 2;
-        for (int q = 0; q < cnt4; q++) {
-            uint32_t m4 = meta32[q]; // same word for every lane: an LDS broadcast
+        const int nskip = __builtin_amdgcn_readfirstlane(s_nskip); // uniform: scalar loop control
+        pk16 vk = (pk16){(short) (2 * tid), (short) (2 * tid + 1)};
+        for (int q = nskip >> 2; 4 * q < cnt; q++) {
+            const uint4 t4 = *(const uint4 *) &sT[4 * q]; // same address in every lane: an LDS broadcast
+            if (4 * q >= nskip && 4 * q + 4 <= cnt) {
+                vk = pk_step(pk_step(pk_step(pk_step(vk, t4.x), t4.y), t4.z), t4.w);
+            } else { // the group holding the end of the LL prefix or the end of the chunk
+                const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                uint32_t m = (m4 >> (8 * b)) & 0xffu;
-                if (m != 0xffu) { // (symbols past cnt hold 0xff too)
-                    int k = vk >> (3 + (int) (m >> 6));
-                    vk = (int) (m & 63u) > k ? vk + 1 : max(vk - 1, 0);
+                for (int b = 0; b < 4; b++) {
+                    if (4 * q + b >= nskip && 4 * q + b < cnt) {
+                        vk = pk_step(vk, tt[b]);
+                    }
                 }
             }
         }
-        J.tables[(size_t) (ps.cbase + lc) * kStates + threadIdx.x] = (uint16_t) vk;
+        *(uint32_t *) &J.tables[(size_t) (ps.cbase + lc) * kStates + 2 * tid] = __builtin_bit_cast(uint32_t, vk);
     }
 }
 
@@ -213,92 +249,116 @@ __global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab
 }
 
 // ---- 4 ----------------------------------------------------------------------------------------------------
-// per chunk: the Rice parameter every symbol is coded with, and the chunk's total code length.  The chunk is staged in
-// LDS by the whole workgroup (code lengths that do not depend on the state are summed in parallel); ONE lane then
-// walks the adaptive state through it out of LDS (~60 clocks a symbol instead of a dependent global load each).
-__global__ __launch_bounds__(256) void k_ent_ks(const EntJob *__restrict__ tab, EntGeom g)
+// per chunk: the Rice parameter every symbol is coded with, and the chunk's total code length.  One wavefront per
+// chunk: its lanes stage the thresholds (and sum the code lengths that do not depend on the state), ONE lane walks the
+// adaptive state from the chunk's now known start state -- four dependent instructions a symbol on thresholds that are
+// already in registers, the state each symbol met going back to LDS -- and the lanes turn those states into parameters.
+// The walk wastes 63 lanes but costs what the 256-state walk of step 2 costs, and eight chunks share a SIMD.
+__global__ __launch_bounds__(64) void k_ent_ks(const EntJob *__restrict__ tab, EntGeom g)
 {
-    __shared__ uint32_t su[kEntChunk];        // Rice-mapped value of every symbol
-    __shared__ uint8_t sm[kEntChunk];         // 0xff: not Rice coded; else damp - 3
-    __shared__ uint8_t sk[kEntChunk];         // the parameter found for it
-    __shared__ unsigned wsum[4];
-    __shared__ unsigned long long dyn_bits;
+    __shared__ __attribute__((aligned(16))) uint16_t sT[kEntChunk];  // T of every symbol
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kEntChunk];  // the state it met
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
     const uint32_t off = (uint32_t) g.qv_off[c];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
         const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
-        __syncthreads();
-        // four consecutive symbols per thread: run code + state-free value code lengths
+        // symbols lane, lane + 64, ...: run code + state-free value code lengths, thresholds
+        uint32_t u[kEntChunk / 64];
+        unsigned dmask = 0; // two bits a symbol: damp - 3, or 3 = not Rice coded
         unsigned stat = 0;
-        const int s0 = threadIdx.x * 4;
-        uint32_t prev_end = 0;
-        if (s0 < cnt) {
-            int i0 = first + s0;
-            prev_end = i0 > ps.first ? J.pos[i0 - 1] - off + 1u : 0u;
-        }
+        int nskip_mine = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint8_t m = 0xff;
-            uint32_t u = 0;
-            if (s0 + j < cnt) {
-                uint32_t p = J.pos[first + s0 + j] - off;
-                int32_t v = J.val[first + s0 + j];
-                int seg = seg_of(g, c, p);
+        for (int j = 0; j < kEntChunk / 64; j++) {
+            const int s = j * 64 + lane;
+            uint32_t t = 0;
+            unsigned d = 3;
+            u[j] = 0;
+            if (s < cnt) {
+                const int i = first + s;
+                const uint32_t p = J.pos[i] - off;
+                const uint32_t prev_end = i > ps.first ? J.pos[i - 1] - off + 1u : 0u;
+                const int32_t v = J.val[i];
+                const int seg = seg_of(g, c, p);
                 stat += (unsigned) ueg_len(p - prev_end);
-                prev_end = p + 1u;
                 if (seg == 0) {
                     uint32_t a = (uint32_t) (v < 0 ? -v : v);
                     stat += (unsigned) ueg_len(a - 1u) + 1u;
+                    nskip_mine++;
                 } else {
-                    u = rice_u(v);
-                    m = (uint8_t) ((seg - 1) / 3);
+                    u[j] = rice_u(v);
+                    d = (unsigned) (seg - 1) / 3u;
+                    t = (uint32_t) bitlen(u[j]) << (3 + d);
                 }
             }
-            su[s0 + j] = u;
-            sm[s0 + j] = m;
-            sk[s0 + j] = 0;
+            dmask |= d << (2 * j);
+            sT[s] = (uint16_t) t;
         }
-        unsigned inc = (unsigned) wave_incl_scan_u(stat, lane);
-        if (lane == 63) {
-            wsum[wv] = inc;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int vk = J.chunk_vk[ps.cbase + lc];
-            unsigned long long bits = 0;
-            for (int s = 0; s < cnt; s++) {
-                unsigned m = sm[s];
-                if (m != 0xffu) {
-                    uint32_t u = su[s];
-                    int kk = vk >> (3 + (int) m);
-                    uint32_t lead = kk < 32 ? u >> kk : 0u;
-                    vk += lead ? 1 : (vk > 0 ? -1 : 0);
-                    bits += (unsigned long long) lead + (unsigned) (kk + 1);
-                    sk[s] = (uint8_t) kk;
-                }
-            }
-            dyn_bits = bits;
-        }
-        __syncthreads();
-        if (s0 < cnt) { // (chunks start at multiples of 1024 symbols of a plane; the plane's first symbol is not aligned)
+        int nskip = nskip_mine;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (s0 + j < cnt) {
-                    J.ksym[first + s0 + j] = sk[s0 + j];
+        for (int o = 32; o > 0; o >>= 1) {
+            nskip += __shfl_xor(nskip, o, 64);
+            stat += (unsigned) __shfl_xor((int) stat, o, 64);
+        }
+        nskip = __builtin_amdgcn_readfirstlane(nskip);
+        __syncthreads();
+        if (lane == 0) {
+            int vk = J.chunk_vk[ps.cbase + lc];
+            for (int q = nskip >> 3; 8 * q < cnt; q++) {
+                const uint4 t8 = *(const uint4 *) &sT[8 * q];
+                const uint32_t tw[4] = {t8.x, t8.y, t8.z, t8.w};
+                uint32_t vw[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int t0 = (int) (tw[b] & 0xffffu), t1 = (int) (tw[b] >> 16);
+                    const int v0 = vk;
+                    if (8 * q + 2 * b >= nskip) { // (behind the end of the chunk the walk runs on harmlessly)
+                        vk = vk < t0 ? vk + 1 : max(vk - 1, 0);
+                    }
+                    const int v1 = vk;
+                    if (8 * q + 2 * b + 1 >= nskip) {
+                        vk = vk < t1 ? vk + 1 : max(vk - 1, 0);
+                    }
+                    vw[b] = (uint32_t) min(v0, 0xffff) | ((uint32_t) min(v1, 0xffff) << 16);
                 }
+                *(uint4 *) &sV[8 * q] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
             }
         }
-        if (threadIdx.x == 0) {
-            unsigned long long bits = dyn_bits + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        unsigned long long bits = 0;
+#pragma unroll
+        for (int j = 0; j < kEntChunk / 64; j++) {
+            const int s = j * 64 + lane;
+            const unsigned d = (dmask >> (2 * j)) & 3u;
+            if (s < cnt) {
+                int kk = 0;
+                if (d != 3u) {
+                    kk = (int) sV[s] >> (3 + (int) d);
+                    if (kk >= 32) { // a state no real picture reaches (a long run of 16-bit values): the host codes it
+                        atomicOr(&J.info[EI_FLAGS], 1);
+                        kk = 31;
+                    }
+                    const uint32_t lead = u[j] >> kk;
+                    bits += (unsigned long long) lead + (unsigned) (kk + 1);
+                }
+                J.ksym[first + s] = (uint8_t) kk;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bits += (unsigned long long) __shfl_xor((long long) bits, o, 64);
+        }
+        if (lane == 0) {
+            bits += stat;
             if (bits >= (1ull << 24)) { // 16 Kbit per symbol on average: not a picture (and keeps the 32-bit scans below exact)
                 atomicOr(&J.info[EI_FLAGS], 4);
                 bits = 0;
             }
             J.chunk_bits[ps.cbase + lc] = (uint32_t) bits;
         }
+        __syncthreads();
     }
 }
 
@@ -559,9 +619,9 @@ void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom 
     }
     const int slots = chunk_slots < 1 ? 1 : chunk_slots;
     DSV2_LAUNCH(k_ent_planes, dim3(n), dim3(64), 0, s, d_jobs, g);
-    DSV2_LAUNCH(k_ent_tables, dim3(slots, n, 3), dim3(kStates), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_tables, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_chain, dim3(n), dim3(64), 0, s, d_jobs);
-    DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(64), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
