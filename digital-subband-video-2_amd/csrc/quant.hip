@@ -140,6 +140,7 @@ struct LevelArgs {
     int dbx, dby;
     int xdep, ydep;
     int off[3], par[3], gpar[3], base[3];
+    int vec; // geometry allows the four-coefficients-per-thread kernel (every row / subband start a multiple of four)
 };
 
 __device__ __forceinline__ int quant_sub(int v, int q, int sub) { return (v >= 0 ? v - sub : v + sub) / q; }
@@ -182,55 +183,62 @@ __device__ __forceinline__ int tmq_for_I(int tmq, int flags, int parc, int l) //
     return tmq;
 }
 
-__device__ __forceinline__ int quant_detail(const QuantCfg &c, const DSV_MV *mvs, int val, int qp, int l, int flags, int bi, int parc,
-                                            int gparc, int &tmq_out)
+// Truncating division by a positive step without the 32-bit divide sequence: for |n| < 2^20 the quotient estimated in
+// single precision (v_rcp_f32: 1 ulp) is within one of the exact one, which a multiply-back settles; anything larger
+// takes the integer divide.
+__device__ __forceinline__ int div_trunc_pos(int n, int q)
 {
-    int tmq = qp, v;
-    bool texture = !parc, gtexture = !gparc;
+    const unsigned a = (unsigned) abs(n);
+    unsigned est;
+    if (__builtin_expect(a < (1u << 20), 1)) {
+        est = (unsigned) ((float) a * __builtin_amdgcn_rcpf((float) q));
+        const int r = (int) a - (int) est * q;
+        est = r < 0 ? est - 1u : (r >= q ? est + 1u : est);
+    } else {
+        est = a / (unsigned) q;
+    }
+    return n < 0 ? -(int) est : (int) est;
+}
+
+// One divide per coefficient: the visual-masking rules of hzcc.c:364-414 only choose the step and the dead-zone offset.
+struct MvBits { // what the P-picture masking rule reads of a block's vector
+    int x, y;
+    uint32_t flags;
+};
+__device__ __forceinline__ bool needs_mv(const QuantCfg &c) { return c.isP && (c.do_psy & DSV_PSY_P_VISUAL_MASKING) && c.plane == 0 && !c.lossless; }
+__device__ __forceinline__ MvBits load_mv(const DSV_MV *mvs, int bi)
+{
+    const DSV_MV mv = mvs[bi];
+    return MvBits{(int) mv.u.mv.x, (int) mv.u.mv.y, mv.flags};
+}
+
+__device__ __forceinline__ int quant_detail(const QuantCfg &c, const MvBits &mv, int val, int qp, int l, int flags, int parc, int gparc,
+                                            int &tmq_out)
+{
+    int tmq = qp, sub = 0;
+    const bool texture = !parc, gtexture = !gparc;
     if (c.isP) {
         tmq = tmq_for_P(tmq, flags, parc);
         if ((c.do_psy & DSV_PSY_P_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:371-380
-            DSV_MV mv = mvs[bi];
-            bool small_mv = abs((int) mv.u.mv.x) < 32 && abs((int) mv.u.mv.y) < 32;
-            if ((gtexture && texture) || (mv.flags & (1u << DSV_MV_BIT_EPRM)) ||
-                ((mv.flags & (1u << DSV_MV_BIT_MAINTAIN)) && small_mv)) {
-                v = quant_sub(val, tmq, tmq >> 3);
-            } else if (texture || !(flags & DSV_IS_SIMCMPLX)) {
-                v = quant_sub(val, tmq, tmq / 6);
-            } else {
-                v = quant_sub(val, tmq, tmq >> 2);
-            }
-        } else {
-            v = val / tmq;
+            const bool small_mv = abs(mv.x) < 32 && abs(mv.y) < 32;
+            const bool fine = (gtexture & texture) | ((mv.flags & (1u << DSV_MV_BIT_EPRM)) != 0) |
+                              (((mv.flags & (1u << DSV_MV_BIT_MAINTAIN)) != 0) & small_mv);
+            const bool mid = texture | !(flags & DSV_IS_SIMCMPLX);
+            sub = fine ? tmq >> 3 : (mid ? tmq / 6 : tmq >> 2);
         }
     } else {
         tmq = tmq_for_I(tmq, flags, parc, l);
         if ((c.do_psy & DSV_PSY_I_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:387-414
-            int smf = flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE);
-            if (flags & DSV_IS_RINGING) {
-                v = quant_sub(val, tmq, -(tmq / 6));
-            } else if (l == 0) {
-                v = quant_sub(val, tmq, -(tmq >> 3));
-            } else {
-                bool edge = sgn(parc) == sgn(val);
-                int stp;
-                if (smf == 0) {
-                    stp = -tmq / 3;
-                } else if (edge && smf == DSV_IS_STABLE) {
-                    stp = tmq >> 3;
-                } else {
-                    stp = -tmq / 6;
-                }
-                v = quant_sub(val, tmq, stp);
-            }
+            const int smf = flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE);
+            const bool edge = sgn(parc) == sgn(val);
+            const int stp = smf == 0 ? -tmq / 3 : ((edge && smf == DSV_IS_STABLE) ? tmq >> 3 : -tmq / 6);
+            sub = (flags & DSV_IS_RINGING) ? -(tmq / 6) : (l == 0 ? -(tmq >> 3) : stp);
         } else if (c.plane) {
-            v = quant_sub(val, tmq, -(tmq >> 3));
-        } else {
-            v = val / tmq;
+            sub = -(tmq >> 3);
         }
     }
     tmq_out = tmq;
-    return v;
+    return div_trunc_pos(val >= 0 ? val - sub : val + sub, tmq);
 }
 
 // Kernels work through PlaneJob records (dev.h): tab == nullptr runs the single job `one`,
@@ -295,7 +303,8 @@ __device__ __forceinline__ void quant_cell(const PlaneJob &J, const QuantCfg &c,
         int parc = coefs[a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1)];
         int gparc = coefs[a.gpar[si] + (size_t) (y >> 2) * c.w + (x >> 2)];
         int tmq;
-        v = quant_detail(c, J.mvs, *cell, J.qp[a.l][si], a.l, J.bd[bi], bi, parc, gparc, tmq);
+        const MvBits mv = needs_mv(c) ? load_mv(J.mvs, bi) : MvBits{0, 0, 0u};
+        v = quant_detail(c, mv, *cell, J.qp[a.l][si], a.l, J.bd[bi], parc, gparc, tmq);
         *cell = v ? dequant_D(v, (unsigned) tmq) : 0;
     }
     J.qv[a.base[si] + (size_t) y * a.sw + x] = v;
@@ -318,6 +327,84 @@ __global__ __launch_bounds__(256) void k_quant_level(const PlaneJob *__restrict_
         return;
     }
     quant_cell(J, c, a, si, x, y);
+}
+
+// The same, four coefficients of a row per thread: 16-byte loads and stores of the coefficients and of the dense symbol
+// values, one parent pair and one grandparent for the four, the block's flags and vector fetched once when the four share
+// a block (levels 0 and 1 of the 16-pixel-block geometries).  A thread whose fourth coefficient is a dependent of the
+// last column, and any job whose buffers are not 16-byte aligned, goes cell by cell.
+__global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int si = blockIdx.z % 3;
+    const PlaneJob &J = tab ? tab[blockIdx.z / 3] : one;
+    if (x >= a.sw || y >= a.sh || (((si + 1) & 2) && a.ydep && y == a.sh - 1)) {
+        return;
+    }
+    const bool coldep = ((si + 1) & 1) && a.xdep && x + 4 == a.sw;
+    const bool aligned = ((((uintptr_t) J.coefs) | ((uintptr_t) J.qv)) & 15) == 0 && (J.qv_base & 3u) == 0;
+    if (c.lossless || coldep || !aligned) {
+        for (int k = 0; k < (coldep ? 3 : 4); k++) {
+            quant_cell(J, c, a, si, x + k, y);
+        }
+        return;
+    }
+    int32_t *coefs = J.coefs;
+    int4 *cell = (int4 *) (coefs + a.off[si] + (size_t) y * c.w + x);
+    const int4 cv = *cell;
+    const int2 pc = *(const int2 *) (coefs + a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1));
+    const int gparc = coefs[a.gpar[si] + (size_t) (y >> 2) * c.w + (x >> 2)];
+    const int rowb = ((y * a.dby) >> kBlockP) * c.nbh;
+    int bk[4], flags[4];
+    MvBits mv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        bk[k] = rowb + (((x + k) * a.dbx) >> kBlockP);
+    }
+    const bool mvq = needs_mv(c);
+    flags[0] = J.bd[bk[0]];
+    mv[0] = mvq ? load_mv(J.mvs, bk[0]) : MvBits{0, 0, 0u};
+    if (__any(bk[3] != bk[0])) {
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            flags[k] = J.bd[bk[k]];
+            mv[k] = mvq ? load_mv(J.mvs, bk[k]) : MvBits{0, 0, 0u};
+        }
+    } else {
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            flags[k] = flags[0];
+            mv[k] = mv[0];
+        }
+    }
+    const int qp = J.qp[a.l][si];
+    const int val[4] = {cv.x, cv.y, cv.z, cv.w};
+    int v[4], dq[4], nzc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int tmq;
+        v[k] = quant_detail(c, mv[k], val[k], qp, a.l, flags[k], k < 2 ? pc.x : pc.y, gparc, tmq);
+        dq[k] = v[k] ? dequant_D(v[k], (unsigned) tmq) : 0;
+        nzc += v[k] != 0;
+    }
+    *cell = make_int4(dq[0], dq[1], dq[2], dq[3]);
+    const size_t pos = a.base[si] + (size_t) y * a.sw + x;
+    *(int4 *) (J.qv + pos) = make_int4(v[0], v[1], v[2], v[3]);
+    if (J.tile_count != nullptr) { // as count_nonzero, with up to four nonzeros a lane (its four positions share a tile)
+        const unsigned tile = (unsigned) ((J.qv_base + pos) >> 10);
+        const unsigned t0 = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
+        const bool here = tile == t0;
+        const int sum = __popcll(__ballot(here && (nzc & 1))) + 2 * __popcll(__ballot(here && (nzc & 2))) + 4 * __popcll(__ballot(here && (nzc & 4)));
+        const unsigned long long active = __ballot(true);
+        const int lane = (int) (threadIdx.x + threadIdx.y * blockDim.x) & 63;
+        if (sum && lane == __ffsll((long long) active) - 1) {
+            atomicAdd(&J.tile_count[t0], sum);
+        }
+        if (nzc && !here) {
+            atomicAdd(&J.tile_count[tile], nzc);
+        }
+    }
 }
 
 // phase B: the dependents (last column, then last row without the shared corner); blockIdx.y = subband - 1
@@ -376,7 +463,15 @@ static void quant_launch(hipStream_t s, const PlaneJob *tab, const PlaneJob &one
             a.par[si] = h_subband_off(l - 1, si + 1, cfg.w, cfg.h);
             a.gpar[si] = h_subband_off(l - 2, si + 1, cfg.w, cfg.h);
         }
-        DSV2_LAUNCH(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
+        a.vec = (cfg.w & 3) == 0 && (a.sw & 3) == 0;
+        for (int si = 0; si < 3; si++) {
+            a.vec = a.vec && (a.off[si] & 3) == 0 && (a.base[si] & 3) == 0 && (a.par[si] & 1) == 0;
+        }
+        if (a.vec) {
+            DSV2_LAUNCH(k_quant_level4, dim3((a.sw / 4 + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
+        } else {
+            DSV2_LAUNCH(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
+        }
         if (a.xdep || a.ydep) {
             DSV2_LAUNCH(k_quant_level_dep, dim3((a.sw + a.sh + 255) / 256, 3, nz), dim3(256), 0, s, tab, one, cfg, a);
         }
