@@ -86,6 +86,24 @@ __device__ __forceinline__ void put_code(uint32_t *out32, uint32_t bitpos, uint6
     }
 }
 
+// the same into a chunk's LDS image of its words (bit 0 of the image = bit 0 of output word `w_base`)
+__device__ __forceinline__ void put_code_lds(uint32_t *img, uint32_t bitpos, uint64_t code, int len)
+{
+    uint64_t c64 = code << (64 - len);
+    uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    uint64_t hi = c64 >> sh;
+    uint32_t w0 = (uint32_t) (hi >> 32), w1 = (uint32_t) hi, w2 = sh ? (uint32_t) ((c64 << (64 - sh)) >> 32) : 0u;
+    if (w0) {
+        atomicOr(&img[w], __builtin_bswap32(w0));
+    }
+    if (w1) {
+        atomicOr(&img[w + 1], __builtin_bswap32(w1));
+    }
+    if (w2) {
+        atomicOr(&img[w + 2], __builtin_bswap32(w2));
+    }
+}
+
 __device__ __forceinline__ int wave_incl_scan_u(unsigned v, int lane)
 {
 #pragma unroll
@@ -422,9 +440,16 @@ __global__ __launch_bounds__(256) void k_ent_zero(const EntJob *__restrict__ tab
     }
 }
 
+// A chunk's code words are ORed together in LDS (a chunk of 1024 symbols is ~1 KB of output) and leave as plain
+// coalesced word stores; only the chunk's first and last word, which it may share with its neighbours or with the
+// section's fixed fields, are ORed into the zeroed output.  A chunk too long for the image (> 127 bits a symbol on
+// average) ORs every code word into global memory as before.
+constexpr int kEmitWords = 4096;
+
 __global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g)
 {
     __shared__ unsigned wsum[4];
+    __shared__ uint32_t img[kEmitWords + 2];
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const int *I = J.info;
@@ -502,14 +527,44 @@ __global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab
         for (int k = 0; k < wv; k++) {
             o += wsum[k];
         }
-        uint32_t bit = J.chunk_off[ps.cbase + lc] + o;
+        const uint32_t b0 = J.chunk_off[ps.cbase + lc], blen = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const uint32_t w_base = b0 >> 5, nw = ((b0 + blen + 31u) >> 5) - w_base;
+        uint32_t bit = b0 + o;
+        if (nw <= (uint32_t) kEmitWords) {
+            for (uint32_t i = threadIdx.x; i < nw + 2u; i += 256u) {
+                img[i] = 0;
+            }
+            __syncthreads();
+            bit -= w_base << 5;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (s0 + j < cnt) {
-                put_code(out32, bit, rc[j], rl[j]);
-                bit += (uint32_t) rl[j] + lead[j];
-                put_code(out32, bit, vc[j], vl[j]);
-                bit += (uint32_t) vl[j];
+            for (int j = 0; j < 4; j++) {
+                if (s0 + j < cnt) {
+                    put_code_lds(img, bit, rc[j], rl[j]);
+                    bit += (uint32_t) rl[j] + lead[j];
+                    put_code_lds(img, bit, vc[j], vl[j]);
+                    bit += (uint32_t) vl[j];
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nw; i += 256u) {
+                const uint32_t w = img[i];
+                if (i == 0 || i == nw - 1u) {
+                    if (w) {
+                        atomicOr(&out32[w_base + i], w);
+                    }
+                } else {
+                    out32[w_base + i] = w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (s0 + j < cnt) {
+                    put_code(out32, bit, rc[j], rl[j]);
+                    bit += (uint32_t) rl[j] + lead[j];
+                    put_code(out32, bit, vc[j], vl[j]);
+                    bit += (uint32_t) vl[j];
+                }
             }
         }
     }
