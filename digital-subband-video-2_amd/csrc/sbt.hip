@@ -334,15 +334,8 @@ __global__ __launch_bounds__(256) void k_fwd_cols(const PlaneJob *__restrict__ t
 }
 
 template <bool U8>
-__global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel,
-                                                  int d_sel, int ovf)
+__device__ __forceinline__ void fwd_haar_quad(const PlaneJob &J, const LevelGeom &g, int idx, int jy, int s_sel, int d_sel, int ovf)
 {
-    const PlaneJob &J = pick_job(tab, one);
-    int idx = blockIdx.x * 64 + threadIdx.x;
-    int jy = blockIdx.y * 4 + threadIdx.y;
-    if (idx >= g.hw || jy >= g.hh) {
-        return;
-    }
     int32_t *D = img(J, d_sel), *C = J.coefs;
     int x = 2 * idx, y = 2 * jy;
     bool hasx = (x + 1) < g.sw, hasy = (y + 1) < g.sh;
@@ -393,6 +386,61 @@ __global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ t
     }
 }
 
+template <bool U8>
+__global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel,
+                                                  int d_sel, int ovf)
+{
+    const PlaneJob &J = pick_job(tab, one);
+    int idx = blockIdx.x * 64 + threadIdx.x;
+    int jy = blockIdx.y * 4 + threadIdx.y;
+    if (idx >= g.hw || jy >= g.hh) {
+        return;
+    }
+    fwd_haar_quad<U8>(J, g, idx, jy, s_sel, d_sel, ovf);
+}
+
+// level 1 from the 8-bit picture, four 2x2 quads (eight pixels of two rows) per thread: two 8-byte loads, four 16-byte
+// stores (one per band).  Launched when the level's half width and the row stride are multiples of four; threads at the
+// picture's right / bottom edge, and jobs whose images are not 16-byte aligned, go quad by quad.
+__global__ __launch_bounds__(256) void k_fwd_haar_u8x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel, int ovf)
+{
+    const PlaneJob &J = pick_job(tab, one);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int jy = blockIdx.y * 4 + threadIdx.y;
+    if (idx >= g.hw || jy >= g.hh) {
+        return;
+    }
+    int32_t *D = img(J, d_sel), *C = J.coefs;
+    const int x = 2 * idx, y = 2 * jy;
+    const bool fast = x + 8 <= min(g.sw, J.pic.w) && y + 2 <= min(g.sh, J.pic.h) &&
+                      ((((uintptr_t) D) | ((uintptr_t) C)) & 15) == 0 && (((uintptr_t) J.pic.data | (uintptr_t) J.pic.stride) & 7) == 0;
+    if (!fast) {
+        for (int q = 0; q < 4 && idx + q < g.hw; q++) {
+            fwd_haar_quad<true>(J, g, idx + q, jy, 0, d_sel, ovf);
+        }
+        return;
+    }
+    const uint8_t *r0 = J.pic.data + (size_t) y * J.pic.stride + x;
+    const uint2 a = *(const uint2 *) r0, b = *(const uint2 *) (r0 + J.pic.stride);
+    const uint32_t aw[2] = {a.x, a.y}, bw[2] = {b.x, b.y};
+    int ll[4], lh[4], hl[4], hh[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t wa = aw[q >> 1] >> (16 * (q & 1)), wb = bw[q >> 1] >> (16 * (q & 1));
+        const int x0 = (int) (wa & 0xffu) - 128, x1 = (int) ((wa >> 8) & 0xffu) - 128;
+        const int x2 = (int) (wb & 0xffu) - 128, x3 = (int) ((wb >> 8) & 0xffu) - 128;
+        ll[q] = ovf ? (x0 + x1 + x2 + x3) / 2 : (x0 + x1 + x2 + x3);
+        lh[q] = x0 - x1 + x2 - x3;
+        hl[q] = x0 + x1 - x2 - x3;
+        hh[q] = x0 - x1 - x2 + x3;
+    }
+    const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+    *(int4 *) (D + oLL) = make_int4(ll[0], ll[1], ll[2], ll[3]);
+    *(int4 *) (C + oLL + g.hw) = make_int4(lh[0], lh[1], lh[2], lh[3]);
+    *(int4 *) (C + oHL) = make_int4(hl[0], hl[1], hl[2], hl[3]);
+    *(int4 *) (C + oHL + g.hw) = make_int4(hh[0], hh[1], hh[2], hh[3]);
+}
+
 __device__ __forceinline__ int round2(int v) { return (v + (v < 0 ? -1 : 1)) / 2; }
 __device__ __forceinline__ int round4(int v) { return (v + (v < 0 ? -2 : 2)) / 4; }
 
@@ -419,15 +467,9 @@ __device__ __forceinline__ uint8_t to_px(int v) { return (uint8_t) clampi(v + 12
 // ll_sel: image holding the LL quadrant of this level; the coefficient plane holds the high bands.
 // hdiv: the smoothing clamp is the job's quantiser / hdiv (sbt.c:903)
 template <bool OUT_U8>
-__global__ __launch_bounds__(256) void k_inv_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel,
-                                                  int d_sel, int ovf, int filtered, int hdiv)
+__device__ __forceinline__ void inv_haar_quad(const PlaneJob &J, const LevelGeom &g, int idx, int jy, int ll_sel, int d_sel, int ovf,
+                                              int filtered, int hdiv)
 {
-    const PlaneJob &J = pick_job(tab, one);
-    int idx = blockIdx.x * 64 + threadIdx.x;
-    int jy = blockIdx.y * 4 + threadIdx.y;
-    if (idx >= g.hw || jy >= g.hh) {
-        return;
-    }
     const int32_t *LLp = img(J, ll_sel), *C = J.coefs;
     int hqp = J.q / hdiv;
     int x = 2 * idx, y = 2 * jy;
@@ -498,6 +540,71 @@ __global__ __launch_bounds__(256) void k_inv_haar(const PlaneJob *__restrict__ t
             }
         }
     }
+}
+
+template <bool OUT_U8>
+__global__ __launch_bounds__(256) void k_inv_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel,
+                                                  int d_sel, int ovf, int filtered, int hdiv)
+{
+    const PlaneJob &J = pick_job(tab, one);
+    int idx = blockIdx.x * 64 + threadIdx.x;
+    int jy = blockIdx.y * 4 + threadIdx.y;
+    if (idx >= g.hw || jy >= g.hh) {
+        return;
+    }
+    inv_haar_quad<OUT_U8>(J, g, idx, jy, ll_sel, d_sel, ovf, filtered, hdiv);
+}
+
+// level 1 to the 8-bit picture, four quads per thread: 16-byte loads of the four bands (and of the LL rows above and
+// below for the smoothing), two 8-byte pixel stores.  Interior threads only; the rest goes quad by quad.
+__global__ __launch_bounds__(256) void k_inv_haar_u8x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel, int ovf,
+                                                       int filtered, int hdiv)
+{
+    const PlaneJob &J = pick_job(tab, one);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int jy = blockIdx.y * 4 + threadIdx.y;
+    if (idx >= g.hw || jy >= g.hh) {
+        return;
+    }
+    const int32_t *LLp = img(J, ll_sel), *C = J.coefs;
+    const int x = 2 * idx, y = 2 * jy;
+    const bool fast = idx > 0 && idx + 4 < g.hw && jy > 0 && jy + 1 < g.hh && x + 8 <= min(g.sw, J.pic.w) && y + 2 <= min(g.sh, J.pic.h) &&
+                      ((((uintptr_t) LLp) | ((uintptr_t) C)) & 15) == 0 && (((uintptr_t) J.pic.data | (uintptr_t) J.pic.stride) & 7) == 0;
+    if (!fast) {
+        for (int q = 0; q < 4 && idx + q < g.hw; q++) {
+            inv_haar_quad<true>(J, g, idx + q, jy, ll_sel, 0, ovf, filtered, hdiv);
+        }
+        return;
+    }
+    const int hqp = J.q / hdiv;
+    const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+    const int4 l4 = *(const int4 *) (LLp + oLL), lh4 = *(const int4 *) (C + oLL + g.hw), hl4 = *(const int4 *) (C + oHL),
+               hh4 = *(const int4 *) (C + oHL + g.hw);
+    const int sc = 1 << ovf;
+    const int L[6] = {filtered ? LLp[oLL - 1] * sc : 0, l4.x * sc, l4.y * sc, l4.z * sc, l4.w * sc, filtered ? LLp[oLL + 4] * sc : 0};
+    int LH[4] = {lh4.x, lh4.y, lh4.z, lh4.w}, HL[4] = {hl4.x, hl4.y, hl4.z, hl4.w};
+    const int HH[4] = {hh4.x, hh4.y, hh4.z, hh4.w};
+    if (filtered) {
+        const int4 u4 = *(const int4 *) (LLp + oLL - g.w), d4 = *(const int4 *) (LLp + oLL + g.w);
+        const int U[4] = {u4.x * sc, u4.y * sc, u4.z * sc, u4.w * sc}, Dn[4] = {d4.x * sc, d4.y * sc, d4.z * sc, d4.w * sc};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            LH[q] = nudge(L[q + 1], L[q], L[q + 2], LH[q], hqp);
+            HL[q] = nudge(L[q + 1], U[q], Dn[q], HL[q], hqp);
+        }
+    }
+    uint32_t r0w[2] = {0, 0}, r1w[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int LL = L[q + 1];
+        const uint32_t v00 = to_px((LL + LH[q] + HL[q] + HH[q]) / 4), v01 = to_px((LL - LH[q] + HL[q] - HH[q]) / 4);
+        const uint32_t v10 = to_px((LL + LH[q] - HL[q] - HH[q]) / 4), v11 = to_px((LL - LH[q] - HL[q] + HH[q]) / 4);
+        r0w[q >> 1] |= (v00 | (v01 << 8)) << (16 * (q & 1));
+        r1w[q >> 1] |= (v10 | (v11 << 8)) << (16 * (q & 1));
+    }
+    uint8_t *r0 = J.pic.data + (size_t) y * J.pic.stride + x;
+    *(uint2 *) r0 = make_uint2(r0w[0], r0w[1]);
+    *(uint2 *) (r0 + J.pic.stride) = make_uint2(r1w[0], r1w[1]);
 }
 
 // columns first (sbt.c:467-469): packed column i of the Mallat image -> full column in scratch image 2
@@ -621,7 +728,9 @@ static void fwd_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
         bool u8 = (l == 1);
         switch (filter) {
             case F_HAAR:
-                if (u8) {
+                if (u8 && (g.hw & 3) == 0 && (g.w & 3) == 0) {
+                    DSV2_LAUNCH(k_fwd_haar_u8x4, grid3(g.hw / 4, g.hh, b), kBlk, 0, s, b.tab, b.one, g, d_sel, ovf);
+                } else if (u8) {
                     DSV2_LAUNCH((k_fwd_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
                 } else {
                     DSV2_LAUNCH((k_fwd_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
@@ -652,7 +761,9 @@ static void inv_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
             case F_HAAR: {
                 int hdiv = (plane_idx == 0) ? (isP ? 14 : (l > 4 ? 2 : 8)) : 2;   // sbt.c:903
                 int filtered = !lossless && (plane_idx == 0 || !isP);               // sbt.c:925
-                if (u8) {
+                if (u8 && (g.hw & 3) == 0 && (g.w & 3) == 0) {
+                    DSV2_LAUNCH(k_inv_haar_u8x4, grid3(g.hw / 4, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, ovf, filtered, hdiv);
+                } else if (u8) {
                     DSV2_LAUNCH((k_inv_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
                                        filtered, hdiv);
                 } else {
