@@ -284,13 +284,16 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
         px = clampi(subpel_luma ? px - 1 : px, -kBorder, limx);
         py = clampi(subpel_luma ? py - 1 : py, -kBorder, limy);
         const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
+        // block sizes are powers of two (16 << e, halved by the chroma shifts): lane -> (row, column) by shifts, not by the
+        // 32-bit divide sequence (a dozen of them per block otherwise)
+        const int lbw = 31 - __builtin_clz((unsigned) bw), lgw = lbw - 2;
         const int ngroups = (bw * bh) >> 2, gw = bw >> 2; // groups of 4 pixels, gw per row
         int dcq[4] = {0, 0, 0, 0};
         if (intra) {
             if (!(c == 0 && mv.dc)) { // quadrant means of the reference block (bmc.c:845-900)
                 int part[4] = {0, 0, 0, 0};
                 for (int g = lane; g < ngroups; g += 64) {
-                    int m = (g % gw) * 4, n = g / gw;
+                    int m = (g & (gw - 1)) * 4, n = g >> lgw;
                     uint32_t v = ((const U32u *) (rbase + (ptrdiff_t) n * rp.stride + m))->v;
                     int s4 = (int) ((v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + (v >> 24));
                     int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
@@ -330,12 +333,15 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
             typedef const __attribute__((address_space(1))) uint8_t *gb_t;
             typedef const __attribute__((address_space(1))) U32u *gu32_t;
             const int ndw = (ww + 3) >> 2, total = wh * ndw;
+            // k / ndw == (k * ndw_inv) >> 16 for k < 4096 (ndw_inv = ceil(65536 / ndw): 5 dwords a row for 16-pixel blocks)
+            const unsigned ndw_inv = ndw == 5 ? 13108u : (65536u + (unsigned) ndw - 1u) / (unsigned) ndw;
             gb_t gbase = (gb_t) rbase;
             uint32_t *win32 = (uint32_t *) L.win;
             wave_lds_sync(); // the previous block's readers are done
             if (total <= 128) { // 16-pixel blocks: 19 rows of 5 dwords
                 const int k0 = lane, k1 = lane + 64 < total ? lane + 64 : 0;
-                const int r0 = k0 / ndw, c0 = k0 % ndw, r1 = k1 / ndw, c1 = k1 % ndw;
+                const int r0 = (int) (((unsigned) k0 * ndw_inv) >> 16), c0 = k0 - r0 * ndw;
+                const int r1 = (int) (((unsigned) k1 * ndw_inv) >> 16), c1 = k1 - r1 * ndw;
                 uint32_t d0 = ((gu32_t) (gbase + (ptrdiff_t) r0 * rp.stride + 4 * c0))->v;
                 uint32_t d1 = ((gu32_t) (gbase + (ptrdiff_t) r1 * rp.stride + 4 * c1))->v;
                 if (k0 < total) {
@@ -346,13 +352,13 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
                 }
             } else {
                 for (int idx = lane; idx < total; idx += 64) {
-                    int r = idx / ndw, cc = idx % ndw;
+                    int r = (int) (((unsigned) idx * ndw_inv) >> 16), cc = idx - r * ndw;
                     win32[r * 9 + cc] = ((gu32_t) (gbase + (ptrdiff_t) r * rp.stride + 4 * cc))->v;
                 }
             }
             wave_lds_sync();
             for (int idx = lane; idx < wh * bw; idx += 64) {
-                int r = idx / bw, m = idx % bw;
+                int r = idx >> lbw, m = idx & (bw - 1);
                 const uint8_t *q = &L.win[r * 36 + m];
                 int a = q[0], b = q[1], cc = q[2], d = q[3];
                 L.hz[r * 32 + m] = (int16_t) qp_blend(hp_tap(a, b, cc, d, soft_x), b, cc, fx);
@@ -374,7 +380,7 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
         typedef const __attribute__((address_space(1))) U32u *gur_t;
         typedef __attribute__((address_space(1))) uint32_t *gw32_t;
         for (int g = lane; g < ngroups; g += 64) {
-            int m = (g % gw) * 4, n = g / gw;
+            int m = (g & (gw - 1)) * 4, n = g >> lgw;
             gbr_t r = (gbr_t) rbase + (ptrdiff_t) n * rp.stride + m;
             // every load of the group up front (explicit global accesses), so that they share one round trip
             const uint32_t sv4 = *(gw32_t) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
@@ -1221,6 +1227,21 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
     __syncthreads();
 }
 
+// The sweeps are ~1000 dependent fronts of one wavefront per SIMD: pure latency.  Sharing a SIMD with the search's and the
+// streaming kernels' wavefronts, a sweep wavefront got a third of the issue slots and took three times as long (the lockstep
+// group behind it idle meanwhile); at raised issue priority it keeps its stand-alone pace and costs the others next to
+// nothing (it issues one instruction in five cycles).
+__device__ __forceinline__ void raise_priority(int prio)
+{
+    if (prio >= 3) {
+        __builtin_amdgcn_s_setprio(3);
+    } else if (prio == 2) {
+        __builtin_amdgcn_s_setprio(2);
+    } else if (prio == 1) {
+        __builtin_amdgcn_s_setprio(1);
+    }
+}
+
 // grid = 3 workgroups: luma filter, U chroma filter, V chroma filter
 __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict__ vecs, FilterParams f, Planes3 pl)
 {
@@ -1238,9 +1259,10 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
 }
 
 // stream-batched filters: grid = (3 planes, n jobs) / (n jobs)
-__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
+__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes, int prio)
 {
     extern __shared__ uint8_t dyn_lds[];
+    raise_priority(prio);
     const McJob &jb = tab[blockIdx.y];
     int c = blockIdx.x;
     const DPlane dp = jb.res.p[c];
@@ -1281,9 +1303,10 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes)
+__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes, int prio)
 {
     extern __shared__ uint8_t dyn_lds[];
+    raise_priority(prio);
     const McJob &jb = tab[blockIdx.x];
     const DPlane dp = jb.res.p[0];
     const FilterParams f = jb.f;
@@ -1411,6 +1434,12 @@ static unsigned ring_lds_bytes(int luma_h)
     return (on && b <= 150 * 1024) ? (unsigned) b : 0u;
 }
 
+static int filter_prio()
+{
+    static int p = getenv("DSV2_FILTER_PRIO") ? atoi(getenv("DSV2_FILTER_PRIO")) : 3;
+    return p;
+}
+
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
 void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
 {
@@ -1424,7 +1453,7 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h), filter_prio());
         }
     }
 }
@@ -1435,7 +1464,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
     if (n > 0) {
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h), filter_prio());
         }
     }
 }
@@ -1443,7 +1472,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h), filter_prio());
     }
 }
 

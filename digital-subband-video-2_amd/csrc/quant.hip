@@ -600,12 +600,26 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
     int32_t *host_val = J.host_val;
     int host_cap = host_pos ? J.host_cap : 0;
     int base = blockIdx.x * kTile;
+    // the scan of the tile counts tells which tiles hold nothing (most of the finest level of a P picture): not read at all
+    const int tb = J.tile_base[blockIdx.x];
+    const int tb_next = (base + kTile < n) ? J.tile_base[blockIdx.x + 1] : *J.total;
+    if (tb_next == tb) {
+        return;
+    }
     int vals[4];
     int cnt = 0;
+    const int i0 = base + threadIdx.x * 4;
+    if (i0 + 3 < n && (((uintptr_t) qv) & 15) == 0) {
+        const int4 q4 = *(const int4 *) (qv + i0);
+        vals[0] = q4.x, vals[1] = q4.y, vals[2] = q4.z, vals[3] = q4.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            vals[j] = (i0 + j < n) ? qv[i0 + j] : 0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        int i = base + threadIdx.x * 4 + j;
-        vals[j] = (i < n) ? qv[i] : 0;
         cnt += vals[j] != 0;
     }
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -627,7 +641,6 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
         }
     }
     const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const int tb = J.tile_base[blockIdx.x];
     __syncthreads();
     for (int k = threadIdx.x; k < total; k += 256) {
         uint32_t p = spos[k];
