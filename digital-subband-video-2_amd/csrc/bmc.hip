@@ -1227,21 +1227,6 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
     __syncthreads();
 }
 
-// The sweeps are ~1000 dependent fronts of one wavefront per SIMD: pure latency.  Sharing a SIMD with the search's and the
-// streaming kernels' wavefronts, a sweep wavefront got a third of the issue slots and took three times as long (the lockstep
-// group behind it idle meanwhile); at raised issue priority it keeps its stand-alone pace and costs the others next to
-// nothing (it issues one instruction in five cycles).
-__device__ __forceinline__ void raise_priority(int prio)
-{
-    if (prio >= 3) {
-        __builtin_amdgcn_s_setprio(3);
-    } else if (prio == 2) {
-        __builtin_amdgcn_s_setprio(2);
-    } else if (prio == 1) {
-        __builtin_amdgcn_s_setprio(1);
-    }
-}
-
 // grid = 3 workgroups: luma filter, U chroma filter, V chroma filter
 __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict__ vecs, FilterParams f, Planes3 pl)
 {
@@ -1259,10 +1244,9 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
 }
 
 // stream-batched filters: grid = (3 planes, n jobs) / (n jobs)
-__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes, int prio)
+__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
-    raise_priority(prio);
     const McJob &jb = tab[blockIdx.y];
     int c = blockIdx.x;
     const DPlane dp = jb.res.p[c];
@@ -1303,10 +1287,9 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes, int prio)
+__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
-    raise_priority(prio);
     const McJob &jb = tab[blockIdx.x];
     const DPlane dp = jb.res.p[0];
     const FilterParams f = jb.f;
@@ -1434,12 +1417,6 @@ static unsigned ring_lds_bytes(int luma_h)
     return (on && b <= 150 * 1024) ? (unsigned) b : 0u;
 }
 
-static int filter_prio()
-{
-    static int p = getenv("DSV2_FILTER_PRIO") ? atoi(getenv("DSV2_FILTER_PRIO")) : 3;
-    return p;
-}
-
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
 void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
 {
@@ -1453,7 +1430,7 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h), filter_prio());
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
         }
     }
 }
@@ -1464,7 +1441,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
     if (n > 0) {
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h), filter_prio());
+            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
         }
     }
 }
@@ -1472,7 +1449,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h), filter_prio());
+        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
     }
 }
 
