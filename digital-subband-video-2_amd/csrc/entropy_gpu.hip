@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void k_ent_zero(const EntJob *__restrict__ tab
 // average) ORs every code word into global memory as before.
 constexpr int kEmitWords = 4096;
 
-__global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g)
+__global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g, unsigned img_words)
 {
     __shared__ unsigned wsum[4];
     __shared__ uint32_t img[kEmitWords + 2];
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab
         const uint32_t b0 = J.chunk_off[ps.cbase + lc], blen = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         const uint32_t w_base = b0 >> 5, nw = ((b0 + blen + 31u) >> 5) - w_base;
         uint32_t bit = b0 + o;
-        if (nw <= (uint32_t) kEmitWords) {
+        if (nw <= img_words) {
             for (uint32_t i = threadIdx.x; i < nw + 2u; i += 256u) {
                 img[i] = 0;
             }
@@ -679,7 +679,9 @@ void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom 
     DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(64), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);
-    DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
+    // (tests shrink the image to send chunks down the global-memory path: DSV2_ENT_EMIT_WORDS)
+    static const unsigned img_words = getenv("DSV2_ENT_EMIT_WORDS") ? (unsigned) min(atoi(getenv("DSV2_ENT_EMIT_WORDS")), kEmitWords) : (unsigned) kEmitWords;
+    DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g, img_words);
     DSV2_LAUNCH(k_ent_out, dim3(8, n), dim3(256), 0, s, d_jobs);
     HIPCHK(hipGetLastError());
 }

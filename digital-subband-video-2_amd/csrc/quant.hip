@@ -152,6 +152,12 @@ __device__ __forceinline__ int32_t dequant_D(int v, unsigned q)
 {
     return (int32_t) ((unsigned) v * q + ((v < 0) ? 0u - (q / 2) : (q / 2)));
 }
+// v ? dequant_D(v, q) : 0 without the branch the compiler makes of it
+__device__ __forceinline__ int32_t dequant_D0(int v, unsigned q)
+{
+    const unsigned h = q / 2;
+    return (int32_t) ((unsigned) v * q + (v < 0 ? 0u - h : (v > 0 ? h : 0u)));
+}
 __device__ __forceinline__ int sgn(int x) { return x < 0 ? -1 : (x > 0 ? 1 : 0); }
 
 __device__ __forceinline__ int tmq_for_P(int tmq, int flags, int parc) // hzcc.c:164
@@ -189,13 +195,11 @@ __device__ __forceinline__ int tmq_for_I(int tmq, int flags, int parc, int l) //
 __device__ __forceinline__ int div_trunc_pos(int n, int q)
 {
     const unsigned a = (unsigned) abs(n);
-    unsigned est;
-    if (__builtin_expect(a < (1u << 20), 1)) {
-        est = (unsigned) ((float) a * __builtin_amdgcn_rcpf((float) q));
-        const int r = (int) a - (int) est * q;
-        est = r < 0 ? est - 1u : (r >= q ? est + 1u : est);
-    } else {
-        est = a / (unsigned) q;
+    unsigned est = (unsigned) ((float) a * __builtin_amdgcn_rcpf((float) q));
+    const int r = (int) (a - est * (unsigned) q); // (wraps harmlessly for the large values that take the divide below)
+    est = r < 0 ? est - 1u : (r >= q ? est + 1u : est);
+    if (__builtin_expect(__any(a >= (1u << 20)), 0)) { // wave-uniform: no exec-mask juggling on the usual path
+        est = a >= (1u << 20) ? a / (unsigned) q : est;
     }
     return n < 0 ? -(int) est : (int) est;
 }
@@ -363,6 +367,9 @@ __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict
         bk[k] = rowb + (((x + k) * a.dbx) >> kBlockP);
     }
     const bool mvq = needs_mv(c);
+    const int qp = J.qp[a.l][si];
+    const int val[4] = {cv.x, cv.y, cv.z, cv.w};
+    int v[4], dq[4], nzc = 0;
     flags[0] = J.bd[bk[0]];
     mv[0] = mvq ? load_mv(J.mvs, bk[0]) : MvBits{0, 0, 0u};
     if (__any(bk[3] != bk[0])) {
@@ -371,21 +378,22 @@ __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict
             flags[k] = J.bd[bk[k]];
             mv[k] = mvq ? load_mv(J.mvs, bk[k]) : MvBits{0, 0, 0u};
         }
-    } else {
 #pragma unroll
-        for (int k = 1; k < 4; k++) {
-            flags[k] = flags[0];
-            mv[k] = mv[0];
+        for (int k = 0; k < 4; k++) {
+            int tmq;
+            v[k] = quant_detail(c, mv[k], val[k], qp, a.l, flags[k], k < 2 ? pc.x : pc.y, gparc, tmq);
+            dq[k] = dequant_D0(v[k], (unsigned) tmq);
+        }
+    } else { // one block for the four: the step / dead-zone rules are evaluated once per parent (the same operands twice)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int tmq;
+            v[k] = quant_detail(c, mv[0], val[k], qp, a.l, flags[0], k < 2 ? pc.x : pc.y, gparc, tmq);
+            dq[k] = dequant_D0(v[k], (unsigned) tmq);
         }
     }
-    const int qp = J.qp[a.l][si];
-    const int val[4] = {cv.x, cv.y, cv.z, cv.w};
-    int v[4], dq[4], nzc = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int tmq;
-        v[k] = quant_detail(c, mv[k], val[k], qp, a.l, flags[k], k < 2 ? pc.x : pc.y, gparc, tmq);
-        dq[k] = v[k] ? dequant_D(v[k], (unsigned) tmq) : 0;
         nzc += v[k] != 0;
     }
     *cell = make_int4(dq[0], dq[1], dq[2], dq[3]);

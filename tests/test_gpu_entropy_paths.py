@@ -48,7 +48,10 @@ print("BAD", bad)
 """
 
 
-@pytest.mark.parametrize("env", [{"DSV2_GPU_ENTROPY_FORCE_FALLBACK": "1"}, {"DSV2_GPU_ENTROPY": "0"}])
+# DSV2_ENT_EMIT_WORDS shrinks the emit kernel's LDS image of a chunk: 8 words sends every chunk down the path that ORs its
+# code words straight into global memory, 40 mixes both paths (short chunks in LDS, long ones not)
+@pytest.mark.parametrize("env", [{"DSV2_GPU_ENTROPY_FORCE_FALLBACK": "1"}, {"DSV2_GPU_ENTROPY": "0"}, {"DSV2_ENT_EMIT_WORDS": "8"},
+                                 {"DSV2_ENT_EMIT_WORDS": "40"}])
 def test_host_coder_paths(env):
     r = subprocess.run([sys.executable, "-c", _CHILD % os.path.dirname(os.path.abspath(__file__))], env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, text=True, timeout=600)
