@@ -190,13 +190,16 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
 {
     __shared__ __attribute__((aligned(16))) uint32_t sT[kEntChunk];
     __shared__ int s_nskip;
+    __shared__ int s_rng[2][2];
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
     const uint32_t off = (uint32_t) g.qv_off[c];
     const int tid = threadIdx.x;
     for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
-        const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
+        // (the plane's span comes from memory: told to the compiler as wave-uniform, or the loop control below goes vector)
+        const int first = __builtin_amdgcn_readfirstlane(ps.first + lc * kEntChunk);
+        const int cnt = __builtin_amdgcn_readfirstlane(min(kEntChunk, ps.end - first));
         __syncthreads();
         if (tid == 0) {
             s_nskip = 0;
@@ -224,19 +227,80 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
         __syncthreads();
         const int nskip = __builtin_amdgcn_readfirstlane(s_nskip); // uniform: scalar loop control
         pk16 vk = (pk16){(short) (2 * tid), (short) (2 * tid + 1)};
-        for (int q = nskip >> 2; 4 * q < cnt; q++) {
-            const uint4 t4 = *(const uint4 *) &sT[4 * q]; // same address in every lane: an LDS broadcast
-            if (4 * q >= nskip && 4 * q + 4 <= cnt) {
-                vk = pk_step(pk_step(pk_step(pk_step(vk, t4.x), t4.y), t4.z), t4.w);
-            } else { // the group holding the end of the LL prefix or the end of the chunk
-                const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        // Phase 1: all 256 states in vector registers.  States above every threshold march down together and the ones that
+        // meet merge for good (same-parity states never cross), so after a few hundred symbols all 256 trajectories sit on at
+        // most two neighbouring values; from there (phase 2) ONE wavefront walks that pair and every start state takes the
+        // result of the value it had joined.  The range of the states is looked at every 64 symbols.  (Walking the pair in
+        // scalar registers instead trades each vector instruction for 1.3 scalar ones and lengthens the dependent chain:
+        // measured 3 % slower end to end -- the scalar port is as loaded as the vector one in this workload.)
+        const int qend = (cnt + 3) >> 2;
+        int q = nskip >> 2;
+        bool joined = false;
+        int m = 0;
+        while (q < qend) {
+            const int qstop = min(qend, q + 16);
+            for (; q < qstop; q++) {
+                const uint4 t4 = *(const uint4 *) &sT[4 * q]; // same address in every lane: an LDS broadcast
+                if (4 * q >= nskip && 4 * q + 4 <= cnt) {
+                    vk = pk_step(pk_step(pk_step(pk_step(vk, t4.x), t4.y), t4.z), t4.w);
+                } else { // the group holding the end of the LL prefix or the end of the chunk
+                    const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    if (4 * q + b >= nskip && 4 * q + b < cnt) {
-                        vk = pk_step(vk, tt[b]);
+                    for (int b = 0; b < 4; b++) {
+                        if (4 * q + b >= nskip && 4 * q + b < cnt) {
+                            vk = pk_step(vk, tt[b]);
+                        }
                     }
                 }
             }
+            if (q < qend && 4 * q - nskip >= 128) {
+                int lo = min((int) vk.x, (int) vk.y), hi = max((int) vk.x, (int) vk.y);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    lo = min(lo, __shfl_xor(lo, o, 64));
+                    hi = max(hi, __shfl_xor(hi, o, 64));
+                }
+                __syncthreads(); // (the previous look's readers are done)
+                if ((tid & 63) == 0) {
+                    s_rng[tid >> 6][0] = lo;
+                    s_rng[tid >> 6][1] = hi;
+                }
+                __syncthreads();
+                // (made scalar explicitly: a loop exit the compiler takes for divergent would put phase 2 in vector registers)
+                lo = __builtin_amdgcn_readfirstlane(min(s_rng[0][0], s_rng[1][0]));
+                hi = __builtin_amdgcn_readfirstlane(max(s_rng[0][1], s_rng[1][1]));
+                if (hi - lo <= 1) {
+                    joined = true;
+                    m = lo;
+                    break;
+                }
+            }
+        }
+        if (joined) {
+            if (tid < 64) { // the pair (m, m + 1), the same five instructions a symbol, ONE wavefront
+                pk16 x = (pk16){(short) m, (short) (m + 1)};
+                for (; q < qend; q++) {
+                    const uint4 t4 = *(const uint4 *) &sT[4 * q];
+                    if (4 * q >= nskip && 4 * q + 4 <= cnt) {
+                        x = pk_step(pk_step(pk_step(pk_step(x, t4.x), t4.y), t4.z), t4.w);
+                    } else {
+                        const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            if (4 * q + b >= nskip && 4 * q + b < cnt) {
+                                x = pk_step(x, tt[b]);
+                            }
+                        }
+                    }
+                }
+                if (tid == 0) {
+                    s_rng[0][0] = x.x;
+                    s_rng[0][1] = x.y;
+                }
+            }
+            __syncthreads();
+            const int x0 = s_rng[0][0], x1 = s_rng[0][1];
+            vk = (pk16){(short) ((int) vk.x == m ? x0 : x1), (short) ((int) vk.y == m ? x0 : x1)};
         }
         *(uint32_t *) &J.tables[(size_t) (ps.cbase + lc) * kStates + 2 * tid] = __builtin_bit_cast(uint32_t, vk);
     }

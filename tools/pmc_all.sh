@@ -13,7 +13,7 @@ frames = 32 * 6
 for d in sorted(glob.glob(f"gpurun_out/pmc_{sys.argv[1]}/*/*_counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(d)):
-        agg[r["Kernel_Name"].split("(")[0][-44:]][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-44:]][r["Counter_Name"]] += float(r["Counter_Value"])
     names = sorted({c for v in agg.values() for c in v})
     tot = collections.defaultdict(float)
     print("per frame (1 intra + 5 inter per stream), thousands:", names)
