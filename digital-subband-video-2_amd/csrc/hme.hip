@@ -72,7 +72,7 @@ struct HmeCtx {
         __device__ __forceinline__ DSV_MV *operator[](int l) const { return l == level ? cur : parent; }
     };
     AnalysisParams a;
-    int effort, lossless, quant, skip_block_thresh, pyr_levels, psyscale;
+    int effort, lossless, quant, skip_block_thresh, pyr_levels, psyscale, b2sr;
     Planes src, ref, ogr;
     Pair srcc, refc;
     Fields mvf;
@@ -97,6 +97,8 @@ __device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
     c.effort = uni(d.effort);
     c.lossless = uni(d.lossless);
     c.quant = uni(d.quant);
+    // dsv_mv_cost's bits-to-SSE ratio (hme.c:163): one value per frame, worked out once per wavefront, not per block
+    c.b2sr = (256 * (c.quant * c.quant >> 12) * c.a.blk_w * c.a.blk_h) / (c.a.width * c.a.height);
     c.skip_block_thresh = uni(d.skip_block_thresh);
     c.pyr_levels = uni(d.pyr_levels);
     c.psyscale = uni(d.psyscale);
@@ -119,6 +121,12 @@ __device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
     c.counters = uni_ptr(d.counters);
     c.host_mvs = uni_ptr(d.host_mvs);
     return c;
+}
+
+__device__ __forceinline__ int b2sr_of(const HmeCtx &c) { return c.b2sr; }
+__device__ __forceinline__ int b2sr_of(const HmeDev &c) // (the single-call kernels work on the job record itself)
+{
+    return (256 * (c.quant * c.quant >> 12) * c.a.blk_w * c.a.blk_h) / (c.a.width * c.a.height);
 }
 
 struct Psy {
@@ -881,7 +889,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     CostCtx cc;
     movec_pred(mvf, nxb, i, j, cc.px, cc.py);
     cc.q = c.quant;
-    cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
+    cc.b2sr = b2sr_of(c);
 
     int best_k = 0, dx, dy;
     unsigned best_score = 0xffffffffu, score_zero = 0xffffffffu, score;

@@ -200,6 +200,27 @@ __device__ __forceinline__ unsigned div_nn(unsigned n, unsigned d)
     return n / d;
 }
 
+// n / d (d > 0) without the ~35-instruction integer sequence: below 2^20 both operands are exact in single precision and the
+// quotient estimated with v_rcp_f32 (1 ulp) is within one of the true one, which a multiply-back settles; larger operands
+// (a choice made for the whole wavefront: the callers' operands are wave-uniform) take the integer divide.
+__device__ __forceinline__ unsigned udiv_fast(unsigned n, unsigned d)
+{
+    unsigned est = (unsigned) ((float) n * __builtin_amdgcn_rcpf((float) d));
+    const int r = (int) (n - est * d);
+    est = r < 0 ? est - 1u : (r >= (int) d ? est + 1u : est);
+    const bool big = (n | d) >= (1u << 20);
+    if (__builtin_expect(__any(big), 0)) {
+        est = big ? n / d : est;
+    }
+    return est;
+}
+// truncating signed / positive
+__device__ __forceinline__ int sdiv_fast(int n, int d)
+{
+    const unsigned q = udiv_fast((unsigned) abs(n), (unsigned) d);
+    return n < 0 ? -(int) q : (int) q;
+}
+
 // ---- search windows staged in LDS ------------------------------------------------------------------
 // Every block starts with ONE round of memory traffic: its source quads, its neighbours' vectors and -- by
 // LDS-DMA (global_load_lds: no registers, the data lands in LDS while the source analysis runs) -- the part of
@@ -349,7 +370,7 @@ __device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int 
     if (avg == 0) {
         avg = 1;
     }
-    unsigned q16 = (8u << 16) / avg;
+    unsigned q16 = udiv_fast(8u << 16, avg);
     if (lane < 16) {
         hist[lane] = 0;
     }
@@ -393,7 +414,7 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
 {
     int lane = threadIdx.x & 63;
     int avg = bavg ? bavg : 1;
-    int q16 = (8 << 16) / avg;
+    int q16 = (int) udiv_fast(8u << 16, (unsigned) avg);
     if (lane < 16) {
         hist[lane] = 0;
     }
@@ -735,7 +756,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     mv.u.mv.y = (int16_t) (fpely * 4 + sy);
     unsigned ratio = 32;
     if ((mv.u.mv.x | mv.u.mv.y) & 3) {
-        ratio = (best << 5) / (best_fp + !best_fp);
+        ratio = udiv_fast(best << 5, best_fp + !best_fp);
     }
 
     HME_MARK(S, 5);
@@ -989,7 +1010,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
                 int R2 = reduceN<16>(w16);
                 int detail_src = ipolvar, nsub = 0;
                 unsigned avg_tot = 0, err_sub = 0, err_src = 0;
-                detail_src += detail_src / max(neidif, 1);
+                detail_src += sdiv_fast(detail_src, max(neidif, 1));
                 for (int k = 0; k < 4; k++) {
                     if (mv.submask & (1 << k)) {
                         continue;
@@ -1021,7 +1042,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
                 }
                 if (mv.submask) {
                     mv.flags |= 1u << DSV_MV_BIT_INTRA;
-                    mv.dc = err_src < err_sub ? (uint16_t) ((avg_tot / (unsigned) nsub) | DSV_SRC_DC_PRED) : 0;
+                    mv.dc = err_src < err_sub ? (uint16_t) (udiv_fast(avg_tot, (unsigned) nsub) | DSV_SRC_DC_PRED) : 0;
                 }
             }
         }
@@ -1240,7 +1261,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
             int npeaks = src_peaks(a, act, (int) avg_src, S.hist);
             motion_bias += tvar * (hvar - qtex) * npeaks;
         }
-        motion_bias = max(motion_bias, 0) / (2 + (abs(gx) + abs(gy)));
+        motion_bias = (int) udiv_fast((unsigned) max(motion_bias, 0), (unsigned) (2 + (abs(gx) + abs(gy))));
         if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
             psy = Psy{2, 1, 2};
             motion_bias = 0;
@@ -1281,20 +1302,20 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         if (npar) {
             int v2[2] = {pvalid ? pvx : 0, pvalid ? pvy : 0};
             int r = reduceN<2>(v2);
-            lax = bcastN<2>(r, 0) / npar;
-            lay = bcastN<2>(r, 1) / npar;
+            lax = sdiv_fast(bcastN<2>(r, 0), npar);
+            lay = sdiv_fast(bcastN<2>(r, 1), npar);
             // find_inliers (hme.c:1260)
             int dist = pvalid ? SQR(pvx - lax) + SQR(pvy - lay) : 0;
-            int avgd = wave_sum(dist) / npar;
+            int avgd = sdiv_fast(wave_sum(dist), npar);
             int ssd = wave_sum(pvalid ? SQR(dist - avgd) : 0);
-            int thresh = avgd + (int) isqrt_u32((unsigned) (ssd / npar));
+            int thresh = avgd + (int) isqrt_u32((unsigned) sdiv_fast(ssd, npar));
             bool inl = pvalid && dist <= thresh;
             int nin = __popcll(__ballot(inl));
             if (nin) {
                 int w2[2] = {inl ? pvx : 0, inl ? pvy : 0};
                 int r2 = reduceN<2>(w2);
-                lax = bcastN<2>(r2, 0) / nin;
-                lay = bcastN<2>(r2, 1) / nin;
+                lax = sdiv_fast(bcastN<2>(r2, 0), nin);
+                lay = sdiv_fast(bcastN<2>(r2, 1), nin);
             }
             // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)
             if (lane == 1) {
@@ -1354,7 +1375,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         __syncthreads();
     }
     cc.q = c.quant;
-    cc.b2sr = (256 * (c.quant * c.quant >> 12) * y_w * y_h) / (c.a.width * c.a.height);
+    cc.b2sr = b2sr_of(c);
     // loads of the first sub-pel search (around the parent average; hme_block_fast_l0 runs it under this same
     // condition): in flight from here on, under candidate scoring and refinement
     SubpelLoads sp_pre;
