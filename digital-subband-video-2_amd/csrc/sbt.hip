@@ -607,6 +607,154 @@ __global__ __launch_bounds__(256) void k_inv_haar_u8x4(const PlaneJob *__restric
     *(uint2 *) (r0 + J.pic.stride) = make_uint2(r1w[0], r1w[1]);
 }
 
+// ---- the Haar tail of a plane in ONE launch --------------------------------------------------------------------
+// From the level whose LL output fits in LDS down to the 1x1 top every level is Haar (pick_filter) and tiny: ten
+// launches of ~15 us per direction and plane kind.  One workgroup per job walks them all, the LL images ping-ponging
+// between two LDS buffers; the detail bands go to / come from the coefficient plane exactly as in the per-level kernels.
+__device__ __forceinline__ LevelGeom tail_geom(int cw, int ch, int l)
+{
+    LevelGeom g;
+    g.w = cw;
+    g.sw = (cw + (1 << (l - 1)) - 1) >> (l - 1);
+    g.sh = (ch + (1 << (l - 1)) - 1) >> (l - 1);
+    g.hw = (g.sw + 1) / 2;
+    g.hh = (g.sh + 1) / 2;
+    g.use_bd = 0;
+    g.nbh = g.dbx = g.dby = 0;
+    return g;
+}
+
+// one forward quad: source image (src, ss), LL destination (dll, ds), detail bands into the coefficient plane C
+__device__ __forceinline__ void fwd_haar_quad_p(const int32_t *src, int ss, int32_t *dll, int ds, int32_t *C, const LevelGeom &g, int idx, int jy,
+                                                int ovf)
+{
+    const int x = 2 * idx, y = 2 * jy;
+    const bool hasx = (x + 1) < g.sw, hasy = (y + 1) < g.sh;
+    const int32_t *r0 = src + (size_t) y * ss + x;
+    const int x0 = r0[0], x1 = hasx ? r0[1] : 0, x2 = hasy ? r0[ss] : 0, x3 = (hasx && hasy) ? r0[ss + 1] : 0;
+    const int dv = ovf ? 2 : 1;
+    const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+    int32_t *d = dll + (size_t) jy * ds + idx;
+    if (hasx && hasy) {
+        *d = (x0 + x1 + x2 + x3) / dv;
+        C[oLL + g.hw] = x0 - x1 + x2 - x3;
+        C[oHL] = x0 + x1 - x2 - x3;
+        C[oHL + g.hw] = x0 - x1 - x2 + x3;
+    } else if (hasy) {
+        *d = 2 * (x0 + x2) / dv;
+        C[oHL] = 2 * (x0 - x2);
+    } else if (hasx) {
+        *d = 2 * (x0 + x1) / dv;
+        C[oLL + g.hw] = 2 * (x0 - x1);
+    } else {
+        *d = (x0 * 4) / dv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fwd_haar_tail(const PlaneJob *__restrict__ tab, PlaneJob one, int cw, int ch, int l0, int lvls, int lossless,
+                                                       int cap_a)
+{
+    extern __shared__ int32_t tail_lds[];
+    const PlaneJob &J = pick_job(tab, one);
+    int32_t *C = J.coefs;
+    const int32_t *src = img(J, l0 & 1); // written by level l0 - 1
+    int ss = cw;
+    for (int l = l0; l <= lvls; l++) {
+        const LevelGeom g = tail_geom(cw, ch, l);
+        const int ovf = (l >= 6 && l >= (lvls - 3) && !lossless); // sbt.c:29
+        int32_t *dll = l == lvls ? C : (((l - l0) & 1) ? tail_lds + cap_a : tail_lds);
+        const int ds = l == lvls ? cw : g.hw;
+        const int nq = g.hw * g.hh;
+        for (int t = threadIdx.x; t < nq; t += 256) {
+            const int jy = t / g.hw, idx = t - jy * g.hw;
+            fwd_haar_quad_p(src, ss, dll, ds, C, g, idx, jy, ovf);
+        }
+        __syncthreads();
+        src = dll;
+        ss = ds;
+    }
+}
+
+// one inverse quad: LL image (LLp, ls), detail bands from C, output image (out, os)
+__device__ __forceinline__ void inv_haar_quad_p(const int32_t *LLp, int ls, const int32_t *C, int32_t *out, int os, const LevelGeom &g, int idx,
+                                                int jy, int ovf, int filtered, int hqp)
+{
+    const int x = 2 * idx, y = 2 * jy;
+    const bool hasx = (x + 1) < g.sw, hasy = (y + 1) < g.sh;
+    const size_t oC = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+    const int32_t *lp0 = LLp + (size_t) jy * ls + idx;
+    const int sc = 1 << ovf;
+    const int LL = lp0[0] * sc;
+    int v00, v01 = 0, v10 = 0, v11 = 0;
+    if (hasx && hasy) {
+        int LH = C[oC + g.hw], HL = C[oHL], HH = C[oHL + g.hw];
+        if (filtered) {
+            if (idx > 0) { // (one past the LL row is the row's first LH coefficient: sbt.c:715,725)
+                const int lp = lp0[-1] * sc, ln = ((idx + 1 < g.hw) ? lp0[1] : C[oC + 1]) * sc;
+                LH = nudge(LL, lp, ln, LH, hqp);
+            }
+            if (jy > 0) {
+                const int lp = lp0[-ls] * sc, ln = ((jy + 1 < g.hh) ? lp0[ls] : C[oC + g.w]) * sc;
+                HL = nudge(LL, lp, ln, HL, hqp);
+            }
+        }
+        v00 = (LL + LH + HL + HH) / 4;
+        v01 = (LL - LH + HL - HH) / 4;
+        v10 = (LL + LH - HL - HH) / 4;
+        v11 = (LL - LH - HL + HH) / 4;
+    } else if (hasy) {
+        const int HL = C[oHL];
+        v00 = (LL + HL) / 4;
+        v10 = (LL - HL) / 4;
+    } else if (hasx) {
+        const int LH = C[oC + g.hw];
+        v00 = (LL + LH) / 4;
+        v01 = (LL - LH) / 4;
+    } else {
+        v00 = LL / 4;
+    }
+    int32_t *r0 = out + (size_t) y * os + x;
+    r0[0] = v00;
+    if (hasx) {
+        r0[1] = v01;
+    }
+    if (hasy) {
+        r0[os] = v10;
+        if (hasx) {
+            r0[os + 1] = v11;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_inv_haar_tail(const PlaneJob *__restrict__ tab, PlaneJob one, int cw, int ch, int l0, int lvls, int lossless,
+                                                       int plane_idx, int isP, int cap_a)
+{
+    extern __shared__ int32_t tail_lds[];
+    const PlaneJob &J = pick_job(tab, one);
+    const int32_t *C = J.coefs;
+    const int32_t *LLp = C;
+    int ls = cw;
+    const int filtered = !lossless && (plane_idx == 0 || !isP); // sbt.c:925
+    for (int l = lvls; l >= l0; l--) {
+        const LevelGeom g = tail_geom(cw, ch, l);
+        const int ovf = (l >= 6 && l >= (lvls - 3) && !lossless);
+        const int hdiv = (plane_idx == 0) ? (isP ? 14 : (l > 4 ? 2 : 8)) : 2; // sbt.c:903
+        const int hqp = J.q / hdiv;
+        // level l0's output is the picture the next (per-level) launch reads: scratch image (lvls - l0) & 1, as the level loop
+        // would have left it; the others alternate between the LDS buffers, the larger one holding level l0 + 1's
+        int32_t *out = l == l0 ? J.t[(lvls - l0) & 1] : (((l - l0) & 1) ? tail_lds : tail_lds + cap_a);
+        const int os = l == l0 ? cw : g.sw;
+        const int nq = g.hw * g.hh;
+        for (int t = threadIdx.x; t < nq; t += 256) {
+            const int jy = t / g.hw, idx = t - jy * g.hw;
+            inv_haar_quad_p(LLp, ls, C, out, os, g, idx, jy, ovf, filtered, hqp);
+        }
+        __syncthreads();
+        LLp = out;
+        ls = os;
+    }
+}
+
 // columns first (sbt.c:467-469): packed column i of the Mallat image -> full column in scratch image 2
 template <int F>
 __global__ __launch_bounds__(256) void k_inv_cols(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel)
@@ -714,11 +862,41 @@ static LevelGeom level_geom(int cw, int ch, int l, int filter, int nbh, int nbv,
     return g;
 }
 
+// first level of the fused Haar tail (lvls + 1: none): every level from it up is Haar, its LL output and the next one fit in
+// 48 KB of LDS, and at least two levels are fused.  DSV2_SBT_TAIL=0 keeps one launch per level.
+constexpr int kTailLdsInts = 12 * 1024;
+static int tail_first_level(int cw, int ch, int plane_idx, int isP, int lossless, int lvls, int *cap_a)
+{
+    static const bool on = !(getenv("DSV2_SBT_TAIL") && atoi(getenv("DSV2_SBT_TAIL")) == 0);
+    int l0 = lvls + 1;
+    *cap_a = 0;
+    if (!on) {
+        return l0;
+    }
+    for (int l = lvls; l >= 2; l--) { // (level 1 reads / writes the 8-bit picture: never part of the tail)
+        int hw = (rshift_up(cw, l - 1) + 1) / 2, hh = (rshift_up(ch, l - 1) + 1) / 2;
+        int hw2 = (hw + 1) / 2, hh2 = (hh + 1) / 2;
+        if (pick_filter(plane_idx, isP, lossless, l, lvls) != F_HAAR || hw * hh + hw2 * hh2 > kTailLdsInts) {
+            break;
+        }
+        l0 = l;
+        *cap_a = hw * hh;
+    }
+    return l0 < lvls ? l0 : lvls + 1;
+}
+
 static void fwd_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_idx, int isP, int lossless, int nbh, int nbv,
                        bool have_bd)
 {
     int lvls = host_lb2((unsigned) (cw > ch ? cw : ch));
+    int cap_a = 0;
+    const int tail0 = tail_first_level(cw, ch, plane_idx, isP, lossless, lvls, &cap_a);
     for (int l = 1; l <= lvls; l++) {
+        if (l == tail0) {
+            DSV2_LAUNCH(k_fwd_haar_tail, dim3(1, 1, b.tab ? b.n : 1), dim3(256), (size_t) kTailLdsInts * sizeof(int32_t), s, b.tab, b.one, cw, ch, tail0,
+                        lvls, lossless, cap_a);
+            break;
+        }
         // level l reads the LL image written by level l-1 and writes its own LL to the other scratch
         int s_sel = l & 1;
         int d_sel = (l == lvls) ? IMG_COEFS : ((l - 1) & 1);
@@ -752,7 +930,16 @@ static void inv_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
 {
     int lvls = host_lb2((unsigned) (cw > ch ? cw : ch));
     int ll_sel = IMG_COEFS, d_sel = 0;
-    for (int l = lvls; l > 0; l--) {
+    int cap_a = 0, top = lvls;
+    const int tail0 = tail_first_level(cw, ch, plane_idx, isP, lossless, lvls, &cap_a);
+    if (tail0 <= lvls) {
+        DSV2_LAUNCH(k_inv_haar_tail, dim3(1, 1, b.tab ? b.n : 1), dim3(256), (size_t) kTailLdsInts * sizeof(int32_t), s, b.tab, b.one, cw, ch, tail0, lvls,
+                    lossless, plane_idx, isP, cap_a);
+        ll_sel = (lvls - tail0) & 1; // where the level loop would have left level tail0's picture
+        d_sel = ll_sel ^ 1;
+        top = tail0 - 1;
+    }
+    for (int l = top; l > 0; l--) {
         int filter = pick_filter(plane_idx, isP, lossless, l, lvls);
         LevelGeom g = level_geom(cw, ch, l, filter, nbh, nbv, have_bd, false);
         int ovf = (l >= 6 && l >= (lvls - 3) && !lossless);
