@@ -262,19 +262,21 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int i, int j, WaveLds &L)
+// one plane of one block.  CC >= 0 fixes the plane AND the geometry at compile time (16x16 luma blocks, 4:2:0: 8x8 chroma):
+// loop bounds, shifts and the lane -> pixel mapping fold to constants, which removes about a third of the kernel's scalar and
+// a fifth of its vector instructions; CC < 0 is the general form (plane c, sizes from the job).
+template <int MODE, int CC>
+__device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p, const DSV_MV &mv, int i, int j, WaveLds &L, int c_rt)
 {
     const int lane = threadIdx.x & 63;
-    const MCParams p = jb.p;
-    const DSV_MV mv = jb.mvs[i + j * p.nbh];
     const int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
     const uint32_t flags = mv.flags;
     const bool intra = flags & (1u << DSV_MV_BIT_INTRA);
     const bool skip = flags & (1u << DSV_MV_BIT_SKIP), eprm = flags & (1u << DSV_MV_BIT_EPRM);
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-        const int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
-        const int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+    const int c = CC >= 0 ? CC : c_rt;
+    {
+        const int sh = CC >= 0 ? (CC ? 1 : 0) : (c ? p.hshift : 0), sv = CC >= 0 ? (CC ? 1 : 0) : (c ? p.vshift : 0);
+        const int bw = CC >= 0 ? (CC ? 8 : 16) : (p.blk_w >> sh), bh = CC >= 0 ? (CC ? 8 : 16) : (p.blk_h >> sv);
         const DPlane rp = jb.ref.p[c], dp = jb.pred.p[c], sp = jb.res.p[c];
         const int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
         const int x = i * bw, y = j * bh;
@@ -442,6 +444,22 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
             } else {
                 *dpx = out;
             }
+        }
+    }
+}
+
+template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int i, int j, WaveLds &L)
+{
+    const MCParams p = jb.p;
+    const DSV_MV mv = jb.mvs[i + j * p.nbh];
+    if (p.blk_w == 16 && p.blk_h == 16 && p.hshift == 1 && p.vshift == 1) { // (uniform over the launch)
+        predict_plane<MODE, 0>(jb, p, mv, i, j, L, 0);
+        predict_plane<MODE, 1>(jb, p, mv, i, j, L, 1);
+        predict_plane<MODE, 2>(jb, p, mv, i, j, L, 2);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            predict_plane<MODE, -1>(jb, p, mv, i, j, L, c);
         }
     }
 }
