@@ -1007,6 +1007,20 @@ __device__ __forceinline__ void neighbordif2(const CellRec &r, int fx, int fy, i
     dy = abs(tx - cx) + abs(ty - cy);
 }
 
+// (a * num) / den for the cell -> block mapping of the filters (a < 2^12, num < 2^10: the product is far below 2^20):
+// single-precision estimate + multiply-back instead of the ~35-instruction integer divide, four to six times per cell
+__device__ __forceinline__ int scale_div(int a, int num, int den)
+{
+    const unsigned n = (unsigned) (a * num), d = (unsigned) den;
+    unsigned est = (unsigned) ((float) n * __builtin_amdgcn_rcpf((float) d));
+    const int r = (int) (n - est * d);
+    est = r < 0 ? est - 1u : (r >= (int) d ? est + 1u : est);
+    if (__builtin_expect(__any((n | d) >= (1u << 20)), 0)) { // (not a picture this library accepts; kept exact anyway)
+        est = n / d;
+    }
+    return (int) est;
+}
+
 // ---- one cell of each filter (oracle/orc_bmc.c: intra_cell, luma_cell, chroma_block) ----------
 
 template <class V>
@@ -1014,7 +1028,7 @@ __device__ void intra_cell(const V &view, const DPlane &dp, const FilterParams &
 {
     int x = i * 4, y = j * 4;
     bool live = !(y + 4 >= dp.h || x + 4 >= dp.w);
-    int flags = live ? bd[(i * f.nbh / nsbx) + (j * f.nbv / nsby) * f.nbh] : DSV_IS_RINGING;
+    int flags = live ? bd[scale_div(i, f.nbh, nsbx) + scale_div(j, f.nbv, nsby) * f.nbh] : DSV_IS_RINGING;
     live = live & !(flags & DSV_IS_RINGING);
     if (!__any(live)) { // nothing to do for the whole wavefront
         return;
@@ -1052,8 +1066,9 @@ __device__ void luma_cell_rec(const V &view, const DPlane &dp, const FilterParam
     int x = i * 4, y = j * 4;
     uint32_t flags = rec.flags;
     bool live = !(y + 4 >= dp.h || (flags & (1u << DSV_MV_BIT_SKIP)) || x + 4 >= dp.w);
-    bool edgeh = (x % f.blk_w) == 0, edgehs = (x % (f.blk_w / 2)) == 0;
-    bool edgev = (y % f.blk_h) == 0, edgevs = (y % (f.blk_h / 2)) == 0;
+    // (block sizes are powers of two: 16 << e)
+    bool edgeh = (x & (f.blk_w - 1)) == 0, edgehs = (x & (f.blk_w / 2 - 1)) == 0;
+    bool edgev = (y & (f.blk_h - 1)) == 0, edgevs = (y & (f.blk_h / 2 - 1)) == 0;
     int mvx = mvx_of(rec.all), mvy = mvy_of(rec.all);
     int amx = abs(mvx), amy = abs(mvy);
     bool intra = (flags & (1u << DSV_MV_BIT_INTRA)) != 0;
@@ -1124,7 +1139,7 @@ __device__ void luma_cell_rec(const V &view, const DPlane &dp, const FilterParam
 template <class V>
 __device__ void luma_cell(const V &view, const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j, int nsbx, int nsby)
 {
-    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby;
+    int fx = scale_div(i, f.nbh, nsbx), fy = scale_div(j, f.nbv, nsby);
     luma_cell_rec(view, dp, f, fetch_cell_rec(vecs, f.nbh, fx, fy), fx, fy, i, j);
 }
 
@@ -1204,7 +1219,7 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
         int jlo = t - (nsbx + 2) > 0 ? (t - (nsbx + 2) + 1) >> 1 : 0;
         int jhi = (t + 12) >> 1;
         jhi = jhi < nsby - 1 ? jhi : nsby - 1;
-        int j = jlo + ((tid - jlo) % nthr + nthr) % nthr;
+        int j = jlo + ((tid - jlo) & (nthr - 1)); // (tid - jlo) mod nthr: the workgroup size is a power of two (256)
         bool active = j <= jhi;
         int ic = t - 2 * j;
         if (pend_row >= 0) { // columns fetched on the previous front enter the window
@@ -1283,7 +1298,7 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
             ring_sweep(
                 dp, dyn_lds,
                 [&](int i, int j) {
-                    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby, key = fx + fy * f.nbh;
+                    int fx = scale_div(i, f.nbh, nsbx), fy = scale_div(j, f.nbv, nsby), key = fx + fy * f.nbh;
                     if (key != cur_key) {
                         cur = key == nxt_key ? nxt : fetch_cell_rec(vecs, f.nbh, fx, fy);
                         cur_key = key;
@@ -1291,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
                     luma_cell_rec(view, dp, f, cur, fx, fy, i, j);
                 },
                 [&](int i, int j) {
-                    int fx = i * f.nbh / nsbx, fy = j * f.nbv / nsby, key = fx + fy * f.nbh;
+                    int fx = scale_div(i, f.nbh, nsbx), fy = scale_div(j, f.nbv, nsby), key = fx + fy * f.nbh;
                     if (key != cur_key && key != nxt_key) {
                         nxt = fetch_cell_rec(vecs, f.nbh, fx, fy);
                         nxt_key = key;
