@@ -1247,6 +1247,36 @@ __device__ __forceinline__ int take_ticket(int *counter)
     }
     return __builtin_amdgcn_readfirstlane(t);
 }
+// XCD-aware tickets.  The rows of one picture read overlapping windows of the same three planes (a row's window reaches 16
+// lines into the rows above and below), and every XCD has its own L2: handed out across the whole chip, the ~20 rows of a
+// picture that are in flight at a time sat on eight XCDs and each fetched the shared lines for itself (FETCH_SIZE 1.36 x
+// the algorithmic bytes, every such line an HBM-latency miss in a kernel that spends half its life waiting).  So the launch's
+// streams are dealt to the XCDs (stream s -> partition s mod 8), every partition has its own ticket counter (kept in the
+// counter block of stream `partition`), and a wavefront takes the next row of ITS XCD's partition (HW_REG_XCC_ID); when that is
+// exhausted it takes from the next partition, so no row is left behind and the tail balances.  Within a partition tickets
+// still run row-major across its streams, and a row's predecessor still holds a lower ticket of the same counter: the
+// progress argument above is unchanged.  DSV2_HME_XCD=0: one partition (the previous behaviour).
+struct RowTicket {
+    int stream, row;
+};
+__device__ __forceinline__ int xcc_id()
+{
+    return (int) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+__device__ __forceinline__ RowTicket take_row(const HmeDev *tab, int level, int nstreams, int nrows, int parts)
+{
+    int x = parts > 1 ? xcc_id() % parts : 0;
+    for (int k = 0; k < parts; k++) {
+        const int ns = (nstreams - x + parts - 1) / parts; // streams x, x + parts, ...
+        const int t = take_ticket(&tab[x].counters[kHmeTicket + level]);
+        if (t < ns * nrows) {
+            const int row = t / ns;
+            return RowTicket{x + parts * (t - row * ns), row};
+        }
+        x = x + 1 == parts ? 0 : x + 1;
+    }
+    return RowTicket{-1, -1};
+}
 constexpr unsigned long long kHmeSpinLimit = 400000000ull; // 100 MHz ticks = 4 s
 
 __device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned need, int *err)
@@ -1384,30 +1414,37 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
 // one group alone is fastest at W = 3 or 4.  DSV2_HME_WAVES / DSV2_HME_WAVES_FAST pick the variants.
 #define HME_ROWS_B(W)                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_w##W(                  \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        const int t_ = take_ticket(&tab[0].counters[kHmeTicket + level]), n_ = (int) gridDim.x;                          \
-        hme_row<false>(tab[t_ % n_], t_ / n_, level, nbx, (int) gridDim.y, allow_fast, S);                               \
+        const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<false>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);                          \
+        }                                                                                                                \
     }                                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_w##W(          \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        const int t_ = take_ticket(&tab[0].counters[kHmeTicket + 0]), n_ = (int) gridDim.x;                              \
-        hme_row<true, 0>(tab[t_ % n_], t_ / n_, 0, nbx, (int) gridDim.y, allow_fast, S);                                 \
+        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<true, 0>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                            \
+        }                                                                                                                \
     }                                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_w##W(          \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast)                                              \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
-        const int t_ = take_ticket(&tab[0].counters[kHmeTicket + level]), n_ = (int) gridDim.x;                          \
-        hme_row<true, 1>(tab[t_ % n_], t_ / n_, level, nbx, (int) gridDim.y, allow_fast, S);                             \
+        const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<true, 1>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);                        \
+        }                                                                                                                \
     }
 HME_ROWS_B(1)
 HME_ROWS_B(2)
 HME_ROWS_B(3)
 HME_ROWS_B(4)
+static int g_hme_xcd = getenv("DSV2_HME_XCD") && atoi(getenv("DSV2_HME_XCD")) >= 1 ? atoi(getenv("DSV2_HME_XCD")) : 8; // ticket partitions (take_row): 8 XCDs on MI355X; 1 = chip-wide tickets
 static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 2;
 static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
 static int g_hme_waves_fast_lx = getenv("DSV2_HME_WAVES_FAST_LX") ? atoi(getenv("DSV2_HME_WAVES_FAST_LX")) : g_hme_waves_fast; // levels > 0
@@ -1630,7 +1667,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             if (prof && level == 0) {
                 prof->begin(s, ST_HME_L0);
             }
-            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1));
+            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1), n < g_hme_xcd ? n : g_hme_xcd);
             if (prof && level == 0) {
                 prof->end(s, ST_HME_L0, n, 1);
             }
