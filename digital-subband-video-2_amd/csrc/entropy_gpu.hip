@@ -307,25 +307,41 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
 }
 
 // ---- 3 ----------------------------------------------------------------------------------------------------
+// One wavefront per plane (grid = (3, streams)).  A link of the chain is one table lookup, but each waits for the one
+// before it: straight from global memory that is a memory round trip per chunk (~1.4 us under load, 250 chunks a luma
+// plane).  So the wavefront stages the tables of 32 chunks at a time in LDS (one coalesced round trip for 16 KB) and lane
+// 0 follows the chain through them there.
+constexpr int kChainBatch = 32;
 __global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab)
 {
-    const EntJob &J = tab[blockIdx.x];
-    const int c = threadIdx.x;
-    if (c >= 3) {
-        return;
-    }
+    __shared__ __attribute__((aligned(16))) uint16_t st[kChainBatch * kStates];
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.x;
     const PlaneSpan ps = plane_span(J.info, c);
+    const int lane = threadIdx.x;
     int vk = 0;
     bool ovf = false;
-    for (int lc = 0; lc < ps.nch; lc++) {
-        J.chunk_vk[ps.cbase + lc] = (uint16_t) vk;
-        vk = J.tables[(size_t) (ps.cbase + lc) * kStates + vk];
-        if (vk >= kStates) {
-            ovf = true;
-            vk = kStates - 1;
+    for (int base = 0; base < ps.nch; base += kChainBatch) {
+        const int nb = min(kChainBatch, ps.nch - base);
+        const uint4 *src = (const uint4 *) (J.tables + (size_t) (ps.cbase + base) * kStates); // 512 bytes a chunk: 16-byte aligned
+        uint4 *dst = (uint4 *) st;
+        for (int i = lane; i < nb * (kStates * 2 / 16); i += 64) {
+            dst[i] = src[i];
         }
+        __syncthreads();
+        if (lane == 0) {
+            for (int k = 0; k < nb; k++) {
+                J.chunk_vk[ps.cbase + base + k] = (uint16_t) vk;
+                vk = st[k * kStates + vk];
+                if (vk >= kStates) {
+                    ovf = true;
+                    vk = kStates - 1;
+                }
+            }
+        }
+        __syncthreads();
     }
-    if (ovf) {
+    if (lane == 0 && ovf) {
         atomicOr(&J.info[EI_FLAGS], 1);
     }
 }
@@ -739,7 +755,7 @@ void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom 
     const int slots = chunk_slots < 1 ? 1 : chunk_slots;
     DSV2_LAUNCH(k_ent_planes, dim3(n), dim3(64), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_tables, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
-    DSV2_LAUNCH(k_ent_chain, dim3(n), dim3(64), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(64), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);

@@ -548,9 +548,12 @@ __global__ __launch_bounds__(256) void k_count(const CompactJob *__restrict__ ta
 }
 
 // exclusive scan of up to 1024*ntile_per_thread tile counts by one workgroup; also emits the total
-__global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restrict__ tab, CompactJob one, int reset)
+// one workgroup of 256 per job (a 1024-thread workgroup needs sixteen free wavefront slots on ONE compute unit at once: beside
+// the search's resident wavefronts its placement alone took ~1 ms in the four-group bench)
+constexpr int kScanThreads = 256;
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const CompactJob *__restrict__ tab, CompactJob one, int reset)
 {
-    __shared__ int wsum[16];
+    __shared__ int wsum[kScanThreads / 64];
     const CompactJob &J = tab ? tab[blockIdx.y] : one;
     const int *tile_count = J.tile_count;
     int ntiles = (J.n + kTile - 1) / kTile;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restric
         carry = 0;
     }
     __syncthreads();
-    for (int start = 0; start < ntiles; start += 1024) {
+    for (int start = 0; start < ntiles; start += kScanThreads) {
         int i = start + threadIdx.x;
         int v = i < ntiles ? tile_count[i] : 0;
         if (reset && i < ntiles) {
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restric
             tile_base[i] = c0 + woff + inc - v;
         }
         __syncthreads();
-        if (threadIdx.x == 1023) {
+        if (threadIdx.x == kScanThreads - 1) {
             carry = c0 + woff + inc;
         }
         __syncthreads();
@@ -591,9 +594,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const CompactJob *__restric
     }
 }
 
-// The tile's symbols are first packed in LDS, then written out as one contiguous run: every store instruction of
-// a wavefront covers 256 consecutive bytes (the host mirror is written across PCIe, where scattered 4-byte
-// stores cost a transaction each).
 __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ tab, CompactJob one)
 {
     __shared__ int wsum[4];
@@ -704,7 +704,7 @@ void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
     CompactJob one = job(qv, n);
     int ntiles = (int) ((n + kTile - 1) / kTile);
     DSV2_LAUNCH(k_count, dim3(ntiles), dim3(256), 0, s, nullptr, one);
-    DSV2_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, s, nullptr, one, 1); // counts always left at zero
+    DSV2_LAUNCH(k_scan_tiles, dim3(1), dim3(kScanThreads), 0, s, nullptr, one, 1); // counts always left at zero
     DSV2_LAUNCH(k_scatter, dim3(ntiles), dim3(256), 0, s, nullptr, one);
     HIPCHK(hipMemcpyAsync(h_total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
@@ -719,7 +719,7 @@ void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n, 
     if (!counted) { // else the quantiser tallied the tiles while writing the values (count_nonzero)
         DSV2_LAUNCH(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     }
-    DSV2_LAUNCH(k_scan_tiles, dim3(1, njobs), dim3(1024), 0, s, d_jobs, CompactJob{}, counted ? 1 : 0);
+    DSV2_LAUNCH(k_scan_tiles, dim3(1, njobs), dim3(kScanThreads), 0, s, d_jobs, CompactJob{}, counted ? 1 : 0);
     DSV2_LAUNCH(k_scatter, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     HIPCHK(hipGetLastError());
 }
