@@ -216,14 +216,24 @@ __device__ __forceinline__ MvBits load_mv(const DSV_MV *mvs, int bi)
     return MvBits{(int) mv.u.mv.x, (int) mv.u.mv.y, mv.flags};
 }
 
-__device__ __forceinline__ int quant_detail(const QuantCfg &c, const MvBits &mv, int val, int qp, int l, int flags, int parc, int gparc,
-                                            int &tmq_out)
+// which of the rule sets applies is a property of the launch: QM_* fixes it at compile time for the hot kernel
+enum { QM_P_PLAIN = 0, QM_P_PSY = 1, QM_I_PSY = 2, QM_I_CHROMA = 3, QM_I_PLAIN = 4 };
+__host__ __device__ __forceinline__ int quant_mode(const QuantCfg &c)
+{
+    if (c.isP) {
+        return ((c.do_psy & DSV_PSY_P_VISUAL_MASKING) && c.plane == 0) ? QM_P_PSY : QM_P_PLAIN;
+    }
+    return ((c.do_psy & DSV_PSY_I_VISUAL_MASKING) && c.plane == 0) ? QM_I_PSY : (c.plane ? QM_I_CHROMA : QM_I_PLAIN);
+}
+
+template <int MODE>
+__device__ __forceinline__ int quant_detail_m(const MvBits &mv, int val, int qp, int l, int flags, int parc, int gparc, int &tmq_out)
 {
     int tmq = qp, sub = 0;
     const bool texture = !parc, gtexture = !gparc;
-    if (c.isP) {
+    if (MODE == QM_P_PLAIN || MODE == QM_P_PSY) {
         tmq = tmq_for_P(tmq, flags, parc);
-        if ((c.do_psy & DSV_PSY_P_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:371-380
+        if (MODE == QM_P_PSY) { // hzcc.c:371-380
             const bool small_mv = abs(mv.x) < 32 && abs(mv.y) < 32;
             const bool fine = (gtexture & texture) | ((mv.flags & (1u << DSV_MV_BIT_EPRM)) != 0) |
                               (((mv.flags & (1u << DSV_MV_BIT_MAINTAIN)) != 0) & small_mv);
@@ -232,17 +242,29 @@ __device__ __forceinline__ int quant_detail(const QuantCfg &c, const MvBits &mv,
         }
     } else {
         tmq = tmq_for_I(tmq, flags, parc, l);
-        if ((c.do_psy & DSV_PSY_I_VISUAL_MASKING) && c.plane == 0) { // hzcc.c:387-414
+        if (MODE == QM_I_PSY) { // hzcc.c:387-414
             const int smf = flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE);
             const bool edge = sgn(parc) == sgn(val);
             const int stp = smf == 0 ? -tmq / 3 : ((edge && smf == DSV_IS_STABLE) ? tmq >> 3 : -tmq / 6);
             sub = (flags & DSV_IS_RINGING) ? -(tmq / 6) : (l == 0 ? -(tmq >> 3) : stp);
-        } else if (c.plane) {
+        } else if (MODE == QM_I_CHROMA) {
             sub = -(tmq >> 3);
         }
     }
     tmq_out = tmq;
     return div_trunc_pos(val >= 0 ? val - sub : val + sub, tmq);
+}
+
+__device__ __forceinline__ int quant_detail(const QuantCfg &c, const MvBits &mv, int val, int qp, int l, int flags, int parc, int gparc,
+                                            int &tmq_out)
+{
+    switch (quant_mode(c)) {
+        case QM_P_PLAIN: return quant_detail_m<QM_P_PLAIN>(mv, val, qp, l, flags, parc, gparc, tmq_out);
+        case QM_P_PSY: return quant_detail_m<QM_P_PSY>(mv, val, qp, l, flags, parc, gparc, tmq_out);
+        case QM_I_PSY: return quant_detail_m<QM_I_PSY>(mv, val, qp, l, flags, parc, gparc, tmq_out);
+        case QM_I_CHROMA: return quant_detail_m<QM_I_CHROMA>(mv, val, qp, l, flags, parc, gparc, tmq_out);
+        default: return quant_detail_m<QM_I_PLAIN>(mv, val, qp, l, flags, parc, gparc, tmq_out);
+    }
 }
 
 // Kernels work through PlaneJob records (dev.h): tab == nullptr runs the single job `one`,
@@ -337,6 +359,7 @@ __global__ __launch_bounds__(256) void k_quant_level(const PlaneJob *__restrict_
 // values, one parent pair and one grandparent for the four, the block's flags and vector fetched once when the four share
 // a block (levels 0 and 1 of the 16-pixel-block geometries).  A thread whose fourth coefficient is a dependent of the
 // last column, and any job whose buffers are not 16-byte aligned, goes cell by cell.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
 {
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict
     for (int k = 0; k < 4; k++) {
         bk[k] = rowb + (((x + k) * a.dbx) >> kBlockP);
     }
-    const bool mvq = needs_mv(c);
+    const bool mvq = MODE == QM_P_PSY;
     const int qp = J.qp[a.l][si];
     const int val[4] = {cv.x, cv.y, cv.z, cv.w};
     int v[4], dq[4], nzc = 0;
@@ -381,14 +404,14 @@ __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int tmq;
-            v[k] = quant_detail(c, mv[k], val[k], qp, a.l, flags[k], k < 2 ? pc.x : pc.y, gparc, tmq);
+            v[k] = quant_detail_m<MODE>(mv[k], val[k], qp, a.l, flags[k], k < 2 ? pc.x : pc.y, gparc, tmq);
             dq[k] = dequant_D0(v[k], (unsigned) tmq);
         }
     } else { // one block for the four: the step / dead-zone rules are evaluated once per parent (the same operands twice)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int tmq;
-            v[k] = quant_detail(c, mv[0], val[k], qp, a.l, flags[0], k < 2 ? pc.x : pc.y, gparc, tmq);
+            v[k] = quant_detail_m<MODE>(mv[0], val[k], qp, a.l, flags[0], k < 2 ? pc.x : pc.y, gparc, tmq);
             dq[k] = dequant_D0(v[k], (unsigned) tmq);
         }
     }
@@ -476,7 +499,14 @@ static void quant_launch(hipStream_t s, const PlaneJob *tab, const PlaneJob &one
             a.vec = a.vec && (a.off[si] & 3) == 0 && (a.base[si] & 3) == 0 && (a.par[si] & 1) == 0;
         }
         if (a.vec) {
-            DSV2_LAUNCH(k_quant_level4, dim3((a.sw / 4 + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
+            const dim3 grid4((a.sw / 4 + 63) / 64, (a.sh + 3) / 4, 3 * nz);
+            switch (quant_mode(cfg)) { // (a lossless launch goes cell by cell inside the kernel: any instance will do)
+                case QM_P_PLAIN: DSV2_LAUNCH(k_quant_level4<QM_P_PLAIN>, grid4, blk, 0, s, tab, one, cfg, a); break;
+                case QM_P_PSY: DSV2_LAUNCH(k_quant_level4<QM_P_PSY>, grid4, blk, 0, s, tab, one, cfg, a); break;
+                case QM_I_PSY: DSV2_LAUNCH(k_quant_level4<QM_I_PSY>, grid4, blk, 0, s, tab, one, cfg, a); break;
+                case QM_I_CHROMA: DSV2_LAUNCH(k_quant_level4<QM_I_CHROMA>, grid4, blk, 0, s, tab, one, cfg, a); break;
+                default: DSV2_LAUNCH(k_quant_level4<QM_I_PLAIN>, grid4, blk, 0, s, tab, one, cfg, a); break;
+            }
         } else {
             DSV2_LAUNCH(k_quant_level, dim3((a.sw + 63) / 64, (a.sh + 3) / 4, 3 * nz), blk, 0, s, tab, one, cfg, a);
         }
