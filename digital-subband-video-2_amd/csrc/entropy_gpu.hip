@@ -10,13 +10,16 @@
 //
 //   1 k_ent_planes   per stream: where each plane's symbols start in the compacted (position, value) list
 //   2 k_ent_tables   per chunk of 1024 symbols: the chunk's TRANSFER FUNCTION vk_in -> vk_out as a 256-entry table,
-//                    by walking all 256 start states through the chunk at once (one lane per state; a state's step
-//                    only needs bitlen(u) of the symbol, staged in LDS)
-//   3 k_ent_chain    per plane: vk at the start of every chunk by following the tables (one lookup per chunk)
-//   4 k_ent_ks       per chunk: one lane walks the chunk (staged in LDS) from its now known start state: k of every
-//                    symbol and the chunk's total code length
+//                    by walking all 256 start states through the chunk at once (two states per lane in packed 16-bit
+//                    arithmetic against one threshold per symbol, staged in LDS; one wavefront alone once all
+//                    trajectories have joined two neighbouring values)
+//   3 k_ent_chain    per plane: vk at the start of every chunk by following the tables (one lookup per chunk, the
+//                    tables staged 32 chunks at a time in LDS)
+//   4 k_ent_ks       per chunk, one wavefront: one lane walks the chunk's thresholds (staged in LDS) from its now known
+//                    start state; the lanes turn the states into k of every symbol and the chunk's total code length
 //   5 k_ent_layout   per stream: exclusive scan of the chunk lengths, byte layout of the three plane sections
-//   6 k_ent_zero / k_ent_emit   every symbol ORs its code words into the (zeroed) output at its bit offset
+//   6 k_ent_zero / k_ent_emit   every symbol ORs its code words into an LDS image of its chunk at its bit offset; the
+//                    image leaves as whole words (only a chunk's first and last word are ORed into the zeroed output)
 //   7 k_ent_out      the finished bytes and their sizes to pinned host memory
 //
 // A state beyond 255 (k >= 32 at damp 3, never seen on real pictures) or a plane that outgrows its buffer raises a
