@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "384")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "768")),
                     help="independent closed-GOP streams (encoder instances) per GPU")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "4")),
                     help="lockstep groups per GPU, one host thread + HIP stream each")

@@ -37,10 +37,10 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     gmax = max(int(r["Grid_Size_X"]) for r in tr)
     full = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if int(r["Grid_Size_X"]) >= gmax - 6 * 64]
     f.write("\nk_hme_rows_b_fast_l0_w2 (level-0 search, the dominant kernel): %d launches, mean %.1f us over all of them (the pre-roll steps "
-            "launch it for fewer streams), mean %.1f us over the %d full-size launches (90-96 inter pictures of a group) -- bench.py HIP-event span of that "
+            "launch it for fewer streams), mean %.1f us over the %d full-size launches (up to %d inter pictures of a group) -- bench.py HIP-event span of that "
             "launch in its profiled steps: %.1f us (the event span also holds the wait for a free queue slot between the group's "
             "launches while the other three groups' kernels are being dispatched)\n"
-            % (len(durs), sum(durs) / max(1, len(durs)), sum(full) / max(1, len(full)), len(full),
+            % (len(durs), sum(durs) / max(1, len(durs)), sum(full) / max(1, len(full)), len(full), gmax // 64,
                traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
 
 # PMC: per-launch HBM-side bytes of the dominant kernel
@@ -55,7 +55,7 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
     f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows_b_fast_l0 -- python3 bench.py "
             "--steps 6 --warmup 3 --no-stagger\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
             "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width); only the launches of the "
-            "level-0 search kernel are listed (96 streams per launch)\n\n")
+            "level-0 search kernel are listed (one lockstep group per launch)\n\n")
     f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
     tot_f = tot_w = nl = 0
     for g in sorted(agg["FETCH_SIZE"]):
