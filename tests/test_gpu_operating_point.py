@@ -134,11 +134,13 @@ print(json.dumps(T.run_once(hip, frames, 32, 2, pinned)))
 """
 
 
-def test_front_per_launch_form_agrees():
-    """the same streams in a process with DSV2_HME_ROWS=0: the search runs one launch per anti-diagonal front"""
+@pytest.mark.parametrize("env_extra", [{"DSV2_HME_ROWS": "0"}, {"DSV2_HME_XCD": "1"}, {"DSV2_HME_XCD": "3"}])
+def test_front_per_launch_form_agrees(env_extra):
+    """the same streams in a process with DSV2_HME_ROWS=0: the search runs one launch per anti-diagonal front; and the row
+    pipeline with chip-wide tickets (one partition) and with three partitions (uneven: the fall-over path takes rows)"""
     frames = gen_inputs()
     want = reference_digests(frames)
-    env = dict(os.environ, DSV2_HME_ROWS="0")
+    env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, "-c", _CHILD % os.path.dirname(os.path.abspath(__file__))], env=env, stdout=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0
     got = json.loads(r.stdout.strip().splitlines()[-1])
