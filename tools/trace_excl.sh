@@ -4,14 +4,14 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/ts
-env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ts/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --streams 96 --groups 1 --steps 12 --warmup 2 > gpurun_out/ts/$tag.json 2> gpurun_out/ts/$tag.err
+env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ts/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --streams ${EXCL_STREAMS:-96} --groups 1 --steps 12 --warmup 2 > gpurun_out/ts/$tag.json 2> gpurun_out/ts/$tag.err
 cp gpurun_out/ts/$tag/*/*_kernel_stats.csv gpurun_out/ts/$tag.csv
 rm -rf gpurun_out/ts/$tag
 python3 - "$tag" <<'PY'
 import csv, json, sys
 t = sys.argv[1]
 r = json.loads([l for l in open(f"gpurun_out/ts/{t}.json") if l.startswith("{")][-1])
-frames = 96 * (r["steps"] + r["warmup"])
+frames = r["config"]["streams_per_gpu"] * (r["steps"] + r["warmup"])
 print(t, r["value"], "fps", r["ms_per_step"], "ms/step;", frames, "frames traced (1 intra + 13 inter per stream)")
 rows = list(csv.DictReader(open(f"gpurun_out/ts/{t}.csv")))
 tot = sum(float(x["TotalDurationNs"]) for x in rows)
