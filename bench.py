@@ -81,6 +81,13 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE.json configurations and the decode leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the extra stage-timing pass that feeds the roofline object")
     ap.add_argument("--no-stagger", action="store_true", help="all streams start their GOP together (one all-intra step per GOP)")
+    ap.add_argument("--no-phase-align", action="store_true",
+                    help="spread every step's intra pictures over all lockstep groups (round 2's layout) instead of giving them to one group")
+    ap.add_argument("--host-cores", type=int, default=0,
+                    help="pin this rank to N of its usable cores (sched_setaffinity, after the pictures are generated and before anything "
+                         "touches the GPU) and size the library's worker pool from them: does the host side fit N cores per GPU?")
+    ap.add_argument("--no-batch-curve", action="store_true", help="skip the small-batch operating points (1 / 8 / 48 / 192 streams)")
+    ap.add_argument("--no-host-share", action="store_true", help="skip the 2-host-cores re-run of the headline")
     ap.add_argument("--device-resident", action="store_true",
                     help="pictures parked in HBM before the clock starts (kernel-side figure; NOT the SURVEY 8d metric)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for exercising the N>1 path "
@@ -138,15 +145,23 @@ def gen_videos(specs, nproc):
 
 
 class EncodeRun:
-    """S encoder instances of one geometry in G lockstep groups, pictures in pinned host memory."""
+    """S encoder instances of one geometry in G lockstep groups, pictures in pinned host memory.
 
-    def __init__(self, hip, A, torch, w, h, fmt, qp, gop, effort, S, G, videos, stagger, device_resident=False):
+    Stream layout: streams 2u and 2u+1 are TWINS -- same input, different lockstep group -- whose packets must be identical
+    frame for frame.  GOP phases (stream s codes its first picture in step r0[s] of an untimed pre-roll, so that every step
+    carries the steady-state 1/gop share of intra pictures) are PHASE-ALIGNED with the groups when the group count divides
+    the GOP length: group g holds the phases g, g + G, g + 2G ..., so in any one step the intra pictures of the whole GPU
+    all belong to ONE group -- its launches carry them all, the other groups launch no intra-only kernel at all
+    (dsv_encoder.c:1247-1271 decides the picture type from the frame number alone)."""
+
+    def __init__(self, hip, A, torch, w, h, fmt, qp, gop, effort, S, G, videos, stagger, device_resident=False, seeds=None, phase_align=True):
         from codec_run import configure_encoder
         self.hip, self.A, self.torch = hip, A, torch
         self.w, self.h, self.fmt, self.qp, self.gop, self.effort = w, h, fmt, qp, gop, effort
         self.S, self.G = S, max(1, min(G, S))
         self.P = len(videos[0][0])
         self.NV, self.NF = len(videos), len(videos[0])
+        self.seeds = list(seeds) if seeds is not None else [None] * self.NV
         self.device_resident = device_resident
         # pictures: one pinned host block per video (or, for the kernel-side figure, one HBM tensor)
         self.vbase, self._keep = [], []
@@ -163,12 +178,17 @@ class EncodeRun:
                     C.memmove(p + i * self.P, fb, self.P)
                 self.vbase.append(p)
         torch.cuda.synchronize()
-        # stream s: twin pairs (2u, 2u+1) share their input and their GOP phase and sit in different groups
+        G = self.G
         self.video = [(s // 2) % self.NV for s in range(S)]
         self.shift = [2 * (((s // 2) // self.NV) % max(1, self.NF // 2)) for s in range(S)]
         self.R = gop if (stagger and gop > 1) else 0
-        self.r0 = [(s // 2) % self.R if self.R else 0 for s in range(S)]
-        self.group_of = [list(range(g, S, self.G)) for g in range(self.G)]
+        self.group_of = [list(range(g, S, G)) for g in range(G)]
+        self.phase_aligned = bool(phase_align and self.R and self.R % G == 0 and G > 1)
+        if self.phase_aligned:
+            slots, nj = self.R // G, (S + G - 1) // G  # a group's phases g + G * slot; few streams: slots spread over the GOP
+            self.r0 = [(s % G + G * (((s // G) * slots) // nj if nj < slots else (s // G) % slots)) % self.R for s in range(S)]
+        else:
+            self.r0 = [(s // 2) % self.R if self.R else 0 for s in range(S)]
         subsamp = A.SUBSAMP_420 if fmt == "420" else A.SUBSAMP_444
         meta = A.mk_meta(w, h, subsamp)
         self.encs = []
@@ -178,6 +198,7 @@ class EncodeRun:
             self.encs.append(e)
         self.out = [[] for _ in range(S)]  # per stream, per frame: list of packets (bytes)
         self.step = 0
+        self.step_ms = None  # per group: wall-clock duration of every step of the current run() (filled when a list)
 
     def frame_index(self, s, t):
         k = self.shift[s] + t
@@ -188,10 +209,42 @@ class EncodeRun:
     def ptr(self, s, t):
         return self.vbase[self.video[s]] + self.P * self.frame_index(s, t)
 
+    def ref_job(self, s, nframes):
+        """this stream's first nframes as a job of tools/ref_encode_worker.py"""
+        assert self.seeds[self.video[s]] is not None
+        return (self.w, self.h, self.fmt, self.seeds[self.video[s]], self.qp, self.gop, self.effort, [self.frame_index(s, t) for t in range(nframes)])
+
+    def pick_reference_streams(self, n):
+        """n streams to re-encode with the reference: GOP phases spread over the whole 0 .. gop-1 range, every lockstep group
+        covered, no two of them twins"""
+        S, G = self.S, self.G
+        n = max(1, min(n, max(1, S // 2)))
+        if not self.R:
+            sel = []
+            for u in range(n):
+                s = 2 * u + ((u >> 1) & 1)
+                sel.append(s if s < S else 2 * u)
+            return sel
+        sel, used_pairs, per_group = [], set(), [0] * G
+        phases = sorted(set(self.r0))
+        for k in range(n):
+            want = phases[(k * (len(phases) - 1)) // max(1, n - 1)] if n > 1 else phases[0]
+            cands = [s for s in range(S) if (s // 2) not in used_pairs]
+            if not cands:
+                break
+            # nearest phase first, then the group that has been picked least, then a video not picked yet
+            vids_used = {self.video[x] for x in sel}
+            s = min(cands, key=lambda x: (abs(self.r0[x] - want), per_group[x % G], self.video[x] in vids_used, x))
+            sel.append(s)
+            used_pairs.add(s // 2)
+            per_group[s % G] += 1
+        return sel
+
     def _group_worker(self, g, g0, g1, bar):
         hip, A = self.hip, self.A
         ids_all = self.group_of[g]
         bar.wait()
+        t_prev = time.perf_counter()
         for step in range(g0, g1):
             ids = [s for s in ids_all if self.r0[s] <= step]
             m = len(ids)
@@ -214,12 +267,17 @@ class EncodeRun:
                     pk.append(C.string_at(b.data, b.len))
                     hip.dsv_buf_free(C.byref(b))
                 self.out[s].append(pk)
+            if self.step_ms is not None:
+                t_now = time.perf_counter()
+                self.step_ms[g].append(1e3 * (t_now - t_prev))
+                t_prev = t_now
         bar.wait()
 
-    def run(self, nsteps, dist=None):
+    def run(self, nsteps, dist=None, record=False):
         """advance every (started) stream by nsteps frames; returns the wall time bracketed by barrier + synchronize"""
         torch = self.torch
         g0, g1 = self.step, self.step + nsteps
+        self.step_ms = [[] for _ in range(self.G)] if record else None
         bar = threading.Barrier(self.G + 1)
         ths = [threading.Thread(target=self._group_worker, args=(g, g0, g1, bar)) for g in range(self.G)]
         for th in ths:
@@ -242,12 +300,18 @@ class EncodeRun:
     def frames_in(self, g0, g1):
         return sum(max(0, g1 - max(g0, self.r0[s])) for s in range(self.S))
 
+    def intra_in(self, g0, g1):
+        return sum(1 for s in range(self.S) for t in range(max(0, g0 - self.r0[s]), g1 - self.r0[s]) if t % self.gop == 0)
+
     def twins_equal(self):
-        """every stream's packets == its twin's (same input, other lockstep group), over the whole run"""
+        """every stream's packets == its twin's (same input, other lockstep group and -- phase-aligned -- another GOP phase),
+        frame for frame over everything both have coded"""
         pairs = bad = 0
         for u in range(self.S // 2):
+            a, b = self.out[2 * u], self.out[2 * u + 1]
+            n = min(len(a), len(b))
             pairs += 1
-            if self.out[2 * u] != self.out[2 * u + 1]:
+            if n == 0 or a[:n] != b[:n]:
                 bad += 1
         return pairs, bad
 
@@ -264,7 +328,7 @@ class EncodeRun:
 
 
 class RefWorkers:
-    """reference encodes on the host CPU (tools/ref_encode_worker.py): parity oracle + CPU baselines"""
+    """reference encodes / decodes on the host CPU (tools/ref_encode_worker.py): parity oracle + CPU baselines"""
 
     def __init__(self, jobs):
         # jobs: list of (w, h, fmt, seed, qp, gop, effort, [frame indices])
@@ -282,11 +346,19 @@ class RefWorkers:
             line = p.stdout.readline().strip()
             assert line == "ready", "reference worker failed to start: %r" % line
 
-    def go(self, which, n):
-        for i in which:
-            self.procs[i].stdin.write("go %d\n" % n)
+    def _cmd(self, which, word, counts):
+        for i, n in zip(which, counts):
+            self.procs[i].stdin.write("%s %d\n" % (word, n))
             self.procs[i].stdin.flush()
         return [json.loads(self.procs[i].stdout.readline()) for i in which]
+
+    def go(self, which, counts):
+        """encode: worker i codes its first counts[k] frames, all the named workers at once"""
+        return self._cmd(which, "go", counts)
+
+    def dec(self, which, counts):
+        """decode the packets of the last encode with the reference decoder: timing + md5 of every picture"""
+        return self._cmd(which, "dec", counts)
 
     def frames(self, i):
         data, out, off = open(self.paths[i], "rb").read(), [], 0
@@ -310,16 +382,51 @@ class RefWorkers:
         os.rmdir(self.tmp)
 
 
-def decode_leg(hip, A, run, g0, nsteps, nstreams, groups):
-    """lockstep batch decoder over the packets the encode run produced for global steps [g0, g0 + nsteps)"""
+class RefCheck:
+    """what one leg of the bench hands to the reference for comparison: the job (how to regenerate the stream's input and
+    encode it) and the bytes this library produced, frame by frame"""
+
+    def __init__(self, leg, run, s, nframes):
+        self.leg, self.stream = leg, s
+        self.n = min(nframes, len(run.out[s]))
+        self.job = run.ref_job(s, self.n)
+        self.got = [b"".join(fr) for fr in run.out[s][:self.n]]
+        self.group, self.phase = s % run.G, run.r0[s]
+
+
+def picture_planes(fp):
+    """a decoded DSV_FRAME's three planes, rows packed tight (one copy; what the reference worker hashes)"""
+    import numpy as np
+    out = []
+    for c in range(3):
+        p = fp.contents.planes[c]
+        out.append(np.ctypeslib.as_array(p.data, shape=(p.h * p.stride,)).reshape(p.h, p.stride)[:, :p.w].copy())
+    return out
+
+
+def planes_md5(planes):
+    import hashlib
+    h = hashlib.md5()
+    for a in planes:
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def decode_leg(hip, A, run, nsteps, nstreams, groups, check):
+    """lockstep batch decoder over the packets the encode run produced: every decoder starts at its stream's first packet.
+    The streams in `check` (the ones the reference re-encodes AND decodes) are among the decoders; their pictures are
+    copied out of the returned DSV_FRAME inside the clock (3 MB each, a few per step) and hashed after it stops."""
     hip.dsv2hip_dec_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(A.DECODER)), C.POINTER(A.BUF), C.POINTER(C.POINTER(A.FRAME)),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     hip.dsv2hip_dec_batch.restype = C.c_int
     D = min(nstreams, run.S)
+    ids_all = list(check) + [s for s in range(run.S) if s not in set(check)][:max(0, D - len(check))]
+    D = len(ids_all)
     G = max(1, min(groups, D))
-    decs = [A.DECODER() for _ in range(D)]
-    group_of = [list(range(g, D, G)) for g in range(G)]
+    decs = {s: A.DECODER() for s in ids_all}
+    group_of = [ids_all[g::G] for g in range(G)]
     decoded = [0] * G
+    held = {s: [] for s in check}
 
     def feed(g, ids, packets):
         m = len(ids)
@@ -336,6 +443,8 @@ def decode_leg(hip, A, run, g0, nsteps, nstreams, groups):
         for i in range(m):
             if rets[i] == A.DEC_OK and outs[i]:
                 decoded[g] += 1
+                if ids[i] in held:
+                    held[ids[i]].append(picture_planes(outs[i]))
                 hip.dsv_frame_ref_dec(outs[i])
 
     def worker(g, t0, t1, bar):
@@ -364,17 +473,49 @@ def decode_leg(hip, A, run, g0, nsteps, nstreams, groups):
             th.join()
         return te - ts
 
-    nfr = min(len(run.out[s]) for s in range(D))
+    nfr = min(len(run.out[s]) for s in ids_all)
     warm = min(4, max(1, nfr - nsteps))
     phase(0, warm)
     before = sum(decoded)
     elapsed = phase(warm, min(nfr, warm + nsteps))
     n = sum(decoded) - before
-    for d in decs:
+    md5 = {s: [planes_md5(pl) for pl in frames] for s, frames in held.items()}
+    for d in decs.values():
         hip.dsv_dec_free(C.byref(d))
     return {"value": round(n / elapsed, 2), "unit": "frames/s", "frames": n, "decoders": D, "groups": G,
             "mpix_per_s": round(n / elapsed * run.w * run.h / 1e6, 1),
-            "note": "lockstep batch decoder (dsv2hip_dec_batch) over this run's own packets, pictures delivered to host memory as DSV_FRAMEs"}
+            "note": "lockstep batch decoder (dsv2hip_dec_batch) over this run's own packets, pictures delivered to host memory as DSV_FRAMEs"}, md5
+
+
+def bind_abi(hip, A):
+    hip.dsv2hip_prof_enable.argtypes = [C.c_int]
+    hip.dsv2hip_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    hip.dsv2hip_prof_read_units.argtypes = [C.POINTER(C.c_longlong)]
+    hip.dsv2hip_enc_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(A.BUF), C.POINTER(C.c_int)]
+    hip.dsv2hip_enc_batch.restype = C.c_int
+    hip.dsv2hip_enc_batch_host.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(A.BUF),
+                                           C.POINTER(C.c_int)]
+    hip.dsv2hip_enc_batch_host.restype = C.c_int
+    hip.dsv2hip_host_alloc.argtypes = [C.c_size_t]
+    hip.dsv2hip_host_alloc.restype = C.c_void_p
+    hip.dsv2hip_host_free.argtypes = [C.c_void_p]
+
+
+def issue_roofline(fps, world):
+    """instruction-issue roofline of the whole encode: vector wavefront-instructions per frame (committed PMC passes over
+    every kernel, profiles/instruction_volume.json) x measured frames/s against what the chip's SIMDs can issue"""
+    try:
+        iv = json.load(open(os.path.join(ROOT, "profiles", "instruction_volume.json")))
+    except (OSError, ValueError):
+        return None
+    simds, clock = 256 * 4, 2.4e9
+    peak = simds * clock / 4 / 1e9  # one vector instruction per SIMD every 4 clocks (a wave64 op occupies the 16-lane SIMD for 4)
+    ach = iv["vector_per_frame"] * fps / max(1, world) / 1e9
+    return {"bound": "vector issue", "vector_inst_per_frame": iv["vector_per_frame"], "scalar_inst_per_frame": iv.get("scalar_per_frame"),
+            "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s per GPU", "frac": round(ach / peak, 4),
+            "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks per wave64 vector instruction; with two or more wavefronts resident on a "
+                         "SIMD, back-to-back issue from different waves (dual issue of transcendental / packed ops aside) does not raise it",
+            "source": "committed PMC passes, not this run: " + iv.get("source", "profiles/instruction_volume.json")}
 
 
 def main():
@@ -386,24 +527,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
         sys.stderr.write("[bench] --gpus %d but WORLD_SIZE=%d: running %d ranks\n" % (args.gpus, world, world))
-    ncpu = usable_cpus()
-    # host phases run on a worker pool inside the library: share the usable cores between the ranks
-    os.environ.setdefault("DSV2_HOST_THREADS", str(min(48, max(8, 3 * ncpu // max(1, world)))))
+    ncpu_box = usable_cpus()
     local = int(os.environ.get("DSV2_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     extras = not args.no_extras and world == 1
 
     # ---- pictures first: forked generators must not inherit an initialised GPU runtime ----
     W_, H_, GOP, QP = 1920, 1080, 48, 60
     NV, NF = (8, 32) if args.streams >= 16 else (max(1, min(4, args.streams // 2)), 24)
-    specs = [(W_, H_, "420", 1 + rank * NV + k, NF) for k in range(NV)]
+    seeds = [1 + rank * NV + k for k in range(NV)]
+    specs = [(W_, H_, "420", seeds[k], NF) for k in range(NV)]
     if extras:
         specs += [(1280, 720, "420", 101 + k, 24) for k in range(4)]
         specs += [(W_, H_, "444", 201, 12)]
     t_gen = time.perf_counter()
     under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
-    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(8, ncpu // max(1, world))))
+    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(8, ncpu_box // max(1, world))))
     vids = gen_videos(specs, gen_procs)
     t_gen = time.perf_counter() - t_gen
+
+    # ---- the host budget of this rank: pinned BEFORE the GPU runtime and the library's worker pool come up ----
+    if args.host_cores > 0:
+        cores = sorted(os.sched_getaffinity(0))
+        k0 = (rank * args.host_cores) % max(1, len(cores))
+        mine = [cores[(k0 + i) % len(cores)] for i in range(min(args.host_cores, len(cores)))]
+        os.sched_setaffinity(0, mine)
+    ncpu = usable_cpus() if args.host_cores <= 0 else min(usable_cpus(), args.host_cores)
+    # host phases run on a worker pool inside the library: share the usable cores between the ranks
+    if args.host_cores > 0:
+        os.environ.setdefault("DSV2_HOST_THREADS", str(max(2, 2 * ncpu)))
+    else:
+        os.environ.setdefault("DSV2_HOST_THREADS", str(min(48, max(8, 3 * ncpu // max(1, world)))))
 
     import torch
     import dsvabi as A
@@ -419,34 +572,27 @@ def main():
     hip = A.load_hip()
     assert hip.dsv2hip_device_ok() == 0, "no HIP device: the product has no CPU path"
     hip.dsv2hip_set_device(local)
-    hip.dsv2hip_prof_enable.argtypes = [C.c_int]
-    hip.dsv2hip_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
-    hip.dsv2hip_prof_read_units.argtypes = [C.POINTER(C.c_longlong)]
-    hip.dsv2hip_enc_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(A.BUF), C.POINTER(C.c_int)]
-    hip.dsv2hip_enc_batch.restype = C.c_int
-    hip.dsv2hip_enc_batch_host.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(A.BUF),
-                                           C.POINTER(C.c_int)]
-    hip.dsv2hip_enc_batch_host.restype = C.c_int
-    hip.dsv2hip_host_alloc.argtypes = [C.c_size_t]
-    hip.dsv2hip_host_alloc.restype = C.c_void_p
-    hip.dsv2hip_host_free.argtypes = [C.c_void_p]
+    bind_abi(hip, A)
     from conftest import load_pkg
     pkg = load_pkg()
 
     S, K, Wm = max(1, args.streams), args.steps, args.warmup
     effort = int(os.environ.get("DSV2_BENCH_EFFORT", "10"))  # (experiments only: the headline is effort 10)
-    run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, args.groups, vids[:NV], not args.no_stagger, args.device_resident)
+    align = not args.no_phase_align
+    run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, args.groups, vids[:NV], not args.no_stagger, args.device_resident,
+                    seeds=seeds, phase_align=align)
     G = run.G
     hip.dsv2hip_prof_enable(0)
     run.run(run.R + Wm)                   # untimed: GOP-phase pre-roll + warm-up (allocations, clocks)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     g_timed = run.step
-    elapsed = run.run(K, dist)            # timed: exactly K steps
+    elapsed = run.run(K, dist, record=True)   # timed: exactly K steps
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    step_ms = sorted(x for g in run.step_ms for x in g)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     frames_rank = run.frames_in(g_timed, g_timed + K)
-    intra_rank = sum(1 for s in range(S) for t in range(g_timed - run.r0[s], g_timed + K - run.r0[s]) if t % GOP == 0)
+    intra_rank = run.intra_in(g_timed, g_timed + K)
 
     # stage profile: a few more steps of the SAME configuration with HIP-event stage timing on (not timed)
     stage_ms, stage_launches, stage_units, prof_steps = None, None, None, 0
@@ -469,16 +615,20 @@ def main():
         sys.stderr.write("[bench] rank %d: %d of %d twin stream pairs DIFFER -- output is not deterministic\n" % (rank, bad, pairs))
         sys.exit(3)
 
-    # final ordered gather of the segment bytes (the only collective of the path)
+    # final ordered gather of the segment bytes (the only exchange of the path); a rank's streams are the closed-GOP
+    # segments sharding.assign_segments deals to it round-robin: global id = local index * world + rank
     xdev = "cuda" if args.backend == "nccl" else "cpu"
     t_max = torch.tensor([elapsed], device=xdev, dtype=torch.float64)
     counts = torch.tensor([frames_rank, intra_rank, pairs], device=xdev, dtype=torch.int64)
+    gather_s = None
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        # segment id = global stream index: rank-major, so the gathered file is the ordered concatenation
-        segs = {rank * S + s: run.stream_bytes(s) for s in range(S)}
+        assert pkg.sharding.assign_segments(S * world, world)[rank] == [pkg.sharding.segment_id(rank, world, s) for s in range(S)]
+        segs = {pkg.sharding.segment_id(rank, world, s): run.stream_bytes(s) for s in range(S)}
+        t_g = time.perf_counter()
         whole = pkg.sharding.gather_segments(dist, rank, world, segs, device=xdev)
+        gather_s = time.perf_counter() - t_g
         total_bytes = len(whole) if rank == 0 else 0
         del whole, segs
     else:
@@ -511,16 +661,21 @@ def main():
                                "pictures in %s; GOP phases %s" %
                                (effort, S, G, "HBM before the clock starts (kernel-side figure)" if args.device_resident else
                                 "pinned host memory, every frame uploaded inside the timed region (double-buffered copy stream)",
-                                "staggered over %d untimed pre-roll steps: every step codes 1/%d of the streams as intra pictures" % (run.R, GOP)
+                                ("staggered over %d untimed pre-roll steps: every step codes 1/%d of the streams as intra pictures%s" %
+                                 (run.R, GOP, ", all of them in ONE lockstep group (phase-aligned groups)" if run.phase_aligned else ""))
                                 if run.R else "aligned: one all-intra step per GOP"),
                    "streams_per_gpu": S, "frames_per_step_per_gpu": S, "groups": G, "frames_timed": frames_total, "intra_frames_timed": intra_total,
+                   "phase_aligned_groups": run.phase_aligned,
                    "input": "pinned_host" if not args.device_resident else "device_resident", "h2d_bytes_per_step_per_gpu": 0 if args.device_resident else S * run.P,
                    "distinct_videos_per_gpu": NV, "unique_frames_per_video": NF,
+                   "ms_per_frame_p50": round(step_ms[len(step_ms) // 2], 3) if step_ms else None,
                    "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2), "mpix_per_s": round(fps * W_ * H_ / 1e6, 1),
-                   "stream_bytes_total": total_bytes, "host_cpus_usable": ncpu, "host_threads": int(os.environ["DSV2_HOST_THREADS"]),
+                   "stream_bytes_total": total_bytes, "host_cpus_usable": ncpu, "host_cores_pinned": args.host_cores or None,
+                   "host_threads": int(os.environ["DSV2_HOST_THREADS"]),
+                   "final_gather_s": round(gather_s, 3) if gather_s is not None else None,
                    "setup_s": {"generate_pictures": round(t_gen, 1)}},
         "parity_checked": {"twin_pairs_equal": pairs_total, "twin_pairs": pairs_total,
-                           "note": "twins = same input, different lockstep group, compared over every packet of the run"},
+                           "note": "twins = same input, different lockstep group (and GOP phase), compared frame by frame over the run"},
     }
     if stage_ms is not None and prof_steps:
         # per stage: span (HIP events on the group's stream) per stream-frame, and the algorithmic
@@ -537,11 +692,13 @@ def main():
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
         # HBM traffic per launch of the dominant kernel cannot be read inside this process: it comes from the separate
         # rocprofv3 --pmc passes of tools/profile_round.sh (profiles/pmc_traffic.json) and is only quoted for the
-        # configuration those passes were taken on
+        # configuration those passes were taken on (streams, groups, GOP-phase layout)
         traffic, traffic_source = None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("stage") == dom and pt.get("streams_per_gpu") == S and pt.get("groups") == G and pt.get("kernel") == STAGE_KERNEL[dom]:
+            same = (pt.get("stage") == dom and pt.get("streams_per_gpu") == S and pt.get("groups") == G and pt.get("kernel") == STAGE_KERNEL[dom]
+                    and bool(pt.get("stagger", False)) == bool(run.R) and bool(pt.get("phase_aligned", False)) == run.phase_aligned)
+            if same:
                 traffic = pt.get("bytes_per_launch")
                 traffic_source = "committed PMC passes, not this run: " + pt.get("source", "profiles/pmc_traffic.json")
         except (OSError, ValueError):
@@ -553,103 +710,221 @@ def main():
                               "launches_per_step": round(nl / prof_steps * G, 1),
                               "algorithmic_bytes_per_launch": round(bytes_per_launch),
                               "stage_us_per_frame": {k: round(1e3 * v, 2) for k, v in per_unit.items()},
-                              "whole_frame_algorithmic_GBps": round(frame_bytes * fps / 1e9, 1)}
+                              "whole_frame_algorithmic_GBps": round(frame_bytes * fps / 1e9, 1),
+                              "note": "the search is an integer kernel bound by instruction issue and dependent latencies, not by bandwidth: "
+                                      "see roofline.issue for the roofline that binds the pipeline"}
+        iss = issue_roofline(fps, world)
+        if iss:
+            result["roofline"]["issue"] = iss
 
-    # ---- parity, part 2 + CPU baselines: the real reference (oracle/_ref) on the host cores ----
-    if not args.no_cpu_baseline and os.path.exists(A.REF_SO):
-        # two streams per lockstep group, early GOP phases (they have run longest)
-        sel = []
-        for u in range(min(NREF_STREAMS, S // 2 if S > 1 else 1)):
-            s = 2 * u + ((u >> 1) & 1)
-            sel.append(s if s < S else 2 * u)
-        nfr = [min(NREF_FRAMES, len(run.out[s])) for s in sel]
-        jobs = [(W_, H_, "420", 1 + rank * NV + run.video[s], QP, GOP, effort, [run.frame_index(s, t) for t in range(nfr[i])]) for i, s in enumerate(sel)]
-        try:
-            rw = RefWorkers(jobs)
-            one = rw.go([0], min(24, nfr[0]))[0]             # one reference thread, alone on the box
-            allr = rw.go(list(range(len(sel))), max(nfr))    # all workers at once (each stops at its own frame count)
-            mism = []
-            for i, s in enumerate(sel):
-                want = rw.frames(i)
-                got = [b"".join(fr) for fr in run.out[s][:len(want)]]
-                if want != got:
-                    first = next((t for t, (a, b) in enumerate(zip(want, got)) if a != b), min(len(want), len(got)))
-                    mism.append((s, first))
-            rw.close()
-        except (OSError, AssertionError, ValueError) as e:  # the reference side failed: say so beside the headline
-            result["parity_checked"]["vs_reference_error"] = repr(e)
-            print(json.dumps(result))
-            sys.exit(5)
-        result["parity_checked"].update({"vs_reference_streams": len(sel), "vs_reference_frames_each": nfr, "streams": sel,
-                                         "groups_covered": sorted(set(s % G for s in sel)), "mismatches": len(mism)})
-        result["cpu_baseline"] = {"value": round(one["frames"] / (one["t1"] - one["t0"]), 3), "unit": "frames/s", "cores": 1, "kind": "reference",
-                                  "sample": "first %d frames (1 I + %d P) of stream %d, reference C library -O3, 1 thread, alone on the box"
-                                            % (one["frames"], one["frames"] - 1, sel[0])}
-        span = max(r["t1"] for r in allr) - min(r["t0"] for r in allr)
-        result["cpu_baseline_8proc"] = {"value": round(sum(r["frames"] for r in allr) / span, 3), "unit": "frames/s", "cores": len(sel), "kind": "reference",
-                                        "sample": "%d reference processes at once, one closed-GOP stream each (%s frames), as parallel_encode_yuv.sh does"
-                                                  % (len(sel), "/".join(str(r["frames"]) for r in allr))}
-        if mism:
-            print(json.dumps(result))
-            sys.stderr.write("[bench] MISMATCH against the reference: (stream, first differing frame) = %s\n" % mism)
-            sys.exit(4)
+    # ---- legs whose packets the reference will re-encode (collected now, compared at the end, all at once) ----
+    checks = []
+    sel = run.pick_reference_streams(NREF_STREAMS)
+    for s in sel:
+        checks.append(RefCheck("headline", run, s, NREF_FRAMES))
 
-    # ---- the decoder on this run's packets, and the other BASELINE.json configurations (N = 1 only) ----
+    # ---- the decoder on this run's packets (N = 1 only) ----
     # (the headline above is complete: whatever goes wrong below is reported beside it, never instead of it)
+    dec_md5 = {}
     if extras:
         try:
-            result["decode"] = decode_leg(hip, A, run, 0, 32, 256, 4)
+            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, 256, 4, sel if not args.no_cpu_baseline else [])
         except Exception as e:  # noqa: BLE001
             result["decode"] = {"error": repr(e)}
     run.free()
+    del run
+
+    # ---- the other BASELINE.json configurations and the small-batch operating points (N = 1 only) ----
     if extras:
         try:
-            result["configs"] = other_configs(hip, A, torch, args, vids, NV, S, W_, H_)
+            result["configs"] = other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks)
         except Exception as e:  # noqa: BLE001
             result["configs"] = {"error": repr(e)}
+    if extras and not args.no_batch_curve:
+        try:
+            result["batch_curve"] = batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
+        except Exception as e:  # noqa: BLE001
+            result["batch_curve"] = {"error": repr(e)}
+
+    # ---- does the host side fit the cores an 8-GPU node leaves per rank?  The headline again, pinned to 2 cores ----
+    if extras and not args.no_host_share and args.host_cores <= 0:
+        result["host_share"] = host_share(args, 2, fps)
+
+    # ---- parity, part 2 + CPU baselines: the real reference (oracle/_ref) on the host cores ----
+    rc = 0
+    if not args.no_cpu_baseline and os.path.exists(A.REF_SO):
+        try:
+            rc = reference_phase(result, checks, dec_md5, sel)
+        except (OSError, AssertionError, ValueError) as e:  # the reference side failed: say so beside the headline
+            result["parity_checked"]["vs_reference_error"] = repr(e)
+            rc = 5
     print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
-def other_configs(hip, A, torch, args, vids, NV, S, W_, H_):
-    """the other BASELINE.json configurations, each a short run of the same engine (N = 1 only)"""
+def reference_phase(result, checks, dec_md5, sel):
+    """Every stream the legs above set aside is re-encoded by the real reference (one process each, CPU) and compared byte
+    for byte; the headline's streams are also DECODED by the reference decoder and every picture's md5 compared with what
+    the lockstep decoder delivered in the decode leg.  The CPU baselines are timed here too: worker 0 alone on the box
+    (encode, then decode), then the headline's 8 workers at once (parallel_encode_yuv.sh's recipe)."""
+    rw = RefWorkers([c.job for c in checks])
+    try:
+        head = [i for i, c in enumerate(checks) if c.leg == "headline"]
+        rest = [i for i, c in enumerate(checks) if c.leg != "headline"]
+        one = rw.go([head[0]], [min(24, checks[head[0]].n)])[0]              # one reference thread, alone on the box
+        one_dec = rw.dec([head[0]], [min(24, checks[head[0]].n)])[0]
+        allr = rw.go(head, [checks[i].n for i in head])                      # the headline's workers at once
+        decr = rw.dec(head, [checks[i].n for i in head]) if dec_md5 else []
+        if rest:
+            rw.go(rest, [checks[i].n for i in rest])                         # every other leg's streams at once
+        mism, per_leg = [], {}
+        for i, c in enumerate(checks):
+            want = rw.frames(i)
+            ok = want == c.got
+            per_leg.setdefault(c.leg, {"streams": 0, "frames": 0, "mismatches": 0})
+            per_leg[c.leg]["streams"] += 1
+            per_leg[c.leg]["frames"] += len(want)
+            if not ok:
+                first = next((t for t, (a, b) in enumerate(zip(want, c.got)) if a != b), min(len(want), len(c.got)))
+                mism.append((c.leg, c.stream, first))
+                per_leg[c.leg]["mismatches"] += 1
+        dec_bad, dec_pics = [], 0
+        for k, i in enumerate(head if dec_md5 else []):
+            got = dec_md5.get(checks[i].stream, [])
+            want = decr[k]["md5"][:len(got)]
+            dec_pics += len(got)
+            if not got or got != want:
+                dec_bad.append(checks[i].stream)
+    finally:
+        rw.close()
+    hc = [checks[i] for i in head]
+    result["parity_checked"].update({"vs_reference_streams": len(hc), "vs_reference_frames_each": [c.n for c in hc], "streams": [c.stream for c in hc],
+                                     "gop_phases": [c.phase for c in hc], "groups_covered": sorted(set(c.group for c in hc)),
+                                     "mismatches": per_leg.get("headline", {}).get("mismatches", 0),
+                                     "legs": per_leg, "mismatches_all_legs": len(mism),
+                                     "decode_vs_reference_decoder": {"streams": len(head) if dec_md5 else 0, "pictures_md5_compared": dec_pics,
+                                                                     "streams_differing": len(dec_bad)}})
+    result["cpu_baseline"] = {"value": round(one["frames"] / (one["t1"] - one["t0"]), 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                              "sample": "first %d frames (1 I + %d P) of stream %d, reference C library -O3, 1 thread, alone on the box"
+                                        % (one["frames"], one["frames"] - 1, hc[0].stream)}
+    span = max(r["t1"] for r in allr) - min(r["t0"] for r in allr)
+    result["cpu_baseline_8proc"] = {"value": round(sum(r["frames"] for r in allr) / span, 3), "unit": "frames/s", "cores": len(head), "kind": "reference",
+                                    "sample": "%d reference processes at once, one closed-GOP stream each (%s frames), as parallel_encode_yuv.sh does"
+                                              % (len(head), "/".join(str(r["frames"]) for r in allr))}
+    if isinstance(result.get("decode"), dict) and "error" not in result["decode"]:
+        result["decode"]["cpu_baseline_decode"] = {"value": round(one_dec["frames"] / max(1e-9, one_dec["t1"] - one_dec["t0"]), 2), "unit": "frames/s", "cores": 1,
+                                                   "kind": "reference", "sample": "the reference decoder (dsv_dec) over the first %d pictures of stream %d, "
+                                                   "1 thread, alone on the box" % (one_dec["frames"], hc[0].stream)}
+        result["decode"]["vs_reference_decoder"] = {"streams": len(head) if dec_md5 else 0, "pictures_md5_compared": dec_pics, "streams_differing": len(dec_bad)}
+    # the legs' own lines carry their verdicts too
+    for leg, v in per_leg.items():
+        if leg.startswith("c") and isinstance(result.get("configs"), dict) and leg in result["configs"]:
+            result["configs"][leg]["vs_reference"] = v
+        if leg.startswith("batch") and isinstance(result.get("batch_curve"), list):
+            for pt in result["batch_curve"]:
+                if "batch_%d" % pt["streams"] == leg:
+                    pt["vs_reference_mismatches"] = v["mismatches"]
+                    pt["vs_reference_frames"] = v["frames"]
+    if mism:
+        sys.stderr.write("[bench] MISMATCH against the reference: (leg, stream, first differing frame) = %s\n" % mism)
+        return 4
+    if dec_bad:
+        sys.stderr.write("[bench] decoded pictures DIFFER from the reference decoder's: streams %s\n" % dec_bad)
+        return 6
+    return 0
+
+
+def timed_leg(run, warm, k):
+    """pre-roll + warm-up, then k timed steps: (frames, seconds, sorted per-step wall times of the groups)"""
+    run.run(run.R + warm)
+    g = run.step
+    e = run.run(k, record=True)
+    ms = sorted(x for grp in run.step_ms for x in grp)
+    return run.frames_in(g, g + k), e, ms
+
+
+def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
+    """the other BASELINE.json configurations, each a short run of the same engine (N = 1 only); two streams of each are
+    set aside for the reference re-encode (another video each, another lockstep group each)"""
     cfgs = {}
+    align = not args.no_phase_align
+
+    def leg(name, run, warm, k, nref_frames, extra):
+        f, e, _ = timed_leg(run, warm, k)
+        p, b = run.twins_equal()
+        cfgs[name] = {"value": round(f / e, 2), "unit": "frames/s", "streams": run.S, "steps": k, "ms_per_step": round(1e3 * e / k, 3),
+                      "mpix_per_s": round(f / e * run.w * run.h / 1e6, 1), "twin_pairs_equal": p - b, "twin_pairs": p}
+        cfgs[name].update(extra)
+        for s in run.pick_reference_streams(2):
+            checks.append(RefCheck(name, run, s, nref_frames))
+        if b:
+            raise AssertionError("%s: %d of %d twin stream pairs differ" % (name, b, p))
+
     # C2: 1280x720 4:2:0 -qp=60 -gop=48 effort 10
-    r2 = EncodeRun(hip, A, torch, 1280, 720, "420", 60, 48, 10, S, args.groups, vids[NV:NV + 4], not args.no_stagger)
-    r2.run(r2.R + 4)
-    k2 = 24
-    g2 = r2.step
-    e2 = r2.run(k2)
-    p2, b2 = r2.twins_equal()
-    f2 = r2.frames_in(g2, g2 + k2)
-    cfgs["c2_720p_420_qp60_gop48"] = {"value": round(f2 / e2, 2), "unit": "frames/s", "streams": S, "steps": k2, "ms_per_step": round(1e3 * e2 / k2, 3),
-                                       "mpix_per_s": round(f2 / e2 * 1280 * 720 / 1e6, 1), "twin_pairs_equal": p2 - b2, "twin_pairs": p2,
-                                       "input": "pinned_host, staggered GOP phases"}
+    r2 = EncodeRun(hip, A, torch, 1280, 720, "420", 60, 48, 10, S, args.groups, vids[NV:NV + 4], not args.no_stagger, seeds=[101 + k for k in range(4)],
+                   phase_align=align)
+    leg("c2_720p_420_qp60_gop48", r2, 4, 24, 24, {"input": "pinned_host, staggered GOP phases"})
     r2.free()
     # C3: 1920x1080 4:2:0 -qp=60 -gop=60 (the headline's geometry with the CLI's default GOP)
-    r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:NV], not args.no_stagger)
-    r3.run(r3.R + 4)
-    k3 = 16
-    g3 = r3.step
-    e3 = r3.run(k3)
-    p3, b3 = r3.twins_equal()
-    f3 = r3.frames_in(g3, g3 + k3)
-    cfgs["c3_1080p_420_qp60_gop60"] = {"value": round(f3 / e3, 2), "unit": "frames/s", "streams": S, "steps": k3, "ms_per_step": round(1e3 * e3 / k3, 3),
-                                        "mpix_per_s": round(f3 / e3 * W_ * H_ / 1e6, 1), "twin_pairs_equal": p3 - b3, "twin_pairs": p3,
-                                        "input": "pinned_host, staggered GOP phases"}
+    r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=align)
+    leg("c3_1080p_420_qp60_gop60", r3, 4, 16, 20, {"input": "pinned_host, staggered GOP phases"})
     r3.free()
     # C4: 1920x1080 4:4:4 lossless (-qp=100), every stream from its first (intra) frame; round trip through the decoder
     s4 = min(32, S)
-    r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, 2, vids[NV + 4:NV + 5], False)
-    r4.run(2)
-    k4 = 8
-    e4 = r4.run(k4)
-    cfgs["c4_1080p_444_lossless"] = {"value": round(s4 * k4 / e4, 2), "unit": "frames/s", "streams": s4, "steps": k4, "ms_per_step": round(1e3 * e4 / k4, 3),
-                                      "mpix_per_s": round(s4 * k4 / e4 * W_ * H_ / 1e6, 1), "frames": "P frames 2..9 of each stream (general ME routine)",
-                                      "round_trip": lossless_round_trip(hip, A, r4, vids[NV + 4])}
+    r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, 2, vids[NV + 4:NV + 5], False, seeds=[201])
+    leg("c4_1080p_444_lossless", r4, 2, 8, 10, {"frames": "P frames 2..9 of each stream (general ME routine)"})
+    cfgs["c4_1080p_444_lossless"]["round_trip"] = lossless_round_trip(hip, A, r4, vids[NV + 4])
     r4.free()
     return cfgs
+
+
+BATCH_POINTS = [(1, 1), (8, 8), (48, 8), (192, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets
+
+
+def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks):
+    """The headline's workload at 1 / 8 / 48 / 192 concurrent streams (BASELINE config 5 runs ONE closed-GOP segment per
+    GPU; parallel_encode_yuv.sh:31-52 runs 8): frames/s, the median time a stream waits for its next frame, and stream 0's
+    first frames set aside for the reference re-encode.  Same timed region as the headline (upload inside)."""
+    out = []
+    for S, G in BATCH_POINTS:
+        G = min(G, S)
+        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, G, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align)
+        k = 48
+        f, e, ms = timed_leg(run, 4, k)
+        p, b = run.twins_equal() if S > 1 else (0, 0)
+        out.append({"streams": S, "groups": run.G, "value": round(f / e, 2), "unit": "frames/s", "steps": k, "ms_per_step": round(1e3 * e / k, 3),
+                    "ms_per_frame_p50": round(ms[len(ms) // 2], 3), "ms_per_frame_p90": round(ms[(len(ms) * 9) // 10], 3),
+                    "intra_frames_timed": run.intra_in(run.step - k, run.step), "twin_pairs_equal": p - b, "twin_pairs": p})
+        checks.append(RefCheck("batch_%d" % S, run, 0, 32))
+        run.free()
+        if b:
+            raise AssertionError("batch curve, %d streams: %d of %d twin stream pairs differ" % (S, b, p))
+    return out
+
+
+def host_share(args, cores, fps_unrestricted):
+    """the headline once more in a fresh process pinned to `cores` host cores (an 8-GPU node's share per rank)"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--host-cores", str(cores), "--streams", str(args.streams), "--groups", str(args.groups),
+           "--steps", str(min(args.steps, 24)), "--warmup", str(min(args.warmup, 4)), "--no-extras", "--no-cpu-baseline", "--no-profile"]
+    if args.no_stagger:
+        cmd.append("--no-stagger")
+    if args.no_phase_align:
+        cmd.append("--no-phase-align")
+    env = dict(os.environ)
+    env.pop("DSV2_HOST_THREADS", None)  # (this process exported its own pool size: the child sizes its pool from its cores)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        j = json.loads(line)
+        return {"cores": cores, "value": j["value"], "unit": "frames/s", "ratio_to_unrestricted": round(j["value"] / fps_unrestricted, 3),
+                "host_cpu_cores_busy": j["config"]["host_cpu_cores_busy"], "host_threads": j["config"]["host_threads"], "steps": j["steps"],
+                "twin_pairs_equal": j["parity_checked"]["twin_pairs_equal"], "twin_pairs": j["parity_checked"]["twin_pairs"],
+                "note": "separate process, sched_setaffinity to %d cores before the GPU runtime starts; same workload and timed region" % cores}
+    except Exception as e:  # noqa: BLE001
+        return {"cores": cores, "error": repr(e)}
 
 
 def lossless_round_trip(hip, A, run, frames):

@@ -1007,15 +1007,17 @@ __device__ __forceinline__ void neighbordif2(const CellRec &r, int fx, int fy, i
     dy = abs(tx - cx) + abs(ty - cy);
 }
 
-// (a * num) / den for the cell -> block mapping of the filters (a < 2^12, num < 2^10: the product is far below 2^20):
-// single-precision estimate + multiply-back instead of the ~35-instruction integer divide, four to six times per cell
+// (a * num) / den for the cell -> block mapping of the filters: single-precision estimate + multiply-back instead of the
+// ~35-instruction integer divide, four to six times per cell.  The estimate is exact while the product stays below 2^20
+// (a cell index below 2^10 times a block count below 2^10: every picture up to ~4096 pixels a side); larger pictures (the
+// decoder accepts up to 16384 x 16384) take the wave-uniform exact divide below -- tests/test_gpu_bmc.py covers both.
 __device__ __forceinline__ int scale_div(int a, int num, int den)
 {
     const unsigned n = (unsigned) (a * num), d = (unsigned) den;
     unsigned est = (unsigned) ((float) n * __builtin_amdgcn_rcpf((float) d));
     const int r = (int) (n - est * d);
     est = r < 0 ? est - 1u : (r >= (int) d ? est + 1u : est);
-    if (__builtin_expect(__any((n | d) >= (1u << 20)), 0)) { // (not a picture this library accepts; kept exact anyway)
+    if (__builtin_expect(__any((n | d) >= (1u << 20)), 0)) { // large pictures: exact integer divide for the whole wave
         est = n / d;
     }
     return (int) est;

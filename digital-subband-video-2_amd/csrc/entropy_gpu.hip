@@ -194,6 +194,7 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
     __shared__ __attribute__((aligned(16))) uint32_t sT[kEntChunk];
     __shared__ int s_nskip;
     __shared__ int s_rng[2][2];
+    __shared__ int s_pair[2]; // phase 2's result: NOT s_rng, which the other wavefront may still be reading for its last look
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
@@ -297,12 +298,12 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
                     }
                 }
                 if (tid == 0) {
-                    s_rng[0][0] = x.x;
-                    s_rng[0][1] = x.y;
+                    s_pair[0] = x.x;
+                    s_pair[1] = x.y;
                 }
             }
             __syncthreads();
-            const int x0 = s_rng[0][0], x1 = s_rng[0][1];
+            const int x0 = s_pair[0], x1 = s_pair[1];
             vk = (pk16){(short) ((int) vk.x == m ? x0 : x1), (short) ((int) vk.y == m ? x0 : x1)};
         }
         *(uint32_t *) &J.tables[(size_t) (ps.cbase + lc) * kStates + 2 * tid] = __builtin_bit_cast(uint32_t, vk);

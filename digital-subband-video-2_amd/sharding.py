@@ -1,18 +1,33 @@
 """Closed-GOP segment sharding across ranks and the final ordered gather.
 
 The reference's only parallelism is process-level: `parallel_encode_yuv.sh:31-52` forks one encoder
-per closed-GOP chunk (`-sfr=N -nfr=chunk -noeos=1`) and `cat`s the outputs in order.  Here each rank
-(one process per GPU) encodes the segments assigned to it with fresh encoder state and the packet
-bytes are gathered to rank 0 in segment order.  There is no collective on the data path; the
-gather is the only exchange: lengths by all_gather, payloads by gather of padded byte tensors
-(RCCL on GPUs, gloo in the CPU tests).
+per closed-GOP chunk (`-sfr=N -nfr=chunk -noeos=1`) and `cat`s the outputs in order (`:50,74`).  Here
+each rank (one process per GPU) encodes the segments assigned to it with fresh encoder state and the
+packet bytes are gathered to rank 0 in segment order.  There is no collective on the data path; the
+gather is the only exchange:
+
+  * one all_gather of a small int64 table per rank: (segment id, byte length) rows, built from a
+    Python list in one go;
+  * the payloads UNPADDED, point to point: every rank > 0 sends its segments as one flat byte tensor
+    in pieces of at most `chunk` bytes, rank 0 receives each piece into one reusable buffer and drops
+    it into a preallocated host array -- rank 0 never holds more than `chunk` bytes of another rank's
+    data on the device, whatever the run's size (RCCL send/recv on GPUs, gloo in the CPU tests);
+  * rank 0 writes every segment at its final offset of ONE output buffer (no per-segment joins).
 """
+import numpy as np
 import torch
+
+CHUNK = 256 << 20  # bytes per point-to-point transfer
 
 
 def assign_segments(nseg, world):
     """Round-robin: segment s belongs to rank s % world.  Returns a list (per rank) of segment ids."""
     return [[s for s in range(nseg) if s % world == r] for r in range(world)]
+
+
+def segment_id(rank, world, local_index):
+    """The global id of a rank's `local_index`-th segment under assign_segments' round-robin."""
+    return local_index * world + rank
 
 
 def frame_range(seg, gop, nframes):
@@ -21,36 +36,76 @@ def frame_range(seg, gop, nframes):
     return start, min(nframes, start + gop)
 
 
-def gather_segments(dist, rank, world, my_segments, device="cpu"):
-    """my_segments: dict seg_id -> bytes.  Returns the ordered concatenation on rank 0, None elsewhere."""
-    ids = sorted(my_segments)
-    blob = b"".join(my_segments[s] for s in ids)
-    # per-rank table: (segment id, length) pairs, padded to a common row count
-    nmax = torch.tensor([len(ids)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(nmax) for _ in range(world)]
-    dist.all_gather(counts, nmax)
-    rows = int(max(int(c.item()) for c in counts))
-    table = torch.full((max(rows, 1), 2), -1, dtype=torch.int64, device=device)
-    for k, s in enumerate(ids):
-        table[k, 0], table[k, 1] = s, len(my_segments[s])
+def _exchange_tables(dist, world, ids, lens, device):
+    """every rank's (segment id, length) rows -> list (per rank) of int64 numpy arrays [n_r, 2]"""
+    nmine = torch.tensor([len(ids)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(nmine) for _ in range(world)]
+    dist.all_gather(counts, nmine)
+    rows = max(1, max(int(c.item()) for c in counts))
+    tab = np.full((rows, 2), -1, dtype=np.int64)
+    if ids:
+        tab[:len(ids), 0] = ids
+        tab[:len(ids), 1] = lens
+    table = torch.from_numpy(tab).to(device)
     tables = [torch.zeros_like(table) for _ in range(world)]
     dist.all_gather(tables, table)
-    totals = [int(t[:, 1].clamp(min=0).sum().item()) for t in tables]
-    cap = max(1, max(totals))
-    payload = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if blob:
-        payload[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
-    gathered = [torch.zeros_like(payload) for _ in range(world)] if rank == 0 else None
-    dist.gather(payload, gathered, dst=0)
-    if rank != 0:
-        return None
-    pieces = {}
+    out = []
     for r in range(world):
-        data = gathered[r].cpu().numpy().tobytes()
-        off = 0
-        for k in range(tables[r].shape[0]):
-            s, n = int(tables[r][k, 0].item()), int(tables[r][k, 1].item())
-            if s >= 0:
-                pieces[s] = data[off:off + n]
+        t = tables[r].cpu().numpy()
+        out.append(t[:int(counts[r].item())])
+    return out
+
+
+def gather_segments(dist, rank, world, my_segments, device="cpu", chunk=CHUNK):
+    """my_segments: dict seg_id -> bytes.  Returns the ordered concatenation on rank 0 (a bytes-like
+    memoryview over one buffer), None elsewhere."""
+    ids = sorted(my_segments)
+    lens = [len(my_segments[s]) for s in ids]
+    tables = _exchange_tables(dist, world, ids, lens, device)
+
+    if rank != 0:
+        total = sum(lens)
+        if total:
+            flat = np.empty(total, dtype=np.uint8)
+            off = 0
+            for s, n in zip(ids, lens):
+                flat[off:off + n] = np.frombuffer(my_segments[s], dtype=np.uint8)
                 off += n
-    return b"".join(pieces[s] for s in sorted(pieces))
+            for a in range(0, total, chunk):
+                piece = torch.from_numpy(flat[a:min(total, a + chunk)]).to(device)
+                dist.send(piece, dst=0)
+        return None
+
+    # rank 0: where every segment lands in the output
+    all_rows = [(int(s), int(n), r) for r in range(world) for s, n in tables[r]]
+    all_rows.sort()
+    seen = set()
+    for s, _, _ in all_rows:
+        if s in seen:
+            raise ValueError("segment %d was produced by more than one rank" % s)
+        seen.add(s)
+    offset, at = {}, 0
+    for s, n, _ in all_rows:
+        offset[s] = at
+        at += n
+    out = np.empty(at, dtype=np.uint8)
+    for s, n in zip(ids, lens):
+        out[offset[s]:offset[s] + n] = np.frombuffer(my_segments[s], dtype=np.uint8)
+    totals = [int(tables[r][:, 1].sum()) if len(tables[r]) else 0 for r in range(world)]
+    rbuf = torch.empty(max(1, min(chunk, max(totals[1:], default=0))), dtype=torch.uint8, device=device)
+    for r in range(1, world):
+        total = totals[r]
+        if not total:
+            continue
+        flat = np.empty(total, dtype=np.uint8)
+        for a in range(0, total, chunk):
+            n = min(total, a + chunk) - a
+            view = rbuf[:n]
+            dist.recv(view, src=r)
+            flat[a:a + n] = view.cpu().numpy()
+        off = 0
+        for s, n in tables[r]:
+            s, n = int(s), int(n)
+            out[offset[s]:offset[s] + n] = flat[off:off + n]
+            off += n
+    return memoryview(out)

@@ -71,3 +71,32 @@ def test_assignment_is_a_partition():
             flat = sorted(s for p in parts for s in p)
             assert flat == list(range(nseg))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _gather_worker(rank, world, port, outdir, nseg, chunk):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    mine = pkg.sharding.assign_segments(nseg, world)[rank]
+    assert all(pkg.sharding.segment_id(rank, world, i) == s for i, s in enumerate(mine))
+    segs = {s: np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8).tobytes() for s in mine}
+    out = pkg.sharding.gather_segments(dist, rank, world, segs, chunk=chunk)
+    if rank == 0:
+        open(os.path.join(outdir, "g.bin"), "wb").write(out)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nseg,chunk", [(9, 1 << 20), (9, 1000), (1, 1000), (2, 7)])
+def test_gather_unpadded_chunked(tmp_path, nseg, chunk):
+    """uneven segment lengths (one of them empty), a rank without segments, payloads split over several transfers"""
+    import numpy as np
+    world = 2
+    port = 29500 + ((os.getpid() + 7 * nseg + chunk) % 1000)
+    mp.spawn(_gather_worker, args=(world, port, str(tmp_path), nseg, chunk), nprocs=world, join=True)
+    want = b"".join(np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8).tobytes() for s in range(nseg))
+    assert open(tmp_path / "g.bin", "rb").read() == want
