@@ -87,6 +87,7 @@ def parse():
                     help="pin this rank to N of its usable cores (sched_setaffinity, after the pictures are generated and before anything "
                          "touches the GPU) and size the library's worker pool from them: does the host side fit N cores per GPU?")
     ap.add_argument("--no-batch-curve", action="store_true", help="skip the small-batch operating points (1 / 8 / 48 / 192 streams)")
+    ap.add_argument("--only-batch-curve", action="store_true", help="of the extras, run only the small-batch operating points (experiments)")
     ap.add_argument("--no-host-share", action="store_true", help="skip the 2-host-cores re-run of the headline")
     ap.add_argument("--device-resident", action="store_true",
                     help="pictures parked in HBM before the clock starts (kernel-side figure; NOT the SURVEY 8d metric)")
@@ -199,6 +200,13 @@ class EncodeRun:
         self.out = [[] for _ in range(S)]  # per stream, per frame: list of packets (bytes)
         self.step = 0
         self.step_ms = None  # per group: wall-clock duration of every step of the current run() (filled when a list)
+        # one host thread per lockstep group for the life of the run (a group keeps its thread from step to step and from
+        # run() to run(), as a long-lived encoding service would)
+        import queue
+        self._cmd = [queue.Queue() for _ in range(G)]
+        self._threads = [threading.Thread(target=self._group_thread, args=(g,), daemon=True) for g in range(G)]
+        for th in self._threads:
+            th.start()
 
     def frame_index(self, s, t):
         k = self.shift[s] + t
@@ -240,6 +248,18 @@ class EncodeRun:
             per_group[s % G] += 1
         return sel
 
+    def _group_thread(self, g):
+        while True:
+            cmd = self._cmd[g].get()
+            if cmd is None:
+                return
+            try:
+                self._group_worker(g, *cmd)
+            except BaseException:  # noqa: BLE001  (a failed group must not leave the others waiting at the barrier)
+                import traceback
+                traceback.print_exc()
+                os._exit(7)
+
     def _group_worker(self, g, g0, g1, bar):
         hip, A = self.hip, self.A
         ids_all = self.group_of[g]
@@ -279,9 +299,8 @@ class EncodeRun:
         g0, g1 = self.step, self.step + nsteps
         self.step_ms = [[] for _ in range(self.G)] if record else None
         bar = threading.Barrier(self.G + 1)
-        ths = [threading.Thread(target=self._group_worker, args=(g, g0, g1, bar)) for g in range(self.G)]
-        for th in ths:
-            th.start()
+        for g in range(self.G):
+            self._cmd[g].put((g0, g1, bar))
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -292,8 +311,6 @@ class EncodeRun:
         if dist is not None:
             dist.barrier()
         t_end = time.perf_counter()
-        for th in ths:
-            th.join()
         self.step = g1
         return t_end - t_start
 
@@ -319,6 +336,10 @@ class EncodeRun:
         return b"".join(p for fr in self.out[s] for p in fr)
 
     def free(self):
+        for q in self._cmd:
+            q.put(None)
+        for th in self._threads:
+            th.join()
         for e in self.encs:
             self.hip.dsv_enc_free(C.byref(e))
         if not self.device_resident:
@@ -487,6 +508,21 @@ def decode_leg(hip, A, run, nsteps, nstreams, groups, check):
             "note": "lockstep batch decoder (dsv2hip_dec_batch) over this run's own packets, pictures delivered to host memory as DSV_FRAMEs"}, md5
 
 
+def thread_cpu():
+    """(name, user + system CPU seconds) of every thread of this process, from /proc"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    for t in os.listdir("/proc/self/task"):
+        try:
+            f = open("/proc/self/task/%s/stat" % t).read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(t)] = (name, (int(rest[11]) + int(rest[12])) / tick)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def bind_abi(hip, A):
     hip.dsv2hip_prof_enable.argtypes = [C.c_int]
     hip.dsv2hip_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
@@ -585,10 +621,15 @@ def main():
     hip.dsv2hip_prof_enable(0)
     run.run(run.R + Wm)                   # untimed: GOP-phase pre-roll + warm-up (allocations, clocks)
     import resource
+    thr0 = thread_cpu() if os.environ.get("DSV2_BENCH_THREADS") else None
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     g_timed = run.step
     elapsed = run.run(K, dist, record=True)   # timed: exactly K steps
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    if thr0 is not None:  # where the host CPU of the timed region went, by thread (name, seconds)
+        thr1 = thread_cpu()
+        rows = sorted(((thr1[t][1] - thr0.get(t, (None, 0.0))[1], thr1[t][0], t) for t in thr1), reverse=True)
+        sys.stderr.write("[bench] host CPU by thread over %.2f s: %s\n" % (elapsed, ", ".join("%s/%d %.2f" % (nm, t, d) for d, nm, t in rows[:24] if d > 0.005)))
     step_ms = sorted(x for g in run.step_ms for x in g)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     frames_rank = run.frames_in(g_timed, g_timed + K)
@@ -726,7 +767,7 @@ def main():
     # ---- the decoder on this run's packets (N = 1 only) ----
     # (the headline above is complete: whatever goes wrong below is reported beside it, never instead of it)
     dec_md5 = {}
-    if extras:
+    if extras and not args.only_batch_curve:
         try:
             result["decode"], dec_md5 = decode_leg(hip, A, run, 32, 256, 4, sel if not args.no_cpu_baseline else [])
         except Exception as e:  # noqa: BLE001
@@ -735,7 +776,7 @@ def main():
     del run
 
     # ---- the other BASELINE.json configurations and the small-batch operating points (N = 1 only) ----
-    if extras:
+    if extras and not args.only_batch_curve:
         try:
             result["configs"] = other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks)
         except Exception as e:  # noqa: BLE001
@@ -747,7 +788,7 @@ def main():
             result["batch_curve"] = {"error": repr(e)}
 
     # ---- does the host side fit the cores an 8-GPU node leaves per rank?  The headline again, pinned to 2 cores ----
-    if extras and not args.no_host_share and args.host_cores <= 0:
+    if extras and not args.no_host_share and not args.only_batch_curve and args.host_cores <= 0:
         result["host_share"] = host_share(args, 2, fps)
 
     # ---- parity, part 2 + CPU baselines: the real reference (oracle/_ref) on the host cores ----
@@ -881,7 +922,7 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     return cfgs
 
 
-BATCH_POINTS = [(1, 1), (8, 8), (48, 8), (192, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets
+BATCH_POINTS = [(1, 1), (8, 4), (48, 4), (192, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets
 
 
 def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks):

@@ -48,7 +48,12 @@ bool prof_enabled();
 
 // geometry + buffers that persist for the life of a codec instance
 struct CodecDev {
+    // Created on first request: a lockstep batch runs on the stream of its FIRST instance only, so a GPU with hundreds of
+    // encoder instances holds a handful of streams, not one per instance (the runtime spreads the streams that exist
+    // over a few hardware queues).
     hipStream_t stream = nullptr;
+    hipStream_t ensure_stream();
+    bool alive = false;
     int format = 0, w = 0, h = 0;
     int blk_w = 0, blk_h = 0, nbh = 0, nbv = 0, pyr_levels = 0;
     int cw[3], ch[3];
@@ -66,6 +71,7 @@ struct CodecDev {
     DSV_MV *d_mvs_stage = nullptr; // analysis output / upload staging
     DSV_MV *d_mvf[DSV_MAX_PYRAMID_LEVELS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *d_counters = nullptr;
+    uint8_t *d_intra_map[2] = {nullptr, nullptr}; // encoder: running intra map of the GOP (committed / being written), hme.h BlockStatsJob
     int32_t *d_ll = nullptr;
     // decoder-side symbol upload
     uint32_t *d_sym_pos = nullptr;

@@ -148,7 +148,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     nbh = (w + blk_w - 1) / blk_w;
     nbv = (h + blk_h - 1) / blk_h;
     pyr_levels = pyr_levels_;
-    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    alive = true;
     coef_dims(format, w, h, cw, ch);
     size_t nb = nblocks();
     for (int i = 0; i < 2; i++) {
@@ -188,6 +188,10 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         HIPCHK(hipMalloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
     }
     HIPCHK(hipMalloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **) &d_intra_map[i], nb));
+        dev_zero(d_intra_map[i], nb);
+    }
     HIPCHK(hipMalloc((void **) &d_ll, 4 * sizeof(int32_t)));
     h_frame_bytes = 0;
     for (int c = 0; c < 3; c++) {
@@ -231,12 +235,23 @@ void CodecDev::ensure_dev_syms(size_t n)
     sym_cap = cap;
 }
 
-void CodecDev::destroy()
+hipStream_t CodecDev::ensure_stream()
 {
     if (!stream) {
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
+    return stream;
+}
+
+void CodecDev::destroy()
+{
+    if (!alive) {
         return;
     }
-    HIPCHK(hipStreamSynchronize(stream));
+    alive = false;
+    if (stream) {
+        HIPCHK(hipStreamSynchronize(stream));
+    }
     prof.destroy();
     for (int i = 0; i < 2; i++) {
         dframe_free(&pics[i].recon);
@@ -265,6 +280,12 @@ void CodecDev::destroy()
         }
     }
     HIPCHK(hipFree(d_counters));
+    for (int i = 0; i < 2; i++) {
+        if (d_intra_map[i]) {
+            HIPCHK(hipFree(d_intra_map[i]));
+            d_intra_map[i] = nullptr;
+        }
+    }
     HIPCHK(hipFree(d_ll));
     if (d_sym_pos) {
         HIPCHK(hipFree(d_sym_pos));
@@ -280,8 +301,10 @@ void CodecDev::destroy()
         HIPCHK(hipHostFree(h_pos));
         HIPCHK(hipHostFree(h_val));
     }
-    HIPCHK(hipStreamDestroy(stream));
-    stream = nullptr;
+    if (stream) {
+        HIPCHK(hipStreamDestroy(stream));
+        stream = nullptr;
+    }
 }
 
 MCParams CodecDev::mc_params(int temporal_mc, int lossless) const

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "batch.h"
@@ -236,8 +237,16 @@ struct DecJob {
     DSV_FRAME *of = nullptr; // output picture: a bordered frame on pinned memory the device writes directly
 };
 
-struct DecScratch { // per calling thread
+struct DecScratch { // held by ONE device round at a time (pool below); owns the stream the round's kernels run on
     TableArena tabs;
+    hipStream_t main = nullptr;
+    hipStream_t main_stream()
+    {
+        if (!main) {
+            HIPCHK(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
+        }
+        return main;
+    }
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
     void ensure_stage(size_t bytes)
@@ -255,7 +264,40 @@ struct DecScratch { // per calling thread
         stage_cap = bytes;
     }
 };
-thread_local DecScratch t_dec_scratch;
+// process-wide pool, last released first (same reasoning as the encoder's ScratchPool): a lockstep group keeps getting the
+// same scratch and stream from whatever thread it calls, and nothing is leaked when caller threads come and go
+struct DecScratchPool {
+    std::mutex mu;
+    std::vector<DecScratch *> idle;
+    DecScratch *acquire(DecScratch *prefer) // (prefer: the one this thread used last, so that a group keeps its stream)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.empty()) {
+            return new DecScratch();
+        }
+        for (size_t i = 0; i < idle.size(); i++) {
+            if (idle[i] == prefer) {
+                idle.erase(idle.begin() + (ptrdiff_t) i);
+                return prefer;
+            }
+        }
+        DecScratch *sc = idle.back();
+        idle.pop_back();
+        return sc;
+    }
+    void release(DecScratch *sc)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.push_back(sc);
+    }
+};
+DecScratchPool g_dec_scratch_pool;
+thread_local DecScratch *t_last_dec_scratch = nullptr;
+struct DecScratchLease {
+    DecScratch *sc = g_dec_scratch_pool.acquire(t_last_dec_scratch);
+    DecScratchLease() { t_last_dec_scratch = sc; }
+    ~DecScratchLease() { g_dec_scratch_pool.release(sc); }
+};
 
 struct DecClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep decode step, printed every 16 steps
     bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
@@ -427,9 +469,10 @@ void dec_parse(DecJob &jb)
 void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
 {
     const int n = (int) ids.size();
-    DecScratch &sc = t_dec_scratch;
+    DecScratchLease lease; // (the round ends with its stream drained: nothing of the scratch is in use after it)
+    DecScratch &sc = *lease.sc;
     CodecDev &dv0 = jobs[ids[0]].im->dev;
-    hipStream_t bs = dv0.stream;
+    hipStream_t bs = dv0.ensure_stream(); // (the first decoder's stream: see the encoder's note on scratch-owned streams)
     const size_t nb = dv0.nblocks();
     const size_t mv_bytes = nb * sizeof(DSV_MV), bd_bytes = (nb + 15) & ~(size_t) 15;
     sc.tabs.reserve((size_t) n * 8192 + 65536);

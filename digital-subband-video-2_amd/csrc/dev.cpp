@@ -109,6 +109,27 @@ void stream_wait(hipStream_t s)
     }
 }
 
+// the same for an event that has been recorded already
+void event_wait(hipEvent_t ev)
+{
+    static const bool spin = getenv("DSV2_SPIN_WAIT") && atoi(getenv("DSV2_SPIN_WAIT")) != 0;
+    if (spin) {
+        HIPCHK(hipEventSynchronize(ev));
+        return;
+    }
+    for (unsigned tries = 0;; tries++) {
+        hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) {
+            return;
+        }
+        if (e != hipErrorNotReady) {
+            HIPCHK(e);
+        }
+        timespec ts = {0, tries < 8 ? 15000 : (tries < 64 ? 40000 : 120000)};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-113, always bordered
 {
     ensure_device();

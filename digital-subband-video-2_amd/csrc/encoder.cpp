@@ -26,6 +26,7 @@
 
 #include "batch.h"
 #include "codec.h"
+#include "sideinfo.h"
 
 using namespace dsv2;
 
@@ -39,6 +40,10 @@ struct EncImpl {
     bool have_ref = false; // pics[cur ^ 1] holds a usable reference
     std::vector<DSV_MV> mvs; // host copy of the current motion field
     std::vector<DSV_MV> intramv;
+    // the running intra map of scene_change_detection lives on the device (CodecDev::d_intra_map, hme.h BlockStatsJob):
+    // which of the two buffers holds the committed map, and whether there is one (none right after an intra picture)
+    int map_cur = 0;
+    bool map_valid = false;
     // pictures handed over in HOST memory (dsv2hip_enc_batch_host): two packed planar staging pictures in HBM;
     // the one not being ingested receives the next step's upload on the group's copy stream meanwhile
     uint8_t *d_stage[2] = {nullptr, nullptr};
@@ -320,35 +325,18 @@ void quality2quant(DSV_ENCODER *enc, FrameCtl *d, DSV_FNUM prev_I, int forced_in
 }
 
 // ---- scene statistics (dsv_encoder.c:129-250) ---------------------------------------------------
-int avg_motion(DSV_ENCODER *enc, const DSV_MV *v, const DSV_PARAMS *p)
+// The per-block sums these start from are taken on the device right behind the search (k_block_stats_b, hme.h
+// BlockStatsJob: `bs` = its BS_* words); what is left here is the scalar arithmetic on them.
+int avg_motion(DSV_ENCODER *enc, const DSV_PARAMS *p, const int *bs)
 {
-    int ax = 0, ay = 0, chaos = 0, stat = 0;
     int nblk = p->nblocks_h * p->nblocks_v;
-    for (int j = 0; j < p->nblocks_v; j++) {
-        for (int i = 0; i < p->nblocks_h; i++) {
-            const DSV_MV *mv = &v[i + j * p->nblocks_h];
-            if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
-                stat++;
-                continue;
-            }
-            ax += mv->u.mv.x;
-            ay += mv->u.mv.y;
-            int ndx, ndy;
-            neighbordif2(v, p->nblocks_h, i, j, &ndx, &ndy);
-            if (ndx > 4 || ndy > 4) {
-                chaos++;
-            } else {
-                stat++;
-            }
-        }
-    }
-    ax = (abs(ax) + abs(ay)) / (nblk * 2);
+    int ax = (abs(bs[BS_AX]) + abs(bs[BS_AY])) / (nblk * 2);
     if (ax < 1) {
         ax = 1;
     }
     enc->curr_avgmot = ax;
-    enc->motion_static = stat * 100 / nblk;
-    chaos = chaos * 100 / nblk;
+    enc->motion_static = bs[BS_STAT] * 100 / nblk;
+    int chaos = bs[BS_CHAOS] * 100 / nblk;
     if (enc->prev_chaos < 0) {
         enc->motion_chaos = chaos;
         enc->prev_chaos = chaos;
@@ -359,40 +347,23 @@ int avg_motion(DSV_ENCODER *enc, const DSV_MV *v, const DSV_PARAMS *p)
     return ax;
 }
 
-int scene_complexity(DSV_ENCODER *enc, const DSV_MV *v, const DSV_PARAMS *p)
+int mv_cost_b2sr(const DSV_PARAMS *p, int q) // the bits-to-SSE ratio of dsv_mv_cost (dsv.c:357)
 {
-    int complexity = 0, maxpot;
+    return (256 * (q * q >> DSV_MAX_QP_BITS) * p->blk_w * p->blk_h) / (p->vidmeta->width * p->vidmeta->height);
+}
+
+int scene_complexity(DSV_ENCODER *enc, const DSV_PARAMS *p, const int *bs)
+{
+    int complexity = bs[BS_COMPLEXITY], maxpot;
     int nblk = p->nblocks_h * p->nblocks_v;
     if (enc->rc_mode == DSV_RATE_CONTROL_ABR) {
-        maxpot = mv_cost(v, p, 0, 0, 64, 64, enc->prev_quant, 0) + 12 + 64;
+        // mv_cost of the vector (64, 64) at block (0, 0): the predictor there is zero
+        int bits = seg_bits(64) + seg_bits(64);
+        bits += bits * mv_cost_b2sr(p, enc->prev_quant) >> 7;
+        maxpot = bits + 12 + 64;
         maxpot = (maxpot * nblk + 1) >> 1;
-        for (int j = 0; j < p->nblocks_v; j++) {
-            for (int i = 0; i < p->nblocks_h; i++) {
-                const DSV_MV *mv = &v[i + j * p->nblocks_h];
-                if (!mvflag(*mv, DSV_MV_BIT_SKIP)) {
-                    complexity += mv_cost(v, p, i, j, mv->u.mv.x, mv->u.mv.y, enc->prev_quant, 0);
-                    complexity += (int) mv->err - enc->avg_err;
-                }
-                if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
-                    complexity += mv->submask == DSV_MASK_ALL_INTRA ? 16 : 4;
-                }
-            }
-        }
     } else if (enc->rc_mode == DSV_RATE_CONTROL_CRF) {
         maxpot = 70 * nblk;
-        for (int j = 0; j < p->nblocks_v; j++) {
-            for (int i = 0; i < p->nblocks_h; i++) {
-                const DSV_MV *mv = &v[i + j * p->nblocks_h];
-                if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
-                    complexity -= 100;
-                } else {
-                    complexity += mv_cost(v, p, i, j, mv->u.mv.x, mv->u.mv.y, enc->prev_quant, 0);
-                }
-                if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
-                    complexity += mv->submask == DSV_MASK_ALL_INTRA ? 100 : 40;
-                }
-            }
-        }
     } else {
         return 0;
     }
@@ -415,17 +386,19 @@ void compute_auto_filter(DSV_ENCODER *enc, const FrameCtl *d) // dsv_encoder.c:5
     enc->auto_filter = chaos <= 1 || relerr > thresh;
 }
 
-// returns 1 when the P frame must be re-coded as an I frame (dsv_encoder.c:545)
-int scene_change_detection(DSV_ENCODER *enc, FrameCtl *d, DSV_MV *mvs)
+// returns 1 when the P frame must be re-coded as an I frame (dsv_encoder.c:545); *map_written: the running intra map
+// took this frame's intra blocks in (the reference updates it between its two tests)
+int scene_change_detection(DSV_ENCODER *enc, FrameCtl *d, const int *bs, bool *map_written)
 {
     DSV_PARAMS *p = &d->params;
+    *map_written = false;
     int intra_pct = enc->curr_intra_pct, scblocks = enc->curr_scblocks;
-    int avgmot = avg_motion(enc, mvs, p);
+    int avgmot = avg_motion(enc, p, bs);
     int chaos = enc->motion_chaos;
     int dchaos = abs(chaos - enc->prev_chaos);
     int gopdiv = abs(enc->gop) * 3 / 4;
     int closeness = (int) d->fnum - (int) enc->prev_gop;
-    int complexity = scene_complexity(enc, mvs, p);
+    int complexity = scene_complexity(enc, p, bs);
     int closefac = closeness / (gopdiv > 1 ? gopdiv : 1);
     int shift;
     if (complexity > 256 && chaos < 5) {
@@ -457,28 +430,10 @@ int scene_change_detection(DSV_ENCODER *enc, FrameCtl *d, DSV_MV *mvs)
         return 1;
     }
     enc->curr_complexity = complexity;
-    int nintra = 0, skipn = 0;
+    *map_written = true;
     int nblk = p->nblocks_h * p->nblocks_v;
-    for (int idx = 0; idx < nblk; idx++) {
-        const DSV_MV *mv = &mvs[idx];
-        enc->intra_map[idx] |= mvflag(*mv, DSV_MV_BIT_INTRA);
-        if (enc->intra_map[idx]) {
-            if (mvflag(*mv, DSV_MV_BIT_SKIP) || mv->u.all == 0) {
-                if (mvflag(*mv, DSV_MV_BIT_MAINTAIN)) {
-                    nintra += 3;
-                    skipn += 2;
-                } else {
-                    nintra += 1;
-                    skipn++;
-                }
-            } else if (mvflag(*mv, DSV_MV_BIT_NOXMITY) && mvflag(*mv, DSV_MV_BIT_MAINTAIN)) {
-                nintra++;
-            }
-        }
-        nintra += enc->intra_map[idx];
-    }
-    nintra = nintra * 100 / nblk;
-    skipn = skipn * 100 / nblk;
+    int nintra = bs[BS_NINTRA] * 100 / nblk;
+    int skipn = bs[BS_SKIPN] * 100 / nblk;
     if (nintra > enc->intra_pct_thresh && enc->curr_avgmot < 10 &&
         enc->motion_chaos <= clampi(enc->prev_chaos / 2 + skipn, 20, 40)) {
         p->has_ref = 0;
@@ -540,8 +495,14 @@ void encode_metadata(DSV_ENCODER *enc, DSV_BUF *buf) // dsv_encoder.c:951
 // ---- per-block metadata ---------------------------------------------------------------------
 enum { ST_STABLE = 0, ST_MAINTAIN, ST_RINGING, ST_MODE, ST_EPRM, ST_MAX };
 
-void gather_stats(DSV_ENCODER *enc, const FrameCtl *d, const DSV_MV *mvs, const DSV_MV *intramv, int *stats) // :992
+void gather_stats(DSV_ENCODER *enc, const FrameCtl *d, const int *bs, const DSV_MV *intramv, int *stats) // :992
 {
+    if (d->params.has_ref) { // the votes over the motion field were counted on the device (BlockStatsJob)
+        stats[ST_MODE] += bs[BS_MODE];
+        stats[ST_EPRM] += bs[BS_EPRM];
+        stats[ST_STABLE] += bs[BS_STABLE];
+        return;
+    }
     int nblk = d->params.nblocks_h * d->params.nblocks_v;
     int avgdiv = (int) enc->refresh_ctr;
     if (enc->refresh_ctr >= enc->stable_refresh) {
@@ -552,14 +513,7 @@ void gather_stats(DSV_ENCODER *enc, const FrameCtl *d, const DSV_MV *mvs, const 
     }
     for (int i = 0; i < nblk; i++) {
         int stable = 0;
-        if (d->params.has_ref) {
-            const DSV_MV *mv = &mvs[i];
-            stable = mvflag(*mv, DSV_MV_BIT_INTRA) ? 0 : mvflag(*mv, DSV_MV_BIT_SKIP);
-            if (!mvflag(*mv, DSV_MV_BIT_SKIP)) {
-                stats[ST_MODE] += mvflag(*mv, DSV_MV_BIT_INTRA) ? 1 : -1;
-                stats[ST_EPRM] += mvflag(*mv, DSV_MV_BIT_EPRM) ? 1 : -1;
-            }
-        } else {
+        {
             const DSV_MV *mv = &intramv[i];
             if (d->fnum > 0 && enc->do_temporal_aq) {
                 stable = (enc->stability[i].x / avgdiv == 0) && (enc->stability[i].y / avgdiv == 0);
@@ -570,6 +524,22 @@ void gather_stats(DSV_ENCODER *enc, const FrameCtl *d, const DSV_MV *mvs, const 
             stats[ST_RINGING] += mvflag(*mv, DSV_MV_BIT_RINGING) ? 1 : -1;
         }
         stats[ST_STABLE] += (stable & 1) ? 1 : -1;
+    }
+}
+
+// the five majority bits of a picture's header (dsv_encoder.c:1066-1078)
+void picture_votes(DSV_ENCODER *enc, const FrameCtl *d, const int *bs, const DSV_MV *intramv, int *stats)
+{
+    for (int i = 0; i < ST_MAX; i++) {
+        stats[i] = 0;
+    }
+    if (enc->effort >= 7) {
+        gather_stats(enc, d, bs, intramv, stats);
+        for (int i = 0; i < ST_MAX; i++) {
+            stats[i] = stats[i] > 0 ? 1 : 0; // 1 = DSV_ZERO_MARKER
+        }
+    } else {
+        stats[ST_MAINTAIN] = stats[ST_RINGING] = 1;
     }
 }
 
@@ -586,7 +556,7 @@ struct ZeroScratch {
         }
         return mem.data();
     }
-    void clear(size_t used) { memset(mem.data(), 0, std::min(used + 16, mem.size())); }
+    void clear(size_t used) { memset(mem.data(), 0, std::min(used + 24, mem.size())); }
 };
 thread_local ZeroScratch t_side[6];
 
@@ -604,6 +574,7 @@ void encode_stable_blocks(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DS
     uint8_t *buf = t_side[5].get((size_t) nblk * 32);
     RleWriter rle;
     rle.bw = BitWriter{buf, 0};
+    rle.bw.wide = true; // (the scratch is sized for the worst case, 32 bytes a block: every 64-bit store stays inside)
     if (enc->refresh_ctr >= enc->stable_refresh) {
         enc->refresh_ctr = 0;
         memset(enc->stability, 0, sizeof(*enc->stability) * (size_t) nblk);
@@ -664,6 +635,7 @@ void encode_motion(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, DSV_MV *m
     mode_rle.bw = BitWriter{bufs[0], 0};
     eprm_rle.bw = BitWriter{bufs[4], 0};
     BitWriter mvx{bufs[1], 0}, mvy{bufs[2], 0}, sbim{bufs[3], 0};
+    mode_rle.bw.wide = eprm_rle.bw.wide = mvx.wide = mvy.wide = sbim.wide = true; // worst-case sized, zero-filled scratch
 
     for (int j = 0; j < p->nblocks_v; j++) {
         for (int i = 0; i < p->nblocks_h; i++) {
@@ -734,6 +706,7 @@ void encode_intra_meta(DSV_ENCODER *enc, const FrameCtl *d, BitWriter &bs, const
     RleWriter rr, rm;
     rr.bw = BitWriter{br, 0};
     rm.bw = BitWriter{bm, 0};
+    rr.bw.wide = rm.bw.wide = true;
     for (int i = 0; i < nblk; i++) {
         int ring = mvflag(intramv[i], DSV_MV_BIT_RINGING), maintain = mvflag(intramv[i], DSV_MV_BIT_MAINTAIN);
         enc->blockdata[i] |= (uint8_t) (ring << 3);
@@ -792,7 +765,7 @@ __global__ void k_grab_ll(const PlaneJob *luma, const PlaneJob *chroma, int n, i
 
 // dsv_encode_picture (dsv_encoder.c:1039): returns the picture packet in `out`
 
-void account(DSV_ENCODER *enc, EncImpl *im, const FrameCtl *d, unsigned len) // dsv_enc tail, dsv_encoder.c:1471-1570
+void account(DSV_ENCODER *enc, EncImpl *im, const FrameCtl *d, unsigned len, const int *bs) // dsv_enc tail, dsv_encoder.c:1471-1570
 {
     const DSV_PARAMS *p = &d->params;
     struct DSV_STATS *st = &enc->stats;
@@ -806,47 +779,22 @@ void account(DSV_ENCODER *enc, EncImpl *im, const FrameCtl *d, unsigned len) // 
         st->pminq = enc->rc_qual < st->pminq ? enc->rc_qual : st->pminq;
         st->pmins = len < st->pmins ? len : st->pmins;
         int nblk = p->nblocks_h * p->nblocks_v;
-        for (int i = 0; i < nblk; i++) {
-            const DSV_MV *mv = &im->mvs[i];
-            if (mvflag(*mv, DSV_MV_BIT_EPRM)) {
-                st->eprm++;
-            }
-            if (mvflag(*mv, DSV_MV_BIT_SKIP)) {
-                st->skip++;
-                continue;
-            }
-            if (mvflag(*mv, DSV_MV_BIT_INTRA)) {
-                st->mbI++;
-                if (mv->dc & DSV_SRC_DC_PRED) {
-                    st->mbdc++;
-                }
-                if (mv->submask != DSV_MASK_ALL_INTRA) {
-                    st->mbsub++;
-                    for (int k = 0; k < 4; k++) {
-                        if (mv->submask & (1 << k)) {
-                            st->mbsubs[k]++;
-                        }
-                    }
-                }
-            } else {
-                st->mbP++;
-                int x = mv->u.mv.x, y = mv->u.mv.y;
-                if (x & 1) {
-                    st->qpx++;
-                } else if (x & 3) {
-                    st->hpx++;
-                } else {
-                    st->fpx++;
-                }
-                if (y & 1) {
-                    st->qpy++;
-                } else if (y & 3) {
-                    st->hpy++;
-                } else {
-                    st->fpy++;
-                }
-            }
+        // the block counts over the field were taken on the device (k_block_stats_b, BS_ST_*)
+        st->eprm += (unsigned) bs[BS_ST_EPRM];
+        st->skip += (unsigned) bs[BS_ST_SKIP];
+        st->mbI += (unsigned) bs[BS_ST_MBI];
+        st->mbdc += (unsigned) bs[BS_ST_MBDC];
+        st->mbsub += (unsigned) bs[BS_ST_MBSUB];
+        for (int k = 0; k < 4; k++) {
+            st->mbsubs[k] += (unsigned) bs[BS_ST_SUB0 + k];
         }
+        st->mbP += (unsigned) bs[BS_ST_MBP];
+        st->qpx += (unsigned) bs[BS_ST_QPX];
+        st->hpx += (unsigned) bs[BS_ST_HPX];
+        st->fpx += (unsigned) bs[BS_ST_FPX];
+        st->qpy += (unsigned) bs[BS_ST_QPY];
+        st->hpy += (unsigned) bs[BS_ST_HPY];
+        st->fpy += (unsigned) bs[BS_ST_FPY];
         st->mb += (unsigned) nblk;
         enc->refresh_ctr++;
     } else {
@@ -904,13 +852,36 @@ struct Job {
     DSV_BUF out;
     BitWriter bs;
     int gop_start, forced_intra, ran_hme, inter_filter, nsym;
+    const int *bstats; // BS_* sums over the search result (pinned, written by k_block_stats_b), P frames only
+    const uint8_t *side_out; // P frames: the six side-information sub-streams as coded by k_side_info (pinned), or null
+    const int *side_info;    // ... their byte lengths ([1 + sub]) and the fall-back flag ([0])
     const uint8_t *gpu_bytes; // the three plane sections as assembled by the GPU (entropy_gpu.hip), or null: the host codes them
     unsigned gpu_plane_bytes[3];
     DSV_FNUM prev_I;
     int stats[ST_MAX];
 };
 
-struct BatchScratch { // per calling thread: pinned + device memory for the job tables
+// A stream whose hardware queue is chosen NOW, one stream at a time.  The runtime binds a stream to one of its
+// GPU_MAX_HW_QUEUES hardware queues when the stream is first used; lockstep groups start together, and streams that are
+// created and first used by several threads at the same moment were seen to land on the SAME queue (two groups' kernels
+// then run one after the other: every device phase of a small batch took twice as long).  So creation and a first,
+// completed, operation happen under one process-wide lock.
+hipStream_t new_bound_stream()
+{
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    static int *d_word = nullptr;
+    if (!d_word) {
+        HIPCHK(hipMalloc((void **) &d_word, 64));
+    }
+    HIPCHK(hipMemsetAsync(d_word, 0, 64, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return s;
+}
+
+struct BatchScratch { // pinned + device memory for the job tables, the step's HIP streams: held by ONE enc_batch call at a time
     void *h_hme = nullptr, *d_hme = nullptr;
     McJob *h_mc = nullptr, *d_mc = nullptr;
     uint8_t *h_stage = nullptr, *d_stage = nullptr; // per stream: transmitted motion field + block flag bytes
@@ -930,6 +901,21 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
     }
     int32_t *h_ll = nullptr, *d_ll = nullptr; // [3 * n] DC coefficients
     int *h_totals = nullptr, *d_totals = nullptr; // [n] symbol counts
+    int *h_bstats = nullptr, *d_bstats = nullptr; // [n][BS_WORDS] block statistics of the search results
+    uint8_t *h_side = nullptr;                    // [n][SIDE_IMG_BYTES] pinned: the side-information sub-streams (k_side_info)
+    int *h_side_info = nullptr;                   // [n][SIDE_INFO_WORDS] pinned: their lengths and fall-back flags
+    hipEvent_t ev_side = nullptr;                 // the sub-streams of this step are in host memory
+    // the step's kernels run on the SCRATCH's stream, not on one of the encoders': a lockstep group then owns one stream (one
+    // hardware queue) however many encoder instances exist (a step starts and ends with that stream drained, so which
+    // stream carried an encoder's previous step does not matter)
+    hipStream_t main = nullptr;
+    hipStream_t main_stream()
+    {
+        if (!main) {
+            main = new_bound_stream();
+        }
+        return main;
+    }
     // uploads of the NEXT step's host pictures run on a stream of their own, under this step's kernels
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
@@ -962,7 +948,7 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
     void ensure_copy_stream()
     {
         if (!copy_stream) {
-            HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+            copy_stream = new_bound_stream();
             HIPCHK(hipEventCreateWithFlags(&copy_done, hipEventDisableTiming));
         }
     }
@@ -983,6 +969,10 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
             HIPCHK(hipFree(d_ll));
             HIPCHK(hipHostFree(h_totals));
             HIPCHK(hipFree(d_totals));
+            HIPCHK(hipHostFree(h_bstats));
+            HIPCHK(hipFree(d_bstats));
+            HIPCHK(hipHostFree(h_side));
+            HIPCHK(hipHostFree(h_side_info));
         }
         HIPCHK(hipHostMalloc(&h_hme, hme_table_bytes(n), hipHostMallocDefault));
         HIPCHK(hipMalloc(&d_hme, hme_table_bytes(n)));
@@ -992,10 +982,55 @@ struct BatchScratch { // per calling thread: pinned + device memory for the job 
         HIPCHK(hipMalloc((void **) &d_ll, 3 * (size_t) n * sizeof(int32_t)));
         HIPCHK(hipHostMalloc((void **) &h_totals, (size_t) n * sizeof(int), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **) &d_totals, (size_t) n * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **) &h_bstats, (size_t) n * BS_WORDS * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **) &d_bstats, (size_t) n * BS_WORDS * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **) &h_side, (size_t) n * SIDE_IMG_BYTES, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **) &h_side_info, (size_t) n * SIDE_INFO_WORDS * sizeof(int), hipHostMallocDefault));
+        if (!ev_side) {
+            HIPCHK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        }
         cap = n;
     }
 };
-thread_local BatchScratch t_scratch;
+// Process-wide pool, last released first: a lockstep group that calls step after step keeps getting the same scratch (its
+// tables are sized, its streams mapped to a hardware queue) whatever thread it calls from, and scratches -- with their
+// streams and events -- are never destroyed, so an upload left in flight by one call (EncImpl::staged_ev) can be awaited
+// by the next, from any thread.  A scratch's copy stream and copy_done event travel together: a later re-record of the
+// event on that stream covers every earlier upload on it.
+struct ScratchPool {
+    std::mutex mu;
+    std::vector<BatchScratch *> idle;
+    // `prefer`: the scratch this thread used last -- a lockstep group driven by one long-lived thread keeps its scratch (and
+    // with it its streams and their hardware queues) from step to step; a new thread takes whatever is idle
+    BatchScratch *acquire(BatchScratch *prefer)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.empty()) {
+            return new BatchScratch();
+        }
+        for (size_t i = 0; i < idle.size(); i++) {
+            if (idle[i] == prefer) {
+                idle.erase(idle.begin() + (ptrdiff_t) i);
+                return prefer;
+            }
+        }
+        BatchScratch *sc = idle.back();
+        idle.pop_back();
+        return sc;
+    }
+    void release(BatchScratch *sc)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.push_back(sc);
+    }
+};
+ScratchPool g_scratch_pool;
+thread_local BatchScratch *t_last_scratch = nullptr;
+struct ScratchLease {
+    BatchScratch *sc = g_scratch_pool.acquire(t_last_scratch);
+    ScratchLease() { t_last_scratch = sc; }
+    ~ScratchLease() { g_scratch_pool.release(sc); }
+};
 
 void ensure_ready(DSV_ENCODER *enc, EncImpl *im)
 {
@@ -1074,7 +1109,6 @@ void phase_h1a(Job &jb)
     DSV_PARAMS *p = &d->params;
     size_t nb = dv.nblocks();
     if (jb.ran_hme) {
-        im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
         if (dv.h_counters[7]) {
             fatal(dv.h_counters[7] == 1 ? "motion estimation row pipeline timed out (a row waited > 4 s for the row above; DSV2_HME_ROWS=0 selects the launch-per-front form)"
                                         : "motion estimation did not deliver its counters (search incomplete)",
@@ -1085,13 +1119,21 @@ void phase_h1a(Job &jb)
         enc->curr_scblocks = ndiff * 100 / (eligible ? eligible : 1);
         enc->avg_err = (int) (total_err / (unsigned) nb);
         enc->curr_intra_pct = nintra * 100 / (int) nb;
-        jb.forced_intra = scene_change_detection(enc, d, im->mvs.data());
+        bool map_written = false;
+        jb.forced_intra = scene_change_detection(enc, d, jb.bstats, &map_written);
+        // the device wrote (committed map | this frame's intra blocks) into the other buffer: it becomes the committed map
+        // exactly when the reference's loop ran and the frame stays a P frame (an intra picture clears the map)
+        if (map_written && !jb.forced_intra) {
+            im->map_cur ^= 1;
+            im->map_valid = true;
+        }
     }
     if (enc->variable_i_interval && jb.forced_intra) {
         enc->prev_gop = d->fnum;
     }
     if (!p->has_ref) {
         memset(enc->intra_map, 0, nb);
+        im->map_valid = false;
     }
     {
         const DPlane &cp = dv.pics[im->cur].src_pyr[dv.pyr_levels - 1].p[0];
@@ -1099,6 +1141,12 @@ void phase_h1a(Job &jb)
     }
     quality2quant(enc, d, jb.prev_I, jb.forced_intra);
     compute_auto_filter(enc, d);
+    if (p->has_ref) {
+        // what the side-information coder on the device and the G2 tables need of H1's second half: the majority votes
+        // (gather_stats, dsv_encoder.c:992: counted by k_block_stats_b) and the in-loop filter switch
+        picture_votes(enc, d, jb.bstats, nullptr, jb.stats);
+        jb.inter_filter = enc->do_inter_filter == 1 || (enc->do_inter_filter == -1 && enc->auto_filter);
+    }
 }
 
 // H1, second half: encode_picture's host part (dsv_encoder.c:1051-1132); needs the intra analysis of
@@ -1136,16 +1184,8 @@ void phase_h1b(Job &jb)
         intramv = im->intramv.data();
     }
     int *stats = jb.stats;
-    for (int i = 0; i < ST_MAX; i++) {
-        stats[i] = 0;
-    }
-    if (enc->effort >= 7) {
-        gather_stats(enc, d, im->mvs.data(), intramv, stats);
-        for (int i = 0; i < ST_MAX; i++) {
-            stats[i] = stats[i] > 0 ? 1 : 0; // 1 = DSV_ZERO_MARKER
-        }
-    } else {
-        stats[ST_MAINTAIN] = stats[ST_RINGING] = 1;
+    if (!isP) { // (a P frame's votes were taken in H1a)
+        picture_votes(enc, d, nullptr, intramv, stats);
     }
     bs.align();
     bs.put_ueg((unsigned) (dsv_lb2((unsigned) p->blk_w) - 4));
@@ -1155,7 +1195,6 @@ void phase_h1b(Job &jb)
     if (isP) {
         bs.put_bit(stats[ST_MODE]);
         bs.put_bit(stats[ST_EPRM]);
-        jb.inter_filter = enc->do_inter_filter == 1 || (enc->do_inter_filter == -1 && enc->auto_filter);
         bs.put_bit(jb.inter_filter);
     } else {
         bs.put_bit(stats[ST_MAINTAIN]);
@@ -1165,6 +1204,32 @@ void phase_h1b(Job &jb)
     bs.put_bits(DSV_MAX_QP_BITS, (unsigned) d->quant);
     bs.put_bit(0);
     bs.align();
+    static const bool side_fallback = getenv("DSV2_SIDE_FORCE_FALLBACK") && atoi(getenv("DSV2_SIDE_FORCE_FALLBACK")) != 0; // (tests)
+    if (isP && jb.side_out && jb.side_info[0] == 0 && !side_fallback) {
+        // the six sub-streams arrive coded (k_side_info); what stays here of encode_stable_blocks (dsv_encoder.c:797) is the
+        // stability accumulator of the temporal AQ, which the next intra picture reads on the host
+        if (enc->refresh_ctr >= enc->stable_refresh) {
+            enc->refresh_ctr = 0;
+            memset(enc->stability, 0, sizeof(*enc->stability) * nb);
+        }
+        int fps = (p->vidmeta->fps_num + p->vidmeta->fps_den / 2) / p->vidmeta->fps_den;
+        int dsf = fps <= 24 ? 6 : (fps <= 30 ? 4 : (fps <= 60 ? 2 : 0));
+        const DSV_MV *mv = dv.h_mvs;
+        for (size_t i = 0; i < nb; i++) {
+            if (!(mv[i].flags & ((1u << DSV_MV_BIT_INTRA) | (1u << DSV_MV_BIT_SKIP)))) {
+                enc->stability[i].x += abs(mv[i].u.mv.x) >> dsf;
+                enc->stability[i].y += abs(mv[i].u.mv.y) >> dsf;
+            }
+        }
+        for (int s2 = 0; s2 < SIDE_SUBS; s2++) {
+            bs.align();
+            append_sub(bs, jb.side_out + side_image_offset(s2), jb.side_info[1 + s2]);
+        }
+        return;
+    }
+    if (isP) { // the host coders work on (and finalise) a copy of the field
+        im->mvs.assign(dv.h_mvs, dv.h_mvs + nb);
+    }
     encode_stable_blocks(enc, d, bs, im->mvs.data(), intramv, stats);
     if (isP) {
         // (the reference predicts between these two calls; the vectors are final after the first)
@@ -1184,13 +1249,15 @@ void phase_h2(Job &jb)
     BitWriter &bs = jb.bs;
     bs.align();
     if (jb.gpu_bytes) { // the sections arrive finished: byte-aligned, length field, DC, count, codes, 0x55 (hzcc.c:586-613)
-        const uint8_t *src = jb.gpu_bytes;
-        for (int c = 0; c < 3; c++) {
-            bs.align();
-            memcpy(bs.start + bs.byte_pos(), src, jb.gpu_plane_bytes[c]);
-            bs.pos += 8u * jb.gpu_plane_bytes[c];
-            src += jb.gpu_plane_bytes[c];
-        }
+        // header + side information were written into the packet scratch by H1; the sections go straight from the GPU's
+        // pinned mirror into the caller's buffer (no pass through the scratch, which then only has its head to clear)
+        const unsigned head = bs.byte_pos();
+        const unsigned len = head + jb.gpu_plane_bytes[0] + jb.gpu_plane_bytes[1] + jb.gpu_plane_bytes[2];
+        dsv_mk_buf(&jb.out, (int) len);
+        memcpy(jb.out.data, im->pkt.data(), head);
+        memcpy(jb.out.data + head, jb.gpu_bytes, len - head);
+        memset(im->pkt.data(), 0, (size_t) head + 8);
+        jb.out.len = len;
     } else {
         int at = 0;
         for (int c = 0; c < 3; c++) {
@@ -1202,13 +1269,11 @@ void phase_h2(Job &jb)
             }
             entropy_encode_plane(bs, dv.h_ll[c], dv.h_pos + begin, dv.h_val + begin, at - begin, dv.scan[c]);
         }
-    }
-    bs.align();
-    {
+        bs.align();
         unsigned len = bs.byte_pos();
         dsv_mk_buf(&jb.out, (int) len);
         memcpy(jb.out.data, im->pkt.data(), len);
-        memset(im->pkt.data(), 0, len);
+        memset(im->pkt.data(), 0, (size_t) len + 8);
         jb.out.len = len;
     }
     jb.nbuf = 0;
@@ -1220,7 +1285,7 @@ void phase_h2(Job &jb)
     }
     jb.bufs[jb.nbuf++] = jb.out;
     set_link_offsets(enc, &jb.bufs[jb.nbuf - 1], 0);
-    account(enc, im, &jb.d, jb.out.len);
+    account(enc, im, &jb.d, jb.out.len, jb.bstats);
     if (jb.d.params.is_ref && enc->gop != DSV_GOP_INTRA) {
         im->cur ^= 1; // this picture set becomes the reference of the next frame
         im->have_ref = true;
@@ -1244,12 +1309,40 @@ struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, 
     void done(int n)
     {
         if (!on || ++steps % every) return;
-        fprintf(stderr, "[batch n=%d] ms/step: p0 %.2f | g1 enqueue %.2f wait %.2f | h1 %.2f | g2 enqueue %.2f wait %.2f | syms %.2f | h2 %.2f\n", n,
-                acc[0] / every, acc[1] / every, acc[2] / every, acc[3] / every, acc[4] / every, acc[5] / every, acc[6] / every, acc[7] / every);
+        fprintf(stderr, "[batch n=%d] ms/step: p0 %.2f | g1 enqueue %.2f wait %.2f | h1 %.2f | g2 enqueue %.2f, h1b under it %.2f, wait %.2f | syms %.2f | h2 %.2f\n", n,
+                acc[0] / every, acc[1] / every, acc[2] / every, acc[3] / every, acc[4] / every, acc[8] / every, acc[5] / every, acc[6] / every, acc[7] / every);
         for (double &a : acc) a = 0;
     }
 };
 thread_local PhaseClock t_clock;
+
+// DSV2_BATCH_TRACE: CPU time (thread clock) the pool tasks of a host phase consume, summed over the streams of a step
+struct TaskCpu {
+    std::atomic<long long> ns[3] = {{0}, {0}, {0}};
+    std::atomic<long long> tasks{0};
+    bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+    static long long now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (long long) ts.tv_sec * 1000000000ll + ts.tv_nsec;
+    }
+    template <class F> void run(int which, F fn)
+    {
+        if (!on) {
+            fn();
+            return;
+        }
+        long long t0 = now();
+        fn();
+        ns[which] += now() - t0;
+        if (which == 2 && (++tasks % 12288) == 0) {
+            fprintf(stderr, "[batch] host task CPU per frame: h1a %.1f us, h1b %.1f us, h2 %.1f us\n", ns[0] / 1e3 / 12288, ns[1] / 1e3 / 12288, ns[2] / 1e3 / 12288);
+            ns[0] = ns[1] = ns[2] = 0;
+        }
+    }
+};
+TaskCpu g_task_cpu;
 
 // the plane sections of the packet are assembled on the GPU (DSV2_GPU_ENTROPY=0: the host codes them from the symbol list)
 static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV2_GPU_ENTROPY")) == 0);
@@ -1277,9 +1370,14 @@ void enc_batch(Job *jobs, int n)
         phase_p0(jb);
     }
     t_clock.lap(0);
-    hipStream_t bs = jobs[0].im->dev.stream;
     StageProf &prof = jobs[0].im->dev.prof;
-    BatchScratch &sc = t_scratch;
+    ScratchLease lease;
+    BatchScratch &sc = *lease.sc;
+    // The step's kernels run on the stream of the batch's FIRST encoder.  (DSV2_SCRATCH_STREAM=1: on a stream owned by the
+    // scratch instead -- measured on MI355X / ROCm 7.2: two lockstep groups then execute one after the other, 19.4 against
+    // 10.8 ms per step at 8 streams in 4 groups, although each group has a stream of its own either way; kept for A/B.)
+    static const bool own_stream = getenv("DSV2_SCRATCH_STREAM") && atoi(getenv("DSV2_SCRATCH_STREAM")) == 1;
+    hipStream_t bs = own_stream ? sc.main_stream() : jobs[0].im->dev.ensure_stream();
     sc.ensure(n);
     const int nbh = jobs[0].im->dev.nbh, nbv = jobs[0].im->dev.nbv;
 
@@ -1308,7 +1406,9 @@ void enc_batch(Job *jobs, int n)
     IntraJob *h_intra = sc.tabs.take<IntraJob>((size_t) n, &d_intra);
     const PlaneOutJob *d_small;
     PlaneOutJob *h_small = sc.tabs.take<PlaneOutJob>((size_t) n, &d_small);
-    int n_ing = 0, n_pyr = 0, n_intra = 0;
+    const BlockStatsJob *d_bsj;
+    BlockStatsJob *h_bsj = sc.tabs.take<BlockStatsJob>((size_t) n, &d_bsj);
+    int n_ing = 0, n_pyr = 0, n_intra = 0, n_bsj = 0;
     {
         // pictures that arrive in host memory: this step's either came up during the previous step (prefetched
         // through host_next) or is uploaded now; the next step's goes up on the copy stream under this step's kernels
@@ -1401,6 +1501,20 @@ void enc_batch(Job *jobs, int n)
             n_intra++;
         }
         h_small[k] = PlaneOutJob{cur.src_pyr[L - 1].p[0], dv.h_small};
+        jb.bstats = nullptr;
+        if (jb.d.params.has_ref) { // the controller's sums over the field this step's search is about to produce
+            BlockStatsJob &bj = h_bsj[n_bsj];
+            bj.mvs = dv.d_mvf[0];
+            bj.counters = dv.d_counters;
+            bj.map_in = jb.im->map_valid ? dv.d_intra_map[jb.im->map_cur] : nullptr;
+            bj.map_out = dv.d_intra_map[jb.im->map_cur ^ 1];
+            bj.host_mvs = dv.h_mvs;
+            bj.out = sc.d_bstats + (size_t) n_bsj * BS_WORDS;
+            bj.b2sr = mv_cost_b2sr(&jb.d.params, jb.enc->prev_quant);
+            bj.rc_mode = jb.enc->rc_mode;
+            jb.bstats = sc.h_bstats + (size_t) n_bsj * BS_WORDS;
+            n_bsj++;
+        }
     }
     sc.tabs.upload(bs);
     {
@@ -1451,7 +1565,7 @@ void enc_batch(Job *jobs, int n)
             }
             f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
             f.counters = dv.d_counters;
-            f.host_mvs = dv.h_mvs; // the search itself delivers its results to the host
+            f.host_mvs = nullptr; // (the field reaches the host through k_block_stats_b right behind the search: BlockStatsJob::host_mvs)
             f.host_counters = dv.h_counters;
             dv.h_counters[7] = -1; // overwritten with 0 by the search's last row (1: a row timed out); -1 left = it never finished
             HmeParams h;
@@ -1472,6 +1586,9 @@ void enc_batch(Job *jobs, int n)
         prof.begin(bs, ST_HME);
         int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof);
         prof.end(bs, ST_HME, (int) pjobs.size(), nfronts); // launches = the per-level search kernels
+        HIPCHK(hipMemsetAsync(sc.d_bstats, 0, (size_t) n_bsj * BS_WORDS * sizeof(int), bs));
+        block_stats_batch(bs, d_bsj, n_bsj, nbh, nbv);
+        HIPCHK(hipMemcpyAsync(sc.h_bstats, sc.d_bstats, (size_t) n_bsj * BS_WORDS * sizeof(int), hipMemcpyDeviceToHost, bs));
     }
     t_clock.lap(1);
     stream_wait(bs);
@@ -1483,7 +1600,7 @@ void enc_batch(Job *jobs, int n)
     }
 
     // ---- H1 ----
-    parallel_for(n, [&](int k) { phase_h1a(jobs[k]); });
+    parallel_for(n, [&](int k) { g_task_cpu.run(0, [&] { phase_h1a(jobs[k]); }); });
     {
         // P frames flipped to intra by the scene-change test: their block analysis is due now
         const IntraJob *d_late;
@@ -1506,7 +1623,39 @@ void enc_batch(Job *jobs, int n)
             stream_wait(bs);
         }
     }
-    parallel_for(n, [&](int k) { phase_h1b(jobs[k]); });
+    // The pictures that stay P frames: their side information is coded on the device (k_side_info), which also finalises
+    // the motion field and forms the block flag bytes in HBM for G2.  It is enqueued now, G2 right behind it; the host
+    // assembles the P packets' heads (H1b) from the pinned sub-streams while G2 runs.  Intra pictures (1 in a GOP) keep
+    // the host coders, whose flag bytes G2 needs: their H1b runs before G2 is built.
+    std::vector<int> p_jobs, i_jobs;
+    for (int k = 0; k < n; k++) {
+        jobs[k].side_out = nullptr;
+        jobs[k].side_info = nullptr;
+        (jobs[k].d.params.has_ref ? p_jobs : i_jobs).push_back(k);
+    }
+    if (!p_jobs.empty()) {
+        const SideJob *d_side;
+        SideJob *h_sj = sc.tabs.take<SideJob>(p_jobs.size(), &d_side);
+        for (size_t q = 0; q < p_jobs.size(); q++) {
+            Job &jb = jobs[p_jobs[q]];
+            CodecDev &dv = jb.im->dev;
+            SideJob &sj = h_sj[q];
+            sj.raw = dv.d_mvf[0];
+            sj.final_mvs = dv.pics[jb.im->cur].d_final_mvs;
+            sj.bd = dv.d_blockdata;
+            sj.out = sc.h_side + q * SIDE_IMG_BYTES;
+            sj.info = sc.h_side_info + q * SIDE_INFO_WORDS;
+            sj.inv_stable = jb.stats[ST_STABLE] != 0;
+            sj.inv_mode = jb.stats[ST_MODE] != 0;
+            sj.inv_eprm = jb.stats[ST_EPRM] != 0;
+            jb.side_out = sj.out;
+            jb.side_info = sj.info;
+        }
+        sc.tabs.upload(bs);
+        side_info_batch(bs, d_side, (int) p_jobs.size(), nbh, nbv);
+        HIPCHK(hipEventRecord(sc.ev_side, bs));
+    }
+    parallel_for((int) i_jobs.size(), [&](int q) { g_task_cpu.run(1, [&] { phase_h1b(jobs[i_jobs[(size_t) q]]); }); });
     t_clock.lap(3);
 
     // ---- G2 ----
@@ -1531,11 +1680,11 @@ void enc_batch(Job *jobs, int n)
     // host -> device hand-over of what H1 decided: per stream the transmitted motion field and the
     // block flag bytes, packed into ONE pinned buffer and shipped with one copy
     const size_t nb0 = dv0.nblocks();
-    const size_t mv_bytes = nb0 * sizeof(DSV_MV), bd_bytes = (nb0 + 15) & ~(size_t) 15, slot = mv_bytes + bd_bytes;
-    sc.ensure_stage(slot * (size_t) n);
+    const size_t mv_bytes = nb0 * sizeof(DSV_MV), slot = (nb0 + 15) & ~(size_t) 15; // (a staging slot: one picture's flag bytes)
+    sc.ensure_stage(slot * (i_jobs.size() + 1));
     const CopyJob *d_mvcopy;
     CopyJob *h_mvcopy = sc.tabs.take<CopyJob>((size_t) n, &d_mvcopy);
-    int nP = 0, nI = 0, n_rext = 0, n_mvcopy = 0;
+    int nP = 0, nI = 0, n_rext = 0, n_mvcopy = 0, n_slots = 0;
     bool any_filter = false;
     for (int i = 0; i < n; i++) {
         int k = order[(size_t) i];
@@ -1547,9 +1696,13 @@ void enc_batch(Job *jobs, int n)
         // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
         h_copy[i] = CopyJob{cur.src.alloc, cur.recon.alloc, cur.src.bytes};
         cur.recon_pyr_valid = false;
-        uint8_t *h_slot = sc.h_stage + slot * (size_t) i, *d_slot = sc.d_stage + slot * (size_t) i;
-        const uint8_t *d_bd = d_slot + mv_bytes;
-        memcpy(h_slot + mv_bytes, jb.enc->blockdata, nb);
+        const uint8_t *d_bd = dv.d_blockdata; // P: formed on the device (k_side_info)
+        if (!p->has_ref) {                      // I: the host coders' flag bytes, staged and shipped with one copy
+            uint8_t *h_slot = sc.h_stage + slot * (size_t) n_slots;
+            d_bd = sc.d_stage + slot * (size_t) n_slots;
+            memcpy(h_slot, jb.enc->blockdata, nb);
+            n_slots++;
+        }
         McJob mj;
         mj.mvs = cur.d_final_mvs;
         mj.bd = d_bd;
@@ -1560,9 +1713,8 @@ void enc_batch(Job *jobs, int n)
             mj.res.p[c] = cur.recon.p[c];
         }
         if (p->has_ref) {
-            // the motion field as transmitted: used by MC now and as temporal candidates of the next frame
-            memcpy(h_slot, jb.im->mvs.data(), mv_bytes);
-            h_mvcopy[n_mvcopy++] = CopyJob{d_slot, cur.d_final_mvs, mv_bytes};
+            // the motion field as transmitted (written into cur.d_final_mvs by k_side_info): used by MC now and as temporal
+            // candidates of the next frame
             cur.has_final_mvs = true;
             mj.f = make_filter_params(mj.p, jb.d.quant, jb.inter_filter, jb.enc->vidmeta.inter_sharpen);
             any_filter = any_filter || !p->lossless;
@@ -1615,7 +1767,9 @@ void enc_batch(Job *jobs, int n)
     }
     sc.tabs.upload(bs);
     HIPCHK(hipMemcpyAsync(sc.d_mc, sc.h_mc, 2 * (size_t) n * sizeof(McJob), hipMemcpyHostToDevice, bs));
-    HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, slot * (size_t) n, hipMemcpyHostToDevice, bs));
+    if (n_slots) {
+        HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, slot * (size_t) n_slots, hipMemcpyHostToDevice, bs));
+    }
     copy_linear_batch(bs, d_mvcopy, n_mvcopy, mv_bytes);
     copy_linear_batch(bs, d_copy, n, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
@@ -1687,6 +1841,11 @@ void enc_batch(Job *jobs, int n)
         sc.join(bs, 0);
     }
     t_clock.lap(4);
+    if (!p_jobs.empty()) { // H1b of the P pictures, under G2's kernels: header + the sub-streams the device coded
+        event_wait(sc.ev_side);
+        parallel_for((int) p_jobs.size(), [&](int q) { g_task_cpu.run(1, [&] { phase_h1b(jobs[p_jobs[(size_t) q]]); }); });
+    }
+    t_clock.lap(8);
     stream_wait(bs);
     t_clock.lap(5);
     bool late_copy = false;
@@ -1753,7 +1912,7 @@ void enc_batch(Job *jobs, int n)
             dsv_frame_ref_dec(rec);
         }
     }
-    parallel_for(n, [&](int k) { phase_h2(jobs[k]); });
+    parallel_for(n, [&](int k) { g_task_cpu.run(2, [&] { phase_h2(jobs[k]); }); });
     t_clock.lap(7);
     t_clock.done(n);
 }

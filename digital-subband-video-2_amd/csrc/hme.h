@@ -52,6 +52,37 @@ struct StageProf;
 // prof (optional): HIP events around the level-0 launch alone (stage ST_HME_L0), for the roofline of the dominant kernel
 int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof = nullptr);
 
+// ---- per-frame block statistics of the finished level-0 field (host controller inputs) -------------------------
+// What the reference's controller sums over the motion field of a P frame before it decides anything
+// (dsv_encoder.c:129-250 avg_motion / scene_complexity, :545-650 the running intra map of scene_change_detection,
+// :992-1037 gather_stats): every term is a function of a block's own vector record and its left / top / top-left
+// neighbours', so the sums are taken by one thread per block right behind the search, and the host's H1 phase starts
+// from ten integers instead of four passes over the field.  Sums are plain 32-bit adds (the reference's `int`s).
+enum {
+    BS_AX = 0, BS_AY, BS_CHAOS, BS_STAT,    // avg_motion: sum of x / y of the non-skipped vectors, chaotic / static block counts
+    BS_COMPLEXITY,                           // scene_complexity numerator (rc_mode decides the terms)
+    BS_NINTRA, BS_SKIPN,                     // scene_change_detection's second test, over map_in | this frame's intra flags
+    BS_MODE, BS_EPRM, BS_STABLE,             // gather_stats majorities (+1 / -1 votes)
+    // the block counts of DSV_STATS (dsv_encoder.c:1505-1550): flags and sub-pel phases of the field (an inter block's
+    // vector and every flag are the same before and after the field is finalised)
+    BS_ST_EPRM, BS_ST_SKIP, BS_ST_MBI, BS_ST_MBDC, BS_ST_MBSUB, BS_ST_SUB0, BS_ST_SUB1, BS_ST_SUB2, BS_ST_SUB3, BS_ST_MBP,
+    BS_ST_QPX, BS_ST_HPX, BS_ST_FPX, BS_ST_QPY, BS_ST_HPY, BS_ST_FPY,
+    BS_USED,
+    BS_WORDS = 32
+};
+struct BlockStatsJob {
+    const DSV_MV *mvs;      // level-0 field as the search left it
+    const int *counters;    // the search's counters ([3] = total_err: avg_err = total_err / nblocks)
+    const uint8_t *map_in;  // running intra map of the GOP so far, or null: all zero (first P frame after an I frame)
+    uint8_t *map_out;       // map_in | this frame's intra flags (committed by the host if the frame stays a P frame)
+    DSV_MV *host_mvs;       // pinned host mirror of the field: written here in whole 16-byte records, coalesced, instead of by
+                            // the search itself block by block (two lone PCIe stores inside every block's drain-and-publish)
+    int *out;               // BS_WORDS ints, zeroed before the launch
+    int b2sr;               // mv_cost's bits-to-SSE ratio for the previous frame's quantiser (dsv.c:357)
+    int rc_mode;            // DSV_RATE_CONTROL_*: which scene_complexity variant
+};
+void block_stats_batch(hipStream_t s, const BlockStatsJob *d_jobs, int n, int nbh, int nbv);
+
 struct CodecDev;
 struct PicSet;
 int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp);

@@ -136,6 +136,9 @@ struct Psy {
 #define UAVG4(a, b, c, d) ((unsigned) ((a) + (b) + (c) + (d) + 2) >> 2)
 #define AVG2(a, b) (((a) + (b) + 1) >> 1)
 #define SQR(x) ((x) * (x))
+// x * x for |x| < 2^11 as ONE full-rate 24-bit multiply (v_mul_i32_i24; the generic 32-bit v_mul_lo_u32 the compiler
+// picks for an int is a quarter-rate instruction, and the metric squares three values per quad and scored vector)
+__device__ __forceinline__ int sq24(int x) { return __mul24(x, x); }
 
 __device__ __forceinline__ int sarx(int v, int s) { return v >> s; }
 
@@ -145,8 +148,8 @@ __device__ __forceinline__ unsigned quad_metric(int a1, int a2, int a3, int a4, 
     int se = (int) UAVG4(abs(a1 - b1), abs(a2 - b2), abs(a3 - b3), abs(a4 - b4));
     int ta = (int) UAVG4(abs(a1 - a2), abs(a2 - a3), abs(a3 - a4), abs(a4 - a1));
     int tb = (int) UAVG4(abs(b1 - b2), abs(b2 - b3), abs(b3 - b4), abs(b4 - b1));
-    return (unsigned) (SQR(se) << psy.err_weight) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
-           (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+    return (unsigned) (sq24(se) << psy.err_weight) + (unsigned) (sq24(ta - tb) << psy.tex_weight) +
+           (unsigned) (sq24(s0 - s1) << psy.avg_weight);
 }
 
 // ---- wave-cooperative block primitives (all 64 lanes call with identical arguments) ----------
@@ -662,17 +665,17 @@ __device__ void ws_err_intra(const uint8_t *a, int as, const uint8_t *b, int bs,
         int ae = (int) UAVG4(abs(a1 - b1), abs(a2 - b2), abs(a3 - b3), abs(a4 - b4));
         int ta = (int) UAVG4(abs(a1 - a2), abs(a2 - a3), abs(a3 - a4), abs(a4 - a1));
         int tb = (int) UAVG4(abs(b1 - b2), abs(b2 - b3), abs(b3 - b4), abs(b4 - b1));
-        inter += (unsigned) (SQR(ae) * ratio >> (5 - psy.err_weight));
-        inter += (unsigned) (SQR(ta - tb) << psy.tex_weight);
-        inter += (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+        inter += (unsigned) (sq24(ae) * ratio >> (5 - psy.err_weight));
+        inter += (unsigned) (sq24(ta - tb) << psy.tex_weight);
+        inter += (unsigned) (sq24(s0 - s1) << psy.avg_weight);
         ae = (int) UAVG4(abs(a1 - avg_sb), abs(a2 - avg_sb), abs(a3 - avg_sb), abs(a4 - avg_sb));
-        isb += (unsigned) (SQR(ae) << psy.err_weight);
-        isb += (unsigned) (SQR(ta) << psy.tex_weight);
-        isb += (unsigned) (SQR(s0 - avg_sb) << (psy.avg_weight + 1));
+        isb += (unsigned) (sq24(ae) << psy.err_weight);
+        isb += (unsigned) (sq24(ta) << psy.tex_weight);
+        isb += (unsigned) (sq24(s0 - avg_sb) << (psy.avg_weight + 1));
         ae = (int) UAVG4(abs(a1 - avg_src), abs(a2 - avg_src), abs(a3 - avg_src), abs(a4 - avg_src));
-        isrc += (unsigned) (SQR(ae) << psy.err_weight);
-        isrc += (unsigned) (SQR(ta) << psy.tex_weight);
-        isrc += (unsigned) (SQR(s0 - avg_src) << (psy.avg_weight + 1));
+        isrc += (unsigned) (sq24(ae) << psy.err_weight);
+        isrc += (unsigned) (sq24(ta) << psy.tex_weight);
+        isrc += (unsigned) (sq24(s0 - avg_src) << (psy.avg_weight + 1));
     }
     intra_err = wave_sum(isb);
     intrasrc_err = wave_sum(isrc);
@@ -1338,7 +1341,7 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
 
 // LV: 0 / 1 = the launch is known to be level 0 / a coarser level (fast-only kernels: the other half of the block routine
 // is not compiled in), -1 = any level
-template <bool FAST_ONLY, int LV = -1>
+template <bool FAST_ONLY, int LV = -1, int CS = 1>
 __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, int allow_fast, FastLds &S)
 {
     const int level = LV == 0 ? 0 : level_rt;
@@ -1373,7 +1376,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
         if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast<LV>(x, level, i, j, gx, gy, S, pcx, pcy);
+            hme_block_fast<LV, CS>(x, level, i, j, gx, gy, S, pcx, pcy);
         } else if constexpr (!FAST_ONLY) {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
             pcx = pcy = 0;
@@ -1431,6 +1434,15 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
             hme_row<true, 0>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                            \
         }                                                                                                                \
     }                                                                                                                    \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_444_w##W(      \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<true, 0, 0>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                         \
+        }                                                                                                                \
+    }                                                                                                                    \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_w##W(          \
         const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
     {                                                                                                                    \
@@ -1465,7 +1477,10 @@ static bool uniform_geometry(const HmeFrames &f, int pyr_levels)
 // host mirror of fast_path_ok() over a whole level
 static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level)
 {
-    if (a.blk_w != 16 || a.blk_h != 16 || a.hshift != 1 || a.vshift != 1) {
+    // the chroma planes only enter at level 0 (mode decision): 4:2:0 and 4:4:4 have a block routine there, the coarser
+    // levels take any format
+    const bool c420 = a.hshift == 1 && a.vshift == 1, c444 = a.hshift == 0 && a.vshift == 0;
+    if (a.blk_w != 16 || a.blk_h != 16 || (level == 0 && !c420 && !c444)) {
         return false;
     }
     int step = 1 << level;
@@ -1574,6 +1589,150 @@ __global__ __launch_bounds__(256) void k_global_motion(HmeDev c, int level)
     }
 }
 
+// ---- block statistics for the host controller (see BlockStatsJob, hme.h) --------------------------------------------
+__device__ __forceinline__ int bs_seg_bits(int v) // dsv.c:344
+{
+    v = abs(v) + 1;
+    return (31 - __clz(v)) * 2 + 2;
+}
+
+// grid = (ceil(nblocks / 256), streams); one thread per block
+__global__ __launch_bounds__(256) void k_block_stats_b(const BlockStatsJob *__restrict__ tab, int nbh, int nbv)
+{
+    const BlockStatsJob &J = tab[blockIdx.y];
+    const int nblk = nbh * nbv;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int v[BS_USED] = {};
+    if (idx < nblk) {
+        const int j = idx / nbh, i = idx - j * nbh;
+        const DSV_MV *mv = &J.mvs[idx];
+        const uint4 rec = *(const uint4 *) mv; // {x | y << 16, flags, err | dc << 16, submask ...}
+        if (J.host_mvs) {
+            *(uint4 *) &J.host_mvs[idx] = rec;
+        }
+        const uint32_t all = rec.x, flags = rec.y;
+        const int mx = (int) (int16_t) (all & 0xffffu), my = (int) (int16_t) (all >> 16);
+        const int err = (int) (rec.z & 0xffffu), submask = (int) (rec.w & 0xffu);
+        const bool skip = (flags >> DSV_MV_BIT_SKIP) & 1, intra = (flags >> DSV_MV_BIT_INTRA) & 1;
+        uint2 l = {0, 0}, t = {0, 0}, tl = {0, 0};
+        if (i > 0) {
+            l = *(const uint2 *) (mv - 1);
+        }
+        if (j > 0) {
+            t = *(const uint2 *) (mv - nbh);
+        }
+        if (i > 0 && j > 0) {
+            tl = *(const uint2 *) (mv - nbh - 1);
+        }
+        // avg_motion (dsv_encoder.c:129)
+        if (skip) {
+            v[BS_STAT] = 1;
+        } else {
+            v[BS_AX] = mx;
+            v[BS_AY] = my;
+            int ndx = 0, ndy = 0; // dsv_neighbordif2 (dsv.c:403)
+            if (!(abs(mx) < 2 && abs(my) < 2)) {
+                int lx = mx, ly = my, tx = mx, ty = my;
+                if (i > 0 && l.x && !((l.y >> DSV_MV_BIT_SKIP) & 1)) {
+                    lx = (int) (int16_t) (l.x & 0xffffu);
+                    ly = (int) (int16_t) (l.x >> 16);
+                }
+                if (j > 0 && t.x && !((t.y >> DSV_MV_BIT_SKIP) & 1)) {
+                    tx = (int) (int16_t) (t.x & 0xffffu);
+                    ty = (int) (int16_t) (t.x >> 16);
+                }
+                ndx = abs(lx - mx) + abs(ly - my);
+                ndy = abs(tx - mx) + abs(ty - my);
+            }
+            if (ndx > 4 || ndy > 4) {
+                v[BS_CHAOS] = 1;
+            } else {
+                v[BS_STAT] = 1;
+            }
+        }
+        // scene_complexity (dsv_encoder.c:188); dsv_mv_cost with the median predictor of the raw field (dsv.c:357, :375)
+        int cost = 0;
+        if (!skip) {
+            const int px = pred1((int) (int16_t) (l.x & 0xffffu), (int) (int16_t) (t.x & 0xffffu), (int) (int16_t) (tl.x & 0xffffu));
+            const int py = pred1((int) (int16_t) (l.x >> 16), (int) (int16_t) (t.x >> 16), (int) (int16_t) (tl.x >> 16));
+            int bits = bs_seg_bits(mx - px) + bs_seg_bits(my - py);
+            bits += bits * J.b2sr >> 7;
+            cost = bits;
+        }
+        if (J.rc_mode == DSV_RATE_CONTROL_ABR) {
+            const int avg_err = (int) ((unsigned) J.counters[3] / (unsigned) nblk);
+            int c = skip ? 0 : cost + err - avg_err;
+            if (intra) {
+                c += submask == DSV_MASK_ALL_INTRA ? 16 : 4;
+            }
+            v[BS_COMPLEXITY] = c;
+        } else if (J.rc_mode == DSV_RATE_CONTROL_CRF) {
+            int c = skip ? -100 : cost;
+            if (intra) {
+                c += submask == DSV_MASK_ALL_INTRA ? 100 : 40;
+            }
+            v[BS_COMPLEXITY] = c;
+        }
+        // the running intra map and the counts of scene_change_detection's second test (dsv_encoder.c:617-640)
+        const int m = (J.map_in ? J.map_in[idx] : 0) | (intra ? 1 : 0);
+        J.map_out[idx] = (uint8_t) m;
+        int nintra = 0, skipn = 0;
+        if (m) {
+            const bool maintain = (flags >> DSV_MV_BIT_MAINTAIN) & 1;
+            if (skip || all == 0) {
+                nintra += maintain ? 3 : 1;
+                skipn += maintain ? 2 : 1;
+            } else if (((flags >> DSV_MV_BIT_NOXMITY) & 1) && maintain) {
+                nintra++;
+            }
+        }
+        nintra += m;
+        v[BS_NINTRA] = nintra;
+        v[BS_SKIPN] = skipn;
+        // gather_stats, P frame (dsv_encoder.c:1004-1012)
+        const int stable = intra ? 0 : (skip ? 1 : 0);
+        if (!skip) {
+            v[BS_MODE] = intra ? 1 : -1;
+            v[BS_EPRM] = ((flags >> DSV_MV_BIT_EPRM) & 1) ? 1 : -1;
+        }
+        v[BS_STABLE] = stable ? 1 : -1;
+        // DSV_STATS block counts (dsv_encoder.c:1505)
+        v[BS_ST_EPRM] = (flags >> DSV_MV_BIT_EPRM) & 1;
+        if (skip) {
+            v[BS_ST_SKIP] = 1;
+        } else if (intra) {
+            const int dc = (int) (rec.z >> 16);
+            v[BS_ST_MBI] = 1;
+            v[BS_ST_MBDC] = (dc & DSV_SRC_DC_PRED) ? 1 : 0;
+            if (submask != DSV_MASK_ALL_INTRA) {
+                v[BS_ST_MBSUB] = 1;
+                v[BS_ST_SUB0] = submask & 1;
+                v[BS_ST_SUB1] = (submask >> 1) & 1;
+                v[BS_ST_SUB2] = (submask >> 2) & 1;
+                v[BS_ST_SUB3] = (submask >> 3) & 1;
+            }
+        } else {
+            v[BS_ST_MBP] = 1;
+            v[(mx & 1) ? BS_ST_QPX : ((mx & 3) ? BS_ST_HPX : BS_ST_FPX)] = 1;
+            v[(my & 1) ? BS_ST_QPY : ((my & 3) ? BS_ST_HPY : BS_ST_FPY)] = 1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BS_USED; k++) {
+        const int r = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0 && r != 0) {
+            atomicAdd(&J.out[k], r);
+        }
+    }
+}
+
+void block_stats_batch(hipStream_t s, const BlockStatsJob *d_jobs, int n, int nbh, int nbv)
+{
+    if (n > 0) {
+        DSV2_LAUNCH(k_block_stats_b, dim3((nbh * nbv + 255) / 256, n), dim3(256), 0, s, d_jobs, nbh, nbv);
+    }
+}
+
 int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &ref, const HmeParams &hp)
 {
     HmeFrames f;
@@ -1658,7 +1817,9 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
             if ((fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
                 int w = level == 0 ? g_hme_waves_fast : g_hme_waves_fast_lx;
-                if (level == 0) {
+                if (level == 0 && g.a.hshift == 0) {
+                    kern = w >= 4 ? k_hme_rows_b_fast_l0_444_w4 : w == 3 ? k_hme_rows_b_fast_l0_444_w3 : w == 2 ? k_hme_rows_b_fast_l0_444_w2 : k_hme_rows_b_fast_l0_444_w1;
+                } else if (level == 0) {
                     kern = w >= 4 ? k_hme_rows_b_fast_l0_w4 : w == 3 ? k_hme_rows_b_fast_l0_w3 : w == 2 ? k_hme_rows_b_fast_l0_w2 : k_hme_rows_b_fast_l0_w1;
                 } else {
                     kern = w >= 4 ? k_hme_rows_b_fast_lx_w4 : w == 3 ? k_hme_rows_b_fast_lx_w3 : w == 2 ? k_hme_rows_b_fast_lx_w2 : k_hme_rows_b_fast_lx_w1;

@@ -88,14 +88,14 @@ __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b) { return __buil
 __device__ __forceinline__ uint32_t rot8(uint32_t a) { return (a >> 8) | (a << 24); } // (p1,p2,p3,p4) -> (p2,p3,p4,p1)
 __device__ __forceinline__ uint32_t rep4(int v) { return (uint32_t) v * 0x01010101u; }
 
-// METR_CALC (hme.c:126): UAVG4 of four absolute differences == (sad + 2) >> 2
+// METR_CALC (hme.c:126): UAVG4 of four absolute differences == (sad + 2) >> 2, so every squared term is at most 255
 __device__ __forceinline__ unsigned qmetric(const Quad &a, const Quad &b, const Psy &psy)
 {
     int se = (int) ((sad4(a.w, b.w) + 2) >> 2);
     int ta = (int) ((sad4(a.w, rot8(a.w)) + 2) >> 2), tb = (int) ((sad4(b.w, rot8(b.w)) + 2) >> 2);
     int s0 = (int) ((sad4(a.w, 0) + 2) >> 2), s1 = (int) ((sad4(b.w, 0) + 2) >> 2);
-    return (unsigned) (SQR(se) << psy.err_weight) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
-           (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+    return (unsigned) (sq24(se) << psy.err_weight) + (unsigned) (sq24(ta - tb) << psy.tex_weight) +
+           (unsigned) (sq24(s0 - s1) << psy.avg_weight);
 }
 
 __device__ __forceinline__ unsigned qsse(const Quad &a, const Quad &b) // sum of squared differences of the 4 bytes
@@ -523,12 +523,12 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
     int s0 = (int) ((sad4(a.w, 0) + 2) >> 2), s1 = (int) ((sad4(b.w, 0) + 2) >> 2);
     int ae = (int) ((sad4(a.w, b.w) + 2) >> 2);
     int ta = (int) ((sad4(a.w, rot8(a.w)) + 2) >> 2), tb = (int) ((sad4(b.w, rot8(b.w)) + 2) >> 2);
-    inter = (unsigned) (SQR(ae) * ratio >> (5 - psy.err_weight)) + (unsigned) (SQR(ta - tb) << psy.tex_weight) +
-            (unsigned) (SQR(s0 - s1) << psy.avg_weight);
+    inter = (unsigned) (sq24(ae) * ratio >> (5 - psy.err_weight)) + (unsigned) (sq24(ta - tb) << psy.tex_weight) +
+            (unsigned) (sq24(s0 - s1) << psy.avg_weight);
     ae = (int) ((sad4(a.w, rep4(avg_sb)) + 2) >> 2);
-    isb = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - avg_sb) << (psy.avg_weight + 1));
+    isb = (unsigned) (sq24(ae) << psy.err_weight) + (unsigned) (sq24(ta) << psy.tex_weight) + (unsigned) (sq24(s0 - avg_sb) << (psy.avg_weight + 1));
     ae = (int) ((sad4(a.w, rep4(dc)) + 2) >> 2);
-    isrc = (unsigned) (SQR(ae) << psy.err_weight) + (unsigned) (SQR(ta) << psy.tex_weight) + (unsigned) (SQR(s0 - dc) << (psy.avg_weight + 1));
+    isrc = (unsigned) (sq24(ae) << psy.err_weight) + (unsigned) (sq24(ta) << psy.tex_weight) + (unsigned) (sq24(s0 - dc) << (psy.avg_weight + 1));
 }
 
 // Measured on MI355X (tools/ab_hme.sh, 1080p, 384 streams / 4 groups, and 128 streams / 1 group): with the windows
@@ -677,8 +677,9 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     }
     unsigned sc = metric_return(acc, 16, 16) + (unsigned) mv_cost(cc, fpelx * 4 + mtx, fpely * 4 + mty, 0);
     int b0 = 0, b1 = 0;
+#pragma unroll
     for (int n = 0; n <= 6; n++) {
-        int t0 = __builtin_amdgcn_readlane(mtx, n), t1 = __builtin_amdgcn_readlane(mty, n);
+        const int t0 = tx[n], t1 = ty[n]; // (wave-uniform: no need to read them back from the lanes that scored them)
         if (((t0 | t1) & 1) && c.effort < 8) {
             continue;
         }
@@ -723,7 +724,9 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
 }
 
 // level-0 tail of hme_block_fast: sub-pel refinement + mode decision (hme.c:1598-1821)
-template <class Ctx>
+// CS: chroma shift of both axes -- 1 = 4:2:0 (a block's chroma is 8x8: one pixel per lane, its 2x2 quads on lanes 0..31),
+// 0 = 4:4:4 (16x16 like the luma: every lane owns the quad (qi, qj) of U and of V)
+template <int CS, class Ctx>
 __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, const Win &W, int &pcx, int &pcy, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
                                   unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, const SubpelLoads &sp_pre)
@@ -761,18 +764,21 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
 
     HME_MARK(S, 5);
     // ---- operands of the mode decision, one load round ----
-    const int cbx = i * 8, cby = j * 8;                     // 4:2:0, 16x16 blocks
-    const int cbmx = cbx + sarx(fpelx, 1), cbmy = cby + sarx(fpely, 1);
-    const int cbw = bw >> 1, cbh = bh >> 1;
-    const int cxp = lane & 7, cyp = lane >> 3;              // chroma pixel owned by this lane
-    const bool actc = cxp < cbw && cyp < cbh;
-    // chroma quads for the sub-block metrics: lanes 0..15 U, 16..31 V
+    const int cbx = (i * 16) >> CS, cby = (j * 16) >> CS;   // 16x16 luma blocks
+    const int cbmx = cbx + sarx(fpelx, CS), cbmy = cby + sarx(fpely, CS);
+    const int cbw = bw >> CS, cbh = bh >> CS;
+    const int cxp = lane & 7, cyp = lane >> 3;              // 4:2:0: chroma pixel owned by this lane
+    const bool actc = CS == 1 && cxp < cbw && cyp < cbh;
+    // 4:2:0: chroma quads for the sub-block metrics: lanes 0..15 U, 16..31 V
     const int cpl = (lane >> 4) & 1, cqi = lane & 3, cqj = (lane >> 2) & 3;
-    const bool actq = lane < 32 && cqi < (cbw >> 1) && cqj < (cbh >> 1);
+    const bool actq = CS == 1 && lane < 32 && cqi < (cbw >> 1) && cqj < (cbh >> 1);
     Quad r, o, rz, cs, cz, cm;
-    int us, vs, um, vm;
+    int us = 0, vs = 0, um = 0, vm = 0;
+    Quad usq, vsq, umq, vmq, uzq, vzq; // 4:4:4: this lane's quad of the source / reference-at-the-vector / reference-at-zero chroma blocks
+    usq.w = vsq.w = umq.w = vmq.w = uzq.w = vzq.w = 0;
+    cs.w = cz.w = cm.w = 0;
     // every operand sits in a staged window when the final vector stayed near the left neighbour's (the usual case)
-    const bool mwin = W.on && win_has(W.rx, kWinW, bx + fpelx, 16, 0, 0) && win_has(W.ry, kWinH, by + fpely, 16, 0, 0) &&
+    const bool mwin = CS == 1 && W.on && win_has(W.rx, kWinW, bx + fpelx, 16, 0, 0) && win_has(W.ry, kWinH, by + fpely, 16, 0, 0) &&
                       win_has(W.rx, kWinW, bx, 16, 0, 0) && win_has(W.ry, kWinH, by, 16, 0, 0) &&
                       win_has(W.ox, kOgrW, bx + fpelx, 16, 0, 0) && win_has(W.oy, kOgrW, by + fpely, 16, 0, 0) &&
                       win_has(W.cx, kCwW, cbmx, 8, 0, 0) && win_has(W.cy, kCwW, cbmy, 8, 0, 0) && win_has(W.cx, kCwW, cbx, 8, 0, 0) &&
@@ -796,13 +802,22 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
         r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
         o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
         rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
-        us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
-        vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
-        um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
-        vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
-        cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
-        cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
-        cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
+        if constexpr (CS == 1) {
+            us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
+            vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
+            um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
+            vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
+            cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
+            cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
+            cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
+        } else {
+            usq = ldq(at(c.srcc[0], cbx, cby), c.srcc[0].stride, qi, qj, act);
+            vsq = ldq(at(c.srcc[1], cbx, cby), c.srcc[1].stride, qi, qj, act);
+            umq = ldq(at(c.refc[0], cbmx, cbmy), c.refc[0].stride, qi, qj, act);
+            vmq = ldq(at(c.refc[1], cbmx, cbmy), c.refc[1].stride, qi, qj, act);
+            uzq = ldq(at(c.refc[0], cbx, cby), c.refc[0].stride, qi, qj, act);
+            vzq = ldq(at(c.refc[1], cbx, cby), c.refc[1].stride, qi, qj, act);
+        }
     }
     const int kq = (qi >= (qw >> 1) ? 1 : 0) | (qj >= (qh >> 1) ? 2 : 0);         // luma quadrant of this lane's quad
     const int kc = (cqi >= (cbw >> 2) ? 1 : 0) | (cqj >= (cbh >> 2) ? 2 : 0);      // chroma quadrant of this lane's chroma quad
@@ -813,19 +828,26 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     {
         int rs, rh, rv;
         quad_grad_partials(r, act, qi, qj, 0, 0, rs, rh, rv);
-        int ul = __shfl_up(us, 1, 64), uu = __shfl_up(us, 8, 64), vl = __shfl_up(vs, 1, 64), vu = __shfl_up(vs, 8, 64);
         v[0] = act ? (int) qmetric(a, o, psy) : 0;
         v[1] = rs;
         v[2] = rh;
         v[3] = rv;
-        v[4] = us;
-        v[5] = vs;
-        v[6] = um;
-        v[7] = vm;
-        v[8] = (actc && cxp > 0) ? abs(us - ul) : 0;
-        v[9] = (actc && cyp > 0) ? abs(us - uu) : 0;
-        v[10] = (actc && cxp > 0) ? abs(vs - vl) : 0;
-        v[11] = (actc && cyp > 0) ? abs(vs - vu) : 0;
+        if constexpr (CS == 1) {
+            int ul = __shfl_up(us, 1, 64), uu = __shfl_up(us, 8, 64), vl = __shfl_up(vs, 1, 64), vu = __shfl_up(vs, 8, 64);
+            v[4] = us;
+            v[5] = vs;
+            v[6] = um;
+            v[7] = vm;
+            v[8] = (actc && cxp > 0) ? abs(us - ul) : 0;
+            v[9] = (actc && cyp > 0) ? abs(us - uu) : 0;
+            v[10] = (actc && cxp > 0) ? abs(vs - vl) : 0;
+            v[11] = (actc && cyp > 0) ? abs(vs - vu) : 0;
+        } else { // pixel sums and first-difference sums of the 16x16 chroma blocks, quad by quad (as for the luma)
+            quad_grad_partials(usq, act, qi, qj, 0, 0, v[4], v[8], v[9]);
+            quad_grad_partials(vsq, act, qi, qj, 0, 0, v[5], v[10], v[11]);
+            v[6] = act ? umq.p1() + umq.p2() + umq.p3() + umq.p4() : 0;
+            v[7] = act ? vmq.p1() + vmq.p2() + vmq.p3() + vmq.p4() : 0;
+        }
         v[12] = v[13] = v[14] = v[15] = 0;
     }
     int R = reduceN<16>(v);
@@ -844,8 +866,13 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             v[1 + k] = (act && kq == k) ? (int) qmetric(a, rz, psy) : 0;
-            v[5 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
-            v[9 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
+            if constexpr (CS == 1) {
+                v[5 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
+                v[9 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
+            } else {
+                v[5 + k] = (act && kq == k) ? (int) qmetric(usq, uzq, psy) : 0;
+                v[9 + k] = (act && kq == k) ? (int) qmetric(vsq, vzq, psy) : 0;
+            }
         }
         v[13] = v[14] = v[15] = 0;
     }
@@ -933,8 +960,13 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     v[k] = (act && kq == k) ? (int) qmetric(a, r, psy) : 0;
-                    v[4 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
-                    v[8 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
+                    if constexpr (CS == 1) {
+                        v[4 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
+                        v[8 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
+                    } else {
+                        v[4 + k] = (act && kq == k) ? (int) qmetric(usq, umq, psy) : 0;
+                        v[8 + k] = (act && kq == k) ? (int) qmetric(vsq, vmq, psy) : 0;
+                    }
                     v[12 + k] = 0;
                 }
                 R = reduceN<16>(v);
@@ -1055,11 +1087,19 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
             if (!(sbw == 0 || sbh == 0 || mad <= thr || thr > 64 || (abs((int) mv.u.mv.x) < 4 && abs((int) mv.u.mv.y) < 4))) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    bool in = actc && kp == k;
-                    v[4 * k + 0] = in ? us : 0;
-                    v[4 * k + 1] = in ? vs : 0;
-                    v[4 * k + 2] = in ? um : 0;
-                    v[4 * k + 3] = in ? vm : 0;
+                    if constexpr (CS == 1) {
+                        bool in = actc && kp == k;
+                        v[4 * k + 0] = in ? us : 0;
+                        v[4 * k + 1] = in ? vs : 0;
+                        v[4 * k + 2] = in ? um : 0;
+                        v[4 * k + 3] = in ? vm : 0;
+                    } else {
+                        bool in = act && kq == k;
+                        v[4 * k + 0] = in ? usq.p1() + usq.p2() + usq.p3() + usq.p4() : 0;
+                        v[4 * k + 1] = in ? vsq.p1() + vsq.p2() + vsq.p3() + vsq.p4() : 0;
+                        v[4 * k + 2] = in ? umq.p1() + umq.p2() + umq.p3() + umq.p4() : 0;
+                        v[4 * k + 3] = in ? vmq.p1() + vmq.p2() + vmq.p3() + vmq.p4() : 0;
+                    }
                 }
                 R = reduceN<16>(v);
                 unsigned avg_ramp = avg_src * avg_src >> 8;
@@ -1137,7 +1177,7 @@ constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {
 // windows; out -- the same for this block
 // LV: what is known about the level at compile time -- 0: it is level 0; 1: it is a coarser level (the sub-pel search and
 // the mode decision are not even compiled in: a third of the registers); -1: decided at run time
-template <bool FULL, int LV, class Ctx>
+template <bool FULL, int LV, int CS, class Ctx>
 __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
 {
     const int level = LV == 0 ? 0 : level_rt;
@@ -1152,7 +1192,8 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     DSV_MV mv = {};
 
     const int bx = (i * y_w) >> level, by = (j * y_h) >> level;
-    const int bw = min(src.w - bx, y_w), bh = min(src.h - by, y_h);
+    // (a whole block is 16x16 by definition: as constants its area divisions, metric normalisations and quadrant tests fold away)
+    const int bw = FULL ? y_w : min(src.w - bx, y_w), bh = FULL ? y_h : min(src.h - by, y_h);
     const int qw = bw >> 1, qh = bh >> 1;
     // The psy metric works on whole 2x2 quads and drops an odd last row / column (hme.c:136: loops to h / 2, w / 2); the squared
     // error of the levels above 1 counts every pixel (hme.c:198).  There an odd row / column is a row / column of HALF quads:
@@ -1181,8 +1222,8 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
             W.oy = win_origin(by, pcy, kOgrMargin, kOgrW, src.h);
             win_issue<kOgrW, kOgrPitch, 8>(S.win.ogr, at(ogr, W.ox & ~3, W.oy), ogr.stride);
             const DPlane cu = c.refc[0], cv = c.refc[1];
-            W.cx = win_origin(i * 8, sarx(pcx, 1), kCwMargin, kCwW, cu.w);
-            W.cy = win_origin(j * 8, sarx(pcy, 1), kCwMargin, kCwW, cu.h);
+            W.cx = win_origin((i * 16) >> CS, sarx(pcx, CS), kCwMargin, kCwW, cu.w);
+            W.cy = win_origin((j * 16) >> CS, sarx(pcy, CS), kCwMargin, kCwW, cu.h);
             win_issue<kCwW, kCwPitch, 12>(S.win.chr[0], at(cu, W.cx & ~3, W.cy), cu.stride);
             win_issue<kCwW, kCwPitch, 12>(S.win.chr[1], at(cv, W.cx & ~3, W.cy), cv.stride);
             if (lane < 32) { // the block's own chroma samples: 8 rows x 2 dwords of U (lanes 0..15) and V (16..31)
@@ -1537,20 +1578,20 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     pre.t_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 4);
     pre.colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
     pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
-    hme_block_fast_l0(c, i, j, S, W, pcx, pcy, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
+    hme_block_fast_l0<CS>(c, i, j, S, W, pcx, pcy, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
                       avg_src, psy, pre, sp_pre);
     }
 }
 
-template <int LV, class Ctx>
+template <int LV, int CS = 1, class Ctx>
 __device__ __forceinline__ void hme_block_fast(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
 {
     const int level = LV == 0 ? 0 : level_rt;
     const DPlane &src = c.src[level];
     int bx = (i * 16) >> level, by = (j * 16) >> level;
     if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_fast_t<true, LV>(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast_t<true, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy);
     } else {
-        hme_block_fast_t<false, LV>(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast_t<false, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy);
     }
 }

@@ -50,8 +50,10 @@ print("BAD", bad)
 
 # DSV2_ENT_EMIT_WORDS shrinks the emit kernel's LDS image of a chunk: 8 words sends every chunk down the path that ORs its
 # code words straight into global memory, 40 mixes both paths (short chunks in LDS, long ones not)
+# DSV2_SIDE_FORCE_FALLBACK: the per-block side information of every P picture is coded by the host (the path a frame takes whose
+# sub-streams do not fit the device coder's images), from the field the device finalised
 @pytest.mark.parametrize("env", [{"DSV2_GPU_ENTROPY_FORCE_FALLBACK": "1"}, {"DSV2_GPU_ENTROPY": "0"}, {"DSV2_ENT_EMIT_WORDS": "8"},
-                                 {"DSV2_ENT_EMIT_WORDS": "40"}])
+                                 {"DSV2_ENT_EMIT_WORDS": "40"}, {"DSV2_SIDE_FORCE_FALLBACK": "1"}])
 def test_host_coder_paths(env):
     r = subprocess.run([sys.executable, "-c", _CHILD % os.path.dirname(os.path.abspath(__file__))], env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, text=True, timeout=600)

@@ -22,5 +22,11 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_{sys.argv[1]}/*/*_counter_collection.
         for c in names:
             tot[c] += v.get(c, 0) / frames / 1e3
     print("  %-46s" % "TOTAL", "  ".join("%9.1f" % tot[c] for c in names))
+    if "SQ_INSTS_VALU" in tot:  # the input of bench.py's roofline.issue
+        import json
+        json.dump({"vector_per_frame": round(tot["SQ_INSTS_VALU"] * 1e3), "scalar_per_frame": round(tot.get("SQ_INSTS_SALU", 0) * 1e3),
+                   "mix": "1 intra + 5 inter pictures per stream, 32 streams in one lockstep group",
+                   "source": "tools/pmc_all.sh %s SQ_INSTS_VALU SQ_INSTS_SALU (rocprofv3 --pmc, every kernel of the run summed)" % sys.argv[1]},
+                  open("gpurun_out/instruction_volume_%s.json" % sys.argv[1], "w"))
 PY
 rm -rf gpurun_out/pmc_$tag
