@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--host-cores", type=int, default=0,
                     help="pin this rank to N of its usable cores (sched_setaffinity, after the pictures are generated and before anything "
                          "touches the GPU) and size the library's worker pool from them: does the host side fit N cores per GPU?")
+    ap.add_argument("--no-mix", action="store_true", help="every stream pans (round 2's content): no scene-cut / static / fast-motion classes")
     ap.add_argument("--no-batch-curve", action="store_true", help="skip the small-batch operating points (1 / 8 / 48 / 192 streams)")
     ap.add_argument("--only-batch-curve", action="store_true", help="of the extras, run only the small-batch operating points (experiments)")
     ap.add_argument("--no-host-share", action="store_true", help="skip the 2-host-cores re-run of the headline")
@@ -155,7 +156,10 @@ class EncodeRun:
     all belong to ONE group -- its launches carry them all, the other groups launch no intra-only kernel at all
     (dsv_encoder.c:1247-1271 decides the picture type from the frame number alone)."""
 
-    def __init__(self, hip, A, torch, w, h, fmt, qp, gop, effort, S, G, videos, stagger, device_resident=False, seeds=None, phase_align=True):
+    CLASSES = ("pan", "cut", "static", "fast")
+
+    def __init__(self, hip, A, torch, w, h, fmt, qp, gop, effort, S, G, videos, stagger, device_resident=False, seeds=None, phase_align=True,
+                 mix=None, timed_from=0, timed_steps=48):
         from codec_run import configure_encoder
         self.hip, self.A, self.torch = hip, A, torch
         self.w, self.h, self.fmt, self.qp, self.gop, self.effort = w, h, fmt, qp, gop, effort
@@ -190,6 +194,27 @@ class EncodeRun:
             self.r0 = [(s % G + G * (((s // G) * slots) // nj if nj < slots else (s // G) % slots)) % self.R for s in range(S)]
         else:
             self.r0 = [(s // 2) % self.R if self.R else 0 for s in range(S)]
+        # Content classes (mix = shares per ten twin pairs, e.g. {"cut": 1, "static": 1, "fast": 1}: the rest pans):
+        #   pan     the generator's own motion (1.5 / 1 pixels a frame + moving squares), frame t of the video
+        #   cut     the same until a scene cut INSIDE the timed window, then another video: the scene-change test flips that
+        #           P picture to an intra picture in mid-batch (dsv_encoder.c:545)
+        #   static  one picture repeated: every block of every P picture is skipped
+        #   fast    every third frame of the video: 4.5 / 3 pixels a frame, squares up to 12
+        # Twins share class, video and local cut time, so their inputs stay identical.
+        self.klass = [0] * S
+        self.cut_t = [1 << 30] * S
+        if mix:
+            order = [c for c in ("cut", "static", "fast") for _ in range(int(mix.get(c, 0)))]
+            for u in range((S + 1) // 2):
+                c = order[u % 10] if u % 10 < len(order) else "pan"
+                for s2 in (2 * u, 2 * u + 1):
+                    if s2 < S:
+                        self.klass[s2] = self.CLASSES.index(c)
+                if c == "cut":
+                    t_local = timed_from - min(self.r0[2 * u], self.r0[min(S - 1, 2 * u + 1)]) + 6 + (5 * u) % max(1, timed_steps - 16)
+                    for s2 in (2 * u, 2 * u + 1):
+                        if s2 < S:
+                            self.cut_t[s2] = max(1, t_local)
         subsamp = A.SUBSAMP_420 if fmt == "420" else A.SUBSAMP_444
         meta = A.mk_meta(w, h, subsamp)
         self.encs = []
@@ -200,27 +225,37 @@ class EncodeRun:
         self.out = [[] for _ in range(S)]  # per stream, per frame: list of packets (bytes)
         self.step = 0
         self.step_ms = None  # per group: wall-clock duration of every step of the current run() (filled when a list)
+        self.in_call_s = [0.0] * self.G
         # one host thread per lockstep group for the life of the run (a group keeps its thread from step to step and from
         # run() to run(), as a long-lived encoding service would)
         import queue
+        self._state = [self._group_setup(g) for g in range(G)]
         self._cmd = [queue.Queue() for _ in range(G)]
         self._threads = [threading.Thread(target=self._group_thread, args=(g,), daemon=True) for g in range(G)]
         for th in self._threads:
             th.start()
 
-    def frame_index(self, s, t):
-        k = self.shift[s] + t
+    def source(self, s, t):
+        """(video, frame of it) that stream s codes as its local frame t"""
+        c = self.klass[s]
+        k = self.shift[s] + (0 if c == 2 else (3 * t if c == 3 else t))
         period = 2 * (self.NF - 1) if self.NF > 1 else 1
         k %= period
-        return k if k < self.NF else period - k
+        v = self.video[s] if t < self.cut_t[s] else (self.video[s] + max(1, self.NV // 2)) % self.NV
+        return v, (k if k < self.NF else period - k)
+
+    def frame_index(self, s, t):
+        return self.source(s, t)[1]
 
     def ptr(self, s, t):
-        return self.vbase[self.video[s]] + self.P * self.frame_index(s, t)
+        v, k = self.source(s, t)
+        return self.vbase[v] + self.P * k
 
     def ref_job(self, s, nframes):
-        """this stream's first nframes as a job of tools/ref_encode_worker.py"""
-        assert self.seeds[self.video[s]] is not None
-        return (self.w, self.h, self.fmt, self.seeds[self.video[s]], self.qp, self.gop, self.effort, [self.frame_index(s, t) for t in range(nframes)])
+        """this stream's first nframes as a job of tools/ref_encode_worker.py: (seed of the video, frame of it) per frame"""
+        src = [self.source(s, t) for t in range(nframes)]
+        assert all(self.seeds[v] is not None for v, _ in src)
+        return (self.w, self.h, self.fmt, 0, self.qp, self.gop, self.effort, ["%d:%d" % (self.seeds[v], k) for v, k in src])
 
     def pick_reference_streams(self, n):
         """n streams to re-encode with the reference: GOP phases spread over the whole 0 .. gop-1 range, every lockstep group
@@ -260,47 +295,90 @@ class EncodeRun:
                 traceback.print_exc()
                 os._exit(7)
 
-    def _group_worker(self, g, g0, g1, bar):
+    def _group_setup(self, g):
+        """per group, once: its streams ordered by GOP phase (the started ones are then always a prefix), the encoder
+        pointer table, and the numbers the per-step picture pointers are computed from -- the step loop itself does no
+        per-stream Python work"""
+        import numpy as np
+        ids = sorted(self.group_of[g], key=lambda s: (self.r0[s], s))
+        M = len(ids)
+        st = {"ids": ids, "M": M,
+              "gp": (C.POINTER(self.A.ENCODER) * M)(*[C.pointer(self.encs[s]) for s in ids]),
+              "r0": np.array([self.r0[s] for s in ids], dtype=np.int64),
+              "shift": np.array([self.shift[s] for s in ids], dtype=np.int64),
+              "klass": np.array([self.klass[s] for s in ids], dtype=np.int64),
+              "cut_t": np.array([self.cut_t[s] for s in ids], dtype=np.int64),
+              "base": np.array([self.vbase[self.video[s]] for s in ids], dtype=np.uint64),
+              "base2": np.array([self.vbase[(self.video[s] + max(1, self.NV // 2)) % self.NV] for s in ids], dtype=np.uint64)}
+        return st
+
+    def _ptrs(self, st, m, step):
+        """host (or device) address of the picture each of the first m streams codes in global step `step`"""
+        import numpy as np
+        t = step - st["r0"][:m]
+        c = st["klass"][:m]
+        k = st["shift"][:m] + np.where(c == 2, 0, np.where(c == 3, 3 * t, t))  # (same rule as source())
+        period = 2 * (self.NF - 1) if self.NF > 1 else 1
+        k %= period
+        k = np.where(k < self.NF, k, period - k)
+        base = np.where(t < st["cut_t"][:m], st["base"][:m], st["base2"][:m])
+        return np.ascontiguousarray(base + (k * self.P).astype(np.uint64))
+
+    def _group_worker(self, g, g0, g1, bar, bar_done):
         hip, A = self.hip, self.A
-        ids_all = self.group_of[g]
+        st = self._state[g]
+        import numpy as np
+        pend = []  # per step: (m, packets, counts) as the library returned them; turned into bytes after the clock stops
         bar.wait()
         t_prev = time.perf_counter()
         for step in range(g0, g1):
-            ids = [s for s in ids_all if self.r0[s] <= step]
-            m = len(ids)
+            m = int(np.searchsorted(st["r0"], step, side="right"))  # streams whose first step has come
             if not m:
                 continue
-            gp = (C.POINTER(A.ENCODER) * m)(*[C.pointer(self.encs[s]) for s in ids])
+            gp = (C.POINTER(A.ENCODER) * m).from_buffer(st["gp"])
             gb = (A.BUF * (4 * m))()
             gn = (C.c_int * m)()
-            cur = (C.c_void_p * m)(*[self.ptr(s, step - self.r0[s]) for s in ids])
+            cur_a = self._ptrs(st, m, step)
+            cur = (C.c_void_p * m).from_buffer(cur_a)
+            t_call = time.perf_counter()
             if self.device_resident:
                 rc = hip.dsv2hip_enc_batch(m, gp, cur, gb, gn)
             else:
-                nxt = (C.c_void_p * m)(*[self.ptr(s, step + 1 - self.r0[s]) for s in ids])
+                nxt_a = self._ptrs(st, m, step + 1)
+                nxt = (C.c_void_p * m).from_buffer(nxt_a)
+                t_call = time.perf_counter()
                 rc = hip.dsv2hip_enc_batch_host(m, gp, cur, nxt, gb, gn)
+            self.in_call_s[g] += time.perf_counter() - t_call
             assert rc == 0
-            for k, s in enumerate(ids):
-                pk = []
-                for i in range(gn[k]):
-                    b = gb[4 * k + i]
-                    pk.append(C.string_at(b.data, b.len))
-                    hip.dsv_buf_free(C.byref(b))
-                self.out[s].append(pk)
+            pend.append((m, gb, gn))
             if self.step_ms is not None:
                 t_now = time.perf_counter()
                 self.step_ms[g].append(1e3 * (t_now - t_prev))
                 t_prev = t_now
         bar.wait()
+        # the packets are finished and in host memory (DSV_BUFs); copying them into Python objects for the checks is the
+        # harness's business, not the codec's: outside the timed region
+        ids = st["ids"]
+        for m, gb, gn in pend:
+            for k in range(m):
+                pk = []
+                for i in range(gn[k]):
+                    b = gb[4 * k + i]
+                    pk.append(C.string_at(b.data, b.len))
+                    hip.dsv_buf_free(C.byref(b))
+                self.out[ids[k]].append(pk)
+        bar_done.wait()
 
     def run(self, nsteps, dist=None, record=False):
         """advance every (started) stream by nsteps frames; returns the wall time bracketed by barrier + synchronize"""
         torch = self.torch
         g0, g1 = self.step, self.step + nsteps
         self.step_ms = [[] for _ in range(self.G)] if record else None
+        self.in_call_s = [0.0] * self.G  # seconds each group spent inside the library during this run()
         bar = threading.Barrier(self.G + 1)
+        bar_done = threading.Barrier(self.G + 1)
         for g in range(self.G):
-            self._cmd[g].put((g0, g1, bar))
+            self._cmd[g].put((g0, g1, bar, bar_done))
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -311,6 +389,7 @@ class EncodeRun:
         if dist is not None:
             dist.barrier()
         t_end = time.perf_counter()
+        bar_done.wait()  # (the groups have turned their packets into Python objects)
         self.step = g1
         return t_end - t_start
 
@@ -319,6 +398,25 @@ class EncodeRun:
 
     def intra_in(self, g0, g1):
         return sum(1 for s in range(self.S) for t in range(max(0, g0 - self.r0[s]), g1 - self.r0[s]) if t % self.gop == 0)
+
+    def class_report(self, g0, g1):
+        """per content class over the global steps [g0, g1): streams, pictures, bytes per picture, and the intra pictures
+        that are NOT at a GOP start (P pictures the scene-change test flipped)"""
+        rep = {}
+        for ci, name in enumerate(self.CLASSES):
+            ss = [s for s in range(self.S) if self.klass[s] == ci]
+            if not ss:
+                continue
+            pics = nbytes = flips = 0
+            for s in ss:
+                for t in range(max(0, g0 - self.r0[s]), min(len(self.out[s]), g1 - self.r0[s])):
+                    pk = self.out[s][t][-1]
+                    pics += 1
+                    nbytes += sum(len(x) for x in self.out[s][t])
+                    if not (pk[5] & 1) and t % self.gop:
+                        flips += 1
+            rep[name] = {"streams": len(ss), "pictures": pics, "bytes_per_picture": round(nbytes / max(1, pics)), "intra_flips": flips}
+        return rep
 
     def twins_equal(self):
         """every stream's packets == its twin's (same input, other lockstep group and -- phase-aligned -- another GOP phase),
@@ -615,8 +713,9 @@ def main():
     S, K, Wm = max(1, args.streams), args.steps, args.warmup
     effort = int(os.environ.get("DSV2_BENCH_EFFORT", "10"))  # (experiments only: the headline is effort 10)
     align = not args.no_phase_align
+    mix = None if args.no_mix else MIX
     run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, args.groups, vids[:NV], not args.no_stagger, args.device_resident,
-                    seeds=seeds, phase_align=align)
+                    seeds=seeds, phase_align=align, mix=mix, timed_from=(GOP if not args.no_stagger else 0) + Wm, timed_steps=K)
     G = run.G
     hip.dsv2hip_prof_enable(0)
     run.run(run.R + Wm)                   # untimed: GOP-phase pre-roll + warm-up (allocations, clocks)
@@ -631,9 +730,11 @@ def main():
         rows = sorted(((thr1[t][1] - thr0.get(t, (None, 0.0))[1], thr1[t][0], t) for t in thr1), reverse=True)
         sys.stderr.write("[bench] host CPU by thread over %.2f s: %s\n" % (elapsed, ", ".join("%s/%d %.2f" % (nm, t, d) for d, nm, t in rows[:24] if d > 0.005)))
     step_ms = sorted(x for g in run.step_ms for x in g)
+    in_call_share = [round(x / elapsed, 3) for x in run.in_call_s]
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     frames_rank = run.frames_in(g_timed, g_timed + K)
     intra_rank = run.intra_in(g_timed, g_timed + K)
+    classes = run.class_report(g_timed, g_timed + K)
 
     # stage profile: a few more steps of the SAME configuration with HIP-event stage timing on (not timed)
     stage_ms, stage_launches, stage_units, prof_steps = None, None, None, 0
@@ -699,17 +800,21 @@ def main():
         "dtype": "u8/int32",
         "data": "synthetic",
         "config": {"workload": "1920x1080 4:2:0 -qp=60 -gop=48 effort=%d CRF, %d closed-GOP streams per GPU in %d lockstep groups; "
-                               "pictures in %s; GOP phases %s" %
+                               "pictures in %s; GOP phases %s; content: %s" %
                                (effort, S, G, "HBM before the clock starts (kernel-side figure)" if args.device_resident else
                                 "pinned host memory, every frame uploaded inside the timed region (double-buffered copy stream)",
                                 ("staggered over %d untimed pre-roll steps: every step codes 1/%d of the streams as intra pictures%s" %
                                  (run.R, GOP, ", all of them in ONE lockstep group (phase-aligned groups)" if run.phase_aligned else ""))
-                                if run.R else "aligned: one all-intra step per GOP"),
+                                if run.R else "aligned: one all-intra step per GOP",
+                                "of ten twin pairs seven pan, one has a scene cut inside the timed window, one is static, one moves three frames per step"
+                                if mix else "every stream pans"),
                    "streams_per_gpu": S, "frames_per_step_per_gpu": S, "groups": G, "frames_timed": frames_total, "intra_frames_timed": intra_total,
                    "phase_aligned_groups": run.phase_aligned,
+                   "content_classes": classes,
                    "input": "pinned_host" if not args.device_resident else "device_resident", "h2d_bytes_per_step_per_gpu": 0 if args.device_resident else S * run.P,
                    "distinct_videos_per_gpu": NV, "unique_frames_per_video": NF,
                    "ms_per_frame_p50": round(step_ms[len(step_ms) // 2], 3) if step_ms else None,
+                   "group_time_inside_library": in_call_share,
                    "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2), "mpix_per_s": round(fps * W_ * H_ / 1e6, 1),
                    "stream_bytes_total": total_bytes, "host_cpus_usable": ncpu, "host_cores_pinned": args.host_cores or None,
                    "host_threads": int(os.environ["DSV2_HOST_THREADS"]),
@@ -786,6 +891,11 @@ def main():
             result["batch_curve"] = batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
         except Exception as e:  # noqa: BLE001
             result["batch_curve"] = {"error": repr(e)}
+    if extras and not args.no_mix and not args.only_batch_curve:
+        try:
+            result["content_class_legs"] = class_legs(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
+        except Exception as e:  # noqa: BLE001
+            result["content_class_legs"] = {"error": repr(e)}
 
     # ---- does the host side fit the cores an 8-GPU node leaves per rank?  The headline again, pinned to 2 cores ----
     if extras and not args.no_host_share and not args.only_batch_curve and args.host_cores <= 0:
@@ -864,6 +974,8 @@ def reference_phase(result, checks, dec_md5, sel):
     for leg, v in per_leg.items():
         if leg.startswith("c") and isinstance(result.get("configs"), dict) and leg in result["configs"]:
             result["configs"][leg]["vs_reference"] = v
+        if leg.startswith("class_") and isinstance(result.get("content_class_legs"), dict) and leg[6:] in result["content_class_legs"]:
+            result["content_class_legs"][leg[6:]]["vs_reference"] = v
         if leg.startswith("batch") and isinstance(result.get("batch_curve"), list):
             for pt in result["batch_curve"]:
                 if "batch_%d" % pt["streams"] == leg:
@@ -876,6 +988,9 @@ def reference_phase(result, checks, dec_md5, sel):
         sys.stderr.write("[bench] decoded pictures DIFFER from the reference decoder's: streams %s\n" % dec_bad)
         return 6
     return 0
+
+
+MIX = {"cut": 1, "static": 1, "fast": 1}  # of every ten twin pairs; the other seven pan
 
 
 def timed_leg(run, warm, k):
@@ -932,8 +1047,9 @@ def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, c
     out = []
     for S, G in BATCH_POINTS:
         G = min(G, S)
-        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, G, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align)
         k = 48
+        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, G, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
+                        mix=None if (args.no_mix or S < 20) else MIX, timed_from=(GOP if not args.no_stagger else 0) + 4, timed_steps=k)
         f, e, ms = timed_leg(run, 4, k)
         p, b = run.twins_equal() if S > 1 else (0, 0)
         out.append({"streams": S, "groups": run.G, "value": round(f / e, 2), "unit": "frames/s", "steps": k, "ms_per_step": round(1e3 * e / k, 3),
@@ -943,6 +1059,27 @@ def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, c
         run.free()
         if b:
             raise AssertionError("batch curve, %d streams: %d of %d twin stream pairs differ" % (S, b, p))
+    return out
+
+
+def class_legs(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks):
+    """frames/s of each content class on its own: 192 streams of ONE class (4 lockstep groups), staggered GOP phases, 24 timed
+    steps; one stream of each leg goes to the reference"""
+    out = {}
+    for name in EncodeRun.CLASSES:
+        k = 24
+        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, 192, 4, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
+                        mix=None if name == "pan" else {name: 10}, timed_from=(GOP if not args.no_stagger else 0) + 4, timed_steps=k)
+        f, e, _ = timed_leg(run, 4, k)
+        p, b = run.twins_equal()
+        rep = run.class_report(run.step - k, run.step)[name]
+        out[name] = {"value": round(f / e, 2), "unit": "frames/s", "streams": run.S, "steps": k, "bytes_per_picture": rep["bytes_per_picture"],
+                     "intra_flips": rep["intra_flips"], "twin_pairs_equal": p - b, "twin_pairs": p}
+        sel = max(range(run.S), key=lambda s: (len(run.out[s]) >= 40, -run.r0[s]))  # a stream whose cut (if any) lies in its first frames? no: longest history
+        checks.append(RefCheck("class_" + name, run, sel, 64))
+        run.free()
+        if b:
+            raise AssertionError("content class %s: %d of %d twin stream pairs differ" % (name, b, p))
     return out
 
 

@@ -1344,6 +1344,41 @@ struct TaskCpu {
 };
 TaskCpu g_task_cpu;
 
+// The search token.  The motion search runs at a fixed two wavefronts per SIMD and is bound by how many of those slots it
+// holds for how long; every other kernel of a step lives in the other half of the register file.  Lockstep groups that
+// reach their search phase together share the slots (each search takes twice as long) and then reach their G2 phases
+// together too, with the search slots idle meanwhile: a convoy, and a stable one.  With the token at most
+// DSV2_SEARCH_SLOTS groups (default 1; 0 = unlimited) have a search in flight; the others wait with their pre-search work
+// (ingest, pyramids) already enqueued, and the searches of the groups follow one another back to back while the rest of
+// each step runs beside them.
+struct SearchToken {
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_slots = getenv("DSV2_SEARCH_SLOTS") ? atoi(getenv("DSV2_SEARCH_SLOTS")) : 1;
+    const bool on = free_slots > 0;
+    void acquire()
+    {
+        if (!on) {
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return free_slots > 0; });
+        free_slots--;
+    }
+    void release()
+    {
+        if (!on) {
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_slots++;
+        }
+        cv.notify_one();
+    }
+};
+SearchToken g_search_token;
+
 // the plane sections of the packet are assembled on the GPU (DSV2_GPU_ENTROPY=0: the host codes them from the symbol list)
 static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV2_GPU_ENTROPY")) == 0);
 static const int kAuxStreams = getenv("DSV2_AUX_STREAMS") ? atoi(getenv("DSV2_AUX_STREAMS")) : 0; // side streams within a step: bit 0 entropy coder, bit 1 intra filter (0: one chain)
@@ -1582,6 +1617,16 @@ void enc_batch(Job *jobs, int n)
         }
     }
     prof.end(bs, ST_INGEST, n);
+    // (a search launch that cannot fill the chip's search slots anyway -- fewer block rows than slots: small batches -- runs
+    // beside the others as before)
+    static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 2048;
+    const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
+    if (searching) {
+        // the token is for the search alone: what precedes it on the stream (this step's upload, ingest, pyramids) is waited
+        // for BEFORE taking it, or the holder would sit on the token while its own pictures are still crossing PCIe
+        stream_wait(bs);
+        g_search_token.acquire(); // (released once the search has drained, below)
+    }
     if (!pjobs.empty()) {
         prof.begin(bs, ST_HME);
         int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof);
@@ -1592,6 +1637,9 @@ void enc_batch(Job *jobs, int n)
     }
     t_clock.lap(1);
     stream_wait(bs);
+    if (searching) {
+        g_search_token.release();
+    }
     t_clock.lap(2);
     for (int k = 0; k < n; k++) {
         if (jobs[k].frame) {

@@ -5,7 +5,8 @@
 It is test/measurement infrastructure (cpu_baseline, cpu_baseline_8proc and the in-bench parity
 check); it never touches the GPU or the product library.  Protocol (line based, stdin/stdout):
 
-    argv:   W H FMT(420|444) SEED QP GOP EFFORT OUT_PATH  i0,i1,i2,...   (frame indices of the synthetic video, in order)
+    argv:   W H FMT(420|444) SEED QP GOP EFFORT OUT_PATH  i0,i1,i2,...   (frame indices of the synthetic video, in order;
+            an entry "seed:index" names a frame of ANOTHER synthetic video -- a stream with a scene cut)
     stdout: "ready"                      after the frames are generated
     stdin:  "go N"                       encode the first N frames with a fresh encoder
     stdout: {"frames": N, "t0": .., "t1": .., "cpu_s": ..}   (wall clock of the encode loop only)
@@ -27,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     w, h, fmt, seed, qp, gop, effort = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     out_path = sys.argv[8]
-    idx = [int(x) for x in sys.argv[9].split(",")]
+    idx = [(int(x.split(":")[0]), int(x.split(":")[1])) if ":" in x else (seed, int(x)) for x in sys.argv[9].split(",")]
     import ctypes as C
 
     import numpy as np
@@ -37,11 +38,13 @@ def main():
     from conftest import load_pkg
 
     pkg = load_pkg()
-    v = pkg.synth.SynthVideo(w, h, fmt, seed=seed)
+    vids = {}
     cache = {}
     for i in idx:
         if i not in cache:
-            cache[i] = np.frombuffer(v.frame_bytes(i), dtype=np.uint8).copy()
+            if i[0] not in vids:
+                vids[i[0]] = pkg.synth.SynthVideo(w, h, fmt, seed=i[0])
+            cache[i] = np.frombuffer(vids[i[0]].frame_bytes(i[1]), dtype=np.uint8).copy()
     ref = A.load_ref()
     subsamp = A.SUBSAMP_420 if fmt == "420" else A.SUBSAMP_444
     print("ready", flush=True)

@@ -53,7 +53,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg[c] = by_grid
 with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
     f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex k_hme_rows_b_fast_l0 -- python3 bench.py "
-            "--steps 6 --warmup 3 --no-stagger\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
+            "--steps 6 --warmup 3 (the bench's own stream layout: staggered GOP phases, phase-aligned groups)\nunits: KiB per launch as reported; narrow (2-byte per lane) loads, so the gfx950 "
             "half-count correction for 16-byte streaming reads is NOT applied (uncalibrated width); only the launches of the "
             "level-0 search kernel are listed (one lockstep group per launch)\n\n")
     f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
@@ -67,16 +67,13 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
     f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
 json.dump({"stage": "hme_level0", "kernel": "k_hme_rows_b_fast_l0_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
-           "groups": traced["config"]["groups"], "bytes_per_launch": round(bytes_per_launch),
+           "groups": traced["config"]["groups"], "stagger": True, "phase_aligned": bool(traced["config"].get("phase_aligned_groups")),
+           "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 if os.path.exists(os.path.join(src, "decode.json")):  # (since round 2 the decode leg is part of the bench line itself)
     dec = [l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")]
     if dec:
         json.dump(json.loads(dec[-1]), open(os.path.join(dst, prefix + "_decode.json"), "w"), indent=1)
-# the bench line was taken before these PMC passes: complete its roofline object with their figure
-if bench.get("roofline") and bench["roofline"].get("traffic") is None:
-    bench["roofline"]["traffic"] = round(bytes_per_launch)
-    bench["roofline"]["traffic_source"] = "profiles/%s_pmc_hme.txt, same round and configuration" % prefix
-    json.dump(bench, open(os.path.join(dst, prefix + "_bench.json"), "w"), indent=1)
-print("wrote", prefix, "summaries; traffic per launch %.2f MB" % (bytes_per_launch / 1e6))
+# (the committed bench line is exactly what bench.py printed: its roofline.traffic comes from profiles/pmc_traffic.json of
+# the passes above when bench.py runs AFTER they have been summarised and their configuration matches)
