@@ -562,11 +562,21 @@ __global__ __launch_bounds__(256) void k_reconstruct(const DSV_MV *__restrict__ 
 // Evaluated without branches: the six range tests are combined bitwise and the four outputs are always
 // formed; callers select between old and new samples.  The wave executes every path of divergent code anyway,
 // so predication costs nothing here and removes ~a thousand exec-mask branches per cell.
+// |a - b| of two non-negative values in ONE instruction (v_sad_u32 with a zero accumulator; the compiler's own form of
+// abs(a - b) is two subtractions and a maximum, and a cell evaluates some 130 of them)
+__device__ __forceinline__ int absdiff(int a, int b)
+{
+    int d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 __device__ __forceinline__ bool smooth6(int e2, int e1, int e0, int i0, int i1, int i2, int t, int o[4])
 {
     int avg = (5 * (e0 + i0) + 3 * (e1 + i1) + 8) >> 4;
-    bool ok = ((int) (abs(e0 - avg) < t) & (int) (abs(i0 - avg) < t) & (int) (abs(e1 - avg) < t) & (int) (abs(i1 - avg) < t) &
-               (int) (abs(e2 - avg) < t) & (int) (abs(i2 - avg) < t)) != 0; // bitwise on purpose: no short-circuit branches
+    // all six samples within t of the average <=> the largest deviation is (bmc.c:53-70: six range tests)
+    int dev = max(max(max(absdiff(e0, avg), absdiff(i0, avg)), max(absdiff(e1, avg), absdiff(i1, avg))), max(absdiff(e2, avg), absdiff(i2, avg)));
+    bool ok = dev < t;
     int a5 = avg * 5;
     o[0] = (3 * (avg + e1) + 2 * e2 + 4) >> 3;
     o[1] = (a5 + 2 * e1 + e2 + 4) >> 3;
@@ -647,6 +657,9 @@ struct Tile {
             if (!V::kStoreAll && !(dirty & (1u << r))) {
                 continue;
             }
+            if (V::kStoreAll && !__any((dirty >> r) & 1u)) { // LDS: a row no cell of the wavefront changed is not packed and written at all
+                continue;
+            }
             if (r >= 3 && r <= 6) {
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
@@ -667,14 +680,15 @@ __device__ __forceinline__ bool line_filter(int (&l)[11], bool in_edge, int tE, 
     int o[4], p[4];
     bool h1 = smooth6(l[0], l[1], l[2], l[3], l[4], l[5], tE, o);
     bool h2 = in_edge & smooth6(l[10], l[9], l[8], l[7], l[6], l[5], tM, p); // reads l[5..10] only: untouched by the first half
-    l[1] = h1 ? (o[0] & 0xff) : l[1];
-    l[2] = h1 ? (o[1] & 0xff) : l[2];
-    l[3] = h1 ? (o[2] & 0xff) : l[3];
-    l[4] = h1 ? (o[3] & 0xff) : l[4];
-    l[6] = h2 ? (p[3] & 0xff) : l[6];
-    l[7] = h2 ? (p[2] & 0xff) : l[7];
-    l[8] = h2 ? (p[1] & 0xff) : l[8];
-    l[9] = h2 ? (p[0] & 0xff) : l[9];
+    // (smooth6's outputs are weighted means of samples <= 255 with weights summing to 8 resp. 16: they fit a byte as they are)
+    l[1] = h1 ? o[0] : l[1];
+    l[2] = h1 ? o[1] : l[2];
+    l[3] = h1 ? o[2] : l[3];
+    l[4] = h1 ? o[3] : l[4];
+    l[6] = h2 ? p[3] : l[6];
+    l[7] = h2 ? p[2] : l[7];
+    l[8] = h2 ? p[1] : l[8];
+    l[9] = h2 ? p[0] : l[9];
     return h1 | h2;
 }
 
@@ -801,8 +815,8 @@ __device__ __forceinline__ void vfilter_mem(const DPlane &dp, int x, int y, int 
 
 __device__ __forceinline__ unsigned dsff_d(int d[4]) // bmc.c:194
 {
-    unsigned sh = (unsigned) abs((d[0] + d[1]) - (d[3] + d[2]));
-    unsigned sv = (unsigned) abs((d[2] + d[1]) - (d[3] + d[0]));
+    unsigned sh = (unsigned) absdiff(d[0] + d[1], d[3] + d[2]);
+    unsigned sv = (unsigned) absdiff(d[2] + d[1], d[3] + d[0]);
     if (max(sh, sv) < 8) {
         return 0;
     }
@@ -829,16 +843,16 @@ __device__ __forceinline__ void artf(const Tile &T, int &sh, int &sv, int &slh, 
 #pragma unroll
         for (int x = 0; x < 4; x += 2) {
             int x0 = TCELL(y, x), x1 = TCELL(y, x + 1), x2 = TCELL(y + 1, x), x3 = TCELL(y + 1, x + 1);
-            int hh = abs(x0 - x1 - x2 + x3) >> 1;
-            sh += abs(x0 - x1 + x2 - x3) + hh;
-            sv += abs(x0 + x1 - x2 - x3) + hh;
+            int hh = absdiff(x0 + x3, x1 + x2) >> 1;
+            sh += absdiff(x0 + x2, x1 + x3) + hh;
+            sv += absdiff(x0 + x1, x2 + x3) + hh;
         }
     }
     int d[4];
     DS2X2(TCELL, d);
-    int hh = abs(d[0] - d[1] - d[2] + d[3]) >> 1;
-    slh = abs(d[0] - d[1] + d[2] - d[3]) + hh;
-    slv = abs(d[0] + d[1] - d[2] - d[3]) + hh;
+    int hh = absdiff(d[0] + d[3], d[1] + d[2]) >> 1;
+    slh = absdiff(d[0] + d[2], d[1] + d[3]) + hh;
+    slv = absdiff(d[0] + d[1], d[2] + d[3]) + hh;
 }
 
 // de-gradient sharpening of 16 pixels px[y * 4 + x] in place (bmc.c:276); returns true when it changed them
@@ -1128,8 +1142,13 @@ __device__ void luma_cell_rec(const V &view, const DPlane &dp, const FilterParam
         vE = intra ? tH : tt + addy;
         vM = intra ? tL : tt;
     }
-    hfilter(T, dp, x, eh, hE, hM, h_on);
-    vfilter(T, dp, y, ev, vE, vM, v_on);
+    // (a pass that no cell of the wavefront wants is a no-op by construction: skipping it is a wave-uniform branch)
+    if (__any(h_on)) {
+        hfilter(T, dp, x, eh, hE, hM, h_on);
+    }
+    if (__any(v_on)) {
+        vfilter(T, dp, y, ev, vE, vM, v_on);
+    }
     if (__any(live & sharp)) {
         if (live & sharp) {
             degrad(T);
@@ -1208,9 +1227,27 @@ __device__ __forceinline__ bool ring_eligible(const DPlane &dp, int nthreads, si
 
 // cell(ic, j) filters one cell; ahead(ic, j) is told which cell this thread will filter four fronts later so
 // that it can fetch that cell's side information off the dependent path
+// phase clock of a debugging build (make prof): shader-clock ticks wave 0 of a luma sweep spends in each part of a front
+#ifdef DSV2_FILTER_PROF
+__device__ unsigned long long g_filt_prof[8];
+#define FILT_MARK(k)                                                     \
+    do {                                                                 \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();           \
+        prof_acc[k] += t_ - prof_t;                                      \
+        prof_t = t_;                                                     \
+    } while (0)
+#else
+#define FILT_MARK(k)                                                     \
+    do {                                                                 \
+    } while (0)
+#endif
+
 template <class CellFn, class AheadFn>
 __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead)
 {
+#ifdef DSV2_FILTER_PROF
+    unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
     const int nsbx = dp.w / 4, nsby = dp.h / 4;
     const int tid = (int) threadIdx.x, nthr = (int) blockDim.x;
     const int t_last = (nsbx + 2) + 2 * (nsby - 1);
@@ -1231,8 +1268,22 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
             }
             pend_row = -1;
         }
+        FILT_MARK(0);
         if (active) {
-            int g = 4 * ic + 48;
+            // Every global-memory operation of a front is ISSUED before its cell is filtered and first waited for at the top
+            // of the next front (vector-memory operations complete in order, stores included: retirements issued behind the
+            // cell would be waited out at once by the next front's column hand-over).
+            int g = 4 * ic - 12;
+            if (g >= 0 && g < dp.w) { // these columns are final: no cell of this or a later front reaches them
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    *(gu32w_t) (dp.data + (ptrdiff_t) (4 * j + r) * dp.stride + g) = *(const uint32_t *) (ring + (4 * j + r) * 64 + (g & 63));
+                }
+            }
+            if (ic + 4 >= 0 && ic + 4 < nsbx) { // one block (four cells) of lead: a global fetch has that long to arrive
+                ahead(ic + 4, j);
+            }
+            g = 4 * ic + 48;
             if (g >= 0 && g < dp.w) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1241,24 +1292,25 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
                 pend_row = 4 * j;
                 pend_col = g;
             }
+            FILT_MARK(1);
             if (ic >= 0 && ic < nsbx) {
                 cell(ic, j);
             }
-            if (ic + 4 >= 0 && ic + 4 < nsbx) { // one block (four cells) of lead: a global fetch has that long to arrive
-                ahead(ic + 4, j);
-            }
-            g = 4 * ic - 12;
-            if (g >= 0 && g < dp.w) { // these columns are final: no later cell reaches them
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    *(gu32w_t) (dp.data + (ptrdiff_t) (4 * j + r) * dp.stride + g) = *(const uint32_t *) (ring + (4 * j + r) * 64 + (g & 63));
-                }
-            }
         }
+        FILT_MARK(2);
         // fronts hand over through LDS only: wait for this wave's LDS traffic and meet the others, but leave
         // the column fetches and retirements in flight (__syncthreads() would drain them every front)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        FILT_MARK(3);
     }
+#ifdef DSV2_FILTER_PROF
+    if (tid == 0) {
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&g_filt_prof[k], prof_acc[k]);
+        }
+        atomicAdd(&g_filt_prof[4], 1ull);
+    }
+#endif
     __syncthreads();
 }
 
@@ -1360,6 +1412,16 @@ void post_process_plane(hipStream_t s, const DPlane &dp)
     DSV2_LAUNCH(k_post_process, dim3((dp.w / 4 + 63) / 64, (dp.h / 4 + 3) / 4), dim3(64, 4), 0, s, dp);
     HIPCHK(hipGetLastError());
 }
+
+#ifdef DSV2_FILTER_PROF
+} // namespace dsv2
+extern "C" void dsv2hip_debug_filter_prof(unsigned long long out[8])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dsv2::g_filt_prof), 8 * sizeof(unsigned long long)));
+}
+namespace dsv2 {
+#endif
 
 // ---- host drivers --------------------------------------------------------------------------
 

@@ -121,6 +121,25 @@ def test_many_streams_concurrent_groups_repeated():
         hip.dsv2hip_host_free(p)
 
 
+def test_192_pictures_per_launch_with_search_token():
+    """the bench's launch size: 192 streams in ONE lockstep group (every kernel launch carries 192 pictures: 13 056 block rows
+    in the level-0 search launch), then 384 streams in two groups of 192 that pass the search token (DSV2_SEARCH_SLOTS) back and
+    forth; every stream against the reference"""
+    hip = A.load_hip()
+    bind(hip)
+    frames = gen_inputs()
+    want = reference_digests(frames)
+    pinned = pin(hip, frames)
+    got = run_once(hip, frames, 192, 1, pinned)
+    bad = [s for s in range(192) if got[s] != want[s % NSEED]]
+    assert not bad, "one group of 192: streams %s differ from the reference" % bad[:8]
+    got = run_once(hip, frames, 384, 2, pinned)
+    bad = [s for s in range(384) if got[s] != want[s % NSEED]]
+    assert not bad, "two groups of 192: streams %s differ from the reference" % bad[:8]
+    for p in pinned:
+        hip.dsv2hip_host_free(p)
+
+
 _CHILD = r"""
 import json, sys
 sys.path.insert(0, %r)
