@@ -1381,13 +1381,17 @@ SearchToken g_search_token;
 
 // the plane sections of the packet are assembled on the GPU (DSV2_GPU_ENTROPY=0: the host codes them from the symbol list)
 static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV2_GPU_ENTROPY")) == 0);
-static const int kAuxStreams = getenv("DSV2_AUX_STREAMS") ? atoi(getenv("DSV2_AUX_STREAMS")) : 0; // side streams within a step: bit 0 entropy coder, bit 1 intra filter (0: one chain)
+// side streams within a step: bit 0 entropy coder, bit 1 intra filter; unset: the entropy kernels of a SMALL batch (fewer than
+// 12 streams: the step is a chain of latency-bound launches on a mostly idle GPU) run beside inverse transform /
+// reconstruction / filters, a large batch keeps one chain (no throughput gain there, more host work)
+static const int kAuxStreamsEnv = getenv("DSV2_AUX_STREAMS") ? atoi(getenv("DSV2_AUX_STREAMS")) : -1;
 static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") && atoi(getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK")) != 0; // (tests)
 // the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
 static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV2_FUSED_COUNT")) == 0);
 
 void enc_batch(Job *jobs, int n)
 {
+    const int kAuxStreams = kAuxStreamsEnv >= 0 ? kAuxStreamsEnv : (n < 12 ? 1 : 0);
     bind_device();
     t_clock.start();
     for (int k = 0; k < n; k++) {
@@ -1617,9 +1621,10 @@ void enc_batch(Job *jobs, int n)
         }
     }
     prof.end(bs, ST_INGEST, n);
-    // (a search launch that cannot fill the chip's search slots anyway -- fewer block rows than slots: small batches -- runs
-    // beside the others as before)
-    static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 2048;
+    // (only launches that keep the chip's 2 048 search slots full for most of their length take the token: a row-pipelined
+    // launch ramps up and down over one picture's critical path, ~2 ms whatever the batch, and launches of a few dozen
+    // pictures hide each other's ramps when they overlap)
+    static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 8192;
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
     if (searching) {
         // the token is for the search alone: what precedes it on the stream (this step's upload, ingest, pyramids) is waited

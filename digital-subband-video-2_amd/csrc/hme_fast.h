@@ -235,11 +235,16 @@ constexpr int kWinW = 48, kWinH = 48, kWinPitch = 52, kWinMargin = 16; // luma r
 constexpr int kOgrW = 28, kOgrPitch = 32, kOgrMargin = 6;               // original-reference window (level 0)
 constexpr int kCwW = 16, kCwPitch = 20, kCwMargin = 4;                  // chroma reference windows (level 0)
 
+#ifndef DSV2_HME_WIN
+#define DSV2_HME_WIN 0
+#endif
+// (without the staged windows -- the default build -- the arrays shrink to one word: 4 KB of LDS per wavefront less)
+constexpr int kWinOn = DSV2_HME_WIN != 0 ? 1 : 0;
 struct WinLds {
-    alignas(16) uint32_t ref[kWinH * kWinPitch / 4];
-    uint32_t ogr[kOgrW * kOgrPitch / 4];
-    uint32_t chr[2][kCwW * kCwPitch / 4];
-    uint32_t csrc[2][16]; // the block's 8x8 source chroma samples (U, V): 8 rows of 2 dwords
+    alignas(16) uint32_t ref[kWinOn ? kWinH * kWinPitch / 4 : 1];
+    uint32_t ogr[kWinOn ? kOgrW * kOgrPitch / 4 : 1];
+    uint32_t chr[2][kWinOn ? kCwW * kCwPitch / 4 : 1];
+    uint32_t csrc[2][kWinOn ? 16 : 1]; // the block's 8x8 source chroma samples (U, V): 8 rows of 2 dwords
 };
 
 // what the windows hold, in plane coordinates (wave-uniform)

@@ -6,7 +6,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 500 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 4 --warmup 2 --streams 32 --groups 1 --gen-procs 1 --no-stagger --no-extras --no-cpu-baseline --no-profile > /dev/null 2>&1
+timeout 500 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 4 --warmup 2 --streams 32 --groups 1 --gen-procs 1 --no-stagger --no-extras --no-cpu-baseline --no-profile --no-mix > /dev/null 2>&1
 python3 - "$tag" <<'PY' | tee gpurun_out/pmc_all_$tag.txt
 import csv, glob, collections, sys
 frames = 32 * 6

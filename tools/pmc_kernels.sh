@@ -7,7 +7,7 @@ set -u
 tag=$1; streams=${2:-96}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pk_$tag; mkdir -p $out
-args="--gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --streams $streams --groups 1 --steps 12 --warmup 2"
+args="--gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --no-mix --streams $streams --groups 1 --steps 12 --warmup 2"
 timeout 500 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py $args > $out/bench.json 2> $out/trace.err
 cp $out/trace/*/*_kernel_trace.csv $out/kernel_trace.csv; rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -9,7 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof
 mkdir -p $out
-python3 bench.py > $out/bench.json 2> $out/bench.err
+# (the default bench line itself is taken LAST, by a separate call, once the PMC passes below have been summarised into
+# profiles/pmc_traffic.json: bench.py quotes that file as roofline.traffic)
+if [ "${WITH_BENCH:-0}" = 1 ]; then python3 bench.py > $out/bench.json 2> $out/bench.err; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras > $out/bench_traced.json 2> $out/trace.err
 cp $out/trace/*/*_kernel_stats.csv $out/kernel_stats.csv
 # the trace itself is large: keep only the dominant kernel's rows for the duration cross-check

@@ -15,8 +15,9 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 prefix = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
-bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
-json.dump(bench, open(os.path.join(dst, prefix + "_bench.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "bench.json")):  # the default bench line, exactly as bench.py printed it
+    bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
+    json.dump(bench, open(os.path.join(dst, prefix + "_bench.json"), "w"), indent=1)
 traced = json.loads([l for l in open(os.path.join(src, "bench_traced.json")) if l.startswith("{")][-1])
 
 rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))

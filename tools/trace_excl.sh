@@ -4,7 +4,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/ts
-env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ts/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --streams ${EXCL_STREAMS:-96} --groups 1 --steps 12 --warmup 2 > gpurun_out/ts/$tag.json 2> gpurun_out/ts/$tag.err
+env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ts/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --no-mix --streams ${EXCL_STREAMS:-96} --groups 1 --steps 12 --warmup 2 > gpurun_out/ts/$tag.json 2> gpurun_out/ts/$tag.err
 cp gpurun_out/ts/$tag/*/*_kernel_stats.csv gpurun_out/ts/$tag.csv
 rm -rf gpurun_out/ts/$tag
 python3 - "$tag" <<'PY'

@@ -5,10 +5,10 @@ tag=$1; shift
 streams=${1:-1}; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/tl
-env "$@" timeout 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --streams $streams --groups 1 --steps 12 --warmup 2 > gpurun_out/tl/$tag.json 2> gpurun_out/tl/$tag.err
+env "$@" timeout 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --no-stagger --no-mix --streams $streams --groups 1 --steps 12 --warmup 2 > gpurun_out/tl/$tag.json 2> gpurun_out/tl/$tag.err
 cp gpurun_out/tl/$tag/*/*_kernel_trace.csv gpurun_out/tl/$tag.csv
 rm -rf gpurun_out/tl/$tag
-python3 - "$tag" <<'PY' | tee gpurun_out/tl/$1_timeline.txt
+python3 - "$tag" <<'PY' | tee gpurun_out/tl/${tag}_timeline.txt
 import csv, json, sys
 t = sys.argv[1]
 r = json.loads([l for l in open(f"gpurun_out/tl/{t}.json") if l.startswith("{")][-1])
