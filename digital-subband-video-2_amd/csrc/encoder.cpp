@@ -1628,7 +1628,9 @@ void enc_batch(Job *jobs, int n)
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
     if (searching) {
         // the token is for the search alone: what precedes it on the stream (this step's upload, ingest, pyramids) is waited
-        // for BEFORE taking it, or the holder would sit on the token while its own pictures are still crossing PCIe
+        // for BEFORE taking it, or the holder would sit on the token while its own pictures are still crossing PCIe.
+        // (Running the coarse levels -- launches that cannot fill the slots -- outside the token, beside another group's
+        // level-0 launch, was tried: hme_run_batch takes a level range for it; no gain, they slow the holder's launch.)
         stream_wait(bs);
         g_search_token.acquire(); // (released once the search has drained, below)
     }

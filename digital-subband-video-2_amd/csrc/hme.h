@@ -50,7 +50,10 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns 
 size_t hme_table_bytes(int n);
 struct StageProf;
 // prof (optional): HIP events around the level-0 launch alone (stage ST_HME_L0), for the roofline of the dominant kernel
-int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof = nullptr);
+// level_hi .. level_lo: the pyramid levels this call runs (default: all, coarse to fine); a search may be split over calls --
+// the one that starts at the coarsest level also ships the job table and clears the hand-off words
+int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof = nullptr,
+                  int level_hi = -1, int level_lo = 0);
 
 // ---- per-frame block statistics of the finished level-0 field (host controller inputs) -------------------------
 // What the reference's controller sums over the motion field of a P frame before it decides anything

@@ -1784,18 +1784,25 @@ static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
 size_t hme_table_bytes(int n) { return (size_t) n * sizeof(HmeDev); }
 
 // n independent streams of identical geometry in lockstep: every front is ONE launch for all of them
-int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof)
+int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof, int level_hi,
+                  int level_lo)
 {
     if (n <= 0) {
         return 0;
     }
-    HmeDev *ht = (HmeDev *) h_table;
-    for (int k = 0; k < n; k++) {
-        fill_hme_dev(ht[k], f[k], hp[k]);
-    }
-    HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
-    const HmeDev *tab = (const HmeDev *) d_table;
     const HmeParams &g = hp[0];
+    const bool from_top = level_hi < 0 || level_hi >= g.pyr_levels; // a call that starts the search: job table, clears
+    if (level_hi < 0 || level_hi > g.pyr_levels) {
+        level_hi = g.pyr_levels;
+    }
+    HmeDev *ht = (HmeDev *) h_table;
+    if (from_top) {
+        for (int k = 0; k < n; k++) {
+            fill_hme_dev(ht[k], f[k], hp[k]);
+        }
+        HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
+    }
+    const HmeDev *tab = (const HmeDev *) d_table;
     int nlaunch = 0;
     int fast = g_hme_fast;
     for (int k = 0; k < n; k++) {
@@ -1804,10 +1811,10 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         }
     }
     int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
-    if (g_hme_rows) { // one clear for all levels; each level's last row then re-arms the hand-off words itself
+    if (g_hme_rows && from_top) { // one clear for all levels; each level's last row then re-arms the hand-off words itself
         DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n, g.pyr_levels + 1), dim3(256), 0, s, tab, -1, nwords, 1);
     }
-    for (int level = g.pyr_levels; level >= 0; level--) {
+    for (int level = level_hi; level >= level_lo; level--) {
         int step = 1 << level;
         int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
         if (!g_hme_rows) {
@@ -1845,7 +1852,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             DSV2_LAUNCH(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
         }
     }
-    if (!g_hme_rows) {
+    if (!g_hme_rows && level_lo == 0) {
         DSV2_LAUNCH(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
     }
     HIPCHK(hipGetLastError());

@@ -59,14 +59,17 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
             "level-0 search kernel are listed (one lockstep group per launch)\n\n")
     f.write("%12s %8s %16s %16s\n" % ("grid size", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB"))
     tot_f = tot_w = nl = 0
+    gmax = max(agg["FETCH_SIZE"])
     for g in sorted(agg["FETCH_SIZE"]):
         fv, wv = agg["FETCH_SIZE"][g], agg["WRITE_SIZE"].get(g, [0.0])
         f.write("%12d %8d %16.1f %16.1f\n" % (g, len(fv), sum(fv) / len(fv), sum(wv) / len(wv)))
-        tot_f += sum(fv)
-        tot_w += sum(wv) * len(fv) / len(wv)
-        nl += len(fv)
+        if g >= 0.9 * gmax:  # the full-size launches (every stream of the group started): what the bench's timed steps launch
+            tot_f += sum(fv)
+            tot_w += sum(wv) * len(fv) / len(wv)
+            nl += len(fv)
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
-    f.write("\nmean over all %d launches: %.2f MB fetched + written per launch\n" % (nl, bytes_per_launch / 1e6))
+    f.write("\nmean over the %d full-size launches (grid >= 0.9 x %d: 176 - 192 inter pictures of a group): %.2f MB fetched + written per launch\n"
+            % (nl, gmax, bytes_per_launch / 1e6))
 json.dump({"stage": "hme_level0", "kernel": "k_hme_rows_b_fast_l0_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
            "groups": traced["config"]["groups"], "stagger": True, "phase_aligned": bool(traced["config"].get("phase_aligned_groups")),
            "bytes_per_launch": round(bytes_per_launch),
