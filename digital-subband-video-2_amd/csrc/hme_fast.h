@@ -748,7 +748,9 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     }
     unsigned best_fp = best;
     if (c.effort >= 4) {
+        bool searched_lax = false;
         if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
+            searched_lax = true;
             best = subpixel_me_fast<kPrefetchSubpelFirst>(c, S, W, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
             if (sx || sy) {
                 fpelx = lax;
@@ -756,7 +758,10 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
                 found_sub = true;
             }
         }
-        if (!found_sub && !good_enough && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
+        // (a second search around the SAME full-pel vector -- the parent average was also the best candidate -- repeats the
+        // first one operand for operand and ends where it did: no sub-pel offset, the same score; it is not run again)
+        const bool same_centre = searched_lax && fpelx == lax && fpely == lay;
+        if (!found_sub && !good_enough && !same_centre && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
             best = subpixel_me_fast<false>(c, S, W, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
         }
     }
