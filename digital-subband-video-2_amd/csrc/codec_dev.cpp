@@ -174,11 +174,11 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         qv_off[c + 1] = qv_off[c] + (size_t) scan[c].base[10];
     }
     HIPCHK(hipMalloc((void **) &qv, qv_off[3] * sizeof(int32_t)));
-    scratch.ensure((size_t) cw[0] * ch[0]);
+    scratch.ensure((size_t) cw[0] * ch[0], sbt_ll_elems(cw[0], ch[0]));
     if (encoder) {
         comp.ensure(qv_off[3]);
-        scratch_uv[0].ensure((size_t) cw[1] * ch[1]);
-        scratch_uv[1].ensure((size_t) cw[2] * ch[2]);
+        scratch_uv[0].ensure((size_t) cw[1] * ch[1], sbt_ll_elems(cw[1], ch[1]));
+        scratch_uv[1].ensure((size_t) cw[2] * ch[2], sbt_ll_elems(cw[2], ch[2]));
     }
     HIPCHK(hipMalloc((void **) &d_blockdata, nb));
     dev_zero(d_blockdata, nb);

@@ -400,8 +400,8 @@ void dec_parse(DecJob &jb)
     }
     if (!im->ready) {
         im->dev.init(meta->subsamp, meta->width, meta->height, blk_w, blk_h, 0, false);
-        im->dev.scratch_uv[0].ensure((size_t) im->dev.cw[1] * im->dev.ch[1]);
-        im->dev.scratch_uv[1].ensure((size_t) im->dev.cw[2] * im->dev.ch[2]);
+        im->dev.scratch_uv[0].ensure((size_t) im->dev.cw[1] * im->dev.ch[1], sbt_ll_elems(im->dev.cw[1], im->dev.ch[1]));
+        im->dev.scratch_uv[1].ensure((size_t) im->dev.cw[2] * im->dev.ch[2], sbt_ll_elems(im->dev.cw[2], im->dev.ch[2]));
         im->ready = true;
     }
     CodecDev &dv = im->dev;

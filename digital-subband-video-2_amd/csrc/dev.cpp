@@ -223,16 +223,20 @@ void dframe_download_full(const DFrame *d, DSV_FRAME *h, hipStream_t s)
     }
 }
 
-void SbtScratch::ensure(size_t n)
+void SbtScratch::ensure(size_t n, size_t n_ll)
 {
-    if (n <= elems) {
+    if (n_ll == 0 || n_ll > n) {
+        n_ll = n;
+    }
+    if (n <= elems && n_ll <= elems_ll) {
         return;
     }
     release();
     for (int i = 0; i < 3; i++) {
-        HIPCHK(hipMalloc((void **) &t[i], n * sizeof(int32_t)));
+        HIPCHK(hipMalloc((void **) &t[i], (i == 2 ? n : n_ll) * sizeof(int32_t)));
     }
     elems = n;
+    elems_ll = n_ll;
 }
 
 void SbtScratch::release()
@@ -243,7 +247,7 @@ void SbtScratch::release()
             t[i] = nullptr;
         }
     }
-    elems = 0;
+    elems = elems_ll = 0;
 }
 
 } // namespace dsv2

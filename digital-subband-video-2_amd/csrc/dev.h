@@ -87,10 +87,13 @@ void coef_dims(int format, int w, int h, int cw[3], int ch[3]);
 // scratch images for the transform: three int32 planes of the luma coefficient size
 struct SbtScratch {
     int32_t *t[3] = {nullptr, nullptr, nullptr};
-    size_t elems = 0;
-    void ensure(size_t n);
+    size_t elems = 0, elems_ll = 0;
+    // t[2] (row-pass temporary) holds a whole plane: n elements.  t[0] / t[1] only ever hold LL images of level >= 1, stored
+    // with the plane's row stride: (ceil(h / 2) + 1) rows of it suffice -- n_ll elements (0: as large as t[2]).
+    void ensure(size_t n, size_t n_ll = 0);
     void release();
 };
+inline size_t sbt_ll_elems(int cw, int ch) { return (size_t) cw * (size_t) ((ch + 1) / 2 + 1); }
 
 // One plane of one stream as the transform and the quantiser see it.  A device table of these
 // (one per stream and plane of a lockstep batch) lets a single launch serve every stream.
