@@ -1033,9 +1033,9 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     leg("c3_1080p_420_qp60_gop60", r3, 4, 16, 20, {"input": "pinned_host, staggered GOP phases"})
     r3.free()
     # C4: 1920x1080 4:4:4 lossless (-qp=100), every stream from its first (intra) frame; round trip through the decoder
-    s4 = min(32, S)
-    r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, 2, vids[NV + 4:NV + 5], False, seeds=[201])
-    leg("c4_1080p_444_lossless", r4, 2, 8, 10, {"frames": "P frames 2..9 of each stream (general ME routine)"})
+    s4 = min(128, S)
+    r4 = EncodeRun(hip, A, torch, W_, H_, "444", 100, 60, 10, s4, min(4, args.groups), vids[NV + 4:NV + 5], False, seeds=[201])
+    leg("c4_1080p_444_lossless", r4, 2, 8, 10, {"frames": "P frames 2..9 of each stream (4:4:4 instance of the fast level-0 search)"})
     cfgs["c4_1080p_444_lossless"]["round_trip"] = lossless_round_trip(hip, A, r4, vids[NV + 4])
     r4.free()
     return cfgs

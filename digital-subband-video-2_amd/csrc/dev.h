@@ -100,7 +100,7 @@ inline size_t sbt_ll_elems(int cw, int ch) { return (size_t) cw * (size_t) ((ch 
 struct PlaneJob {
     DPlane pic;        // working picture plane: residual in (forward level 1), reconstruction out (inverse level 1)
     int32_t *coefs;    // coefficient plane
-    int32_t *t[3];     // scratch images, each >= coefficient plane size
+    int32_t *t[3];     // scratch images with the plane's row stride: t[2] a whole plane, t[0] / t[1] the LL images (half the rows)
     const uint8_t *bd; // per-block flag bytes
     int32_t *qv;       // dense quantised values of this plane, scan order
     const DSV_MV *mvs; // motion field (P frames)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 4 alone (1080p 4:4:4 lossless, 32 streams in 2 lockstep groups, frames 0 .. 9 of each stream): one JSON line"""
+"""BASELINE config 4 alone (1080p 4:4:4 lossless, 128 streams in 4 lockstep groups, frames 0 .. 9 of each stream): one JSON line"""
 import json
 import os
 import sys
@@ -17,9 +17,9 @@ import dsvabi as A  # noqa: E402
 hip = A.load_hip()
 assert hip.dsv2hip_device_ok() == 0
 bench.bind_abi(hip, A)
-run = bench.EncodeRun(hip, A, torch, 1920, 1080, "444", 100, 60, 10, 32, 2, vids, False, seeds=[201])
+run = bench.EncodeRun(hip, A, torch, 1920, 1080, "444", 100, 60, 10, 128, 4, vids, False, seeds=[201])
 run.run(2)
 k = 8
 e = run.run(k)
-print(json.dumps({"value": round(32 * k / e, 2), "unit": "frames/s", "frames": 32 * (k + 2), "ms_per_step": round(1e3 * e / k, 2)}))
+print(json.dumps({"value": round(128 * k / e, 2), "unit": "frames/s", "frames": 128 * (k + 2), "ms_per_step": round(1e3 * e / k, 2)}))
 run.free()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/trace_c4.sh -- kernel totals of BASELINE config 4 (1080p 4:4:4 lossless, 32 streams / 2 groups) per frame
+# usage (GPU box): tools/trace_c4.sh -- kernel totals of BASELINE config 4 (1080p 4:4:4 lossless, 128 streams / 4 groups) per frame
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/c4
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c4/t -- python3 tools/ab_c4_run.py > gpurun_out/c4/run.json 2> gpurun_out/c4/run.err
