@@ -269,9 +269,21 @@ struct DecScratch { // held by ONE device round at a time (pool below); owns the
 struct DecScratchPool {
     std::mutex mu;
     std::vector<DecScratch *> idle;
+    bool primed = false;
     DecScratch *acquire(DecScratch *prefer) // (prefer: the one this thread used last, so that a group keeps its stream)
     {
         std::lock_guard<std::mutex> lk(mu);
+        if (!primed) { // the first four scratches' streams are made once, in a row, and kept (see the encoder's ScratchPool)
+            primed = true;
+            DecScratch *first[4];
+            for (int k = 0; k < 4; k++) {
+                first[k] = new DecScratch();
+                first[k]->main_stream();
+            }
+            for (int k = 3; k >= 0; k--) {
+                idle.push_back(first[k]);
+            }
+        }
         if (idle.empty()) {
             return new DecScratch();
         }
@@ -472,7 +484,7 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     DecScratchLease lease; // (the round ends with its stream drained: nothing of the scratch is in use after it)
     DecScratch &sc = *lease.sc;
     CodecDev &dv0 = jobs[ids[0]].im->dev;
-    hipStream_t bs = dv0.ensure_stream(); // (the first decoder's stream: see the encoder's note on scratch-owned streams)
+    hipStream_t bs = sc.main_stream(); // (a stream of the scratch pool, made once: see the encoder's ScratchPool)
     const size_t nb = dv0.nblocks();
     const size_t mv_bytes = nb * sizeof(DSV_MV), bd_bytes = (nb + 15) & ~(size_t) 15;
     sc.tabs.reserve((size_t) n * 8192 + 65536);

@@ -997,14 +997,43 @@ struct BatchScratch { // pinned + device memory for the job tables, the step's H
 // streams and events -- are never destroyed, so an upload left in flight by one call (EncImpl::staged_ev) can be awaited
 // by the next, from any thread.  A scratch's copy stream and copy_done event travel together: a later re-record of the
 // event on that stream covers every earlier upload on it.
+inline bool use_own_streams()
+{
+    static const bool on = !(getenv("DSV2_SCRATCH_STREAM") && atoi(getenv("DSV2_SCRATCH_STREAM")) == 0);
+    return on;
+}
+
 struct ScratchPool {
     std::mutex mu;
     std::vector<BatchScratch *> idle;
     // `prefer`: the scratch this thread used last -- a lockstep group driven by one long-lived thread keeps its scratch (and
     // with it its streams and their hardware queues) from step to step; a new thread takes whatever is idle
+    bool primed = false;
     BatchScratch *acquire(BatchScratch *prefer)
     {
         std::lock_guard<std::mutex> lk(mu);
+        if (!primed) {
+            // The first four scratches and their streams are made HERE, once, in a fixed order -- main streams first, then
+            // the copy streams -- and live for the rest of the process.  The runtime binds a stream to one of its hardware
+            // queues when it is created, by the queues' load at that moment (tools/probe/queue_pairs.cpp: sixteen streams made
+            // in a row land on queues 0 .. 7, 7 .. 0; four made beside six long-lived ones share TWO queues).  Streams that
+            // come and go with the encoder instances of a run therefore end up two to a queue sooner or later and two
+            // lockstep groups then execute one after the other; a fixed set made up front does not.
+            primed = true;
+            if (use_own_streams()) {
+                BatchScratch *first[4];
+                for (int k = 0; k < 4; k++) {
+                    first[k] = new BatchScratch();
+                    first[k]->main_stream();
+                }
+                for (int k = 0; k < 4; k++) {
+                    first[k]->ensure_copy_stream();
+                }
+                for (int k = 3; k >= 0; k--) {
+                    idle.push_back(first[k]);
+                }
+            }
+        }
         if (idle.empty()) {
             return new BatchScratch();
         }
@@ -1412,11 +1441,10 @@ void enc_batch(Job *jobs, int n)
     StageProf &prof = jobs[0].im->dev.prof;
     ScratchLease lease;
     BatchScratch &sc = *lease.sc;
-    // The step's kernels run on the stream of the batch's FIRST encoder.  (DSV2_SCRATCH_STREAM=1: on a stream owned by the
-    // scratch instead -- measured on MI355X / ROCm 7.2: two lockstep groups then execute one after the other, 19.4 against
-    // 10.8 ms per step at 8 streams in 4 groups, although each group has a stream of its own either way; kept for A/B.)
-    static const bool own_stream = getenv("DSV2_SCRATCH_STREAM") && atoi(getenv("DSV2_SCRATCH_STREAM")) == 1;
-    hipStream_t bs = own_stream ? sc.main_stream() : jobs[0].im->dev.ensure_stream();
+    // The step's kernels run on a stream that belongs to the batch scratch (made once, see ScratchPool::acquire), not on one
+    // of the encoders': a step starts and ends with that stream drained, so which stream carried an encoder's previous step
+    // does not matter.  (DSV2_SCRATCH_STREAM=0: the first encoder's stream, created with the instance: A/B.)
+    hipStream_t bs = use_own_streams() ? sc.main_stream() : jobs[0].im->dev.ensure_stream();
     sc.ensure(n);
     const int nbh = jobs[0].im->dev.nbh, nbv = jobs[0].im->dev.nbv;
 
