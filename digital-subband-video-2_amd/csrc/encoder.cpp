@@ -1635,6 +1635,7 @@ void enc_batch(Job *jobs, int n)
             f.host_mvs = nullptr; // (the field reaches the host through k_block_stats_b right behind the search: BlockStatsJob::host_mvs)
             f.host_counters = dv.h_counters;
             dv.h_counters[7] = -1; // overwritten with 0 by the search's last row (1: a row timed out); -1 left = it never finished
+            dv.h_counters[kHmeHostTailWord] = 0;
             HmeParams h;
             h.a = analysis_params(dv, jb.d.params.do_psy);
             h.effort = jb.d.params.effort;
@@ -1671,10 +1672,25 @@ void enc_batch(Job *jobs, int n)
         HIPCHK(hipMemcpyAsync(sc.h_bstats, sc.d_bstats, (size_t) n_bsj * BS_WORDS * sizeof(int), hipMemcpyDeviceToHost, bs));
     }
     t_clock.lap(1);
-    stream_wait(bs);
     if (searching) {
+        // The token is passed on when the level-0 launch has handed out its last block row (the kernel says so in the first
+        // stream's pinned counter block): what is left of it is a tail of draining wavefronts -- one row's walk, ~2 ms --
+        // whose freed slots the next group's search can take.  (Launch-per-front form, or a launch that ends first: the
+        // stream's completion.)
+        volatile int *tail = &jobs[pjobs[0]].im->dev.h_counters[kHmeHostTailWord];
+        // DSV2_SEARCH_EARLY_RELEASE: 1 (default) at the tail; 0 when the launch has finished; 2 right after it was enqueued
+        static const int early = getenv("DSV2_SEARCH_EARLY_RELEASE") ? atoi(getenv("DSV2_SEARCH_EARLY_RELEASE")) : 1;
+        if (early == 0) {
+            stream_wait(bs);
+        } else if (early == 1) {
+            while (!*tail && hipStreamQuery(bs) == hipErrorNotReady) {
+                timespec ts = {0, 100000};
+                nanosleep(&ts, nullptr);
+            }
+        }
         g_search_token.release();
     }
+    stream_wait(bs);
     t_clock.lap(2);
     for (int k = 0; k < n; k++) {
         if (jobs[k].frame) {

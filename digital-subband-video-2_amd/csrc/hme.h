@@ -37,13 +37,15 @@ struct HmeFrames {
     DSV_MV *mvf[6];        // out: one field per level, nblocks entries each
     const DSV_MV *ref_mvf; // previous frame's transmitted field or null
     DSV_MV *host_mvs = nullptr;   // batched driver only: pinned host mirror of mvf[0], filled by the search itself
-    int *host_counters = nullptr; // batched driver only: pinned host copy of counters[0..7]
+    int *host_counters = nullptr; // batched driver only: pinned host copy of counters[0..7]; word 12 (kHmeHostTailWord) of the FIRST
+                                  // stream's block is set when the level-0 launch has handed out its last block row
     int *counters;         // hme_counter_words(nbv) ints. out: [0] nintra [1] ndiff [2] eligible [3] total_err
                            // ([4],[5] global motion, [7] row-pipeline timeout flag, [16..] row progress)
 };
 
 // dsv_hme (hme.c:2001): all levels coarse to fine, asynchronous on `s`
 inline size_t hme_counter_words(int nbv) { return 16 + (size_t) nbv; }
+constexpr int kHmeHostTailWord = 12;
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns the number of front launches
 
 // lockstep variant for n streams of identical geometry; h_table (pinned) / d_table hold hme_table_bytes(n)

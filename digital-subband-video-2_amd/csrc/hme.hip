@@ -1236,6 +1236,8 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
 // block delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front does.  Every spin
 // is bounded by the wall clock and reports through counters[7] and the host's pinned counter block.
 constexpr int kHmeErrWord = 7, kHmeTicket = 8 /* 8 .. 13: one ticket counter per pyramid level */, kHmeProgress = 16;
+constexpr int kHmeExhausted = 14; // level 0: ticket partitions whose last row has been handed out (counter block of stream 0)
+constexpr int kHmeHostTail = 12;  // ... and the word of the pinned host counter block that says "all of them" (hme.h)
 
 // Which row a workgroup works on is NOT its index in the grid: every wavefront takes the next TICKET of its launch from a
 // counter (rows in row-major order across the launch's streams).  A row only ever waits for the row above it, whose
@@ -1273,6 +1275,19 @@ __device__ __forceinline__ RowTicket take_row(const HmeDev *tab, int level, int 
         const int ns = (nstreams - x + parts - 1) / parts; // streams x, x + parts, ...
         const int t = take_ticket(&tab[x].counters[kHmeTicket + level]);
         if (t < ns * nrows) {
+            if (level == 0 && t == ns * nrows - 1) {
+                // the LAST row of this partition has just been handed out; when that is true of every partition the launch
+                // has no work left to give -- from here on its wavefronts only drain -- and the host is told (pinned word 12
+                // of the first stream's counter block), so that the next lockstep group's search may start filling the
+                // slots this one frees (encoder.cpp: the search token is passed on at that point, not at the launch's end)
+                int done = 0;
+                if ((threadIdx.x & 63) == 0) {
+                    done = __hip_atomic_fetch_add(&tab[0].counters[kHmeExhausted], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (done + 1 == parts && tab[0].host_counters) {
+                        __hip_atomic_store(&tab[0].host_counters[kHmeHostTail], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
             const int row = t / ns;
             return RowTicket{x + parts * (t - row * ns), row};
         }
