@@ -24,4 +24,4 @@ tot = float(sum(out[:4])) or 1.0
 fronts = 1046.0  # nsbx + 2 + 2 (nsby - 1) + 13 at 1080p
 for k, nm in enumerate(names):
     print("%d %-48s %6.2f %%  %9.0f ticks per sweep  %7.1f per front" % (k, nm, out[k] / tot * 100, out[k] / sweeps, out[k] / sweeps / fronts), file=sys.stderr)
-print("sweeps %d, %.0f ticks per sweep (s_memtime: 100 MHz)" % (out[4], tot / sweeps), file=sys.stderr)
+print("sweeps %d, %.0f ticks per sweep (s_memtime ticks: the shader clock, ~2.2 GHz here)" % (out[4], tot / sweeps), file=sys.stderr)
