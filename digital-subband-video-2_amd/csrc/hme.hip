@@ -1167,7 +1167,18 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
 static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
 // DSV2_HME_ROWS=0 falls back to one launch per anti-diagonal front in the batched driver
 static int g_hme_rows = getenv("DSV2_HME_ROWS") ? atoi(getenv("DSV2_HME_ROWS")) : 1;
-static int g_hme_fence = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 1; // 1 acquire, 2 release, 3 both
+// DSV2_HME_FENCE: bit 0 = an agent-scope ACQUIRE fence behind every row hand-off poll, bit 1 = an agent-scope RELEASE before
+// every publication.  Default 0 since round 3.  Neither is needed by the protocol: everything a wavefront reads that another
+// wavefront of the SAME launch wrote -- the progress words and the 8-byte vector heads -- is read by agent-scope atomic
+// loads (sc1: coherent for the location itself, no stale L1 / per-XCD L2 line can answer them), written by agent-scope
+// atomic stores that the producer has drained (s_waitcnt vmcnt(0)) before it publishes, and the vector loads are
+// control-dependent on the poll (a wavefront does not issue them before the poll's value is back).  Nothing else a block
+// reads is written during the launch (parent-level and previous-frame fields, pictures: earlier launches).  What the
+// acquire cost: `s_waitcnt vmcnt(0); buffer_inv sc1` in front of every block, i.e. the CU's L1 emptied 8 160 times a
+// picture under the other wavefronts' feet -- 11 % of the search's span in the four-group bench (5 590 -> 5 990 frames/s on
+// the same box).  Both forms are run against the reference at the benchmarked operating point
+// (tests/test_gpu_operating_point.py), tools/stress_hme.sh repeats the stage test under each.
+static int g_hme_fence = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 0;
 
 // true when hme_block_fast() handles this block (see hme_fast.h preconditions)
 __device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, int j)
