@@ -1212,7 +1212,9 @@ __global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, in
     int i = bi << level, j = bj << level;
     if (allow_fast && fast_path_ok(c, level, i, j)) {
         int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
-        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy);
+        RowAcc acc;
+        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
+        acc.flush(c.counters);
     } else {
         hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
     }
@@ -1233,7 +1235,9 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
     int i = bi << level, j = bj << level;
     if (allow_fast && fast_path_ok(c, level, i, j)) {
         int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
-        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy);
+        RowAcc acc;
+        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
+        acc.flush(c.counters);
     } else {
         hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
     }
@@ -1385,6 +1389,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
     }
 #endif
     int pcx = 0, pcy = 0; // where the previous block of this row ended up: centre of the next block's LDS windows
+    RowAcc acc;           // this row's share of the frame's counters (flushed behind the loop)
     for (int bi = 0; bi < nbx; bi++) {
         if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
             // the row above never got there (or another row gave up): tell the host directly -- the level's
@@ -1402,7 +1407,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
         if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast<LV, CS>(x, level, i, j, gx, gy, S, pcx, pcy);
+            hme_block_fast<LV, CS>(x, level, i, j, gx, gy, S, pcx, pcy, acc);
         } else if constexpr (!FAST_ONLY) {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
             pcx = pcy = 0;
@@ -1424,6 +1429,9 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         }
     }
 #endif
+    // this row's counter sums, drained before the row counts as arrived (the last row to arrive hands the counters on)
+    acc.flush(c.counters);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // arrival of this row; its vectors and counter updates were drained above
     int done = 0;
     if ((threadIdx.x & 63) == 0) {

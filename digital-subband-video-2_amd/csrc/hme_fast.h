@@ -708,6 +708,31 @@ struct NbPre {
     bool colo_ok;
 };
 
+// The four per-frame sums the level-0 blocks feed (hme.c:1825-1832: intra blocks, scene-change votes, eligible blocks, total
+// error), carried by the wavefront along its block row and added to the stream's counters ONCE, at the row's end: as up to
+// four atomics per block they sat in front of every block's drain-and-publish.
+struct RowAcc {
+    int intra = 0, ndiff = 0, elig = 0, err = 0;
+    __device__ __forceinline__ void flush(int *counters)
+    {
+        if ((threadIdx.x & 63) == 0) {
+            if (intra) {
+                atomicAdd(&counters[0], intra);
+            }
+            if (ndiff) {
+                atomicAdd(&counters[1], ndiff);
+            }
+            if (elig) {
+                atomicAdd(&counters[2], elig);
+            }
+            if (err) {
+                atomicAdd(&counters[3], err);
+            }
+        }
+        intra = ndiff = elig = err = 0;
+    }
+};
+
 // neighbour difference of the current block (vector cx,cy not yet stored) -- dsv.c:403
 __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, int cx, int cy, int &dx, int &dy)
 {
@@ -732,7 +757,7 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
 // CS: chroma shift of both axes -- 1 = 4:2:0 (a block's chroma is 8x8: one pixel per lane, its 2x2 quads on lanes 0..31),
 // 0 = 4:4:4 (16x16 like the luma: every lane owns the quad (qi, qj) of U and of V)
 template <int CS, class Ctx>
-__device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, const Win &W, int &pcx, int &pcy, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
+__device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, const Win &W, int &pcx, int &pcy, RowAcc &acc, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
                                   unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, const SubpelLoads &sp_pre)
 {
@@ -1160,19 +1185,11 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     pcy = sarx((int) mv.u.mv.y, 2);
     if (lane == 0) {
         st_mv_final(c, out, mv);
-        if (is_intra) {
-            atomicAdd(&c.counters[0], 1);
-        }
-        if (add_ndiff) {
-            atomicAdd(&c.counters[1], add_ndiff);
-        }
-        if (best > 0) {
-            atomicAdd(&c.counters[2], 1);
-        }
-        if (add_err) {
-            atomicAdd(&c.counters[3], add_err);
-        }
     }
+    acc.intra += is_intra;
+    acc.ndiff += add_ndiff;
+    acc.elig += best > 0 ? 1 : 0;
+    acc.err += add_err;
 }
 
 
@@ -1188,7 +1205,7 @@ constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {
 // LV: what is known about the level at compile time -- 0: it is level 0; 1: it is a coarser level (the sub-pel search and
 // the mode decision are not even compiled in: a third of the registers); -1: decided at run time
 template <bool FULL, int LV, int CS, class Ctx>
-__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
+__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy, RowAcc &acc)
 {
     const int level = LV == 0 ? 0 : level_rt;
     const int lane = threadIdx.x & 63;
@@ -1588,20 +1605,20 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     pre.t_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 4);
     pre.colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
     pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
-    hme_block_fast_l0<CS>(c, i, j, S, W, pcx, pcy, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
+    hme_block_fast_l0<CS>(c, i, j, S, W, pcx, pcy, acc, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
                       avg_src, psy, pre, sp_pre);
     }
 }
 
 template <int LV, int CS = 1, class Ctx>
-__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy)
+__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy, RowAcc &acc)
 {
     const int level = LV == 0 ? 0 : level_rt;
     const DPlane &src = c.src[level];
     int bx = (i * 16) >> level, by = (j * 16) >> level;
     if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_fast_t<true, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast_t<true, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
     } else {
-        hme_block_fast_t<false, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy);
+        hme_block_fast_t<false, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
     }
 }
