@@ -600,23 +600,19 @@ struct GlobalView {
     __device__ __forceinline__ void st(int row, int col, uint32_t v) const { *(uint32_t *) (dp.data + (ptrdiff_t) row * dp.stride + col) = v; }
 };
 // ... or the LDS ring of a plane-resident sweep (ring_sweep below): one 64-byte ring per pixel row holding a
-// sliding 64-column window.  Rows outside the plane are never filtered (the filters skip y < 4 and
-// y > h - 4), so their loads are clamped and their stores dropped.
+// sliding 64-column window, plus guard rows above and below the plane.
 struct RingView {
     static constexpr bool kStoreAll = true; // LDS: cheaper to write the whole cross back than to branch per row
-    uint8_t *ring;
+    static constexpr int kGuardTop = 3, kGuardRows = 7; // a cell's cross reaches 3 rows above and 4 below the plane's rows
+    uint8_t *ring; // row 0 of the plane (kGuardTop rows into the allocation)
     int h;
-    __device__ __forceinline__ uint32_t ld(int row, int col) const
-    {
-        row = row < 0 ? 0 : (row >= h ? h - 1 : row);
-        return *(const uint32_t *) (ring + row * 64 + (col & 63));
-    }
-    __device__ __forceinline__ void st(int row, int col, uint32_t v) const
-    {
-        if (row >= 0 && row < h) {
-            *(uint32_t *) (ring + row * 64 + (col & 63)) = v;
-        }
-    }
+    // Rows outside the plane are never filtered (the filters skip y < 4 and y > h - 4): what is loaded from the guard rows
+    // is never used and what is stored there never retired, so neither is clamped or tested.
+    __device__ __forceinline__ uint32_t ld(int row, int col) const { return *(const uint32_t *) (ring + row * 64 + (col & 63)); }
+    __device__ __forceinline__ void st(int row, int col, uint32_t v) const { *(uint32_t *) (ring + row * 64 + (col & 63)) = v; }
+    // two pixels (col even)
+    __device__ __forceinline__ uint32_t ld16(int row, int col) const { return *(const uint16_t *) (ring + row * 64 + (col & 63)); }
+    __device__ __forceinline__ void st16(int row, int col, uint32_t v) const { *(uint16_t *) (ring + row * 64 + (col & 63)) = (uint16_t) v; }
 };
 
 struct Tile {
@@ -1197,6 +1193,349 @@ __device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_
     }
 }
 
+// ---- two lanes per cell (the batched luma sweeps) ------------------------------------------------------------------
+// The sweep's critical path is one cell routine per front, run by one wavefront per SIMD at the 4 - 5 clocks per
+// instruction a lone wavefront issues at.  Here an even / odd lane pair shares a cell: lane p owns the cell's pixel rows
+// 2p, 2p + 1 for the horizontal pass and its pixel columns 2p, 2p + 1 for the vertical one (every 11-sample line is
+// filtered exactly as before, by one lane), the 2 x 2 hand-over between the passes and the cell's joint statistics go
+// through DPP lane swaps.  Half the instructions per lane, two wavefronts per SIMD.
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); } // quad_perm [1,0,3,2]
+
+struct PairTile {
+    int h[2][12]; // my two pixel rows y + 2p + a, columns x - 4 .. x + 7
+    int o[2][7];  // my two pixel columns x + 2p + c in the rows above (y - 3 .. y - 1) and below (y + 4 .. y + 7) the cell
+    bool rows_dirty, outer_dirty;
+
+    __device__ __forceinline__ void load(const RingView &view, int x, int y, int p)
+    {
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                uint32_t v = view.ld(y + 2 * p + a, x - 4 + 4 * d);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    h[a][4 * d + k] = (int) ((v >> (8 * k)) & 0xffu);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            uint32_t v = view.ld16(y + (k < 3 ? k - 3 : k + 1), x + 2 * p);
+            o[0][k] = (int) (v & 0xffu);
+            o[1][k] = (int) (v >> 8);
+        }
+        rows_dirty = outer_dirty = false;
+    }
+
+    __device__ __forceinline__ void store(const RingView &view, int x, int y, int p) const
+    {
+        if (__any(rows_dirty)) {
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    view.st(y + 2 * p + a, x - 4 + 4 * d,
+                            (uint32_t) h[a][4 * d] | ((uint32_t) h[a][4 * d + 1] << 8) | ((uint32_t) h[a][4 * d + 2] << 16) |
+                                ((uint32_t) h[a][4 * d + 3] << 24));
+                }
+            }
+        }
+        if (__any(outer_dirty)) { // rows y - 2, y - 1, y + 4, y + 5, y + 6 (the vertical pass leaves y - 3 and y + 7 alone)
+#pragma unroll
+            for (int k = 1; k < 6; k++) {
+                view.st16(y + (k < 3 ? k - 3 : k + 1), x + 2 * p, (uint32_t) o[0][k] | ((uint32_t) o[1][k] << 8));
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void hfilter2(PairTile &T, const DPlane &dp, int x, bool edge, int tE, int tM, bool on)
+{
+    on = on & !(x < 4 || x > dp.w - 4 || (edge && tE <= 0) || tM <= 0);
+    tE = edge ? tE : tM;
+    tE = on ? tE : 0;
+    tM = on ? tM : 0;
+    bool in_edge = x < dp.w - 8;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        int l[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            l[k] = T.h[a][1 + k];
+        }
+        bool hit = line_filter(l, in_edge, tE, tM);
+#pragma unroll
+        for (int k = 1; k < 10; k++) {
+            T.h[a][1 + k] = l[k];
+        }
+        T.rows_dirty |= hit;
+    }
+}
+
+__device__ __forceinline__ void vfilter2(PairTile &T, const DPlane &dp, int y, int p, bool edge, int tE, int tM, bool on)
+{
+    on = on & !(y < 4 || y > dp.h - 4 || (edge && tE <= 0) || tM <= 0);
+    tE = edge ? tE : tM;
+    tE = on ? tE : 0;
+    tM = on ? tM : 0;
+    bool in_edge = y < dp.h - 8;
+    // rows -> columns: of the cell's four rows I hold two; the partner's two, in MY columns, come over
+    int mine[2][2], recv[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            mine[a][c] = p ? T.h[a][6 + c] : T.h[a][4 + c];
+            recv[a][c] = pair_swap(p ? T.h[a][4 + c] : T.h[a][6 + c]);
+        }
+    }
+    bool hit = false;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        int l[11];
+        l[0] = T.o[c][0];
+        l[1] = T.o[c][1];
+        l[2] = T.o[c][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            l[3 + a] = p ? recv[a][c] : mine[a][c];
+            l[5 + a] = p ? mine[a][c] : recv[a][c];
+        }
+        l[7] = T.o[c][3];
+        l[8] = T.o[c][4];
+        l[9] = T.o[c][5];
+        l[10] = T.o[c][6];
+        hit |= line_filter(l, in_edge, tE, tM);
+        T.o[c][1] = l[1];
+        T.o[c][2] = l[2];
+        T.o[c][3] = l[7];
+        T.o[c][4] = l[8];
+        T.o[c][5] = l[9];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            mine[a][c] = p ? l[5 + a] : l[3 + a];
+            recv[a][c] = p ? l[3 + a] : l[5 + a]; // the partner's rows, my columns: goes back
+        }
+    }
+    // columns -> rows
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            int got = pair_swap(recv[a][c]); // my rows, the partner's columns
+            T.h[a][4 + c] = p ? got : mine[a][c];
+            T.h[a][6 + c] = p ? mine[a][c] : got;
+        }
+    }
+    hit |= (bool) pair_swap((int) hit);
+    T.rows_dirty |= hit;
+    T.outer_dirty |= hit;
+}
+
+#define PCELL(a, xx) T.h[a][4 + (xx)]
+__device__ __forceinline__ void artf2(const PairTile &T, int p, int &sh, int &sv, int &slh, int &slv) // bmc.c:224-270
+{
+    sh = sv = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x += 2) {
+        int x0 = PCELL(0, x), x1 = PCELL(0, x + 1), x2 = PCELL(1, x), x3 = PCELL(1, x + 1);
+        int hh = absdiff(x0 + x3, x1 + x2) >> 1;
+        sh += absdiff(x0 + x2, x1 + x3) + hh;
+        sv += absdiff(x0 + x1, x2 + x3) + hh;
+    }
+    sh += pair_swap(sh);
+    sv += pair_swap(sv);
+    int dA = (PCELL(0, 0) + PCELL(0, 1) + PCELL(1, 0) + PCELL(1, 1) + 2) >> 2;
+    int dB = (PCELL(0, 2) + PCELL(0, 3) + PCELL(1, 2) + PCELL(1, 3) + 2) >> 2;
+    int oA = pair_swap(dA), oB = pair_swap(dB);
+    int d0 = p ? oA : dA, d1 = p ? oB : dB, d2 = p ? dA : oA, d3 = p ? dB : oB;
+    int hh = absdiff(d0 + d3, d1 + d2) >> 1;
+    slh = absdiff(d0 + d2, d1 + d3) + hh;
+    slv = absdiff(d0 + d1, d2 + d3) + hh;
+}
+
+__device__ __forceinline__ unsigned dsff2(const PairTile &T, int p)
+{
+    int dA = (PCELL(0, 0) + PCELL(0, 1) + PCELL(1, 0) + PCELL(1, 1) + 2) >> 2;
+    int dB = (PCELL(0, 2) + PCELL(0, 3) + PCELL(1, 2) + PCELL(1, 3) + 2) >> 2;
+    int oA = pair_swap(dA), oB = pair_swap(dB);
+    int d[4] = {p ? oA : dA, p ? oB : dB, p ? dA : oA, p ? dB : oB};
+    return dsff_d(d);
+}
+
+// de-gradient sharpening (bmc.c:276) of the cell, eight of its pixels per lane; both lanes of a pair take the same path
+__device__ __forceinline__ void degrad2(PairTile &T)
+{
+    int px[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        px[k] = PCELL(k >> 2, k & 3);
+    }
+    int lo = 16, hi = -1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo = min(lo, px[k] >> 4);
+        hi = max(hi, px[k] >> 4);
+    }
+    lo = min(lo, pair_swap(lo));
+    hi = max(hi, pair_swap(hi));
+    if (lo >= hi) {
+        return;
+    }
+    int nlo = 0, nhi = 0, slo = 0, shi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int b = px[k] >> 4;
+        if (b == lo) {
+            nlo++;
+            slo += px[k];
+        }
+        if (b == hi) {
+            nhi++;
+            shi += px[k];
+        }
+    }
+    nlo += pair_swap(nlo);
+    nhi += pair_swap(nhi);
+    slo += pair_swap(slo);
+    shi += pair_swap(shi);
+    int alo = slo / nlo, ahi = shi / nhi;
+    if (alo == 0) {
+        alo = 1;
+    }
+    if (ahi == 0) {
+        ahi = 1;
+    }
+    int t = (alo + ahi + 1) >> 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int os = px[k];
+        if (os < t) {
+            px[k] = (os + (nlo * (alo - os)) / 16) & 0xff;
+        } else if (os > t) {
+            px[k] = (os + (nhi * (ahi - os)) / 16) & 0xff;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        PCELL(k >> 2, k & 3) = px[k];
+    }
+    T.rows_dirty = true;
+}
+
+__device__ void intra_cell2(const RingView &view, const DPlane &dp, const FilterParams &f, const uint8_t *bd, int i, int j, int p, int nsbx, int nsby)
+{
+    int x = i * 4, y = j * 4;
+    bool live = !(y + 4 >= dp.h || x + 4 >= dp.w);
+    int flags = live ? bd[scale_div(i, f.nbh, nsbx) + scale_div(j, f.nbv, nsby) * f.nbh] : DSV_IS_RINGING;
+    live = live & !(flags & DSV_IS_RINGING);
+    if (!__any(live)) { // nothing to do for the whole wavefront
+        return;
+    }
+    PairTile T;
+    T.load(view, x, y, p);
+    int sh, sv, shl, svl;
+    artf2(T, p, sh, sv, shl, svl);
+    int mx = max(sh, sv);
+    live = live & (mx < 256 && mx > 8);
+    int tt = 32;
+    {
+        int td = (int) dsff2(T, p);
+        td = (flags & DSV_IS_STABLE) ? (td * 5 >> 2) : td;
+        tt = (flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE)) ? td : (tt >> 2);
+    }
+    tt = tt * 2 / 3;
+    tt = (tt * f.q) >> 12;
+    tt = clampi(tt, 0, f.fthresh);
+    hfilter2(T, dp, x, false, tt, tt, live);
+    vfilter2(T, dp, y, p, false, tt, tt, live);
+    tt = sh > sv ? (3 * sh + sv) : (3 * sv + sh);
+    tt = curve_tex(tt);
+    tt = 16 + ((tt + 2) >> 2);
+    tt = (tt * f.q) >> 12;
+    tt = clampi(tt, 0, f.fthresh);
+    hfilter2(T, dp, x, false, tt, tt, live);
+    vfilter2(T, dp, y, p, false, tt, tt, live);
+    T.store(view, x, y, p);
+}
+
+__device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const FilterParams &f, const CellRec &rec, int fx, int fy, int i, int j, int p)
+{
+    int x = i * 4, y = j * 4;
+    uint32_t flags = rec.flags;
+    bool live = !(y + 4 >= dp.h || (flags & (1u << DSV_MV_BIT_SKIP)) || x + 4 >= dp.w);
+    bool edgeh = (x & (f.blk_w - 1)) == 0, edgehs = (x & (f.blk_w / 2 - 1)) == 0;
+    bool edgev = (y & (f.blk_h - 1)) == 0, edgevs = (y & (f.blk_h / 2 - 1)) == 0;
+    int mvx = mvx_of(rec.all), mvy = mvy_of(rec.all);
+    int amx = abs(mvx), amy = abs(mvy);
+    bool intra = (flags & (1u << DSV_MV_BIT_INTRA)) != 0;
+    int ndx = 0, ndy = 0;
+    if (f.do_filter) {
+        neighbordif2(rec, fx, fy, ndx, ndy);
+    }
+    bool filt = !intra && (ndx || ndy);
+    bool sharp = !intra && f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8;
+    live = live & (intra | filt | sharp);
+    if (!__any(live)) { // nothing to do for the whole wavefront
+        return;
+    }
+    PairTile T;
+    T.load(view, x, y, p);
+    // the two passes and their thresholds, by block type (bmc.c:527-596): as luma_cell_rec
+    bool h_on, v_on, eh, ev;
+    int hE, hM, vE, vM;
+    {
+        int tH = clampi((64 * f.q) >> 12, 2, 32), tL = clampi((32 * f.q) >> 12, 2, 32);
+        bool part = rec.submask != DSV_MASK_ALL_INTRA;
+        bool ieh = edgeh | (part & edgehs), iev = edgev | (part & edgevs);
+        bool eprm = (flags & (1u << DSV_MV_BIT_EPRM)) != 0;
+        int tndc = (ndx + ndy + 1) >> 1;
+        int sh, sv, shl, svl, tt;
+        artf2(T, p, sh, sv, shl, svl);
+        int n_dx = ndx, n_dy = ndy;
+        bool mixed = sh < 2 * sv && sv < 2 * sh;
+        {
+            int mdx = ndx < amx ? ndx >> 1 : ndx, mdy = ndy < amy ? ndy >> 1 : ndy;
+            int shl2 = shl > 128 ? 0 : 128 - shl, svl2 = svl > 128 ? 0 : 128 - svl;
+            int ix = min(amx, 32), iy = min(amy, 32);
+            int tm = ((sh * (32 - iy) + shl2 * iy) + 16) >> 5;
+            tm += ((sv * (32 - ix) + svl2 * ix) + 16) >> 5;
+            tm = (tm + 1) >> 1;
+            tm = (mdx < amy && mdy < amx) ? 0 : tm;
+            tt = mixed ? tm : ((sh + sv + 1) >> 1);
+            n_dx = mixed ? mdx : ndx;
+            n_dy = mixed ? mdy : ndy;
+        }
+        tt = (tt * tndc + 4) >> 3;
+        tt = (min(tt, f.fthresh) * f.q) >> 12;
+        int addx = (min(n_dy, f.fthresh) * f.q) >> 12;
+        int addy = (min(n_dx, f.fthresh) * f.q) >> 12;
+        bool v_only = sh > 2 * sv || amy > 2 * amx;
+        bool h_only = !v_only && (sv > 2 * sh || amx > 2 * amy);
+        h_on = live & (intra | (filt & !v_only));
+        v_on = live & (intra | (filt & !h_only));
+        eh = intra ? ieh : (edgeh | eprm);
+        ev = intra ? iev : (edgev | eprm);
+        hE = intra ? tH : tt + addx;
+        hM = intra ? tL : tt;
+        vE = intra ? tH : tt + addy;
+        vM = intra ? tL : tt;
+    }
+    if (__any(h_on)) {
+        hfilter2(T, dp, x, eh, hE, hM, h_on);
+    }
+    if (__any(v_on)) {
+        vfilter2(T, dp, y, p, ev, vE, vM, v_on);
+    }
+    if (__any(live & sharp)) {
+        if (live & sharp) {
+            degrad2(T);
+        }
+    }
+    T.store(view, x, y, p);
+}
+
 // wavefront sweep helper: front t holds the cells (i, j) with i + 2j == t
 template <class Body> __device__ __forceinline__ void sweep_fronts(int nx, int ny, Body body)
 {
@@ -1222,7 +1561,7 @@ template <class Body> __device__ __forceinline__ void sweep_fronts(int nx, int n
 // rows that are active on a front is at most (nsbx + 14) / 2 + 1 rows wide).
 __device__ __forceinline__ bool ring_eligible(const DPlane &dp, int nthreads, size_t lds_bytes)
 {
-    return (dp.w & 3) == 0 && (dp.h & 3) == 0 && dp.w >= 64 && (size_t) dp.h * 64 <= lds_bytes && (dp.w / 4 + 14) / 2 + 1 <= nthreads;
+    return (dp.w & 3) == 0 && (dp.h & 3) == 0 && dp.w >= 64 && (size_t) (dp.h + RingView::kGuardRows) * 64 <= lds_bytes && (dp.w / 4 + 14) / 2 + 1 <= nthreads;
 }
 
 // cell(ic, j) filters one cell; ahead(ic, j) is told which cell this thread will filter four fronts later so
@@ -1314,6 +1653,75 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
     __syncthreads();
 }
 
+// the same sweep with a lane pair per cell (cell(ic, j, p): lane p of the pair): thread pair = cell row mod (blockDim / 2),
+// each lane retires and fetches the columns of its own two pixel rows
+template <class CellFn, class AheadFn>
+__device__ __forceinline__ void ring_sweep2(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead)
+{
+#ifdef DSV2_FILTER_PROF
+    unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
+    const int nsbx = dp.w / 4, nsby = dp.h / 4;
+    const int tid = (int) threadIdx.x >> 1, nthr = (int) blockDim.x >> 1, p = (int) threadIdx.x & 1;
+    const int t_last = (nsbx + 2) + 2 * (nsby - 1);
+    uint32_t pend[2] = {0, 0};
+    int pend_row = -1, pend_col = 0;
+    for (int t = -12; t <= t_last; t++) {
+        int jlo = t - (nsbx + 2) > 0 ? (t - (nsbx + 2) + 1) >> 1 : 0;
+        int jhi = (t + 12) >> 1;
+        jhi = jhi < nsby - 1 ? jhi : nsby - 1;
+        int j = jlo + ((tid - jlo) & (nthr - 1));
+        bool active = j <= jhi;
+        int ic = t - 2 * j;
+        if (pend_row >= 0) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                *(uint32_t *) (ring + (pend_row + r) * 64 + (pend_col & 63)) = pend[r];
+            }
+            pend_row = -1;
+        }
+        FILT_MARK(0);
+        if (active) {
+            const int row0 = 4 * j + 2 * p;
+            int g = 4 * ic - 12;
+            if (g >= 0 && g < dp.w) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    *(gu32w_t) (dp.data + (ptrdiff_t) (row0 + r) * dp.stride + g) = *(const uint32_t *) (ring + (row0 + r) * 64 + (g & 63));
+                }
+            }
+            if (ic + 4 >= 0 && ic + 4 < nsbx) {
+                ahead(ic + 4, j);
+            }
+            g = 4 * ic + 48;
+            if (g >= 0 && g < dp.w) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    pend[r] = *(gu32_t) (dp.data + (ptrdiff_t) (row0 + r) * dp.stride + g);
+                }
+                pend_row = row0;
+                pend_col = g;
+            }
+            FILT_MARK(1);
+            if (ic >= 0 && ic < nsbx) {
+                cell(ic, j, p);
+            }
+        }
+        FILT_MARK(2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        FILT_MARK(3);
+    }
+#ifdef DSV2_FILTER_PROF
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&g_filt_prof[k], prof_acc[k]);
+        }
+        atomicAdd(&g_filt_prof[4], 1ull);
+    }
+#endif
+    __syncthreads();
+}
+
 // grid = 3 workgroups: luma filter, U chroma filter, V chroma filter
 __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict__ vecs, FilterParams f, Planes3 pl)
 {
@@ -1345,14 +1753,26 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
     if (c == 0) {
         int nsbx = dp.w / 4, nsby = dp.h / 4;
         if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
-            RingView view{dyn_lds, dp.h};
+            uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
+            RingView view{ring0, dp.h};
             // the block record of the cell at hand and, fetched one front early, of the next one
             CellRec cur = {}, nxt = {};
             int cur_key = -1, nxt_key = -1;
+            // cell -> block (bmc.c:505-506 scales the cell index): a thread stays on its cell row, and with 16-pixel blocks
+            // on a width that is a multiple of 16 four cells make a block
+            const bool quarter_x = f.nbh * 4 == nsbx;
+            int fy_j = -1, fy_v = 0;
+            auto row_block = [&](int j) {
+                if (j != fy_j) {
+                    fy_v = scale_div(j, f.nbv, nsby);
+                    fy_j = j;
+                }
+                return fy_v;
+            };
             ring_sweep(
-                dp, dyn_lds,
+                dp, ring0,
                 [&](int i, int j) {
-                    int fx = scale_div(i, f.nbh, nsbx), fy = scale_div(j, f.nbv, nsby), key = fx + fy * f.nbh;
+                    int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
                     if (key != cur_key) {
                         cur = key == nxt_key ? nxt : fetch_cell_rec(vecs, f.nbh, fx, fy);
                         cur_key = key;
@@ -1360,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
                     luma_cell_rec(view, dp, f, cur, fx, fy, i, j);
                 },
                 [&](int i, int j) {
-                    int fx = scale_div(i, f.nbh, nsbx), fy = scale_div(j, f.nbv, nsby), key = fx + fy * f.nbh;
+                    int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
                     if (key != cur_key && key != nxt_key) {
                         nxt = fetch_cell_rec(vecs, f.nbh, fx, fy);
                         nxt_key = key;
@@ -1374,6 +1794,78 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
     }
 }
 
+// the same with a lane pair per luma cell: 512 threads (the chroma workgroups use all of them as block rows)
+__global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
+{
+    extern __shared__ uint8_t dyn_lds[];
+    const McJob &jb = tab[blockIdx.y];
+    int c = blockIdx.x;
+    const DPlane dp = jb.res.p[c];
+    const FilterParams f = jb.f;
+    const DSV_MV *vecs = jb.mvs;
+    if (f.lossless) {
+        return;
+    }
+    if (c == 0) {
+        int nsbx = dp.w / 4, nsby = dp.h / 4;
+        if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
+            uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
+            RingView view{ring0, dp.h};
+            CellRec cur = {}, nxt = {};
+            int cur_key = -1, nxt_key = -1;
+            // cell -> block (bmc.c:505-506 scales the cell index): a thread stays on its cell row, and with 16-pixel blocks
+            // on a width that is a multiple of 16 four cells make a block
+            const bool quarter_x = f.nbh * 4 == nsbx;
+            int fy_j = -1, fy_v = 0;
+            auto row_block = [&](int j) {
+                if (j != fy_j) {
+                    fy_v = scale_div(j, f.nbv, nsby);
+                    fy_j = j;
+                }
+                return fy_v;
+            };
+            ring_sweep2(
+                dp, ring0,
+                [&](int i, int j, int p) {
+                    int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
+                    if (key != cur_key) {
+                        cur = key == nxt_key ? nxt : fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        cur_key = key;
+                    }
+                    luma_cell_rec2(view, dp, f, cur, fx, fy, i, j, p);
+                },
+                [&](int i, int j) {
+                    int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
+                    if (key != cur_key && key != nxt_key) {
+                        nxt = fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        nxt_key = key;
+                    }
+                });
+        } else {
+            sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
+        }
+    } else {
+        sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
+    }
+}
+
+__global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
+{
+    extern __shared__ uint8_t dyn_lds[];
+    const McJob &jb = tab[blockIdx.x];
+    const DPlane dp = jb.res.p[0];
+    const FilterParams f = jb.f;
+    const uint8_t *bd = jb.bd;
+    int nsbx = dp.w / 4, nsby = dp.h / 4;
+    if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
+        uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
+            RingView view{ring0, dp.h};
+        ring_sweep2(dp, ring0, [&](int i, int j, int p) { intra_cell2(view, dp, f, bd, i, j, p, nsbx, nsby); }, [](int, int) {});
+    } else {
+        sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
+    }
+}
+
 __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
@@ -1383,8 +1875,9 @@ __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict_
     const uint8_t *bd = jb.bd;
     int nsbx = dp.w / 4, nsby = dp.h / 4;
     if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
-        RingView view{dyn_lds, dp.h};
-        ring_sweep(dp, dyn_lds, [&](int i, int j) { intra_cell(view, dp, f, bd, i, j, nsbx, nsby); }, [](int, int) {});
+        uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
+            RingView view{ring0, dp.h};
+        ring_sweep(dp, ring0, [&](int i, int j) { intra_cell(view, dp, f, bd, i, j, nsbx, nsby); }, [](int, int) {});
     } else {
         sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
@@ -1508,10 +2001,19 @@ static unsigned ring_lds_bytes(int luma_h)
     if (!raised) { // more than the default 64 KB of dynamic LDS has to be asked for (gfx950 has 160 KB per CU)
         HIPCHK(hipFuncSetAttribute((const void *) k_inter_filters_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *) k_intra_filter_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_inter_filters_b2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_intra_filter_b2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         raised = true;
     }
-    size_t b = (size_t) luma_h * 64;
+    size_t b = (size_t) (luma_h + RingView::kGuardRows) * 64;
     return (on && b <= 150 * 1024) ? (unsigned) b : 0u;
+}
+
+// DSV2_FILTER_PAIR=0: one lane per luma cell (256 threads) instead of a lane pair (512)
+static bool filter_pair()
+{
+    static int on = getenv("DSV2_FILTER_PAIR") ? atoi(getenv("DSV2_FILTER_PAIR")) : 1;
+    return on != 0;
 }
 
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
@@ -1527,7 +2029,11 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+            if (filter_pair()) {
+                DSV2_LAUNCH(k_inter_filters_b2, dim3(3, n), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+            } else {
+                DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+            }
         }
     }
 }
@@ -1538,7 +2044,11 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
     if (n > 0) {
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+            if (filter_pair()) {
+                DSV2_LAUNCH(k_inter_filters_b2, dim3(3, n), dim3(512), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+            } else {
+                DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+            }
         }
     }
 }
@@ -1546,7 +2056,11 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+        if (filter_pair()) {
+            DSV2_LAUNCH(k_intra_filter_b2, dim3(n), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+        } else {
+            DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+        }
     }
 }
 

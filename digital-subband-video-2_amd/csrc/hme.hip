@@ -1179,6 +1179,8 @@ static int g_hme_rows = getenv("DSV2_HME_ROWS") ? atoi(getenv("DSV2_HME_ROWS")) 
 // the same box).  Both forms are run against the reference at the benchmarked operating point
 // (tests/test_gpu_operating_point.py), tools/stress_hme.sh repeats the stage test under each.
 static int g_hme_fence = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 0;
+// issue priority of the search wavefronts while they work on a block (s_setprio; 0 while they wait for the row above)
+static int g_hme_prio = getenv("DSV2_HME_PRIO") ? atoi(getenv("DSV2_HME_PRIO")) & 3 : 0;
 
 // true when hme_block_fast() handles this block (see hme_fast.h preconditions)
 __device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, int j)
@@ -1400,6 +1402,13 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
             return;
         }
         HME_MARK(S, 0);
+        if ((allow_fast & 24) == 24) {
+            __builtin_amdgcn_s_setprio(3);
+        } else if (allow_fast & 16) {
+            __builtin_amdgcn_s_setprio(2);
+        } else if (allow_fast & 8) {
+            __builtin_amdgcn_s_setprio(1);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // no neighbour load may move above the poll
         if (allow_fast & 2) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1419,6 +1428,9 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((threadIdx.x & 63) == 0) {
             __hip_atomic_store(&progress[bj], (unsigned) bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (allow_fast & 24) {
+            __builtin_amdgcn_s_setprio(0);
         }
         HME_MARK(S, 9);
     }
@@ -1869,7 +1881,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             if (prof && level == 0) {
                 prof->begin(s, ST_HME_L0);
             }
-            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1), n < g_hme_xcd ? n : g_hme_xcd);
+            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1) | (g_hme_prio << 3), n < g_hme_xcd ? n : g_hme_xcd);
             if (prof && level == 0) {
                 prof->end(s, ST_HME_L0, n, 1);
             }
