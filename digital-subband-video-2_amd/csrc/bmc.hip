@@ -603,7 +603,7 @@ struct GlobalView {
 // sliding 64-column window, plus guard rows above and below the plane.
 struct RingView {
     static constexpr bool kStoreAll = true; // LDS: cheaper to write the whole cross back than to branch per row
-    static constexpr int kGuardTop = 3, kGuardRows = 7; // a cell's cross reaches 3 rows above and 4 below the plane's rows
+    static constexpr int kGuardTop = 3, kGuardBelow = 4, kGuardRows = 11; // a cell's cross reaches 3 rows above and 4 below the plane's rows; 4 parking rows (ring_sweep)
     uint8_t *ring; // row 0 of the plane (kGuardTop rows into the allocation)
     int h;
     // Rows outside the plane are never filtered (the filters skip y < 4 and y > h - 4): what is loaded from the guard rows
@@ -851,6 +851,24 @@ __device__ __forceinline__ void artf(const Tile &T, int &sh, int &sv, int &slh, 
     slv = absdiff(d[0] + d[1], d[2] + d[3]) + hh;
 }
 
+// n / d for 0 <= n < 2^12, 1 <= d <= 16 (sums of at most 16 pixels over their count): reciprocal estimate + one correction
+__device__ __forceinline__ int div_small(int n, int d)
+{
+    int q = (int) ((float) n * __builtin_amdgcn_rcpf((float) d));
+    int r = n - q * d;
+    return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
+}
+
+// one pixel of the de-gradient step (bmc.c:318-330), without branches: pulled towards the mean of the darkest / brightest
+// bin by count / 16 (C division: towards zero; |count * difference| < 2^12, a 24-bit multiply)
+__device__ __forceinline__ int degrad_px(int os, int t, int nlo, int alo, int nhi, int ahi)
+{
+    bool lt = os < t;
+    int v = __mul24(lt ? nlo : nhi, (lt ? alo : ahi) - os);
+    int adj = (v + ((v >> 31) & 15)) >> 4;
+    return os == t ? os : (os + adj) & 0xff;
+}
+
 // de-gradient sharpening of 16 pixels px[y * 4 + x] in place (bmc.c:276); returns true when it changed them
 __device__ __forceinline__ bool degrad16(int (&px)[16])
 {
@@ -876,7 +894,7 @@ __device__ __forceinline__ bool degrad16(int (&px)[16])
             shi += px[k];
         }
     }
-    int alo = slo / nlo, ahi = shi / nhi;
+    int alo = div_small(slo, nlo), ahi = div_small(shi, nhi);
     if (alo == 0) {
         alo = 1;
     }
@@ -886,12 +904,7 @@ __device__ __forceinline__ bool degrad16(int (&px)[16])
     int t = (alo + ahi + 1) >> 1;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        int os = px[k];
-        if (os < t) {
-            px[k] = (os + (nlo * (alo - os)) / 16) & 0xff;
-        } else if (os > t) {
-            px[k] = (os + (nhi * (ahi - os)) / 16) & 0xff;
-        }
+        px[k] = degrad_px(px[k], t, nlo, alo, nhi, ahi);
     }
     return true;
 }
@@ -976,13 +989,22 @@ struct CellRec {
     uint32_t l_all, l_flags, t_all, t_flags;
 };
 
+// (opaque to the compiler, which would otherwise narrow the load to a byte and extend it right behind the load: a record
+// fetched ahead would be waited for at once)
+__device__ __forceinline__ uint32_t low_byte(uint32_t v)
+{
+    uint32_t r;
+    asm("v_and_b32 %0, 0xff, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ CellRec fetch_cell_rec(const DSV_MV *vecs, int nbh, int fx, int fy)
 {
     gu32_t c = (gu32_t) &vecs[fx + fy * nbh];
     CellRec r;
     r.all = c[0];
     r.flags = c[1];
-    r.submask = c[3] & 0xffu;
+    r.submask = c[3]; // raw: landed() masks it
     r.l_all = r.l_flags = r.t_all = r.t_flags = 0;
     if (fx > 0) {
         r.l_all = c[-4];
@@ -992,6 +1014,13 @@ __device__ __forceinline__ CellRec fetch_cell_rec(const DSV_MV *vecs, int nbh, i
         r.t_all = c[-4 * nbh];
         r.t_flags = c[-4 * nbh + 1];
     }
+    return r;
+}
+
+// a fetched record made usable (behind the wait for its loads)
+__device__ __forceinline__ CellRec landed(CellRec r)
+{
+    r.submask = low_byte(r.submask);
     return r;
 }
 
@@ -1157,7 +1186,7 @@ template <class V>
 __device__ void luma_cell(const V &view, const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j, int nsbx, int nsby)
 {
     int fx = scale_div(i, f.nbh, nsbx), fy = scale_div(j, f.nbv, nsby);
-    luma_cell_rec(view, dp, f, fetch_cell_rec(vecs, f.nbh, fx, fy), fx, fy, i, j);
+    luma_cell_rec(view, dp, f, landed(fetch_cell_rec(vecs, f.nbh, fx, fy)), fx, fy, i, j);
 }
 
 __device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_MV *vecs, int i, int j)
@@ -1199,31 +1228,89 @@ __device__ void chroma_block(const DPlane &dp, const FilterParams &f, const DSV_
 // 2p, 2p + 1 for the horizontal pass and its pixel columns 2p, 2p + 1 for the vertical one (every 11-sample line is
 // filtered exactly as before, by one lane), the 2 x 2 hand-over between the passes and the cell's joint statistics go
 // through DPP lane swaps.  Half the instructions per lane, two wavefronts per SIMD.
+#ifdef DSV2_FILTER_PROF
+__device__ unsigned long long g_filt_cnt[8]; // (wavefront, front) pairs of the pair sweep: [0] all [1] any live [2] any horizontal [3] any vertical [4] any sharpen [5] live cells
+#define FILT_COUNT(k, cond)                                                                  \
+    do {                                                                                     \
+        unsigned long long b_ = __ballot(cond);                                              \
+        if (b_ && (int) (threadIdx.x & 63) == __ffsll((long long) __ballot(1)) - 1) {        \
+            atomicAdd(&g_filt_cnt[k], (k) == 5 ? (unsigned long long) __popcll(b_) : 1ull);  \
+        }                                                                                    \
+    } while (0)
+#else
+#define FILT_COUNT(k, cond)                                                                  \
+    do {                                                                                     \
+    } while (0)
+#endif
 __device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); } // quad_perm [1,0,3,2]
 
+// Two 11-sample lines at once: a lane's two lines as the 16-bit halves of one register (v_pk_*_u16).  Every intermediate
+// of smooth6 fits 16 bits (samples <= 255, weights summing to <= 16, thresholds < 2^15).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk16(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t un16(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2 splat16(int v) { return u16x2{(unsigned short) v, (unsigned short) v}; }
+__device__ __forceinline__ u16x2 max16(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u16x2 min16(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); } // v_bfi_b32
+
+// smooth6 (bmc.c:53-70) on two lines; returns per half 0xffff where the six range tests pass
+__device__ __forceinline__ uint32_t smooth6_pk(uint32_t e2_, uint32_t e1_, uint32_t e0_, uint32_t i0_, uint32_t i1_, uint32_t i2_, uint32_t t_, uint32_t o[4])
+{
+    u16x2 e2 = pk16(e2_), e1 = pk16(e1_), e0 = pk16(e0_), i0 = pk16(i0_), i1 = pk16(i1_), i2 = pk16(i2_);
+    u16x2 avg = ((e0 + i0) * splat16(5) + (e1 + i1) * splat16(3) + splat16(8)) >> splat16(4);
+    // largest deviation from the average = max(max6 - avg, avg - min6)
+    u16x2 mx = max16(max16(max16(e0, i0), max16(e1, i1)), max16(e2, i2));
+    u16x2 mn = min16(min16(min16(e0, i0), min16(e1, i1)), min16(e2, i2));
+    u16x2 dev = max16(__builtin_elementwise_sub_sat(mx, avg), __builtin_elementwise_sub_sat(avg, mn));
+    // dev < t per half -> 0xffff (kept from the compiler, which would turn it back into compares and selects per half)
+    uint32_t m;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\tv_pk_sub_u16 %0, 0, %0 op_sel_hi:[0,1]"
+        : "=&v"(m)
+        : "v"(t_), "v"(un16(dev)));
+    u16x2 a5 = avg * splat16(5);
+    o[0] = un16(((avg + e1) * splat16(3) + e2 * splat16(2) + splat16(4)) >> splat16(3));
+    o[1] = un16((a5 + e1 * splat16(2) + e2 + splat16(4)) >> splat16(3));
+    o[2] = un16(avg);
+    o[3] = un16((a5 + i1 * splat16(2) + i2 + splat16(4)) >> splat16(3));
+    return m;
+}
+
+// line_filter on two lines (tE, tM: the cell's thresholds, the same for both)
+__device__ __forceinline__ bool line_filter_pk(uint32_t (&l)[11], bool in_edge, int tE, int tM)
+{
+    uint32_t o[4], q[4];
+    uint32_t m1 = smooth6_pk(l[0], l[1], l[2], l[3], l[4], l[5], un16(splat16(tE)), o);
+    uint32_t m2 = smooth6_pk(l[10], l[9], l[8], l[7], l[6], l[5], un16(splat16(in_edge ? tM : 0)), q);
+    l[1] = bsel(m1, o[0], l[1]);
+    l[2] = bsel(m1, o[1], l[2]);
+    l[3] = bsel(m1, o[2], l[3]);
+    l[4] = bsel(m1, o[3], l[4]);
+    l[6] = bsel(m2, q[3], l[6]);
+    l[7] = bsel(m2, q[2], l[7]);
+    l[8] = bsel(m2, q[1], l[8]);
+    l[9] = bsel(m2, q[0], l[9]);
+    return (m1 | m2) != 0;
+}
+
 struct PairTile {
-    int h[2][12]; // my two pixel rows y + 2p + a, columns x - 4 .. x + 7
-    int o[2][7];  // my two pixel columns x + 2p + c in the rows above (y - 3 .. y - 1) and below (y + 4 .. y + 7) the cell
+    uint32_t h[12]; // my two pixel rows y + 2p, y + 2p + 1 (low / high half), columns x - 4 .. x + 7
+    uint32_t o[7];  // my two pixel columns x + 2p, x + 2p + 1 (low / high half) in the rows above (y - 3 .. y - 1) and below (y + 4 .. y + 7)
     bool rows_dirty, outer_dirty;
 
     __device__ __forceinline__ void load(const RingView &view, int x, int y, int p)
     {
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                uint32_t v = view.ld(y + 2 * p + a, x - 4 + 4 * d);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    h[a][4 * d + k] = (int) ((v >> (8 * k)) & 0xffu);
-                }
-            }
+        for (int d = 0; d < 3; d++) {
+            uint32_t r0 = view.ld(y + 2 * p, x - 4 + 4 * d), r1 = view.ld(y + 2 * p + 1, x - 4 + 4 * d);
+            h[4 * d + 0] = __builtin_amdgcn_perm(r1, r0, 0x0c040c00u);
+            h[4 * d + 1] = __builtin_amdgcn_perm(r1, r0, 0x0c050c01u);
+            h[4 * d + 2] = __builtin_amdgcn_perm(r1, r0, 0x0c060c02u);
+            h[4 * d + 3] = __builtin_amdgcn_perm(r1, r0, 0x0c070c03u);
         }
 #pragma unroll
         for (int k = 0; k < 7; k++) {
-            uint32_t v = view.ld16(y + (k < 3 ? k - 3 : k + 1), x + 2 * p);
-            o[0][k] = (int) (v & 0xffu);
-            o[1][k] = (int) (v >> 8);
+            o[k] = __builtin_amdgcn_perm(0u, view.ld16(y + (k < 3 ? k - 3 : k + 1), x + 2 * p), 0x0c010c00u);
         }
         rows_dirty = outer_dirty = false;
     }
@@ -1232,22 +1319,22 @@ struct PairTile {
     {
         if (__any(rows_dirty)) {
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    view.st(y + 2 * p + a, x - 4 + 4 * d,
-                            (uint32_t) h[a][4 * d] | ((uint32_t) h[a][4 * d + 1] << 8) | ((uint32_t) h[a][4 * d + 2] << 16) |
-                                ((uint32_t) h[a][4 * d + 3] << 24));
-                }
+            for (int d = 0; d < 3; d++) {
+                // (row0 px0, row0 px1, row1 px0, row1 px1) of two columns, then the rows' dwords from two such
+                uint32_t t01 = __builtin_amdgcn_perm(h[4 * d + 1], h[4 * d], 0x06020400u), t23 = __builtin_amdgcn_perm(h[4 * d + 3], h[4 * d + 2], 0x06020400u);
+                view.st(y + 2 * p, x - 4 + 4 * d, __builtin_amdgcn_perm(t23, t01, 0x05040100u));
+                view.st(y + 2 * p + 1, x - 4 + 4 * d, __builtin_amdgcn_perm(t23, t01, 0x07060302u));
             }
         }
         if (__any(outer_dirty)) { // rows y - 2, y - 1, y + 4, y + 5, y + 6 (the vertical pass leaves y - 3 and y + 7 alone)
 #pragma unroll
             for (int k = 1; k < 6; k++) {
-                view.st16(y + (k < 3 ? k - 3 : k + 1), x + 2 * p, (uint32_t) o[0][k] | ((uint32_t) o[1][k] << 8));
+                view.st16(y + (k < 3 ? k - 3 : k + 1), x + 2 * p, __builtin_amdgcn_perm(0u, o[k], 0x0c0c0200u));
             }
         }
     }
+    // pixel (row a, column xx) of the cell's half I own
+    __device__ __forceinline__ int px(int a, int xx) const { return (int) (a ? h[4 + xx] >> 16 : h[4 + xx] & 0xffffu); }
 };
 
 __device__ __forceinline__ void hfilter2(PairTile &T, const DPlane &dp, int x, bool edge, int tE, int tM, bool on)
@@ -1257,20 +1344,17 @@ __device__ __forceinline__ void hfilter2(PairTile &T, const DPlane &dp, int x, b
     tE = on ? tE : 0;
     tM = on ? tM : 0;
     bool in_edge = x < dp.w - 8;
+    uint32_t l[11];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-        int l[11];
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            l[k] = T.h[a][1 + k];
-        }
-        bool hit = line_filter(l, in_edge, tE, tM);
-#pragma unroll
-        for (int k = 1; k < 10; k++) {
-            T.h[a][1 + k] = l[k];
-        }
-        T.rows_dirty |= hit;
+    for (int k = 0; k < 11; k++) {
+        l[k] = T.h[1 + k];
     }
+    bool hit = line_filter_pk(l, in_edge, tE, tM);
+#pragma unroll
+    for (int k = 1; k < 10; k++) {
+        T.h[1 + k] = l[k];
+    }
+    T.rows_dirty |= hit;
 }
 
 __device__ __forceinline__ void vfilter2(PairTile &T, const DPlane &dp, int y, int p, bool edge, int tE, int tM, bool on)
@@ -1280,60 +1364,49 @@ __device__ __forceinline__ void vfilter2(PairTile &T, const DPlane &dp, int y, i
     tE = on ? tE : 0;
     tM = on ? tM : 0;
     bool in_edge = y < dp.h - 8;
-    // rows -> columns: of the cell's four rows I hold two; the partner's two, in MY columns, come over
-    int mine[2][2], recv[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            mine[a][c] = p ? T.h[a][6 + c] : T.h[a][4 + c];
-            recv[a][c] = pair_swap(p ? T.h[a][4 + c] : T.h[a][6 + c]);
-        }
-    }
-    bool hit = false;
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        int l[11];
-        l[0] = T.o[c][0];
-        l[1] = T.o[c][1];
-        l[2] = T.o[c][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            l[3 + a] = p ? recv[a][c] : mine[a][c];
-            l[5 + a] = p ? mine[a][c] : recv[a][c];
-        }
-        l[7] = T.o[c][3];
-        l[8] = T.o[c][4];
-        l[9] = T.o[c][5];
-        l[10] = T.o[c][6];
-        hit |= line_filter(l, in_edge, tE, tM);
-        T.o[c][1] = l[1];
-        T.o[c][2] = l[2];
-        T.o[c][3] = l[7];
-        T.o[c][4] = l[8];
-        T.o[c][5] = l[9];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            mine[a][c] = p ? l[5 + a] : l[3 + a];
-            recv[a][c] = p ? l[3 + a] : l[5 + a]; // the partner's rows, my columns: goes back
-        }
-    }
+    // rows -> columns.  h[] pairs the two ROWS of one column; the vertical lines want the two COLUMNS of one row.
+    // Of the cell's four rows I hold two; the partner's two, in MY columns, come over.
+    uint32_t mc0 = p ? T.h[6] : T.h[4], mc1 = p ? T.h[7] : T.h[5]; // my columns (rows: mine)
+    uint32_t oc0 = p ? T.h[4] : T.h[6], oc1 = p ? T.h[5] : T.h[7]; // the partner's columns (rows: mine)
+    uint32_t mine0 = __builtin_amdgcn_perm(mc1, mc0, 0x05040100u), mine1 = __builtin_amdgcn_perm(mc1, mc0, 0x07060302u);
+    uint32_t recv0 = (uint32_t) pair_swap((int) __builtin_amdgcn_perm(oc1, oc0, 0x05040100u));
+    uint32_t recv1 = (uint32_t) pair_swap((int) __builtin_amdgcn_perm(oc1, oc0, 0x07060302u));
+    uint32_t l[11];
+    l[0] = T.o[0];
+    l[1] = T.o[1];
+    l[2] = T.o[2];
+    l[3] = p ? recv0 : mine0;
+    l[4] = p ? recv1 : mine1;
+    l[5] = p ? mine0 : recv0;
+    l[6] = p ? mine1 : recv1;
+    l[7] = T.o[3];
+    l[8] = T.o[4];
+    l[9] = T.o[5];
+    l[10] = T.o[6];
+    bool hit = line_filter_pk(l, in_edge, tE, tM);
+    T.o[1] = l[1];
+    T.o[2] = l[2];
+    T.o[3] = l[7];
+    T.o[4] = l[8];
+    T.o[5] = l[9];
     // columns -> rows
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            int got = pair_swap(recv[a][c]); // my rows, the partner's columns
-            T.h[a][4 + c] = p ? got : mine[a][c];
-            T.h[a][6 + c] = p ? mine[a][c] : got;
-        }
-    }
+    mine0 = p ? l[5] : l[3];
+    mine1 = p ? l[6] : l[4];
+    uint32_t got0 = (uint32_t) pair_swap((int) (p ? l[3] : l[5])), got1 = (uint32_t) pair_swap((int) (p ? l[4] : l[6])); // my rows, the partner's columns
+    mc0 = __builtin_amdgcn_perm(mine1, mine0, 0x05040100u);
+    mc1 = __builtin_amdgcn_perm(mine1, mine0, 0x07060302u);
+    oc0 = __builtin_amdgcn_perm(got1, got0, 0x05040100u);
+    oc1 = __builtin_amdgcn_perm(got1, got0, 0x07060302u);
+    T.h[4] = p ? oc0 : mc0;
+    T.h[5] = p ? oc1 : mc1;
+    T.h[6] = p ? mc0 : oc0;
+    T.h[7] = p ? mc1 : oc1;
     hit |= (bool) pair_swap((int) hit);
     T.rows_dirty |= hit;
     T.outer_dirty |= hit;
 }
 
-#define PCELL(a, xx) T.h[a][4 + (xx)]
+#define PCELL(a, xx) T.px(a, xx)
 __device__ __forceinline__ void artf2(const PairTile &T, int p, int &sh, int &sv, int &slh, int &slv) // bmc.c:224-270
 {
     sh = sv = 0;
@@ -1400,7 +1473,7 @@ __device__ __forceinline__ void degrad2(PairTile &T)
     nhi += pair_swap(nhi);
     slo += pair_swap(slo);
     shi += pair_swap(shi);
-    int alo = slo / nlo, ahi = shi / nhi;
+    int alo = div_small(slo, nlo), ahi = div_small(shi, nhi);
     if (alo == 0) {
         alo = 1;
     }
@@ -1410,16 +1483,11 @@ __device__ __forceinline__ void degrad2(PairTile &T)
     int t = (alo + ahi + 1) >> 1;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        int os = px[k];
-        if (os < t) {
-            px[k] = (os + (nlo * (alo - os)) / 16) & 0xff;
-        } else if (os > t) {
-            px[k] = (os + (nhi * (ahi - os)) / 16) & 0xff;
-        }
+        px[k] = degrad_px(px[k], t, nlo, alo, nhi, ahi);
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        PCELL(k >> 2, k & 3) = px[k];
+    for (int k = 0; k < 4; k++) {
+        T.h[4 + k] = (uint32_t) px[k] | ((uint32_t) px[4 + k] << 16);
     }
     T.rows_dirty = true;
 }
@@ -1477,6 +1545,9 @@ __device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const Fil
     bool filt = !intra && (ndx || ndy);
     bool sharp = !intra && f.sharpen && (mvx & 3) && (mvy & 3) && ((mvx | mvy) & 1) && amx < 8 && amy < 8;
     live = live & (intra | filt | sharp);
+    FILT_COUNT(0, true);
+    FILT_COUNT(1, live);
+    FILT_COUNT(5, live);
     if (!__any(live)) { // nothing to do for the whole wavefront
         return;
     }
@@ -1522,6 +1593,9 @@ __device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const Fil
         vE = intra ? tH : tt + addy;
         vM = intra ? tL : tt;
     }
+    FILT_COUNT(2, h_on);
+    FILT_COUNT(3, v_on);
+    FILT_COUNT(4, live & sharp);
     if (__any(h_on)) {
         hfilter2(T, dp, x, eh, hE, hM, h_on);
     }
@@ -1565,7 +1639,8 @@ __device__ __forceinline__ bool ring_eligible(const DPlane &dp, int nthreads, si
 }
 
 // cell(ic, j) filters one cell; ahead(ic, j) is told which cell this thread will filter four fronts later so
-// that it can fetch that cell's side information off the dependent path
+// that it can fetch that cell's side information off the dependent path; land() runs at the top of every front, behind
+// the wait for the previous front's vector-memory operations: what ahead() fetched is copied out of its load registers there
 // phase clock of a debugging build (make prof): shader-clock ticks wave 0 of a luma sweep spends in each part of a front
 #ifdef DSV2_FILTER_PROF
 __device__ unsigned long long g_filt_prof[8];
@@ -1581,8 +1656,8 @@ __device__ unsigned long long g_filt_prof[8];
     } while (0)
 #endif
 
-template <class CellFn, class AheadFn>
-__device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead)
+template <class CellFn, class AheadFn, class LandFn>
+__device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead, LandFn land)
 {
 #ifdef DSV2_FILTER_PROF
     unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
@@ -1600,12 +1675,16 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
         int j = jlo + ((tid - jlo) & (nthr - 1)); // (tid - jlo) mod nthr: the workgroup size is a power of two (256)
         bool active = j <= jhi;
         int ic = t - 2 * j;
-        if (pend_row >= 0) { // columns fetched on the previous front enter the window
+        { // Columns fetched on the previous front enter the window.  A thread with nothing pending parks stale registers below
+          // the plane: the wait for the fetch then stands at the top of EVERY front for every thread, and whatever was fetched
+          // ahead on earlier fronts (land()) is used without a wait of its own.
+            const int prow = pend_row >= 0 ? pend_row : dp.h + RingView::kGuardBelow, pcol = pend_row >= 0 ? (pend_col & 63) : 4 * (tid & 15);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                *(uint32_t *) (ring + (pend_row + r) * 64 + (pend_col & 63)) = pend[r];
+                *(uint32_t *) (ring + (prow + r) * 64 + pcol) = pend[r];
             }
             pend_row = -1;
+            land();
         }
         FILT_MARK(0);
         if (active) {
@@ -1655,8 +1734,8 @@ __device__ __forceinline__ void ring_sweep(const DPlane &dp, uint8_t *ring, Cell
 
 // the same sweep with a lane pair per cell (cell(ic, j, p): lane p of the pair): thread pair = cell row mod (blockDim / 2),
 // each lane retires and fetches the columns of its own two pixel rows
-template <class CellFn, class AheadFn>
-__device__ __forceinline__ void ring_sweep2(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead)
+template <class CellFn, class AheadFn, class LandFn>
+__device__ __forceinline__ void ring_sweep2(const DPlane &dp, uint8_t *ring, CellFn cell, AheadFn ahead, LandFn land)
 {
 #ifdef DSV2_FILTER_PROF
     unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
@@ -1673,12 +1752,14 @@ __device__ __forceinline__ void ring_sweep2(const DPlane &dp, uint8_t *ring, Cel
         int j = jlo + ((tid - jlo) & (nthr - 1));
         bool active = j <= jhi;
         int ic = t - 2 * j;
-        if (pend_row >= 0) {
+        { // (as in ring_sweep: unconditional, so that the wait for the fetch stands at the top of every front)
+            const int prow = pend_row >= 0 ? pend_row : dp.h + RingView::kGuardBelow, pcol = pend_row >= 0 ? (pend_col & 63) : 4 * (tid & 15);
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                *(uint32_t *) (ring + (pend_row + r) * 64 + (pend_col & 63)) = pend[r];
+                *(uint32_t *) (ring + (prow + r) * 64 + pcol) = pend[r];
             }
             pend_row = -1;
+            land();
         }
         FILT_MARK(0);
         if (active) {
@@ -1756,8 +1837,8 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
             uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
             // the block record of the cell at hand and, fetched one front early, of the next one
-            CellRec cur = {}, nxt = {};
-            int cur_key = -1, nxt_key = -1;
+            CellRec cur = {}, nxt = {}, raw = {}; // raw: the load registers of ahead()
+            int cur_key = -1, nxt_key = -1, raw_key = -1;
             // cell -> block (bmc.c:505-506 scales the cell index): a thread stays on its cell row, and with 16-pixel blocks
             // on a width that is a multiple of 16 four cells make a block
             const bool quarter_x = f.nbh * 4 == nsbx;
@@ -1774,7 +1855,7 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
                 [&](int i, int j) {
                     int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
                     if (key != cur_key) {
-                        cur = key == nxt_key ? nxt : fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        cur = key == nxt_key ? nxt : landed(fetch_cell_rec(vecs, f.nbh, fx, fy));
                         cur_key = key;
                     }
                     luma_cell_rec(view, dp, f, cur, fx, fy, i, j);
@@ -1782,9 +1863,13 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
                 [&](int i, int j) {
                     int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
                     if (key != cur_key && key != nxt_key) {
-                        nxt = fetch_cell_rec(vecs, f.nbh, fx, fy);
-                        nxt_key = key;
+                        raw = fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        raw_key = key;
                     }
+                },
+                [&]() {
+                    nxt = landed(raw);
+                    nxt_key = raw_key;
                 });
         } else {
             sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
@@ -1811,8 +1896,8 @@ __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restric
         if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
             uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
-            CellRec cur = {}, nxt = {};
-            int cur_key = -1, nxt_key = -1;
+            CellRec cur = {}, nxt = {}, raw = {}; // raw: the load registers of ahead()
+            int cur_key = -1, nxt_key = -1, raw_key = -1;
             // cell -> block (bmc.c:505-506 scales the cell index): a thread stays on its cell row, and with 16-pixel blocks
             // on a width that is a multiple of 16 four cells make a block
             const bool quarter_x = f.nbh * 4 == nsbx;
@@ -1829,7 +1914,7 @@ __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restric
                 [&](int i, int j, int p) {
                     int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
                     if (key != cur_key) {
-                        cur = key == nxt_key ? nxt : fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        cur = key == nxt_key ? nxt : landed(fetch_cell_rec(vecs, f.nbh, fx, fy));
                         cur_key = key;
                     }
                     luma_cell_rec2(view, dp, f, cur, fx, fy, i, j, p);
@@ -1837,9 +1922,13 @@ __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restric
                 [&](int i, int j) {
                     int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
                     if (key != cur_key && key != nxt_key) {
-                        nxt = fetch_cell_rec(vecs, f.nbh, fx, fy);
-                        nxt_key = key;
+                        raw = fetch_cell_rec(vecs, f.nbh, fx, fy);
+                        raw_key = key;
                     }
+                },
+                [&]() {
+                    nxt = landed(raw);
+                    nxt_key = raw_key;
                 });
         } else {
             sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
@@ -1860,7 +1949,7 @@ __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict
     if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
         uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
-        ring_sweep2(dp, ring0, [&](int i, int j, int p) { intra_cell2(view, dp, f, bd, i, j, p, nsbx, nsby); }, [](int, int) {});
+        ring_sweep2(dp, ring0, [&](int i, int j, int p) { intra_cell2(view, dp, f, bd, i, j, p, nsbx, nsby); }, [](int, int) {}, []() {});
     } else {
         sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
@@ -1877,7 +1966,7 @@ __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict_
     if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
         uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
-        ring_sweep(dp, ring0, [&](int i, int j) { intra_cell(view, dp, f, bd, i, j, nsbx, nsby); }, [](int, int) {});
+        ring_sweep(dp, ring0, [&](int i, int j) { intra_cell(view, dp, f, bd, i, j, nsbx, nsby); }, [](int, int) {}, []() {});
     } else {
         sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
@@ -1908,6 +1997,13 @@ void post_process_plane(hipStream_t s, const DPlane &dp)
 
 #ifdef DSV2_FILTER_PROF
 } // namespace dsv2
+#ifdef DSV2_FILTER_PROF
+extern "C" void dsv2hip_debug_filter_counts(unsigned long long out[8])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dsv2::g_filt_cnt), 8 * sizeof(unsigned long long)));
+}
+#endif
 extern "C" void dsv2hip_debug_filter_prof(unsigned long long out[8])
 {
     HIPCHK(hipDeviceSynchronize());
@@ -2009,11 +2105,14 @@ static unsigned ring_lds_bytes(int luma_h)
     return (on && b <= 150 * 1024) ? (unsigned) b : 0u;
 }
 
-// DSV2_FILTER_PAIR=0: one lane per luma cell (256 threads) instead of a lane pair (512)
-static bool filter_pair()
+// Which luma sweep a launch of n pictures gets.  The lane-pair kernels shorten a sweep's critical path (one picture:
+// 4.3 -> 3.2 ms) and cost more instructions per cell; launches that fill the chip several times over (192 pictures of the
+// headline: 7 060 against 6 700 - 7 010 frames/s) are bound by those and keep a lane per cell.
+// DSV2_FILTER_PAIR_MAX = largest n that takes the pair kernels (0: never).
+static bool filter_pair(int n)
 {
-    static int on = getenv("DSV2_FILTER_PAIR") ? atoi(getenv("DSV2_FILTER_PAIR")) : 1;
-    return on != 0;
+    static int nmax = getenv("DSV2_FILTER_PAIR_MAX") ? atoi(getenv("DSV2_FILTER_PAIR_MAX")) : 64;
+    return n <= nmax;
 }
 
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
@@ -2029,7 +2128,7 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            if (filter_pair()) {
+            if (filter_pair(n)) {
                 DSV2_LAUNCH(k_inter_filters_b2, dim3(3, n), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
             } else {
                 DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
@@ -2044,7 +2143,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
     if (n > 0) {
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            if (filter_pair()) {
+            if (filter_pair(n)) {
                 DSV2_LAUNCH(k_inter_filters_b2, dim3(3, n), dim3(512), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
             } else {
                 DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
@@ -2056,7 +2155,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_h)
 {
     if (n > 0) {
-        if (filter_pair()) {
+        if (filter_pair(n)) {
             DSV2_LAUNCH(k_intra_filter_b2, dim3(n), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
         } else {
             DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));

@@ -25,3 +25,9 @@ fronts = 1046.0  # nsbx + 2 + 2 (nsby - 1) + 13 at 1080p
 for k, nm in enumerate(names):
     print("%d %-48s %6.2f %%  %9.0f ticks per sweep  %7.1f per front" % (k, nm, out[k] / tot * 100, out[k] / sweeps, out[k] / sweeps / fronts), file=sys.stderr)
 print("sweeps %d, %.0f ticks per sweep (s_memtime ticks: the shader clock, ~2.2 GHz here)" % (out[4], tot / sweeps), file=sys.stderr)
+cnt = (ctypes.c_ulonglong * 8)()
+if hasattr(lib, "dsv2hip_debug_filter_counts"):
+    lib.dsv2hip_debug_filter_counts(cnt)
+    n = float(cnt[0]) or 1.0
+    print("pair sweep, (wavefront, front) pairs with a cell: %d; any live cell %.3f, horizontal pass %.3f, vertical pass %.3f, sharpen %.3f; live cells per such pair %.1f of 32"
+          % (cnt[0], cnt[1] / n, cnt[2] / n, cnt[3] / n, cnt[4] / n, cnt[5] / 2.0 / (float(cnt[1]) or 1.0)), file=sys.stderr)
