@@ -71,6 +71,7 @@ struct CodecDev {
     DSV_MV *d_mvs_stage = nullptr; // analysis output / upload staging
     DSV_MV *d_mvf[DSV_MAX_PYRAMID_LEVELS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *d_counters = nullptr;
+    void *d_src_stats = nullptr; // hme_src_stats_bytes(): the search's source pre-pass (encoder)
     uint8_t *d_intra_map[2] = {nullptr, nullptr}; // encoder: running intra map of the GOP (committed / being written), hme.h BlockStatsJob
     int32_t *d_ll = nullptr;
     // decoder-side symbol upload

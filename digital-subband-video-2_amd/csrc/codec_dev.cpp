@@ -188,6 +188,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         HIPCHK(hipMalloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
     }
     HIPCHK(hipMalloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
+    HIPCHK(hipMalloc(&d_src_stats, hme_src_stats_bytes(nbh, nbv)));
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **) &d_intra_map[i], nb));
         dev_zero(d_intra_map[i], nb);
@@ -280,6 +281,7 @@ void CodecDev::destroy()
         }
     }
     HIPCHK(hipFree(d_counters));
+    HIPCHK(hipFree(d_src_stats));
     for (int i = 0; i < 2; i++) {
         if (d_intra_map[i]) {
             HIPCHK(hipFree(d_intra_map[i]));

@@ -1632,6 +1632,7 @@ void enc_batch(Job *jobs, int n)
             }
             f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
             f.counters = dv.d_counters;
+            f.src_stats = dv.d_src_stats;
             f.host_mvs = nullptr; // (the field reaches the host through k_block_stats_b right behind the search: BlockStatsJob::host_mvs)
             f.host_counters = dv.h_counters;
             dv.h_counters[7] = -1; // overwritten with 0 by the search's last row (1: a row timed out); -1 left = it never finished
@@ -1649,6 +1650,9 @@ void enc_batch(Job *jobs, int n)
             jb.ran_hme = 1;
         }
     }
+    if (!pjobs.empty()) { // job table, clears, the source blocks' statistics: nothing the token is for
+        hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, nullptr, -1, 0, HME_PREPARE);
+    }
     prof.end(bs, ST_INGEST, n);
     // (only launches that keep the chip's 2 048 search slots full for most of their length take the token: a row-pipelined
     // launch ramps up and down over one picture's critical path, ~2 ms whatever the batch, and launches of a few dozen
@@ -1665,7 +1669,7 @@ void enc_batch(Job *jobs, int n)
     }
     if (!pjobs.empty()) {
         prof.begin(bs, ST_HME);
-        int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof);
+        int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof, -1, 0, HME_LEVELS);
         prof.end(bs, ST_HME, (int) pjobs.size(), nfronts); // launches = the per-level search kernels
         HIPCHK(hipMemsetAsync(sc.d_bstats, 0, (size_t) n_bsj * BS_WORDS * sizeof(int), bs));
         block_stats_batch(bs, d_bsj, n_bsj, nbh, nbv);

@@ -39,12 +39,15 @@ struct HmeFrames {
     DSV_MV *host_mvs = nullptr;   // batched driver only: pinned host mirror of mvf[0], filled by the search itself
     int *host_counters = nullptr; // batched driver only: pinned host copy of counters[0..7]; word 12 (kHmeHostTailWord) of the FIRST
                                   // stream's block is set when the level-0 launch has handed out its last block row
+    void *src_stats = nullptr; // batched driver only: hme_src_stats_bytes() of device memory for the source pre-pass, or null
     int *counters;         // hme_counter_words(nbv) ints. out: [0] nintra [1] ndiff [2] eligible [3] total_err
                            // ([4],[5] global motion, [7] row-pipeline timeout flag, [16..] row progress)
 };
 
 // dsv_hme (hme.c:2001): all levels coarse to fine, asynchronous on `s`
 inline size_t hme_counter_words(int nbv) { return 16 + (size_t) nbv; }
+// source statistics of every block of levels 0 and 1, 16 bytes each (k_hme_src_stats_b)
+inline size_t hme_src_stats_bytes(int nbh, int nbv) { return ((size_t) nbh * nbv + (size_t) ((nbh + 1) / 2) * ((nbv + 1) / 2)) * 16; }
 constexpr int kHmeHostTailWord = 12;
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns the number of front launches
 
@@ -54,8 +57,12 @@ struct StageProf;
 // prof (optional): HIP events around the level-0 launch alone (stage ST_HME_L0), for the roofline of the dominant kernel
 // level_hi .. level_lo: the pyramid levels this call runs (default: all, coarse to fine); a search may be split over calls --
 // the one that starts at the coarsest level also ships the job table and clears the hand-off words
+// phases: HME_PREPARE = what needs neither the reference's search slots nor any order -- the job table, the clears and the
+// source pre-pass (k_hme_src_stats_b) --, HME_LEVELS = the levels' launches; a caller that serialises searches (the
+// encoder's search token) prepares before it queues for its turn
+enum { HME_PREPARE = 1, HME_LEVELS = 2 };
 int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof = nullptr,
-                  int level_hi = -1, int level_lo = 0);
+                  int level_hi = -1, int level_lo = 0, int phases = HME_PREPARE | HME_LEVELS);
 
 // ---- per-frame block statistics of the finished level-0 field (host controller inputs) -------------------------
 // What the reference's controller sums over the motion field of a P frame before it decides anything

@@ -34,6 +34,7 @@ struct HmeDev {
     int *counters; // [0] nintra [1] ndiff [2] eligible [3] total_err [4] gx [5] gy
     DSV_MV *host_mvs;   // optional pinned host mirror of the level-0 field (written straight over PCIe)
     int *host_counters; // optional pinned host copy of counters[0..7]
+    int4 *stats[2];     // optional: source statistics of every block of levels 0 and 1 (k_hme_src_stats_b), or null
 };
 
 // What the blocks of ONE level need, copied out of the job table once per row as wave-uniform scalars: the table
@@ -79,7 +80,11 @@ struct HmeCtx {
     const DSV_MV *ref_mvf;
     int *counters;
     DSV_MV *host_mvs;
+    const int4 *stats; // this level's source statistics or null
 };
+
+__device__ __forceinline__ const int4 *src_stats_of(const HmeCtx &c, int) { return c.stats; }
+__device__ __forceinline__ const int4 *src_stats_of(const HmeDev &c, int level) { return c.stats[level]; }
 
 __device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
 {
@@ -120,6 +125,7 @@ __device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
     c.ref_mvf = uni_ptr(d.ref_mvf);
     c.counters = uni_ptr(d.counters);
     c.host_mvs = uni_ptr(d.host_mvs);
+    c.stats = level <= 1 ? uni_ptr((const int4 *) d.stats[level]) : nullptr;
     return c;
 }
 
@@ -1802,6 +1808,42 @@ int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &r
     return hme_run(s, f, hp);
 }
 
+// ---- source statistics ahead of the search (see source_analysis in hme_fast.h) -----------------------------------------
+// grid = (ceil(blocks of level 0 + blocks of level 1, per_wg), streams); one wavefront works through per_wg blocks.
+static int g_hme_prestats = getenv("DSV2_HME_PRESTATS") ? atoi(getenv("DSV2_HME_PRESTATS")) : 1;
+__global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int per_wg)
+{
+    __shared__ int hist[16];
+    const HmeDev &c = tab[blockIdx.y];
+    const int lane = threadIdx.x & 63, qi = lane & 7, qj = lane >> 3;
+    const int n0 = nb0x * nb0y, total = n0 + nb1x * nb1y;
+    const int quant = uni(c.quant);
+    int4 *const out0 = uni_ptr(c.stats[0]), *const out1 = uni_ptr(c.stats[1]);
+    const DPlane src0 = uni(c.src[0]), src1 = uni(c.src[1]), ogr0 = uni(c.ogr[0]), ogr1 = uni(c.ogr[1]);
+    const int b_end = min(total, ((int) blockIdx.x + 1) * per_wg);
+    for (int b = (int) blockIdx.x * per_wg; b < b_end; b++) {
+        const bool l1 = b >= n0;
+        const int idx = l1 ? b - n0 : b, nbx = l1 ? nb1x : nb0x;
+        const int bi = idx % nbx, bj = idx / nbx;
+        const DPlane src = l1 ? src1 : src0;
+        const int bx = bi * 16, by = bj * 16;
+        const int bw = min(src.w - bx, 16), bh = min(src.h - by, 16);
+        if (bw <= 0 || bh <= 0) {
+            continue;
+        }
+        const int qw = bw >> 1, qh = bh >> 1;
+        const bool act = qi < qw && qj < qh;
+        Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
+        const DPlane ogr = l1 ? ogr1 : ogr0;
+        const Quad o = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
+        SrcStats st = source_analysis(a, act, qi, qj, qw, bw, bh, quant, hist);
+        st.zoscore = metric_return(wave_sum(act ? qmetric(a, o, psy_of_source(st.var_src, bw, bh, quant)) : 0u), bw, bh);
+        if (lane == 0) {
+            (l1 ? out1 : out0)[idx] = int4{st.bias_raw, (int) st.var_src, (int) st.avg_src, (int) st.zoscore};
+        }
+    }
+}
+
 static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
 {
     c.a = hp.a;
@@ -1825,19 +1867,21 @@ static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
     c.counters = f.counters;
     c.host_mvs = f.host_mvs;
     c.host_counters = f.host_counters;
+    c.stats[0] = c.stats[1] = nullptr; // (hme_run_batch sets them when it runs the source pre-pass)
 }
 
 size_t hme_table_bytes(int n) { return (size_t) n * sizeof(HmeDev); }
 
 // n independent streams of identical geometry in lockstep: every front is ONE launch for all of them
 int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof, int level_hi,
-                  int level_lo)
+                  int level_lo, int phases)
 {
     if (n <= 0) {
         return 0;
     }
     const HmeParams &g = hp[0];
-    const bool from_top = level_hi < 0 || level_hi >= g.pyr_levels; // a call that starts the search: job table, clears
+    // a call that starts the search: job table, clears, source pre-pass
+    const bool from_top = (phases & HME_PREPARE) && (level_hi < 0 || level_hi >= g.pyr_levels);
     if (level_hi < 0 || level_hi > g.pyr_levels) {
         level_hi = g.pyr_levels;
     }
@@ -1846,7 +1890,6 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         for (int k = 0; k < n; k++) {
             fill_hme_dev(ht[k], f[k], hp[k]);
         }
-        HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
     }
     const HmeDev *tab = (const HmeDev *) d_table;
     int nlaunch = 0;
@@ -1856,11 +1899,30 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             fast &= ~1;
         }
     }
+    if (from_top) {
+        // the source statistics of levels 0 and 1, ahead of the search: whenever the block routine that reads them can run
+        bool pre = g_hme_prestats && (fast & 1) && g.a.blk_w == 16 && g.a.blk_h == 16;
+        for (int k = 0; k < n; k++) {
+            pre = pre && f[k].src_stats != nullptr;
+        }
+        const int nb0x = g.a.nbh, nb0y = g.a.nbv, nb1x = g.pyr_levels >= 1 ? (g.a.nbh + 1) / 2 : 0, nb1y = g.pyr_levels >= 1 ? (g.a.nbv + 1) / 2 : 0;
+        if (pre) {
+            for (int k = 0; k < n; k++) {
+                ht[k].stats[0] = (int4 *) f[k].src_stats;
+                ht[k].stats[1] = nb1x ? (int4 *) f[k].src_stats + (size_t) nb0x * nb0y : nullptr;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
+        if (pre) {
+            const int per_wg = 4, total = nb0x * nb0y + nb1x * nb1y;
+            DSV2_LAUNCH(k_hme_src_stats_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, per_wg);
+        }
+    }
     int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
     if (g_hme_rows && from_top) { // one clear for all levels; each level's last row then re-arms the hand-off words itself
         DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n, g.pyr_levels + 1), dim3(256), 0, s, tab, -1, nwords, 1);
     }
-    for (int level = level_hi; level >= level_lo; level--) {
+    for (int level = level_hi; (phases & HME_LEVELS) && level >= level_lo; level--) {
         int step = 1 << level;
         int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
         if (!g_hme_rows) {
@@ -1930,6 +1992,7 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
     c.counters = f.counters;
     c.host_mvs = nullptr;
     c.host_counters = nullptr;
+    c.stats[0] = c.stats[1] = nullptr;
     size_t nb = (size_t) hp.a.nbh * hp.a.nbv;
     HIPCHK(hipMemsetAsync(f.counters, 0, hme_counter_words(hp.a.nbv) * sizeof(int), s));
     for (int level = hp.pyr_levels; level >= 0; level--) {

@@ -454,6 +454,54 @@ __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
     return np;
 }
 
+// ---- what the search needs to know about a SOURCE block before it looks at a single candidate (hme.c:1392-1441) --------
+// A function of the block's own pixels and of the frame's quantiser alone: not of any neighbour, not of the reference.
+// The row pipeline of the search is serial along a row and down the rows; this is not, so the batched driver works it out
+// for every block of levels 0 and 1 in a launch of its own (k_hme_src_stats_b: one wavefront per block, no order) and a
+// block of the search starts from 12 bytes instead of ~600 instructions and two LDS histograms.
+struct SrcStats {
+    int bias_raw;     // motion_bias before it is divided by the global motion (known only when the level above is done)
+    unsigned var_src; // block_detail of the source
+    unsigned avg_src;
+    unsigned zoscore; // pre-pass only: the metric against the co-located block of the previous SOURCE picture ("good enough" test, hme.c:1559)
+};
+
+// the metric's weights for a source block of this detail (hme.c:1431-1441)
+__device__ __forceinline__ Psy psy_of_source(unsigned var_src, int bw, int bh, int quant)
+{
+    Psy psy = var_src <= (unsigned) (8 * bw * bh * quant >> 9) ? Psy{2, 1, 2} : Psy{1, 2, 1};
+    if (var_src > (unsigned) (24 * bw * bh)) {
+        psy.avg_weight = 0;
+    }
+    return psy;
+}
+
+__device__ __forceinline__ SrcStats source_analysis(const Quad &a, bool act, int qi, int qj, int qw, int bw, int bh, int quant, int *hist)
+{
+    SrcStats st;
+    int ps, ph, pv;
+    quad_grad_partials(a, act, qi, qj, 0, 0, ps, ph, pv);
+    int v4[4] = {ps, ph, pv, 0};
+    int r = reduceN<4>(v4);
+    int sum = bcastN<4>(r, 0);
+    unsigned sh = (unsigned) bcastN<4>(r, 1), sv = (unsigned) bcastN<4>(r, 2);
+    int mean = div_nn(sum, bw * bh);
+    st.avg_src = (unsigned) mean;
+    int var = wave_sum(quad_absdev(a, act, mean)) >> 1;
+    int tex = (int) (max(sh, sv) - (unsigned) var);
+    st.var_src = (unsigned) (var + max(tex, 0));
+    int tvar = (int) (st.var_src + SQR(st.var_src >> 10));
+    tvar = div_nn(8 * tvar * quant >> 9, bw * bh);
+    st.bias_raw = 16 * 16;
+    if (tvar) {
+        int hvar = src_hist_var(a, act, sum, bw, bh, hist);
+        int qtex = src_quant_tex(a, act, qi, qj, qw, bw, bh);
+        int npeaks = src_peaks(a, act, (int) st.avg_src, hist);
+        st.bias_raw += tvar * (hvar - qtex) * npeaks;
+    }
+    return st;
+}
+
 // scores up to 16 displacement vectors held in LDS (s.cx/cy[first .. first+cnt)) against the
 // register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
 // first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
@@ -1235,7 +1283,18 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     const uint8_t *sblk = at(src, bx, by);
     Quad a = ldq(sblk, src.stride, qi, qj, act);
     a.w &= smask;
-    const Quad o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act); // for the "good enough" test far below: same load round
+    // the block's source statistics, if the driver had them worked out ahead (levels 0 and 1): a scalar load, same round
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
+    const int4 *pre_stats = level <= 1 ? src_stats_of(c, level) : nullptr;
+    v4i_t pre_words = {0, 0, 0, 0};
+    Quad o_zero; // for the "good enough" test far below: same load round (its outcome comes with the statistics if they were worked out ahead)
+    o_zero.w = 0;
+    if (pre_stats != nullptr) {
+        pre_words = *(cv4i_t) &pre_stats[(i >> level) + (j >> level) * ((nxb + step - 1) >> level)];
+    } else {
+        o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
+    }
     // the same round also stages the search windows in LDS (LDS-DMA, no registers: see WinLds)
     Win W;
     W.on = kUseWin;
@@ -1310,35 +1369,22 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     unsigned var_src = 0, avg_src = 0;
     Psy psy = {2, 1, 0};
     if (level <= 1) {
-        int ps, ph, pv;
-        quad_grad_partials(a, act, qi, qj, 0, 0, ps, ph, pv);
-        int v4[4] = {ps, ph, pv, 0};
-        int r = reduceN<4>(v4);
-        int sum = bcastN<4>(r, 0);
-        unsigned sh = (unsigned) bcastN<4>(r, 1), sv = (unsigned) bcastN<4>(r, 2);
-        int mean = div_nn(sum, bw * bh);
-        avg_src = (unsigned) mean;
-        int var = wave_sum(quad_absdev(a, act, mean)) >> 1;
-        int tex = (int) (max(sh, sv) - (unsigned) var);
-        var_src = (unsigned) (var + max(tex, 0));
-        int tvar = (int) (var_src + SQR(var_src >> 10));
-        tvar = div_nn(8 * tvar * c.quant >> 9, bw * bh);
-        if (tvar) {
-            int hvar = src_hist_var(a, act, sum, bw, bh, S.hist);
-            int qtex = src_quant_tex(a, act, qi, qj, qw, bw, bh);
-            int npeaks = src_peaks(a, act, (int) avg_src, S.hist);
-            motion_bias += tvar * (hvar - qtex) * npeaks;
-        }
-        motion_bias = (int) udiv_fast((unsigned) max(motion_bias, 0), (unsigned) (2 + (abs(gx) + abs(gy))));
-        if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
-            psy = Psy{2, 1, 2};
-            motion_bias = 0;
+        SrcStats st;
+        if (pre_stats != nullptr) { // (worked out ahead of the search, see source_analysis)
+            st.bias_raw = pre_words.x;
+            st.var_src = (unsigned) pre_words.y;
+            st.avg_src = (unsigned) pre_words.z;
+            st.zoscore = (unsigned) pre_words.w;
         } else {
-            psy = Psy{1, 2, 1};
+            st = source_analysis(a, act, qi, qj, qw, bw, bh, c.quant, S.hist);
         }
-        if (var_src > (unsigned) (24 * bw * bh)) {
-            psy.avg_weight = 0;
+        var_src = st.var_src;
+        avg_src = st.avg_src;
+        motion_bias = (int) udiv_fast((unsigned) max(st.bias_raw, 0), (unsigned) (2 + (abs(gx) + abs(gy))));
+        if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
+            motion_bias = 0;
         }
+        psy = psy_of_source(var_src, bw, bh, c.quant);
     }
 
     HME_MARK(S, 1);
@@ -1502,7 +1548,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
     {
-        unsigned zoscore = metric_return(wave_sum(actM ? qmetric(a, o_zero, psy) : 0u), bw, bh);
+        unsigned zoscore = pre_stats != nullptr ? (unsigned) pre_words.w : metric_return(wave_sum(actM ? qmetric(a, o_zero, psy) : 0u), bw, bh);
         if (abs(dx) <= 1 && abs(dy) <= 1) {
             qthresh *= 2;
         }
