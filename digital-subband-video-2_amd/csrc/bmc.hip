@@ -1492,7 +1492,129 @@ __device__ __forceinline__ void degrad2(PairTile &T)
     T.rows_dirty = true;
 }
 
-__device__ void intra_cell2(const RingView &view, const DPlane &dp, const FilterParams &f, const uint8_t *bd, int i, int j, int p, int nsbx, int nsby)
+// the cell as the routines below see it: a lane pair sharing it (PairCell, lane p) ...
+struct PairCell {
+    PairTile T;
+    int p;
+    __device__ __forceinline__ void load(const RingView &view, int x, int y) { T.load(view, x, y, p); }
+    __device__ __forceinline__ void store(const RingView &view, int x, int y) const { T.store(view, x, y, p); }
+    __device__ __forceinline__ void hfilter(const DPlane &dp, int x, bool edge, int tE, int tM, bool on) { hfilter2(T, dp, x, edge, tE, tM, on); }
+    __device__ __forceinline__ void vfilter(const DPlane &dp, int y, bool edge, int tE, int tM, bool on) { vfilter2(T, dp, y, p, edge, tE, tM, on); }
+    __device__ __forceinline__ void artf(int &sh, int &sv, int &slh, int &slv) const { artf2(T, p, sh, sv, slh, slv); }
+    __device__ __forceinline__ unsigned dsff() const { return dsff2(T, p); }
+    __device__ __forceinline__ void degrad() { degrad2(T); }
+};
+
+// ... or one lane holding both halves (launches that fill the chip several times over are bound by instructions per cell, not
+// by the front's latency: the packed line filters without the second wavefront).  What the pair hands over by lane swaps
+// moves between the halves' registers here.
+struct DualCell {
+    PairTile H[2];
+    __device__ __forceinline__ void load(const RingView &view, int x, int y)
+    {
+        H[0].load(view, x, y, 0);
+        H[1].load(view, x, y, 1);
+    }
+    __device__ __forceinline__ void store(const RingView &view, int x, int y) const
+    {
+        H[0].store(view, x, y, 0);
+        H[1].store(view, x, y, 1);
+    }
+    __device__ __forceinline__ void hfilter(const DPlane &dp, int x, bool edge, int tE, int tM, bool on)
+    {
+        hfilter2(H[0], dp, x, edge, tE, tM, on);
+        hfilter2(H[1], dp, x, edge, tE, tM, on);
+    }
+    __device__ __forceinline__ void vfilter(const DPlane &dp, int y, bool edge, int tE, int tM, bool on)
+    {
+        on = on & !(y < 4 || y > dp.h - 4 || (edge && tE <= 0) || tM <= 0);
+        tE = edge ? tE : tM;
+        tE = on ? tE : 0;
+        tM = on ? tM : 0;
+        bool in_edge = y < dp.h - 8;
+        uint32_t l[2][11];
+#pragma unroll
+        for (int p = 0; p < 2; p++) { // half p's columns 2p, 2p + 1 through all four rows: rows 0, 1 sit in H[0], rows 2, 3 in H[1]
+            l[p][0] = H[p].o[0];
+            l[p][1] = H[p].o[1];
+            l[p][2] = H[p].o[2];
+            l[p][3] = __builtin_amdgcn_perm(H[0].h[5 + 2 * p], H[0].h[4 + 2 * p], 0x05040100u);
+            l[p][4] = __builtin_amdgcn_perm(H[0].h[5 + 2 * p], H[0].h[4 + 2 * p], 0x07060302u);
+            l[p][5] = __builtin_amdgcn_perm(H[1].h[5 + 2 * p], H[1].h[4 + 2 * p], 0x05040100u);
+            l[p][6] = __builtin_amdgcn_perm(H[1].h[5 + 2 * p], H[1].h[4 + 2 * p], 0x07060302u);
+            l[p][7] = H[p].o[3];
+            l[p][8] = H[p].o[4];
+            l[p][9] = H[p].o[5];
+            l[p][10] = H[p].o[6];
+        }
+        bool hit = false;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            hit |= line_filter_pk(l[p], in_edge, tE, tM);
+            H[p].o[1] = l[p][1];
+            H[p].o[2] = l[p][2];
+            H[p].o[3] = l[p][7];
+            H[p].o[4] = l[p][8];
+            H[p].o[5] = l[p][9];
+            H[0].h[4 + 2 * p] = __builtin_amdgcn_perm(l[p][4], l[p][3], 0x05040100u);
+            H[0].h[5 + 2 * p] = __builtin_amdgcn_perm(l[p][4], l[p][3], 0x07060302u);
+            H[1].h[4 + 2 * p] = __builtin_amdgcn_perm(l[p][6], l[p][5], 0x05040100u);
+            H[1].h[5 + 2 * p] = __builtin_amdgcn_perm(l[p][6], l[p][5], 0x07060302u);
+        }
+        H[0].rows_dirty |= hit;
+        H[1].rows_dirty |= hit;
+        H[0].outer_dirty |= hit;
+        H[1].outer_dirty |= hit;
+    }
+    // the cell's pixel (yy, xx)
+    __device__ __forceinline__ int cpx(int yy, int xx) const { return H[yy >> 1].px(yy & 1, xx); }
+    __device__ __forceinline__ void artf(int &sh, int &sv, int &slh, int &slv) const // bmc.c:224-270
+    {
+        sh = sv = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y += 2) {
+#pragma unroll
+            for (int x = 0; x < 4; x += 2) {
+                int x0 = cpx(y, x), x1 = cpx(y, x + 1), x2 = cpx(y + 1, x), x3 = cpx(y + 1, x + 1);
+                int hh = absdiff(x0 + x3, x1 + x2) >> 1;
+                sh += absdiff(x0 + x2, x1 + x3) + hh;
+                sv += absdiff(x0 + x1, x2 + x3) + hh;
+            }
+        }
+        int d[4];
+        DS2X2(cpx, d);
+        int hh = absdiff(d[0] + d[3], d[1] + d[2]) >> 1;
+        slh = absdiff(d[0] + d[2], d[1] + d[3]) + hh;
+        slv = absdiff(d[0] + d[1], d[2] + d[3]) + hh;
+    }
+    __device__ __forceinline__ unsigned dsff() const
+    {
+        int d[4];
+        DS2X2(cpx, d);
+        return dsff_d(d);
+    }
+    __device__ __forceinline__ void degrad()
+    {
+        int px[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            px[k] = cpx(k >> 2, k & 3);
+        }
+        if (degrad16(px)) {
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    H[hh].h[4 + k] = (uint32_t) px[8 * hh + k] | ((uint32_t) px[8 * hh + 4 + k] << 16);
+                }
+            }
+            H[0].rows_dirty = H[1].rows_dirty = true;
+        }
+    }
+};
+
+template <class Cell>
+__device__ void intra_cell_pk(Cell &T, const RingView &view, const DPlane &dp, const FilterParams &f, const uint8_t *bd, int i, int j, int nsbx, int nsby)
 {
     int x = i * 4, y = j * 4;
     bool live = !(y + 4 >= dp.h || x + 4 >= dp.w);
@@ -1501,34 +1623,34 @@ __device__ void intra_cell2(const RingView &view, const DPlane &dp, const Filter
     if (!__any(live)) { // nothing to do for the whole wavefront
         return;
     }
-    PairTile T;
-    T.load(view, x, y, p);
+    T.load(view, x, y);
     int sh, sv, shl, svl;
-    artf2(T, p, sh, sv, shl, svl);
+    T.artf(sh, sv, shl, svl);
     int mx = max(sh, sv);
     live = live & (mx < 256 && mx > 8);
     int tt = 32;
     {
-        int td = (int) dsff2(T, p);
+        int td = (int) T.dsff();
         td = (flags & DSV_IS_STABLE) ? (td * 5 >> 2) : td;
         tt = (flags & (DSV_IS_MAINTAIN | DSV_IS_STABLE)) ? td : (tt >> 2);
     }
     tt = tt * 2 / 3;
     tt = (tt * f.q) >> 12;
     tt = clampi(tt, 0, f.fthresh);
-    hfilter2(T, dp, x, false, tt, tt, live);
-    vfilter2(T, dp, y, p, false, tt, tt, live);
+    T.hfilter(dp, x, false, tt, tt, live);
+    T.vfilter(dp, y, false, tt, tt, live);
     tt = sh > sv ? (3 * sh + sv) : (3 * sv + sh);
     tt = curve_tex(tt);
     tt = 16 + ((tt + 2) >> 2);
     tt = (tt * f.q) >> 12;
     tt = clampi(tt, 0, f.fthresh);
-    hfilter2(T, dp, x, false, tt, tt, live);
-    vfilter2(T, dp, y, p, false, tt, tt, live);
-    T.store(view, x, y, p);
+    T.hfilter(dp, x, false, tt, tt, live);
+    T.vfilter(dp, y, false, tt, tt, live);
+    T.store(view, x, y);
 }
 
-__device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const FilterParams &f, const CellRec &rec, int fx, int fy, int i, int j, int p)
+template <class Cell>
+__device__ void luma_cell_rec_pk(Cell &T, const RingView &view, const DPlane &dp, const FilterParams &f, const CellRec &rec, int fx, int fy, int i, int j)
 {
     int x = i * 4, y = j * 4;
     uint32_t flags = rec.flags;
@@ -1551,8 +1673,7 @@ __device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const Fil
     if (!__any(live)) { // nothing to do for the whole wavefront
         return;
     }
-    PairTile T;
-    T.load(view, x, y, p);
+    T.load(view, x, y);
     // the two passes and their thresholds, by block type (bmc.c:527-596): as luma_cell_rec
     bool h_on, v_on, eh, ev;
     int hE, hM, vE, vM;
@@ -1563,7 +1684,7 @@ __device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const Fil
         bool eprm = (flags & (1u << DSV_MV_BIT_EPRM)) != 0;
         int tndc = (ndx + ndy + 1) >> 1;
         int sh, sv, shl, svl, tt;
-        artf2(T, p, sh, sv, shl, svl);
+        T.artf(sh, sv, shl, svl);
         int n_dx = ndx, n_dy = ndy;
         bool mixed = sh < 2 * sv && sv < 2 * sh;
         {
@@ -1597,17 +1718,17 @@ __device__ void luma_cell_rec2(const RingView &view, const DPlane &dp, const Fil
     FILT_COUNT(3, v_on);
     FILT_COUNT(4, live & sharp);
     if (__any(h_on)) {
-        hfilter2(T, dp, x, eh, hE, hM, h_on);
+        T.hfilter(dp, x, eh, hE, hM, h_on);
     }
     if (__any(v_on)) {
-        vfilter2(T, dp, y, p, ev, vE, vM, v_on);
+        T.vfilter(dp, y, ev, vE, vM, v_on);
     }
     if (__any(live & sharp)) {
         if (live & sharp) {
-            degrad2(T);
+            T.degrad();
         }
     }
-    T.store(view, x, y, p);
+    T.store(view, x, y);
 }
 
 // wavefront sweep helper: front t holds the cells (i, j) with i + 2j == t
@@ -1819,12 +1940,15 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
     }
 }
 
-// stream-batched filters: grid = (3 planes, n jobs) / (n jobs)
+// stream-batched filters: grid = (n jobs, 3 planes) / (n jobs).  A luma sweep holds ~70 KB of LDS -- two fit a CU, 512 the
+// chip -- and the launch reserves that for the chroma workgroups too: with the plane as the SLOW grid index all luma sweeps of
+// a 192-picture launch (576 workgroups) are dispatched first and start at once; the short chroma sweeps fill in behind them.
+// (Plane-major order had a fifth of the luma sweeps start when the first chroma sweeps had finished.)
 __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
-    const McJob &jb = tab[blockIdx.y];
-    int c = blockIdx.x;
+    const McJob &jb = tab[blockIdx.x];
+    int c = blockIdx.y; // (the luma sweeps -- the long ones, and the ones that need the LDS -- are dispatched first)
     const DPlane dp = jb.res.p[c];
     const FilterParams f = jb.f;
     const DSV_MV *vecs = jb.mvs;
@@ -1858,7 +1982,8 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
                         cur = key == nxt_key ? nxt : landed(fetch_cell_rec(vecs, f.nbh, fx, fy));
                         cur_key = key;
                     }
-                    luma_cell_rec(view, dp, f, cur, fx, fy, i, j);
+                    DualCell C;
+                    luma_cell_rec_pk(C, view, dp, f, cur, fx, fy, i, j);
                 },
                 [&](int i, int j) {
                     int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
@@ -1883,8 +2008,8 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
 __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
-    const McJob &jb = tab[blockIdx.y];
-    int c = blockIdx.x;
+    const McJob &jb = tab[blockIdx.x];
+    int c = blockIdx.y; // (the luma sweeps -- the long ones, and the ones that need the LDS -- are dispatched first)
     const DPlane dp = jb.res.p[c];
     const FilterParams f = jb.f;
     const DSV_MV *vecs = jb.mvs;
@@ -1917,7 +2042,9 @@ __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restric
                         cur = key == nxt_key ? nxt : landed(fetch_cell_rec(vecs, f.nbh, fx, fy));
                         cur_key = key;
                     }
-                    luma_cell_rec2(view, dp, f, cur, fx, fy, i, j, p);
+                    PairCell C;
+                    C.p = p;
+                    luma_cell_rec_pk(C, view, dp, f, cur, fx, fy, i, j);
                 },
                 [&](int i, int j) {
                     int fx = quarter_x ? i >> 2 : scale_div(i, f.nbh, nsbx), fy = row_block(j), key = fx + fy * f.nbh;
@@ -1949,7 +2076,11 @@ __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict
     if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
         uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
-        ring_sweep2(dp, ring0, [&](int i, int j, int p) { intra_cell2(view, dp, f, bd, i, j, p, nsbx, nsby); }, [](int, int) {}, []() {});
+        ring_sweep2(dp, ring0, [&](int i, int j, int p) {
+            PairCell C;
+            C.p = p;
+            intra_cell_pk(C, view, dp, f, bd, i, j, nsbx, nsby);
+        }, [](int, int) {}, []() {});
     } else {
         sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
@@ -1966,7 +2097,13 @@ __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict_
     if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
         uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
-        ring_sweep(dp, ring0, [&](int i, int j) { intra_cell(view, dp, f, bd, i, j, nsbx, nsby); }, [](int, int) {}, []() {});
+        ring_sweep(
+            dp, ring0,
+            [&](int i, int j) {
+                DualCell C;
+                intra_cell_pk(C, view, dp, f, bd, i, j, nsbx, nsby);
+            },
+            [](int, int) {}, []() {});
     } else {
         sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
@@ -2129,9 +2266,9 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
             if (filter_pair(n)) {
-                DSV2_LAUNCH(k_inter_filters_b2, dim3(3, n), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+                DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
             } else {
-                DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
             }
         }
     }
@@ -2144,9 +2281,9 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
             if (filter_pair(n)) {
-                DSV2_LAUNCH(k_inter_filters_b2, dim3(3, n), dim3(512), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+                DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
             } else {
-                DSV2_LAUNCH(k_inter_filters_b, dim3(3, n), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
             }
         }
     }
