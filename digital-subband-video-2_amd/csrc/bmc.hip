@@ -1944,7 +1944,7 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
 // chip -- and the launch reserves that for the chroma workgroups too: with the plane as the SLOW grid index all luma sweeps of
 // a 192-picture launch (576 workgroups) are dispatched first and start at once; the short chroma sweeps fill in behind them.
 // (Plane-major order had a fifth of the luma sweeps start when the first chroma sweeps had finished.)
-__global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
@@ -1957,7 +1957,7 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
     }
     if (c == 0) {
         int nsbx = dp.w / 4, nsby = dp.h / 4;
-        if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
+        { // (the host launches this kernel only where the ring fits: ring_fits())
             uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
             // the block record of the cell at hand and, fetched one front early, of the next one
@@ -1996,8 +1996,6 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
                     nxt = landed(raw);
                     nxt_key = raw_key;
                 });
-        } else {
-            sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
         }
     } else {
         sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
@@ -2005,7 +2003,7 @@ __global__ __launch_bounds__(256) void k_inter_filters_b(const McJob *__restrict
 }
 
 // the same with a lane pair per luma cell: 512 threads (the chroma workgroups use all of them as block rows)
-__global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inter_filters_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
@@ -2018,7 +2016,7 @@ __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restric
     }
     if (c == 0) {
         int nsbx = dp.w / 4, nsby = dp.h / 4;
-        if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
+        { // (the host launches this kernel only where the ring fits: ring_fits())
             uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
             CellRec cur = {}, nxt = {}, raw = {}; // raw: the load registers of ahead()
@@ -2057,8 +2055,6 @@ __global__ __launch_bounds__(512) void k_inter_filters_b2(const McJob *__restric
                     nxt = landed(raw);
                     nxt_key = raw_key;
                 });
-        } else {
-            sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
         }
     } else {
         sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
@@ -2073,7 +2069,7 @@ __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict
     const FilterParams f = jb.f;
     const uint8_t *bd = jb.bd;
     int nsbx = dp.w / 4, nsby = dp.h / 4;
-    if (ring_eligible(dp, (int) blockDim.x / 2, lds_bytes)) {
+    { // (launched only where the ring fits: ring_fits())
         uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
         ring_sweep2(dp, ring0, [&](int i, int j, int p) {
@@ -2081,8 +2077,6 @@ __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict
             C.p = p;
             intra_cell_pk(C, view, dp, f, bd, i, j, nsbx, nsby);
         }, [](int, int) {}, []() {});
-    } else {
-        sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
 }
 
@@ -2094,7 +2088,7 @@ __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict_
     const FilterParams f = jb.f;
     const uint8_t *bd = jb.bd;
     int nsbx = dp.w / 4, nsby = dp.h / 4;
-    if (ring_eligible(dp, (int) blockDim.x, lds_bytes)) {
+    { // (launched only where the ring fits: ring_fits())
         uint8_t *ring0 = dyn_lds + RingView::kGuardTop * 64;
             RingView view{ring0, dp.h};
         ring_sweep(
@@ -2104,9 +2098,37 @@ __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict_
                 intra_cell_pk(C, view, dp, f, bd, i, j, nsbx, nsby);
             },
             [](int, int) {}, []() {});
-    } else {
-        sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
     }
+}
+
+// the batched filters where the plane-resident ring does not fit (width not a multiple of 4, more cell rows in flight than
+// threads, taller than the LDS): the same fronts through global memory; grid = (n jobs, 3 planes) / (n jobs)
+__global__ __launch_bounds__(256) void k_inter_filters_g(const McJob *__restrict__ tab)
+{
+    const McJob &jb = tab[blockIdx.x];
+    int c = blockIdx.y;
+    const DPlane dp = jb.res.p[c];
+    const FilterParams f = jb.f;
+    const DSV_MV *vecs = jb.mvs;
+    if (f.lossless) {
+        return;
+    }
+    if (c == 0) {
+        int nsbx = dp.w / 4, nsby = dp.h / 4;
+        sweep_fronts(nsbx, nsby, [&](int i, int j) { luma_cell(GlobalView{dp}, dp, f, vecs, i, j, nsbx, nsby); });
+    } else {
+        sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
+    }
+}
+
+__global__ __launch_bounds__(256) void k_intra_filter_g(const McJob *__restrict__ tab)
+{
+    const McJob &jb = tab[blockIdx.x];
+    const DPlane dp = jb.res.p[0];
+    const FilterParams f = jb.f;
+    const uint8_t *bd = jb.bd;
+    int nsbx = dp.w / 4, nsby = dp.h / 4;
+    sweep_fronts(nsbx, nsby, [&](int i, int j) { intra_cell(GlobalView{dp}, dp, f, bd, i, j, nsbx, nsby); });
 }
 
 __global__ __launch_bounds__(256) void k_intra_filter(const uint8_t *__restrict__ bd, FilterParams f, DPlane dp)
@@ -2226,8 +2248,9 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
     HIPCHK(hipGetLastError());
 }
 
-// dynamic LDS of the plane-resident luma sweep: one 64-byte ring per pixel row (0 = use the global-memory sweep)
-static unsigned ring_lds_bytes(int luma_h)
+// dynamic LDS of the plane-resident luma sweep: one 64-byte ring per pixel row + guard rows (0 = the ring does not fit this
+// picture: the global-memory kernels run).  Host mirror of what the ring sweeps assume (ring_eligible).
+static unsigned ring_lds_bytes(int luma_w, int luma_h)
 {
     static int on = getenv("DSV2_FILTER_RING") ? atoi(getenv("DSV2_FILTER_RING")) : 1;
     static bool raised = false;
@@ -2239,7 +2262,8 @@ static unsigned ring_lds_bytes(int luma_h)
         raised = true;
     }
     size_t b = (size_t) (luma_h + RingView::kGuardRows) * 64;
-    return (on && b <= 150 * 1024) ? (unsigned) b : 0u;
+    const bool fits = on && (luma_w & 3) == 0 && (luma_h & 3) == 0 && luma_w >= 64 && b <= 150 * 1024 && (luma_w / 4 + 14) / 2 + 1 <= 256;
+    return fits ? (unsigned) b : 0u;
 }
 
 // Which luma sweep a launch of n pictures gets.  The lane-pair kernels shorten a sweep's critical path (one picture:
@@ -2260,42 +2284,51 @@ void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nb
     }
 }
 
-void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_h, int blk_w, int blk_h)
+void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_w, int blk_h)
 {
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            if (filter_pair(n)) {
-                DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+            const unsigned lds = ring_lds_bytes(luma_w, luma_h);
+            if (!lds) {
+                DSV2_LAUNCH(k_inter_filters_g, dim3(n, 3), dim3(256), 0, s, d_tab);
+            } else if (filter_pair(n)) {
+                DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), lds, s, d_tab, lds);
             } else {
-                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), lds, s, d_tab, lds);
             }
         }
     }
 }
 
 // decoder: d_pred jobs {ref, pred = output picture, res = residual}; d_filt jobs {res = output picture}
-void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_h)
+void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h)
 {
     if (n > 0) {
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            if (filter_pair(n)) {
-                DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+            const unsigned lds = ring_lds_bytes(luma_w, luma_h);
+            if (!lds) {
+                DSV2_LAUNCH(k_inter_filters_g, dim3(n, 3), dim3(256), 0, s, d_filt);
+            } else if (filter_pair(n)) {
+                DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), lds, s, d_filt, lds);
             } else {
-                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), ring_lds_bytes(luma_h), s, d_filt, ring_lds_bytes(luma_h));
+                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), lds, s, d_filt, lds);
             }
         }
     }
 }
 
-void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_h)
+void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_w, int luma_h)
 {
     if (n > 0) {
-        if (filter_pair(n)) {
-            DSV2_LAUNCH(k_intra_filter_b2, dim3(n), dim3(512), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+        const unsigned lds = ring_lds_bytes(luma_w, luma_h);
+        if (!lds) {
+            DSV2_LAUNCH(k_intra_filter_g, dim3(n), dim3(256), 0, s, d_tab);
+        } else if (filter_pair(n)) {
+            DSV2_LAUNCH(k_intra_filter_b2, dim3(n), dim3(512), lds, s, d_tab, lds);
         } else {
-            DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), ring_lds_bytes(luma_h), s, d_tab, ring_lds_bytes(luma_h));
+            DSV2_LAUNCH(k_intra_filter_b, dim3(n), dim3(256), lds, s, d_tab, lds);
         }
     }
 }

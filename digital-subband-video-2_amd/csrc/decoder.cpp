@@ -654,8 +654,8 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
         }
     }
     zero_linear_batch(bs, d_zfail, n_zfail, max_plane_bytes);
-    intra_filter_batch(bs, d_mc_intra, nIf, dv0.h);
-    mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter, dv0.h);
+    intra_filter_batch(bs, d_mc_intra, nIf, dv0.w, dv0.h);
+    mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter, dv0.w, dv0.h);
     for (int c = 0; c < 3; c++) {
         const DPlane &pl = dv0.pics[0].recon.p[c];
         copy_planes_batch(bs, d_icopy[c], nI, pl.w, pl.h);

@@ -1927,11 +1927,11 @@ void enc_batch(Job *jobs, int n)
     if (side_intra) {
         sc.ensure_aux();
         sc.fork(bs, 1);
-        intra_filter_batch(sc.aux[1], sc.d_mc + n, nI, dv0.h);
+        intra_filter_batch(sc.aux[1], sc.d_mc + n, nI, dv0.w, dv0.h);
     } else {
-        intra_filter_batch(bs, sc.d_mc + n, nI, dv0.h);
+        intra_filter_batch(bs, sc.d_mc + n, nI, dv0.w, dv0.h);
     }
-    mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter, dv0.h, dv0.blk_w, dv0.blk_h);
+    mc_add_res_batch(bs, sc.d_mc, nP, nbh, nbv, any_filter, dv0.w, dv0.h, dv0.blk_w, dv0.blk_h);
     if (side_intra) {
         sc.join(bs, 1);
     }
