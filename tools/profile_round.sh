@@ -56,7 +56,7 @@ by = {}
 for s, e, n in rows:
     s, e = max(s, lo), min(e, hi)
     if e > s:
-        nm = n.split("(")[0].replace("void ", "").replace("dsv2::", "").replace("(anonymous namespace)::", "")[:40]
+        nm = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dsv2::", "")[:40]
         by[nm] = by.get(nm, 0) + (e - s)
 print("  kernel time summed over streams, %% of the region (can exceed 100 in total):")
 for nm, v in sorted(by.items(), key=lambda x: -x[1])[:14]:

@@ -15,7 +15,7 @@ r = json.loads([l for l in open(f"gpurun_out/tl/{t}.json") if l.startswith("{")]
 print(t, r["value"], "fps", r["ms_per_step"], "ms/step")
 rows = sorted(csv.DictReader(open(f"gpurun_out/tl/{t}.csv")), key=lambda x: int(x["Start_Timestamp"]))
 def nm(x):
-    return x["Kernel_Name"].split("(")[0].replace("void ", "").replace("dsv2::", "").replace("(anonymous namespace)::", "")[:52]
+    return x["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dsv2::", "")[:52]
 # steps are delimited by the ingest kernel; take the third from the end
 starts = [i for i, x in enumerate(rows) if nm(x).startswith("k_ingest")]
 a, b = starts[-3], starts[-2]
