@@ -1811,20 +1811,32 @@ int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &r
 // ---- source statistics ahead of the search (see source_analysis in hme_fast.h) -----------------------------------------
 // grid = (ceil(blocks of level 0 + blocks of level 1, per_wg), streams); one wavefront works through per_wg blocks.
 static int g_hme_prestats = getenv("DSV2_HME_PRESTATS") ? atoi(getenv("DSV2_HME_PRESTATS")) : 1;
-__global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int per_wg)
+__global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int fb0x, int fb0y,
+                                                        int fb1x, int fb1y, int per_wg)
 {
+    // [0, fbx) x [0, fby) of a level is left to k_hme_src_stats4_b; what is enumerated here is the strip of block rows below it,
+    // then the strip of block columns to its right (fb = 0: every block)
     __shared__ int hist[16];
     const HmeDev &c = tab[blockIdx.y];
     const int lane = threadIdx.x & 63, qi = lane & 7, qj = lane >> 3;
-    const int n0 = nb0x * nb0y, total = n0 + nb1x * nb1y;
+    const int n0 = nb0x * nb0y - fb0x * fb0y, total = n0 + nb1x * nb1y - fb1x * fb1y;
     const int quant = uni(c.quant);
     int4 *const out0 = uni_ptr(c.stats[0]), *const out1 = uni_ptr(c.stats[1]);
     const DPlane src0 = uni(c.src[0]), src1 = uni(c.src[1]), ogr0 = uni(c.ogr[0]), ogr1 = uni(c.ogr[1]);
     const int b_end = min(total, ((int) blockIdx.x + 1) * per_wg);
     for (int b = (int) blockIdx.x * per_wg; b < b_end; b++) {
         const bool l1 = b >= n0;
-        const int idx = l1 ? b - n0 : b, nbx = l1 ? nb1x : nb0x;
-        const int bi = idx % nbx, bj = idx / nbx;
+        const int e = l1 ? b - n0 : b, nbx = l1 ? nb1x : nb0x, nby = l1 ? nb1y : nb0y, fbx = l1 ? fb1x : fb0x, fby = l1 ? fb1y : fb0y;
+        const int below = (nby - fby) * nbx;
+        int bi, bj;
+        if (e < below) {
+            bj = fby + e / nbx;
+            bi = e % nbx;
+        } else {
+            bj = (e - below) / (nbx - fbx);
+            bi = fbx + (e - below) % (nbx - fbx);
+        }
+        const int idx = bi + bj * nbx;
         const DPlane src = l1 ? src1 : src0;
         const int bx = bi * 16, by = bj * 16;
         const int bw = min(src.w - bx, 16), bh = min(src.h - by, 16);
@@ -1841,6 +1853,171 @@ __global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict
         if (lane == 0) {
             (l1 ? out1 : out0)[idx] = int4{st.bias_raw, (int) st.var_src, (int) st.avg_src, (int) st.zoscore};
         }
+    }
+}
+
+// ---- the same statistics, FOUR whole 16x16 blocks per wavefront -------------------------------------------------------------
+// source_analysis() is written as the block routine needs it: one block per wavefront, a 2x2 quad per lane, full-width
+// reductions -- 330 vector instructions per block, more than the search saves by not running it.  Every quantity in it is an
+// integer sum over the block's pixels, pixel pairs or quads, so the order of evaluation is free: here 16 lanes share a block
+// (a DPP row), lane r holds pixel row r as four dwords, sums go through v_sad_u8 / v_dot4_u32_u8 on whole dwords, row
+// totals through four DPP steps.  Same results (the batched encoder's parity tests run both forms), a third of the instructions.
+// Clipped blocks of the last column / row keep the one-block form (k_hme_src_stats_b over the edge strips).
+template <int CTRL> __device__ __forceinline__ int dppmov(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int row16_sum(int v) // total over the 16 lanes of a DPP row, in every lane of it
+{
+    v += dppmov<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dppmov<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dppmov<0x141>(v); // row_half_mirror
+    v += dppmov<0x140>(v); // row_mirror
+    return v;
+}
+__device__ __forceinline__ int row16_max(int v)
+{
+    v = max(v, dppmov<0xB1>(v));
+    v = max(v, dppmov<0x4E>(v));
+    v = max(v, dppmov<0x141>(v));
+    v = max(v, dppmov<0x140>(v));
+    return v;
+}
+
+typedef unsigned uint4v_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_hme_src_stats4_b(const HmeDev *__restrict__ tab, int nb0x, int nb1x, int fb0x, int fb0y, int fb1x, int fb1y)
+{
+    __shared__ int hist[2][4][16];
+    const HmeDev &c = tab[blockIdx.y];
+    const int lane = threadIdx.x & 63, blk = lane >> 4, r = lane & 15;
+    const int gpr0 = (fb0x + 3) >> 2, gpr1 = (fb1x + 3) >> 2, G0 = gpr0 * fb0y;
+    const bool l1 = (int) blockIdx.x >= G0;
+    const int g = l1 ? (int) blockIdx.x - G0 : (int) blockIdx.x, gpr = l1 ? gpr1 : gpr0, fbx = l1 ? fb1x : fb0x;
+    const int bj = g / gpr, bi_raw = (g % gpr) * 4 + blk;
+    const bool valid = bi_raw < fbx;
+    const int bi = valid ? bi_raw : fbx - 1;
+    const DPlane src = uni(c.src[l1 ? 1 : 0]), ogr = uni(c.ogr[l1 ? 1 : 0]);
+    const int quant = uni(c.quant);
+    typedef const __attribute__((address_space(1))) uint4v_t *gu4_t;
+    const uint4v_t A = *(gu4_t) (src.data + (ptrdiff_t) (bj * 16 + r) * src.stride + bi * 16);
+    const uint4v_t O = *(gu4_t) (ogr.data + (ptrdiff_t) (bj * 16 + r) * ogr.stride + bi * 16);
+    const uint32_t a[4] = {A[0], A[1], A[2], A[3]}, o[4] = {O[0], O[1], O[2], O[3]};
+    // the row shifted by one pixel (the last pixel stands for itself: a difference of zero) and the row below (the last
+    // row stands for itself)
+    const uint32_t s[4] = {__builtin_amdgcn_alignbit(a[1], a[0], 8), __builtin_amdgcn_alignbit(a[2], a[1], 8), __builtin_amdgcn_alignbit(a[3], a[2], 8),
+                           (a[3] >> 8) | (a[3] & 0xff000000u)};
+    uint32_t d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        d[k] = (uint32_t) __shfl_down((int) a[k], 1, 16);
+    }
+    // block sum and first-difference sums (quad_grad_partials over every quad), mean, mean absolute deviation
+    unsigned ps = 0, ph = 0, pv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ps = __builtin_amdgcn_sad_u8(a[k], 0u, ps);
+        ph = __builtin_amdgcn_sad_u8(a[k], s[k], ph);
+        pv = __builtin_amdgcn_sad_u8(a[k], d[k], pv);
+    }
+    const int sum = row16_sum((int) ps);
+    const unsigned sh = (unsigned) row16_sum((int) ph), sv = (unsigned) row16_sum((int) pv);
+    const int bw = 16, bh = 16;
+    const int mean = div_nn(sum, bw * bh);
+    unsigned pd = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        pd = __builtin_amdgcn_sad_u8(a[k], rep4(mean), pd);
+    }
+    const int var = row16_sum((int) pd) >> 1;
+    const int tex = (int) (max(sh, sv) - (unsigned) var);
+    const unsigned var_src = (unsigned) (var + max(tex, 0));
+    int tvar = (int) (var_src + SQR(var_src >> 10));
+    tvar = div_nn(8 * tvar * quant >> 9, bw * bh);
+    // src_hist_var: 16-bin histogram of the pixels scaled by 8 / mean
+    unsigned avg = (unsigned) div_nn(sum, bw * bh);
+    if (avg == 0) {
+        avg = 1;
+    }
+    const unsigned q16 = udiv_fast(8u << 16, avg);
+    hist[0][blk][r] = 0;
+    hist[1][blk][r] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            atomicAdd(&hist[0][blk][min((int) (((a[k] >> (8 * b)) & 0xffu) * q16 >> 16), 15)], 1);
+        }
+    }
+    // the cell's quads: an even / odd lane pair holds two pixel rows = eight quads; the even lane takes the left four
+    // (its own dwords 0, 1 on top of the partner's), the odd lane the right four (the partner's dwords 2, 3 on top of its own)
+    const bool odd = (r & 1) != 0;
+    uint32_t tq[2], bq[2], to[2], bo[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t ra = (uint32_t) dppmov<0xB1>((int) (odd ? a[k] : a[2 + k])), ro = (uint32_t) dppmov<0xB1>((int) (odd ? o[k] : o[2 + k]));
+        tq[k] = odd ? ra : a[k];
+        bq[k] = odd ? a[2 + k] : ra;
+        to[k] = odd ? ro : o[k];
+        bo[k] = odd ? o[2 + k] : ro;
+    }
+    const Psy psy = psy_of_source(var_src, bw, bh, quant);
+    // src_peaks (histogram of the quads' means, same scale) and the metric against the previous source picture, quad by quad
+    const int q16p = (int) udiv_fast(8u << 16, (unsigned) (mean ? mean : 1));
+    unsigned zacc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t sel = (k & 1) ? 0x07060302u : 0x05040100u;
+        Quad qa, qo;
+        qa.w = __builtin_amdgcn_perm(bq[k >> 1], tq[k >> 1], sel);
+        qo.w = __builtin_amdgcn_perm(bo[k >> 1], to[k >> 1], sel);
+        const int ds = (int) ((sad4(qa.w, 0u) + 2) >> 2);
+        atomicAdd(&hist[1][blk][min(ds * q16p >> 16, 15)], 1);
+        zacc += qmetric(qa, qo, psy);
+    }
+    const unsigned zoscore = metric_return((unsigned) row16_sum((int) zacc), bw, bh);
+    __syncthreads();
+    int hvar;
+    {
+        const unsigned dd = (unsigned) hist[0][blk][r] - (unsigned) (bw * bh) / 16;
+        const unsigned hv = (unsigned) row16_sum((int) (dd * dd));
+        hvar = (int) div_nn(hv * 16 * 16, 16u * (unsigned) (bw * bh * bw * bh));
+    }
+    // src_quant_tex: squared first differences of the pixels' high nibbles, sum (a - b)^2 = a.a + b.b - 2 a.b on whole dwords
+    int qtex;
+    {
+        unsigned aa = 0, ss = 0, as = 0, dd = 0, ad = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t na = (a[k] >> 4) & 0x0f0f0f0fu, ns = (s[k] >> 4) & 0x0f0f0f0fu, nd = (d[k] >> 4) & 0x0f0f0f0fu;
+            aa = __builtin_amdgcn_udot4(na, na, aa, false);
+            ss = __builtin_amdgcn_udot4(ns, ns, ss, false);
+            as = __builtin_amdgcn_udot4(na, ns, as, false);
+            dd = __builtin_amdgcn_udot4(nd, nd, dd, false);
+            ad = __builtin_amdgcn_udot4(na, nd, ad, false);
+        }
+        const unsigned qsh = (unsigned) row16_sum((int) (aa + ss - 2u * as)), qsv = (unsigned) row16_sum((int) (aa + dd - 2u * ad));
+        qtex = (int) div_nn(isqrt_u32(max(qsh, qsv)), (unsigned) ((bw + bh + 1) >> 1));
+    }
+    int npeaks;
+    {
+        const int cnt = hist[1][blk][r];
+        const int total = row16_sum(cnt);
+        const int maxv = row16_max(cnt) >> 2;
+        const int left = __shfl_up(cnt, 1, 16), right = __shfl_down(cnt, 1, 16);
+        int pk = 1;
+        if (r > 0) {
+            pk &= cnt > left;
+        }
+        if (r < 15) {
+            pk &= cnt > right;
+        }
+        pk &= (cnt > maxv) || (cnt > total / 16);
+        npeaks = row16_sum(pk);
+    }
+    int bias_raw = 16 * 16;
+    if (tvar) {
+        bias_raw += tvar * (hvar - qtex) * npeaks;
+    }
+    if (valid && r == 0) {
+        uni_ptr(c.stats[l1 ? 1 : 0])[bi + bj * (l1 ? nb1x : nb0x)] = int4{bias_raw, (int) var_src, mean, (int) zoscore};
     }
 }
 
@@ -1914,8 +2091,31 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         }
         HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
         if (pre) {
-            const int per_wg = 4, total = nb0x * nb0y + nb1x * nb1y;
-            DSV2_LAUNCH(k_hme_src_stats_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, per_wg);
+            // whole blocks four to a wavefront (DSV2_HME_PRESTATS=2: one block per wavefront everywhere, the form the block
+            // routine itself would run), clipped blocks of the last block row / column one to a wavefront
+            bool four = g_hme_prestats == 1;
+            for (int k = 0; k < n && four; k++) {
+                for (int l = 0; l <= (nb1x ? 1 : 0); l++) {
+                    four = four && (((uintptr_t) f[k].src[l].data | (uintptr_t) f[k].ogr[l].data | (uintptr_t) f[k].src[l].stride | (uintptr_t) f[k].ogr[l].stride) & 15) == 0;
+                }
+            }
+            int fb0x = 0, fb0y = 0, fb1x = 0, fb1y = 0;
+            if (four) {
+                fb0x = std::min(f[0].src[0].w / 16, nb0x);
+                fb0y = std::min(f[0].src[0].h / 16, nb0y);
+                if (nb1x) {
+                    fb1x = std::min(f[0].src[1].w / 16, nb1x);
+                    fb1y = std::min(f[0].src[1].h / 16, nb1y);
+                }
+                const int groups = ((fb0x + 3) / 4) * fb0y + ((fb1x + 3) / 4) * fb1y;
+                if (groups > 0) {
+                    DSV2_LAUNCH(k_hme_src_stats4_b, dim3(groups, n), dim3(64), 0, s, tab, nb0x, nb1x, fb0x, fb0y, fb1x, fb1y);
+                }
+            }
+            const int per_wg = 4, total = nb0x * nb0y - fb0x * fb0y + nb1x * nb1y - fb1x * fb1y;
+            if (total > 0) {
+                DSV2_LAUNCH(k_hme_src_stats_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, fb0x, fb0y, fb1x, fb1y, per_wg);
+            }
         }
     }
     int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
