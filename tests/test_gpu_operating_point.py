@@ -154,13 +154,13 @@ print(json.dumps(T.run_once(hip, frames, 32, 2, pinned)))
 
 
 @pytest.mark.parametrize("env_extra", [{"DSV2_HME_ROWS": "0"}, {"DSV2_HME_XCD": "1"}, {"DSV2_HME_XCD": "3"}, {"DSV2_HME_FENCE": "1"},
-                                       {"DSV2_HME_FENCE": "3"}, {"DSV2_FILTER_PAIR_MAX": "0"}, {"DSV2_FILTER_PAIR_MAX": "100000"}, {"DSV2_HME_PRESTATS": "0"}, {"DSV2_HME_PRESTATS": "2"}])
+                                       {"DSV2_HME_FENCE": "3"}, {"DSV2_FILTER_PAIR_MAX": "0"}, {"DSV2_FILTER_PAIR_MAX": "100000"}, {"DSV2_HME_PRESTATS": "0"}, {"DSV2_HME_PRESTATS": "2"}, {"DSV2_FILTER_RING": "0"}])
 def test_front_per_launch_form_agrees(env_extra):
     """the same streams in a process with DSV2_HME_ROWS=0: the search runs one launch per anti-diagonal front; and the row
     pipeline with chip-wide tickets (one partition) and with three partitions (uneven: the fall-over path takes rows); the
     in-loop filter's luma sweep with a lane per cell / a lane pair per cell whatever the batch; the search with the source
     blocks' statistics worked out inside the block routine instead of ahead of it, and ahead of it one block per wavefront
-    everywhere (2) instead of four whole blocks per wavefront"""
+    everywhere (2) instead of four whole blocks per wavefront; the in-loop filters' global-memory kernels (no LDS ring)"""
     frames = gen_inputs()
     want = reference_digests(frames)
     env = dict(os.environ, **env_extra)
