@@ -1407,6 +1407,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         cc.px = pred1((int) (int16_t) (v0 & 0xffff), (int) (int16_t) (v1 & 0xffff), (int) (int16_t) (v2 & 0xffff));
         cc.py = pred1(v0 >> 16, v1 >> 16, v2 >> 16);
     }
+    HME_MARK(S, 2);
     if (parent != nullptr) {
         if (!pvalid) {
             pvx = tvalid ? pvx : 0;
@@ -1431,6 +1432,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
                 lax = sdiv_fast(bcastN<2>(r2, 0), nin);
                 lay = sdiv_fast(bcastN<2>(r2, 1), nin);
             }
+            HME_MARK(S, 15);
             // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)
             if (lane == 1) {
                 exist = true;

@@ -22,6 +22,8 @@ tot = float(sum(out[:10])) or 1.0
 for k, nm in enumerate(names):
     print(f"{k} {nm:34s} {out[k] / tot * 100:6.2f} %  {out[k] / 1e9:9.3f} Gticks", file=sys.stderr)
 print(f"total {tot / 1e9:.3f} Gticks", file=sys.stderr)
+if out[15]:
+    print(f"(inside candidate gather: parent average + inliers {out[15] / 1e9:.3f} Gticks = {out[15] / tot * 100:.2f} % of the above total)", file=sys.stderr)
 blocks = float(out[10]) or 1.0
 print(f"blocks {out[10]}  refined {out[11] / blocks:.3f}  refinement rounds/block {out[12] / blocks:.3f}  "
       f"sub-pel searches/block {out[13] / blocks:.3f}  candidates/block {out[14] / blocks:.2f}  ticks/block {tot / blocks:.0f}", file=sys.stderr)
