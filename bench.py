@@ -51,7 +51,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 STAGES = ["ingest_pyramid", "hme", "predict_subtract", "fwd_sbt", "quant_compact", "inv_sbt", "recon_filters", "extend", "hme_level0"]
 NST = len(STAGES)
 # dominant-kernel name per stage (rocprofv3 --kernel-trace name prefix)
-STAGE_KERNEL = {"hme": "k_hme_rows_b_*", "hme_level0": "k_hme_rows_b_fast_l0_w2", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
+STAGE_KERNEL = {"hme": "k_hme_rows_b_*", "hme_level0": "k_hme_rows_b_fast_l0_pre_w2", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
                 "quant_compact": "k_quant_level", "recon_filters": "k_inter_filters", "predict_subtract": "k_predict_w",
                 "ingest_pyramid": "k_extend/k_ds2x", "extend": "k_extend"}
 HBM_PEAK_GBS = 8000.0

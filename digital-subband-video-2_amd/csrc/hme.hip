@@ -1379,7 +1379,7 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
 
 // LV: 0 / 1 = the launch is known to be level 0 / a coarser level (fast-only kernels: the other half of the block routine
 // is not compiled in), -1 = any level
-template <bool FAST_ONLY, int LV = -1, int CS = 1>
+template <bool FAST_ONLY, int LV = -1, int CS = 1, bool PRE = false>
 __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, int allow_fast, FastLds &S)
 {
     const int level = LV == 0 ? 0 : level_rt;
@@ -1422,7 +1422,7 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
         if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast<LV, CS>(x, level, i, j, gx, gy, S, pcx, pcy, acc);
+            hme_block_fast<LV, CS, PRE>(x, level, i, j, gx, gy, S, pcx, pcy, acc);
         } else if constexpr (!FAST_ONLY) {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
             pcx = pcy = 0;
@@ -1502,6 +1502,34 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
         if (t_.row >= 0) {                                                                                               \
             hme_row<true, 1>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);                        \
+        }                                                                                                                \
+    }                                                                                                                    \
+    /* the same three with the source statistics guaranteed (k_hme_src_stats4_b / _b ran): no source analysis inside */ \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_pre_w##W(      \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<true, 0, 1, true>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                   \
+        }                                                                                                                \
+    }                                                                                                                    \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_444_pre_w##W(  \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<true, 0, 0, true>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                   \
+        }                                                                                                                \
+    }                                                                                                                    \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_pre_w##W(      \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
+        if (t_.row >= 0) {                                                                                               \
+            hme_row<true, 1, 1, true>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);               \
         }                                                                                                                \
     }
 HME_ROWS_B(1)
@@ -2076,12 +2104,13 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             fast &= ~1;
         }
     }
+    // the source statistics of levels 0 and 1, ahead of the search: whenever the block routine that reads them can run
+    // (a function of the jobs alone: a call that only runs the levels, behind a separate HME_PREPARE call, comes to the same answer)
+    bool pre = g_hme_prestats && (fast & 1) && g.a.blk_w == 16 && g.a.blk_h == 16;
+    for (int k = 0; k < n; k++) {
+        pre = pre && f[k].src_stats != nullptr;
+    }
     if (from_top) {
-        // the source statistics of levels 0 and 1, ahead of the search: whenever the block routine that reads them can run
-        bool pre = g_hme_prestats && (fast & 1) && g.a.blk_w == 16 && g.a.blk_h == 16;
-        for (int k = 0; k < n; k++) {
-            pre = pre && f[k].src_stats != nullptr;
-        }
         const int nb0x = g.a.nbh, nb0y = g.a.nbv, nb1x = g.pyr_levels >= 1 ? (g.a.nbh + 1) / 2 : 0, nb1y = g.pyr_levels >= 1 ? (g.a.nbv + 1) / 2 : 0;
         if (pre) {
             for (int k = 0; k < n; k++) {
@@ -2132,13 +2161,15 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
             if ((fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
                 int w = level == 0 ? g_hme_waves_fast : g_hme_waves_fast_lx;
+#define HME_PICK(base) (w >= 4 ? base##4 : w == 3 ? base##3 : w == 2 ? base##2 : base##1)
                 if (level == 0 && g.a.hshift == 0) {
-                    kern = w >= 4 ? k_hme_rows_b_fast_l0_444_w4 : w == 3 ? k_hme_rows_b_fast_l0_444_w3 : w == 2 ? k_hme_rows_b_fast_l0_444_w2 : k_hme_rows_b_fast_l0_444_w1;
+                    kern = pre ? HME_PICK(k_hme_rows_b_fast_l0_444_pre_w) : HME_PICK(k_hme_rows_b_fast_l0_444_w);
                 } else if (level == 0) {
-                    kern = w >= 4 ? k_hme_rows_b_fast_l0_w4 : w == 3 ? k_hme_rows_b_fast_l0_w3 : w == 2 ? k_hme_rows_b_fast_l0_w2 : k_hme_rows_b_fast_l0_w1;
+                    kern = pre ? HME_PICK(k_hme_rows_b_fast_l0_pre_w) : HME_PICK(k_hme_rows_b_fast_l0_w);
                 } else {
-                    kern = w >= 4 ? k_hme_rows_b_fast_lx_w4 : w == 3 ? k_hme_rows_b_fast_lx_w3 : w == 2 ? k_hme_rows_b_fast_lx_w2 : k_hme_rows_b_fast_lx_w1;
+                    kern = pre ? HME_PICK(k_hme_rows_b_fast_lx_pre_w) : HME_PICK(k_hme_rows_b_fast_lx_w);
                 }
+#undef HME_PICK
             }
             if (prof && level == 0) {
                 prof->begin(s, ST_HME_L0);

@@ -1252,7 +1252,9 @@ constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {
 // windows; out -- the same for this block
 // LV: what is known about the level at compile time -- 0: it is level 0; 1: it is a coarser level (the sub-pel search and
 // the mode decision are not even compiled in: a third of the registers); -1: decided at run time
-template <bool FULL, int LV, int CS, class Ctx>
+// PRE: the source statistics of levels 0 and 1 are KNOWN to have been worked out ahead (the batched driver's kernels of that
+// name): the block routine's own source analysis is not even compiled in
+template <bool FULL, int LV, int CS, bool PRE, class Ctx>
 __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy, RowAcc &acc)
 {
     const int level = LV == 0 ? 0 : level_rt;
@@ -1287,10 +1289,11 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
     const int4 *pre_stats = level <= 1 ? src_stats_of(c, level) : nullptr;
+    const bool have_pre = PRE ? level <= 1 : pre_stats != nullptr;
     v4i_t pre_words = {0, 0, 0, 0};
     Quad o_zero; // for the "good enough" test far below: same load round (its outcome comes with the statistics if they were worked out ahead)
     o_zero.w = 0;
-    if (pre_stats != nullptr) {
+    if (have_pre) {
         pre_words = *(cv4i_t) &pre_stats[(i >> level) + (j >> level) * ((nxb + step - 1) >> level)];
     } else {
         o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
@@ -1370,12 +1373,12 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     Psy psy = {2, 1, 0};
     if (level <= 1) {
         SrcStats st;
-        if (pre_stats != nullptr) { // (worked out ahead of the search, see source_analysis)
+        if (have_pre) { // (worked out ahead of the search, see source_analysis)
             st.bias_raw = pre_words.x;
             st.var_src = (unsigned) pre_words.y;
             st.avg_src = (unsigned) pre_words.z;
             st.zoscore = (unsigned) pre_words.w;
-        } else {
+        } else if constexpr (!PRE) {
             st = source_analysis(a, act, qi, qj, qw, bw, bh, c.quant, S.hist);
         }
         var_src = st.var_src;
@@ -1550,7 +1553,7 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
     {
-        unsigned zoscore = pre_stats != nullptr ? (unsigned) pre_words.w : metric_return(wave_sum(actM ? qmetric(a, o_zero, psy) : 0u), bw, bh);
+        unsigned zoscore = have_pre ? (unsigned) pre_words.w : metric_return(wave_sum(actM ? qmetric(a, o_zero, psy) : 0u), bw, bh);
         if (abs(dx) <= 1 && abs(dy) <= 1) {
             qthresh *= 2;
         }
@@ -1658,15 +1661,15 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     }
 }
 
-template <int LV, int CS = 1, class Ctx>
+template <int LV, int CS = 1, bool PRE = false, class Ctx>
 __device__ __forceinline__ void hme_block_fast(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy, RowAcc &acc)
 {
     const int level = LV == 0 ? 0 : level_rt;
     const DPlane &src = c.src[level];
     int bx = (i * 16) >> level, by = (j * 16) >> level;
     if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_fast_t<true, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
+        hme_block_fast_t<true, LV, CS, PRE>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
     } else {
-        hme_block_fast_t<false, LV, CS>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
+        hme_block_fast_t<false, LV, CS, PRE>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
     }
 }

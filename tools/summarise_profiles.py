@@ -37,7 +37,7 @@ with open(os.path.join(dst, prefix + "_rocprof_kernel_stats.txt"), "w") as f:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
     gmax = max(int(r["Grid_Size_X"]) for r in tr)
     full = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if int(r["Grid_Size_X"]) >= gmax - 6 * 64]
-    f.write("\nk_hme_rows_b_fast_l0_w2 (level-0 search, the dominant kernel): %d launches, mean %.1f us over all of them (the pre-roll steps "
+    f.write("\nk_hme_rows_b_fast_l0_pre_w2 (level-0 search, the dominant kernel): %d launches, mean %.1f us over all of them (the pre-roll steps "
             "launch it for fewer streams), mean %.1f us over the %d full-size launches (up to %d inter pictures of a group) -- bench.py HIP-event span of that "
             "launch in its profiled steps: %.1f us (the event span also holds the wait for a free queue slot between the group's "
             "launches while the other three groups' kernels are being dispatched)\n"
@@ -70,7 +70,7 @@ with open(os.path.join(dst, prefix + "_pmc_hme.txt"), "w") as f:
     bytes_per_launch = (tot_f + tot_w) * 1024.0 / max(1, nl)
     f.write("\nmean over the %d full-size launches (grid >= 0.9 x %d: 176 - 192 inter pictures of a group): %.2f MB fetched + written per launch\n"
             % (nl, gmax, bytes_per_launch / 1e6))
-json.dump({"stage": "hme_level0", "kernel": "k_hme_rows_b_fast_l0_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
+json.dump({"stage": "hme_level0", "kernel": "k_hme_rows_b_fast_l0_pre_w2", "streams_per_gpu": traced["config"]["streams_per_gpu"],
            "groups": traced["config"]["groups"], "stagger": True, "phase_aligned": bool(traced["config"].get("phase_aligned_groups")),
            "bytes_per_launch": round(bytes_per_launch),
            "source": "profiles/%s_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)" % prefix},
