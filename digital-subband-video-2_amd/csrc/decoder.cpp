@@ -682,6 +682,10 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
 
 void dec_batch(DecJob *jobs, int n)
 {
+    {
+        static const int fine_max = getenv("DSV2_WAIT_FINE_MAX") ? atoi(getenv("DSV2_WAIT_FINE_MAX")) : 1;
+        set_wait_fine(n <= fine_max); // (dev.cpp: a few streams are a latency chain, their waits poll finely)
+    }
     bind_device();
     t_dec_clock.start();
     parallel_for(n, [&](int k) { dec_parse(jobs[k]); });

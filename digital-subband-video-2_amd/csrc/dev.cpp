@@ -81,6 +81,21 @@ void dev_zero(void *p, size_t bytes)
 // resource once the kernels are fast (a container's CPU quota is shared with the entropy back end).  Here the
 // thread sleeps between completion queries; the added latency is bounded by the sleep (tens of microseconds
 // against waits of several milliseconds).  DSV2_SPIN_WAIT=1 restores the runtime's polling wait.
+// Polling interval of the two waits below.  A single stream's step is a chain of latency-bound kernels with a host phase
+// between them, and a wake-up that comes late (up to 120 us on the sparse schedule a multi-millisecond wait ends up in) two or
+// three times per frame is 1 % of its frame: such a caller polls at 20 us throughout (DSV2_WAIT_FINE_MAX, default 1 stream).
+// Several lockstep groups polling that finely at once was measured too: 4 x 2 streams lose 9 % (the queries contend with the
+// other groups' launches inside the runtime), so batches keep the sparse schedule -- their host is shared by every rank.
+static thread_local bool t_wait_fine = false;
+void set_wait_fine(bool fine) { t_wait_fine = fine; }
+static inline long wait_interval_ns(unsigned tries)
+{
+    if (t_wait_fine) {
+        return tries < 8 ? 10000 : 20000;
+    }
+    return tries < 8 ? 15000 : (tries < 64 ? 40000 : 120000);
+}
+
 void stream_wait(hipStream_t s)
 {
     static const bool spin = getenv("DSV2_SPIN_WAIT") && atoi(getenv("DSV2_SPIN_WAIT")) != 0;
@@ -104,7 +119,7 @@ void stream_wait(hipStream_t s)
         }
         // short waits are answered quickly, long ones (tens of milliseconds of kernels) are polled sparsely: every
         // wake-up costs several microseconds of host CPU, and the host is shared by every rank of the node
-        timespec ts = {0, tries < 8 ? 15000 : (tries < 64 ? 40000 : 120000)};
+        timespec ts = {0, wait_interval_ns(tries)};
         nanosleep(&ts, nullptr);
     }
 }
@@ -125,7 +140,7 @@ void event_wait(hipEvent_t ev)
         if (e != hipErrorNotReady) {
             HIPCHK(e);
         }
-        timespec ts = {0, tries < 8 ? 15000 : (tries < 64 ? 40000 : 120000)};
+        timespec ts = {0, wait_interval_ns(tries)};
         nanosleep(&ts, nullptr);
     }
 }

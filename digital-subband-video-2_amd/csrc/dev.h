@@ -68,6 +68,7 @@ struct BlockMap {
 
 void dev_zero(void *p, size_t bytes); // synchronous zero fill of device memory
 void event_wait(hipEvent_t ev);        // ... for a recorded event
+void set_wait_fine(bool fine);         // this thread's waits poll at 20 us (small batches: DSV2_WAIT_FINE_MAX) instead of up to 120 us
 void stream_wait(hipStream_t s);       // host wait for the stream to drain, parked on the interrupt (no polling)
 // pinned host blocks the GPU may write (hostutil.cpp): recycled through dsv_free
 void *pinned_pool_take(size_t bytes);

@@ -1420,6 +1420,10 @@ static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV
 
 void enc_batch(Job *jobs, int n)
 {
+    {
+        static const int fine_max = getenv("DSV2_WAIT_FINE_MAX") ? atoi(getenv("DSV2_WAIT_FINE_MAX")) : 1;
+        set_wait_fine(n <= fine_max);
+    }
     const int kAuxStreams = kAuxStreamsEnv >= 0 ? kAuxStreamsEnv : (n < 12 ? 1 : 0);
     bind_device();
     t_clock.start();
