@@ -448,14 +448,143 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
     }
 }
 
+// Both 8x8 chroma blocks of a 16x16 luma block in 4:2:0 in ONE pass: lanes 0..15 take U, 16..31 V (predict_plane gives a
+// chroma plane 16 of the 64 lanes, twice).  Same arithmetic as predict_plane<MODE, 1 / 2>; the intra block's quadrant means
+// are sums over the 16 lanes of a plane (a DPP row).  The two planes have one geometry (dframe_alloc).
+__device__ __forceinline__ int row16_sum_i(int v)
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true); // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true); // row_mirror
+    return v;
+}
+
+#ifndef DSV2_CHROMA_PAIR
+#define DSV2_CHROMA_PAIR 1
+#endif
+constexpr bool kChromaPair = DSV2_CHROMA_PAIR != 0; // (build switch for A/B: make EXTRA=-DDSV2_CHROMA_PAIR=0)
+template <int MODE>
+__device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCParams &p, const DSV_MV &mv, int i, int j)
+{
+    const int lane = threadIdx.x & 63;
+    const int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
+    const uint32_t flags = mv.flags;
+    const bool intra = flags & (1u << DSV_MV_BIT_INTRA);
+    const bool skip = flags & (1u << DSV_MV_BIT_SKIP), eprm = flags & (1u << DSV_MV_BIT_EPRM);
+    const bool v_plane = (lane & 16) != 0, on = lane < 32;
+    const int bw = 8, bh = 8, sbw = 4, sbh = 4;
+    const DPlane rp1 = jb.ref.p[1], dp1 = jb.pred.p[1], sp1 = jb.res.p[1];
+    const uint8_t *rdata = v_plane ? jb.ref.p[2].data : rp1.data;
+    uint8_t *ddata = v_plane ? jb.pred.p[2].data : dp1.data, *sdata = v_plane ? jb.res.p[2].data : sp1.data;
+    const int limx = (dp1.w - bw) + kBorder - 1, limy = (dp1.h - bh) + kBorder - 1;
+    const int x = i * bw, y = j * bh;
+    const int px = clampi(x + sar(mvx, 3), -kBorder, limx), py = clampi(y + sar(mvy, 3), -kBorder, limy);
+    const uint8_t *rbase = rdata + (ptrdiff_t) py * rp1.stride + px;
+    const int g = lane & 15, m = (g & 1) * 4, n = g >> 1; // 16 groups of 4 pixels, two per row
+    typedef const __attribute__((address_space(1))) uint8_t *gbr_t;
+    typedef const __attribute__((address_space(1))) U32u *gur_t;
+    typedef __attribute__((address_space(1))) uint32_t *gw32_t;
+    gbr_t r = (gbr_t) rbase + (ptrdiff_t) n * rp1.stride + m;
+    int dcq[4] = {0, 0, 0, 0};
+    if (intra) { // quadrant means of the reference block (bmc.c:845-900); a transmitted DC is luma only
+        const uint32_t v = ((gur_t) r)->v;
+        const int s4 = (int) ((v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + (v >> 24));
+        const int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+        const int q0 = row16_sum_i(k == 0 ? s4 : 0), q1 = row16_sum_i(k == 1 ? s4 : 0), q2 = row16_sum_i(k == 2 ? s4 : 0),
+                  q3 = row16_sum_i(k == 3 ? s4 : 0);
+        if (mv.submask == DSV_MASK_ALL_INTRA) {
+            dcq[0] = dcq[1] = dcq[2] = dcq[3] = (q0 + q1 + q2 + q3) / (bw * bh); // bmc.c:857
+        } else {
+            dcq[0] = q0 / (sbw * sbh); // bmc.c:884
+            dcq[1] = q1 / (sbw * sbh);
+            dcq[2] = q2 / (sbw * sbh);
+            dcq[3] = q3 / (sbw * sbh);
+        }
+    }
+    int f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+    const int sf = 6, af = 32; // bmc.c:778-798 with eighth-pel chroma vectors
+    bool chroma_frac = false;
+    if (!intra) {
+        const int dx = mvx & 7, dy = mvy & 7;
+        chroma_frac = (dx | dy) != 0;
+        f0 = (8 - dx) * (8 - dy);
+        f1 = dx * (8 - dy);
+        f2 = (8 - dx) * dy;
+        f3 = dx * dy;
+    }
+    if (!on) {
+        return;
+    }
+    const bool noxmit = (flags & (1u << DSV_MV_BIT_NOXMITC)) != 0;
+    const uint32_t sv4 = *(gw32_t) (sdata + (ptrdiff_t) (y + n) * sp1.stride + (x + m));
+    int pv[4];
+    if (intra) {
+        const uint32_t v = ((gur_t) r)->v;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            const int k = ((m + k4) >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
+            const bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
+            pv[k4] = fill ? (dcq[k] & 0xff) : (int) ((v >> (8 * k4)) & 0xff);
+        }
+    } else if (chroma_frac) {
+        gbr_t r2 = r + rp1.stride;
+        const uint32_t va = ((gur_t) r)->v, vb = ((gur_t) r2)->v; // five pixels of two rows: a dword and a byte each
+        const int a4 = r[4], b4 = r2[4];
+        const int a0 = va & 0xff, a1 = (va >> 8) & 0xff, a2 = (va >> 16) & 0xff, a3 = va >> 24;
+        const int b0 = vb & 0xff, b1 = (vb >> 8) & 0xff, b2 = (vb >> 16) & 0xff, b3 = vb >> 24;
+        pv[0] = ((f0 * a0 + f1 * a1 + f2 * b0 + f3 * b1 + af) >> sf) & 0xff;
+        pv[1] = ((f0 * a1 + f1 * a2 + f2 * b1 + f3 * b2 + af) >> sf) & 0xff;
+        pv[2] = ((f0 * a2 + f1 * a3 + f2 * b2 + f3 * b3 + af) >> sf) & 0xff;
+        pv[3] = ((f0 * a3 + f1 * a4 + f2 * b3 + f3 * b4 + af) >> sf) & 0xff;
+    } else {
+        const uint32_t v = ((gur_t) r)->v;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            pv[k4] = (int) ((v >> (8 * k4)) & 0xff);
+        }
+    }
+    gw32_t dpx = (gw32_t) (ddata + (ptrdiff_t) (y + n) * dp1.stride + (x + m));
+    gw32_t spx = (gw32_t) (sdata + (ptrdiff_t) (y + n) * sp1.stride + (x + m));
+    uint32_t out = 0;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++) {
+        const int s1 = (int) ((sv4 >> (8 * k4)) & 0xff);
+        int o;
+        if (MODE == MC_SUBTRACT) { // residual_px (bmc.c:1015-1050)
+            if (p.lossless) {
+                o = (s1 - pv[k4] + 128) & 0xff;
+            } else if (!intra && (skip || noxmit)) {
+                o = 128;
+            } else {
+                o = eprm ? clamp_u8((s1 - pv[k4] + 256) >> 1) : clamp_u8(s1 - pv[k4] + 128);
+            }
+        } else { // recon_px (bmc.c:953-983)
+            const bool plain = !eprm || (!intra && skip);
+            o = p.lossless ? ((pv[k4] + s1 - 128) & 0xff) : (plain ? clamp_u8(pv[k4] + s1 - 128) : clamp_u8(pv[k4] + (s1 - 128) * 2));
+        }
+        out |= (uint32_t) o << (8 * k4);
+    }
+    if (MODE == MC_SUBTRACT) {
+        *dpx = (uint32_t) pv[0] | ((uint32_t) pv[1] << 8) | ((uint32_t) pv[2] << 16) | ((uint32_t) pv[3] << 24);
+        *spx = out;
+    } else {
+        *dpx = out;
+    }
+}
+
 template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int i, int j, WaveLds &L)
 {
     const MCParams p = jb.p;
     const DSV_MV mv = jb.mvs[i + j * p.nbh];
     if (p.blk_w == 16 && p.blk_h == 16 && p.hshift == 1 && p.vshift == 1) { // (uniform over the launch)
         predict_plane<MODE, 0>(jb, p, mv, i, j, L, 0);
-        predict_plane<MODE, 1>(jb, p, mv, i, j, L, 1);
-        predict_plane<MODE, 2>(jb, p, mv, i, j, L, 2);
+        if (kChromaPair) {
+            predict_chroma_pair<MODE>(jb, p, mv, i, j);
+        } else {
+            predict_plane<MODE, 1>(jb, p, mv, i, j, L, 1);
+            predict_plane<MODE, 2>(jb, p, mv, i, j, L, 2);
+        }
     } else {
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
