@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--no-batch-curve", action="store_true", help="skip the small-batch operating points (1 / 8 / 48 / 192 streams)")
     ap.add_argument("--only-batch-curve", action="store_true", help="of the extras, run only the small-batch operating points (experiments)")
     ap.add_argument("--no-host-share", action="store_true", help="skip the 2-host-cores re-run of the headline")
+    ap.add_argument("--no-api-legs", action="store_true", help="skip the legs through the reference's own entry points (threads of dsv_enc / dsv_dec, 8 drop-in CLI processes)")
+    ap.add_argument("--only-api-legs", action="store_true", help="of the extras, run only those legs (experiments)")
     ap.add_argument("--device-resident", action="store_true",
                     help="pictures parked in HBM before the clock starts (kernel-side figure; NOT the SURVEY 8d metric)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for exercising the N>1 path "
@@ -511,6 +513,7 @@ class RefCheck:
         self.job = run.ref_job(s, self.n)
         self.got = [b"".join(fr) for fr in run.out[s][:self.n]]
         self.group, self.phase = s % run.G, run.r0[s]
+        self.dec_md5 = None  # (legs that also decode: md5 of every picture this library decoded from self.got, frame by frame)
 
 
 def picture_planes(fp):
@@ -876,7 +879,7 @@ def main():
     # ---- the decoder on this run's packets (N = 1 only) ----
     # (the headline above is complete: whatever goes wrong below is reported beside it, never instead of it)
     dec_md5 = {}
-    if extras and not args.only_batch_curve:
+    if extras and not args.only_batch_curve and not args.only_api_legs:
         try:
             result["decode"], dec_md5 = decode_leg(hip, A, run, 32, 256, 4, sel if not args.no_cpu_baseline else [])
         except Exception as e:  # noqa: BLE001
@@ -885,24 +888,35 @@ def main():
     del run
 
     # ---- the other BASELINE.json configurations and the small-batch operating points (N = 1 only) ----
-    if extras and not args.only_batch_curve:
+    if extras and not args.only_batch_curve and not args.only_api_legs:
         try:
             result["configs"] = other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks)
         except Exception as e:  # noqa: BLE001
             result["configs"] = {"error": repr(e)}
-    if extras and not args.no_batch_curve:
+    if extras and not args.no_batch_curve and not args.only_api_legs:
         try:
             result["batch_curve"] = batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
         except Exception as e:  # noqa: BLE001
             result["batch_curve"] = {"error": repr(e)}
-    if extras and not args.no_mix and not args.only_batch_curve:
+    if extras and not args.no_mix and not args.only_batch_curve and not args.only_api_legs:
         try:
             result["content_class_legs"] = class_legs(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
         except Exception as e:  # noqa: BLE001
             result["content_class_legs"] = {"error": repr(e)}
 
+    # ---- the reference's own entry points and its own parallel recipe (row h of the round-3 review) ----
+    if extras and not args.only_batch_curve and not args.no_api_legs:
+        try:
+            result["api_legs"] = api_thread_legs(hip, A, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
+        except Exception as e:  # noqa: BLE001
+            result["api_legs"] = {"error": repr(e)}
+        try:
+            result["api_legs"]["processes"] = api_process_leg(vids, W_, H_, QP, GOP)
+        except Exception as e:  # noqa: BLE001
+            result["api_legs"]["processes"] = {"error": repr(e)}
+
     # ---- does the host side fit the cores an 8-GPU node leaves per rank?  The headline again, pinned to 2 cores ----
-    if extras and not args.no_host_share and not args.only_batch_curve and args.host_cores <= 0:
+    if extras and not args.no_host_share and not args.only_batch_curve and not args.only_api_legs and args.host_cores <= 0:
         result["host_share"] = host_share(args, 2, fps)
 
     # ---- parity, part 2 + CPU baselines: the real reference (oracle/_ref) on the host cores ----
@@ -933,8 +947,13 @@ def reference_phase(result, checks, dec_md5, sel):
         one_dec = rw.dec([head[0]], [min(24, checks[head[0]].n)])[0]
         allr = rw.go(head, [checks[i].n for i in head])                      # the headline's workers at once
         decr = rw.dec(head, [checks[i].n for i in head]) if dec_md5 else []
+        dec_rest = {}
         if rest:
             rw.go(rest, [checks[i].n for i in rest])                         # every other leg's streams at once
+            wd = [i for i in rest if checks[i].dec_md5 is not None]
+            if wd:
+                for i, r in zip(wd, rw.dec(wd, [checks[i].n for i in wd])):
+                    dec_rest[i] = r["md5"]
         mism, per_leg = [], {}
         for i, c in enumerate(checks):
             want = rw.frames(i)
@@ -946,6 +965,12 @@ def reference_phase(result, checks, dec_md5, sel):
                 first = next((t for t, (a, b) in enumerate(zip(want, c.got)) if a != b), min(len(want), len(c.got)))
                 mism.append((c.leg, c.stream, first))
                 per_leg[c.leg]["mismatches"] += 1
+            if i in dec_rest:  # this leg's decoder output against the reference decoder's, picture by picture
+                nd = len(c.dec_md5)
+                per_leg[c.leg]["decoded_pictures_compared"] = per_leg[c.leg].get("decoded_pictures_compared", 0) + nd
+                if nd == 0 or c.dec_md5 != dec_rest[i][:nd]:
+                    mism.append((c.leg + " (decode)", c.stream, -1))
+                    per_leg[c.leg]["mismatches"] += 1
         dec_bad, dec_pics = [], 0
         for k, i in enumerate(head if dec_md5 else []):
             got = dec_md5.get(checks[i].stream, [])
@@ -980,6 +1005,10 @@ def reference_phase(result, checks, dec_md5, sel):
             result["configs"][leg]["vs_reference"] = v
         if leg.startswith("class_") and isinstance(result.get("content_class_legs"), dict) and leg[6:] in result["content_class_legs"]:
             result["content_class_legs"][leg[6:]]["vs_reference"] = v
+        if leg.startswith("api_") and isinstance(result.get("api_legs"), dict):
+            for name, pt in result["api_legs"].items():
+                if isinstance(pt, dict) and pt.get("check_leg") == leg:
+                    pt["vs_reference"] = v
         if leg.startswith("batch") and isinstance(result.get("batch_curve"), list):
             for pt in result["batch_curve"]:
                 if "batch_%d" % pt["streams"] == leg:
@@ -1085,6 +1114,194 @@ def class_legs(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, ch
         if b:
             raise AssertionError("content class %s: %d of %d twin stream pairs differ" % (name, b, p))
     return out
+
+
+class ApiRun:
+    """what RefCheck needs of a leg that is not an EncodeRun: per stream the packets of every frame, and how to regenerate its input"""
+
+    def __init__(self, w, h, fmt, qp, gop, effort, seeds, src):
+        self.w, self.h, self.fmt, self.qp, self.gop, self.effort, self.seeds = w, h, fmt, qp, gop, effort, seeds
+        self.src = src  # per stream: [(video, frame of it)] per local frame
+        self.G, self.r0 = 1, [0] * len(src)
+        self.out = [[] for _ in src]
+
+    def ref_job(self, s, nframes):
+        return (self.w, self.h, self.fmt, 0, self.qp, self.gop, self.effort, ["%d:%d" % (self.seeds[v], k) for v, k in self.src[s][:nframes]])
+
+
+API_THREADS = (1, 4, 16)
+
+
+def api_thread_legs(hip, A, vids, NV, seeds, W_, H_, QP, GOP, effort, checks):
+    """Throughput through the reference's OWN entry points, used the way the reference is used: T host threads, each looping
+    plain dsv_enc (dsv_encoder.h:190-199) on an encoder of its own with ordinary pageable DSV_FRAMEs (dsv_load_planar_frame over
+    the caller's memory), then T threads looping dsv_dec (dsv_decoder.h:54-61) over those packets.  Nothing library-specific is
+    called; concurrent callers are merged into lockstep steps inside the library (csrc/batch.h: Coalescer).  Thread 0's packets of
+    every leg go to the reference for re-encode AND decode."""
+    import numpy as np
+    from codec_run import configure_encoder
+    for name in ("dsv2hip_enc_queue_stats", "dsv2hip_dec_queue_stats"):
+        getattr(hip, name).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        getattr(hip, name).restype = None
+    NF = len(vids[0])
+    period = 2 * (NF - 1) if NF > 1 else 1
+    warm, K = 4, 32
+    legs = {}
+    for T in API_THREADS:
+        src = [[(s % NV, (lambda k: k if k < NF else period - k)(t % period)) for t in range(warm + K)] for s in range(T)]
+        run = ApiRun(W_, H_, "420", QP, GOP, effort, seeds, src)
+        # pageable copies of the pictures, made before the clock starts (a caller's own frame buffers)
+        pics = {}
+        for s in range(T):
+            for v, k in src[s]:
+                if (s, v, k) not in pics:
+                    pics[(s, v, k)] = np.frombuffer(vids[v][k], dtype=np.uint8).copy()
+        meta = A.mk_meta(W_, H_, A.SUBSAMP_420)
+        encs = [A.ENCODER() for _ in range(T)]
+        for e in encs:
+            configure_encoder(hip, e, meta, qp=QP, gop=GOP, effort=effort)
+        held = [[] for _ in range(T)]  # per thread, per frame: (BUF array, count) -- turned into bytes after the clock stops
+        bar = threading.Barrier(T + 1)
+
+        def enc_worker(s):
+            e = encs[s]
+            for phase, (a, b) in enumerate(((0, warm), (warm, warm + K))):
+                bar.wait()
+                for t in range(a, b):
+                    v, k = src[s][t]
+                    fr = hip.dsv_load_planar_frame(A.SUBSAMP_420, pics[(s, v, k)].ctypes.data, W_, H_)
+                    bufs = (A.BUF * 4)()
+                    n = hip.dsv_enc(C.byref(e), fr, bufs)
+                    held[s].append((bufs, n))
+                bar.wait()
+
+        ths = [threading.Thread(target=enc_worker, args=(s,)) for s in range(T)]
+        for th in ths:
+            th.start()
+        bar.wait()
+        bar.wait()  # warm-up done (allocations, the intra picture)
+        hip.dsv2hip_enc_queue_stats(None, 1)
+        t0 = time.perf_counter()
+        bar.wait()
+        bar.wait()
+        t_enc = time.perf_counter() - t0
+        for th in ths:
+            th.join()
+        st = (C.c_ulonglong * 4)()
+        hip.dsv2hip_enc_queue_stats(st, 0)
+        for s in range(T):
+            for bufs, n in held[s]:
+                pk = []
+                for i in range(n):
+                    pk.append(C.string_at(bufs[i].data, bufs[i].len))
+                    hip.dsv_buf_free(C.byref(bufs[i]))
+                run.out[s].append(pk)
+        for e in encs:
+            hip.dsv_enc_free(C.byref(e))
+        same = sum(1 for s in range(NV, T) if run.out[s] == run.out[s % NV])  # threads beyond the distinct videos repeat one: same bytes
+        chk = RefCheck("api_enc_%d" % T, run, 0, warm + K)
+        legs["dsv_enc_threads_%d" % T] = {"value": round(T * K / t_enc, 2), "unit": "frames/s", "threads": T, "frames_per_thread": K, "ms_per_call": round(1e3 * t_enc / K, 3),
+                                          "queue": {"calls": st[0], "lockstep_steps": st[1], "largest_step": st[2], "leader_wait_us_per_step": round(st[3] / max(1, st[1]), 1)},
+                                          "repeat_threads_equal": "%d/%d" % (same, max(0, T - NV)), "check_leg": "api_enc_%d" % T}
+        if same != max(0, T - NV):
+            raise AssertionError("dsv_enc threads leg, T=%d: threads coding the same video produced different packets" % T)
+
+        # ---- the decode twin: T threads, each looping dsv_dec over its stream's packets ----
+        decs = [A.DECODER() for _ in range(T)]
+        got = [[] for _ in range(T)]
+        bar2 = threading.Barrier(T + 1)
+
+        def dec_worker(s):
+            d = decs[s]
+            for a, b in ((0, warm), (warm, warm + K)):
+                bar2.wait()
+                for t in range(a, b):
+                    for pk in run.out[s][t]:
+                        buf = A.BUF()
+                        hip.dsv_mk_buf(C.byref(buf), len(pk) + 64)
+                        C.memmove(buf.data, pk, len(pk))
+                        buf.len = len(pk)
+                        fp = C.POINTER(A.FRAME)()
+                        fn = C.c_uint32(0)
+                        if hip.dsv_dec(C.byref(d), C.byref(buf), C.byref(fp), C.byref(fn)) == A.DEC_OK and fp:
+                            got[s].append(picture_planes(fp) if s == 0 or s >= NV else None)
+                            hip.dsv_frame_ref_dec(fp)
+                bar2.wait()
+
+        ths = [threading.Thread(target=dec_worker, args=(s,)) for s in range(T)]
+        for th in ths:
+            th.start()
+        bar2.wait()
+        bar2.wait()
+        hip.dsv2hip_dec_queue_stats(None, 1)
+        t0 = time.perf_counter()
+        bar2.wait()
+        bar2.wait()
+        t_dec = time.perf_counter() - t0
+        for th in ths:
+            th.join()
+        hip.dsv2hip_dec_queue_stats(st, 0)
+        for d in decs:
+            hip.dsv_dec_free(C.byref(d))
+        ndec = sum(len(g) for g in got)
+        chk.dec_md5 = [planes_md5(pl) for pl in got[0]]
+        checks.append(chk)
+        legs["dsv_dec_threads_%d" % T] = {"value": round(T * K / t_dec, 2), "unit": "frames/s", "threads": T, "pictures": ndec, "ms_per_call": round(1e3 * t_dec / K, 3),
+                                          "queue": {"calls": st[0], "lockstep_steps": st[1], "largest_step": st[2], "leader_wait_us_per_step": round(st[3] / max(1, st[1]), 1)},
+                                          "check_leg": "api_enc_%d" % T}
+        if ndec != T * (warm + K):
+            raise AssertionError("dsv_dec threads leg, T=%d: %d pictures for %d packets" % (T, ndec, T * (warm + K)))
+    legs["note"] = ("T host threads, each looping the reference's plain dsv_enc / dsv_dec on an instance of its own with pageable DSV_FRAMEs; %d warm-up + %d timed "
+                    "calls per thread; thread 0 of every leg re-encoded and decoded by the reference (parity_checked.legs api_enc_T)" % (warm, K))
+    return legs
+
+
+def api_process_leg(vids, W_, H_, QP, GOP):
+    """The reference's own parallel recipe (parallel_encode_yuv.sh:31-52) with the reference's own CLI: P = 8 processes, each
+    `e -sfr=.. -nfr=.. -noeos=1` on one raw .yuv file, once with the CLI linked against this library (oracle/_ref/dsv2_dropin: 8
+    processes share the one GPU) and once with the pure reference build (oracle/_ref/dsv2_ref: 8 CPU processes), timed end to end
+    (process start, file input, encode, file output).  The concatenated outputs must be identical."""
+    import dsvabi as A
+    dropin = os.path.join(ROOT, "oracle", "_ref", "dsv2_dropin")
+    if not (os.path.exists(dropin) and os.path.exists(A.REF_CLI)):
+        return {"error": "oracle/_ref CLIs not built"}
+    P, chunk = 8, 12
+    tmp = tempfile.mkdtemp(prefix="dsv2api", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        yuv = os.path.join(tmp, "in.yuv")
+        NF = len(vids[0])
+        with open(yuv, "wb") as f:  # P segments of `chunk` frames each: segment p = frames of video p % len(vids)
+            for p in range(P):
+                for t in range(chunk):
+                    f.write(vids[p % len(vids)][t % NF])
+        base = ["-y", "-inp=" + yuv, "-w=%d" % W_, "-h=%d" % H_, "-fps_num=30", "-fps_den=1", "-gop=%d" % GOP, "-qp=%d" % QP, "-rc_mode=0"]
+
+        def recipe(exe, tag, nproc):
+            outs = [os.path.join(tmp, "%s%d.dsv" % (tag, p)) for p in range(nproc)]
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([exe, "e"] + base + ["-out=" + outs[p], "-sfr=%d" % (p * chunk), "-nfr=%d" % chunk, "-noeos=1"],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for p in range(nproc)]
+            rcs = [pr.wait() for pr in procs]
+            dt = time.perf_counter() - t0
+            data = b"".join(open(o, "rb").read() for o in outs)
+            return dt, data, rcs
+
+        recipe(dropin, "w", 1)  # (first process of the box pages the runtime in)
+        d1, one, rc1 = recipe(dropin, "a", 1)
+        d8, all8, rc8 = recipe(dropin, "b", P)
+        r8, ref8, rcr = recipe(A.REF_CLI, "r", P)
+        ok = all8 == ref8 and one == ref8[:len(one)] and not any(rc1 + rc8 + rcr)
+        out = {"processes": P, "frames_per_process": chunk, "dropin_1_process_fps": round(chunk / d1, 2), "dropin_8_processes_fps": round(P * chunk / d8, 2),
+               "ratio_8_to_1": round((P * chunk / d8) / (chunk / d1), 2), "reference_8_processes_fps": round(P * chunk / r8, 2),
+               "speedup_vs_reference_recipe": round(r8 / d8, 2), "bytes": len(all8), "identical_to_reference_output": bool(ok),
+               "note": "end to end per process: exec, HIP runtime + device context start-up, raw .yuv read, %d frames encoded, .dsv written; "
+                       "8 drop-in processes share ONE GPU" % chunk}
+        if not ok:
+            raise AssertionError("drop-in CLI recipe: outputs differ from the reference's (rcs %s %s %s)" % (rc1, rc8, rcr))
+        return out
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def host_share(args, cores, fps_unrestricted):

@@ -3,13 +3,16 @@
 // tables are built in.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include "dev.h"
 
@@ -135,6 +138,209 @@ class WorkerPool {
     std::mutex mu_;
     std::condition_variable cv_, done_;
     std::deque<std::shared_ptr<Batch>> active_;
+};
+
+// Submit queue of the single-call entry points (dsv_enc, dsv_dec).  The reference's interface is one synchronous call per
+// frame (dsv_encoder.h:190-199, dsv_decoder.h:54-61) and its only parallelism is one encoder per thread or process
+// (parallel_encode_yuv.sh:31-52); a caller that keeps that shape -- T threads, each looping dsv_enc on its own encoder -- would
+// give the GPU T lockstep steps of ONE picture each.  Here concurrent callers whose jobs can share a step (same key: picture
+// geometry and what else a batch must agree on) are run as ONE lockstep step by whichever of them arrived first:
+//   * the first caller to arrive becomes the LEADER; it waits -- bounded: `window` -- until the callers it can expect have
+//     arrived (those seen within the last 100 ms under this key, less the ones inside a running step), takes them, runs the
+//     batch on its own thread, and hands every caller its results; each call still returns when ITS frame is done;
+//   * with many callers (>= 2 * kMinSplit) a leader takes only its share (1 / groups), the rest elect the next leader at once:
+//     two or more steps then run side by side, one's host phases and latency-bound kernels under another's;
+//   * a single caller finds nobody to wait for and runs at once: the plain dsv_enc path.
+// DSV2_COALESCE=0 turns it off, DSV2_COALESCE_US sets the longest wait (default 10 % of the last step, 100 us .. 2 ms),
+// DSV2_COALESCE_GROUPS the number of concurrent steps a crowd is split into (default 2).
+template <class JobT> class Coalescer {
+  public:
+    using RunFn = void (*)(JobT *jobs, int n);
+    struct Stats {
+        unsigned long long calls = 0, steps = 0, largest = 0, waited_us = 0;
+    };
+    // runs `job` (by value in, results copied back) as part of some lockstep step; `who` identifies the caller's instance
+    void submit(JobT &job, unsigned long long key, const void *who, RunFn run)
+    {
+        using clock = std::chrono::steady_clock;
+        Pending me;
+        me.job = &job;
+        me.key = key;
+        std::unique_lock<std::mutex> lk(mu_);
+        const auto now = clock::now();
+        seen(who, key, now);
+        pending_.push_back(&me);
+        st_.calls++;
+        cv_.notify_all(); // (a collecting leader counts arrivals)
+        for (;;) {
+            if (me.done) {
+                return;
+            }
+            if (!me.taken && !collecting_) {
+                break; // nobody is collecting: this caller leads
+            }
+            cv_.wait(lk);
+        }
+        collecting_ = true;
+        const int groups = std::max(1, groups_);
+        auto mine = [&] {
+            int c = 0;
+            for (Pending *p : pending_) {
+                c += p->key == key && !p->taken;
+            }
+            return c;
+        };
+        auto want = [&] {
+            int l = live(key, clock::now());
+            int share = l >= 2 * kMinSplit ? (l + groups - 1) / groups : l;
+            int free_callers = l - inflight(key);
+            return std::max(1, std::min(share, free_callers));
+        };
+        const auto t0 = clock::now();
+        const auto deadline = t0 + std::chrono::microseconds(window_us());
+        while (mine() < want()) {
+            if (cv_.wait_until(lk, deadline) == std::cv_status::timeout) {
+                break;
+            }
+        }
+        st_.waited_us += (unsigned long long) std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
+        // take this key's callers in arrival order, up to the share
+        std::vector<Pending *> batch;
+        {
+            const int cap = want();
+            std::vector<Pending *> rest;
+            for (Pending *p : pending_) {
+                if (p->key == key && !p->taken && ((int) batch.size() < cap || p == &me)) {
+                    p->taken = true;
+                    batch.push_back(p);
+                } else {
+                    rest.push_back(p);
+                }
+            }
+            pending_.swap(rest);
+        }
+        running_.push_back(Running{key, (int) batch.size()});
+        collecting_ = false;
+        cv_.notify_all(); // whoever is left elects the next leader
+        lk.unlock();
+        std::vector<JobT> jobs;
+        jobs.reserve(batch.size());
+        for (Pending *p : batch) {
+            jobs.push_back(*p->job);
+        }
+        const auto r0 = clock::now();
+        run(jobs.data(), (int) jobs.size());
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - r0).count();
+        lk.lock();
+        last_step_us_ = us;
+        st_.steps++;
+        st_.largest = std::max<unsigned long long>(st_.largest, batch.size());
+        for (size_t i = 0; i < running_.size(); i++) {
+            if (running_[i].key == key && running_[i].n == (int) batch.size()) {
+                running_.erase(running_.begin() + (ptrdiff_t) i);
+                break;
+            }
+        }
+        for (size_t i = 0; i < batch.size(); i++) {
+            *batch[i]->job = jobs[i];
+            batch[i]->done = true;
+        }
+        cv_.notify_all();
+    }
+    // the instance will not call again (freed / end of stream): leaders stop expecting it
+    void forget(const void *who)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t i = 0; i < recent_.size(); i++) {
+            if (recent_[i].who == who) {
+                recent_.erase(recent_.begin() + (ptrdiff_t) i);
+                break;
+            }
+        }
+        cv_.notify_all();
+    }
+    Stats stats()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return st_;
+    }
+    void reset_stats()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        st_ = Stats();
+    }
+    static bool enabled()
+    {
+        static const bool on = !(getenv("DSV2_COALESCE") && atoi(getenv("DSV2_COALESCE")) == 0);
+        return on;
+    }
+
+  private:
+    static constexpr int kMinSplit = 4; // a crowd is split only when every part keeps at least this many callers
+    struct Pending {
+        JobT *job = nullptr;
+        unsigned long long key = 0;
+        bool taken = false, done = false;
+    };
+    struct Recent {
+        const void *who;
+        unsigned long long key;
+        std::chrono::steady_clock::time_point at;
+    };
+    struct Running {
+        unsigned long long key;
+        int n;
+    };
+    void seen(const void *who, unsigned long long key, std::chrono::steady_clock::time_point now)
+    {
+        for (Recent &r : recent_) {
+            if (r.who == who) {
+                r.key = key;
+                r.at = now;
+                return;
+            }
+        }
+        recent_.push_back(Recent{who, key, now});
+    }
+    int live(unsigned long long key, std::chrono::steady_clock::time_point now)
+    {
+        int c = 0;
+        for (size_t i = 0; i < recent_.size();) {
+            if (now - recent_[i].at > std::chrono::milliseconds(100) && !busy(recent_[i].who)) {
+                recent_.erase(recent_.begin() + (ptrdiff_t) i); // has not called for 100 ms: no longer expected
+                continue;
+            }
+            c += recent_[i].key == key;
+            i++;
+        }
+        return c;
+    }
+    bool busy(const void *) { return !running_.empty(); } // (callers inside a step do not age out while steps are running)
+    int inflight(unsigned long long key)
+    {
+        int c = 0;
+        for (const Running &r : running_) {
+            c += r.key == key ? r.n : 0;
+        }
+        return c;
+    }
+    long long window_us()
+    {
+        static const long long fixed = getenv("DSV2_COALESCE_US") ? atoll(getenv("DSV2_COALESCE_US")) : -1;
+        if (fixed >= 0) {
+            return fixed;
+        }
+        return std::min<long long>(2000, std::max<long long>(100, last_step_us_ / 10));
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Pending *> pending_;
+    std::vector<Recent> recent_;
+    std::vector<Running> running_;
+    bool collecting_ = false;
+    long long last_step_us_ = 0;
+    const int groups_ = getenv("DSV2_COALESCE_GROUPS") ? atoi(getenv("DSV2_COALESCE_GROUPS")) : 2;
+    Stats st_;
 };
 
 template <class F> inline void parallel_for(int n, F fn)

@@ -2381,15 +2381,21 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
 // picture: the global-memory kernels run).  Host mirror of what the ring sweeps assume (ring_eligible).
 static unsigned ring_lds_bytes(int luma_w, int luma_h)
 {
-    static int on = getenv("DSV2_FILTER_RING") ? atoi(getenv("DSV2_FILTER_RING")) : 1;
-    static bool raised = false;
-    if (!raised) { // more than the default 64 KB of dynamic LDS has to be asked for (gfx950 has 160 KB per CU)
-        HIPCHK(hipFuncSetAttribute((const void *) k_inter_filters_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_intra_filter_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_inter_filters_b2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_intra_filter_b2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        raised = true;
-    }
+    // The ring needs more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU): asked for once, only when the ring
+    // is selected at all, and a device that refuses (64 KB parts) gets the global-memory kernels instead of an abort.
+    static const int on = [] {
+        if (getenv("DSV2_FILTER_RING") && atoi(getenv("DSV2_FILTER_RING")) == 0) {
+            return 0;
+        }
+        const void *ks[4] = {(const void *) k_inter_filters_b, (const void *) k_intra_filter_b, (const void *) k_inter_filters_b2, (const void *) k_intra_filter_b2};
+        for (const void *k : ks) {
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+                (void) hipGetLastError();
+                return 0;
+            }
+        }
+        return 1;
+    }();
     size_t b = (size_t) (luma_h + RingView::kGuardRows) * 64;
     const bool fits = on && (luma_w & 3) == 0 && (luma_h & 3) == 0 && luma_w >= 64 && b <= 150 * 1024 && (luma_w / 4 + 14) / 2 + 1 <= 256;
     return fits ? (unsigned) b : 0u;

@@ -714,12 +714,15 @@ void dec_batch(DecJob *jobs, int n)
     }
 }
 
+Coalescer<DecJob> g_dec_queue; // dsv_dec callers share lockstep steps (batch.h)
+
 } // namespace
 
 extern "C" {
 
 void dsv_dec_free(DSV_DECODER *d)
 {
+    g_dec_queue.forget(d);
     if (d->ref) {
         DecImpl *im = (DecImpl *) d->ref;
         if (im->ready) {
@@ -744,8 +747,32 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn) // d
     jb.buf = buffer;
     jb.out = out;
     jb.fn = fn;
-    dec_batch(&jb, 1);
+    if (!Coalescer<DecJob>::enabled()) {
+        dec_batch(&jb, 1);
+        return jb.ret;
+    }
+    // concurrent callers (a decoder per thread) share one lockstep step; dec_batch itself sorts mixed geometries into rounds,
+    // so every caller carries the same key
+    g_dec_queue.submit(jb, 0, d, dec_batch);
+    if (jb.ret == DSV_DEC_EOS) {
+        g_dec_queue.forget(d);
+    }
     return jb.ret;
+}
+
+/* what the submit queue of dsv_dec did so far (see dsv2hip_enc_queue_stats) */
+void dsv2hip_dec_queue_stats(unsigned long long *out4, int reset)
+{
+    Coalescer<DecJob>::Stats st = g_dec_queue.stats();
+    if (out4) {
+        out4[0] = st.calls;
+        out4[1] = st.steps;
+        out4[2] = st.largest;
+        out4[3] = st.waited_us;
+    }
+    if (reset) {
+        g_dec_queue.reset_stats();
+    }
 }
 
 /* every picture this decoder returns from now on is converted to 4:2:0 by the GPU while it is written to the output

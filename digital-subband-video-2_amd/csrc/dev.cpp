@@ -1,6 +1,7 @@
 // dev.cpp -- device memory, frame transfer and error plumbing for libdsv2hip.
 #include "dev.h"
 
+#include <string.h>
 #include <sys/prctl.h>
 #include <time.h>
 
@@ -53,6 +54,19 @@ void bind_device()
 {
     ensure_device();
     HIPCHK(hipSetDevice(g_device_ordinal));
+}
+
+bool device_arch_is(const char *prefix)
+{
+    ensure_device();
+    static std::once_flag once;
+    static char arch[256];
+    std::call_once(once, [] {
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, g_device_ordinal));
+        snprintf(arch, sizeof(arch), "%s", pr.gcnArchName);
+    });
+    return strncmp(arch, prefix, strlen(prefix)) == 0;
 }
 
 void coef_dims(int format, int w, int h, int cw[3], int ch[3]) // frame.c:30-60

@@ -69,7 +69,7 @@ struct BlockMap {
 void dev_zero(void *p, size_t bytes); // synchronous zero fill of device memory
 void event_wait(hipEvent_t ev);        // ... for a recorded event
 void set_wait_fine(bool fine);         // this thread's waits poll at 20 us (small batches: DSV2_WAIT_FINE_MAX) instead of up to 120 us
-void stream_wait(hipStream_t s);       // host wait for the stream to drain, parked on the interrupt (no polling)
+void stream_wait(hipStream_t s);       // host wait for the stream to drain: sleeps between completion queries (dev.cpp: 10 - 120 us apart), no busy spin
 // pinned host blocks the GPU may write (hostutil.cpp): recycled through dsv_free
 void *pinned_pool_take(size_t bytes);
 bool pinned_pool_release(void *p);
@@ -168,5 +168,6 @@ void ensure_device();
 void set_default_device(int ordinal);
 void bind_device(); // ensure_device + hipSetDevice(default ordinal) for the calling thread
 int device_status(); // 0 = usable HIP device present
+bool device_arch_is(const char *prefix); // the default device's gcnArchName starts with `prefix`
 
 } // namespace dsv2

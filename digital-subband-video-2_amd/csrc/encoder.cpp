@@ -50,6 +50,8 @@ struct EncImpl {
     int stage_cur = 0;
     const void *staged_src = nullptr; // host picture whose upload into d_stage[stage_cur ^ 1] is in flight / done
     hipEvent_t staged_ev = nullptr;   // ... and the event (of the uploading group) that marks its completion
+    uint8_t *h_pack = nullptr;        // dsv_enc: the caller's DSV_FRAME packed (Y, U, V rows without padding) into pinned host memory
+    size_t h_pack_bytes = 0;
     std::vector<uint8_t> big_bytes;   // plane sections of a picture too large for the pinned mirror of the GPU entropy coder
     bool input_uyvy = false;          // packed pictures arrive as interleaved UYVY rows (de-interleaved by the ingest kernel)
 };
@@ -846,6 +848,7 @@ struct Job {
     const uint8_t *dev_planar; // ... or packed planar picture already in HBM
     const uint8_t *host_planar; // ... or packed planar picture in host memory, uploaded by the batch engine (pinned: asynchronously)
     const uint8_t *host_next;   // the picture this stream will bring to the NEXT step: uploaded under this step's kernels
+    bool from_frame;            // host_planar is a DSV_FRAME packed by dsv_enc: planar whatever the encoder's packed-input format
     DSV_BUF *bufs;
     int nbuf;
     FrameCtl d;
@@ -1323,14 +1326,31 @@ void phase_h2(Job &jb)
 
 struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, printed every 16 steps
     bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+    // =3: every phase boundary of every step with its absolute time (CLOCK_MONOTONIC, ms) -- lines up the groups' host phases
+    bool abs_on = on && atoi(getenv("DSV2_BATCH_TRACE")) == 3;
+    void mark(const char *what, int n)
+    {
+        if (!abs_on) return;
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        fprintf(stderr, "[t %p] %.3f %s n=%d\n", (void *) this, ts.tv_sec * 1e3 + ts.tv_nsec / 1e6, what, n);
+    }
     int every = on && atoi(getenv("DSV2_BATCH_TRACE")) == 2 ? 1 : 16; // =2: print every step
     double acc[10] = {0};
     int steps = 0;
     std::chrono::steady_clock::time_point t0;
-    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void start()
+    {
+        if (on) {
+            mark("enter", 0);
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
     void lap(int i)
     {
         if (!on) return;
+        static const char *const names[10] = {"p0", "g1-enqueued", "g1-done", "h1-done", "g2-enqueued", "g2-done", "syms", "h2-done", "h1b-done", ""};
+        mark(names[i], 0);
         auto t1 = std::chrono::steady_clock::now();
         acc[i] += std::chrono::duration<double, std::milli>(t1 - t0).count();
         t0 = t1;
@@ -1385,14 +1405,31 @@ struct SearchToken {
     std::condition_variable cv;
     int free_slots = getenv("DSV2_SEARCH_SLOTS") ? atoi(getenv("DSV2_SEARCH_SLOTS")) : 1;
     const bool on = free_slots > 0;
+    // first come, first served (DSV2_SEARCH_FIFO=0: whoever the condition variable wakes first): a group that has waited longest
+    // searches next, so the groups keep their rotation and none of them falls a step behind the others
+    const bool fifo = !(getenv("DSV2_SEARCH_FIFO") && atoi(getenv("DSV2_SEARCH_FIFO")) == 0);
+    unsigned long long next_ticket = 0, serving = 0;
     void acquire()
     {
         if (!on) {
             return;
         }
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return free_slots > 0; });
+        const unsigned long long mine = next_ticket++;
+        // bounded: a holder that never lets go (a search that hangs, a bug between acquire and release) must not park every
+        // other lockstep group of the process silently
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return free_slots > 0 && (!fifo || serving == mine); })) {
+            fatal("search token not released within 120 s (another lockstep group's motion search never finished)", __FILE__, __LINE__);
+        }
+        if (fifo) {
+            serving++;
+        } else {
+            serving = next_ticket;
+        }
         free_slots--;
+        if (fifo && free_slots > 0) {
+            cv.notify_all(); // (more than one slot: the next in line may go as well)
+        }
     }
     void release()
     {
@@ -1403,10 +1440,26 @@ struct SearchToken {
             std::lock_guard<std::mutex> lk(mu);
             free_slots++;
         }
-        cv.notify_one();
+        cv.notify_all();
     }
 };
 SearchToken g_search_token;
+struct SearchTokenGuard { // releases on every way out of the scope that took the token
+    bool held = false;
+    void acquire()
+    {
+        g_search_token.acquire();
+        held = true;
+    }
+    void release()
+    {
+        if (held) {
+            held = false;
+            g_search_token.release();
+        }
+    }
+    ~SearchTokenGuard() { release(); }
+};
 
 // the plane sections of the packet are assembled on the GPU (DSV2_GPU_ENTROPY=0: the host codes them from the symbol list)
 static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV2_GPU_ENTROPY")) == 0);
@@ -1480,6 +1533,7 @@ void enc_batch(Job *jobs, int n)
     const BlockStatsJob *d_bsj;
     BlockStatsJob *h_bsj = sc.tabs.take<BlockStatsJob>((size_t) n, &d_bsj);
     int n_ing = 0, n_pyr = 0, n_intra = 0, n_bsj = 0;
+    std::function<void()> upload_next;
     {
         // pictures that arrive in host memory: this step's either came up during the previous step (prefetched
         // through host_next) or is uploaded now; the next step's goes up on the copy stream under this step's kernels
@@ -1516,19 +1570,31 @@ void enc_batch(Job *jobs, int n)
             im->staged_src = nullptr;
             jb.dev_planar = im->d_stage[im->stage_cur];
         }
-        for (int k = 0; k < n; k++) {
-            Job &jb = jobs[k];
-            if (jb.host_planar && jb.host_next) {
-                sc.ensure_copy_stream();
-                HIPCHK(hipMemcpyAsync(jb.im->d_stage[jb.im->stage_cur ^ 1], jb.host_next, pbytes, hipMemcpyHostToDevice, sc.copy_stream));
-                jb.im->staged_src = jb.host_next;
-                jb.im->staged_ev = sc.copy_done;
-                any_next = true;
+        // the next step's pictures go up on the copy stream under this step's kernels.  The calls themselves -- one per stream --
+        // cost the host several milliseconds for a large batch: they are made once this step's pre-search work and its search
+        // have been handed to the GPU (DSV2_UPLOAD_EARLY=1: before anything else of the step, as up to round 3)
+        upload_next = [&jobs, n, pbytes, &sc] {
+            bool any = false;
+            for (int k = 0; k < n; k++) {
+                Job &jb = jobs[k];
+                if (jb.host_planar && jb.host_next) {
+                    sc.ensure_copy_stream();
+                    HIPCHK(hipMemcpyAsync(jb.im->d_stage[jb.im->stage_cur ^ 1], jb.host_next, pbytes, hipMemcpyHostToDevice, sc.copy_stream));
+                    jb.im->staged_src = jb.host_next;
+                    jb.im->staged_ev = sc.copy_done;
+                    any = true;
+                }
             }
+            if (any) {
+                HIPCHK(hipEventRecord(sc.copy_done, sc.copy_stream));
+            }
+        };
+        static const bool upload_early = getenv("DSV2_UPLOAD_EARLY") && atoi(getenv("DSV2_UPLOAD_EARLY")) != 0;
+        if (upload_early) {
+            upload_next();
+            upload_next = nullptr;
         }
-        if (any_next) {
-            HIPCHK(hipEventRecord(sc.copy_done, sc.copy_stream));
-        }
+        (void) any_next;
     }
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
@@ -1540,7 +1606,7 @@ void enc_batch(Job *jobs, int n)
         if (jb.frame) {
             dframe_upload(&cur.src, jb.frame, bs);
         } else {
-            IngestJob &ij = jb.im->input_uyvy ? h_ingu[n_ingu++] : h_ing[n_ing++];
+            IngestJob &ij = jb.im->input_uyvy && !jb.from_frame ? h_ingu[n_ingu++] : h_ing[n_ing++];
             ij.src = jb.dev_planar;
             for (int c = 0; c < 3; c++) {
                 ij.dst[c] = cur.src.p[c];
@@ -1663,13 +1729,16 @@ void enc_batch(Job *jobs, int n)
     // pictures hide each other's ramps when they overlap)
     static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 8192;
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
+    SearchTokenGuard token;
     if (searching) {
         // the token is for the search alone: what precedes it on the stream (this step's upload, ingest, pyramids) is waited
         // for BEFORE taking it, or the holder would sit on the token while its own pictures are still crossing PCIe.
         // (Running the coarse levels -- launches that cannot fill the slots -- outside the token, beside another group's
         // level-0 launch, was tried: hme_run_batch takes a level range for it; no gain, they slow the holder's launch.)
         stream_wait(bs);
-        g_search_token.acquire(); // (released once the search has drained, below)
+        t_clock.mark("pre-search-drained", n);
+        token.acquire(); // (released once the search has drained, below)
+        t_clock.mark("token", n);
     }
     if (!pjobs.empty()) {
         prof.begin(bs, ST_HME);
@@ -1678,6 +1747,9 @@ void enc_batch(Job *jobs, int n)
         HIPCHK(hipMemsetAsync(sc.d_bstats, 0, (size_t) n_bsj * BS_WORDS * sizeof(int), bs));
         block_stats_batch(bs, d_bsj, n_bsj, nbh, nbv);
         HIPCHK(hipMemcpyAsync(sc.h_bstats, sc.d_bstats, (size_t) n_bsj * BS_WORDS * sizeof(int), hipMemcpyDeviceToHost, bs));
+    }
+    if (upload_next) {
+        upload_next();
     }
     t_clock.lap(1);
     if (searching) {
@@ -1696,7 +1768,8 @@ void enc_batch(Job *jobs, int n)
                 nanosleep(&ts, nullptr);
             }
         }
-        g_search_token.release();
+        token.release();
+        t_clock.mark("token-released", n);
     }
     stream_wait(bs);
     t_clock.lap(2);
@@ -2024,6 +2097,8 @@ void enc_batch(Job *jobs, int n)
     t_clock.done(n);
 }
 
+Coalescer<Job> g_enc_queue; // dsv_enc callers share lockstep steps (batch.h)
+
 } // namespace
 
 
@@ -2083,10 +2158,15 @@ void dsv_enc_start(DSV_ENCODER *enc) // dsv_encoder.c:1360
 
 void dsv_enc_free(DSV_ENCODER *enc)
 {
+    g_enc_queue.forget(enc);
     if (enc->ref) {
         EncImpl *im = (EncImpl *) enc->ref;
         if (im->ready) {
             im->dev.destroy();
+        }
+        if (im->h_pack) {
+            pinned_pool_release(im->h_pack);
+            im->h_pack = nullptr;
         }
         for (int i = 0; i < 2; i++) {
             if (im->d_stage[i]) {
@@ -2117,6 +2197,7 @@ void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
 
 void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs) // dsv_encoder.c:1416
 {
+    g_enc_queue.forget(enc); // (this caller will not join another step: leaders stop waiting for it)
     dsv_mk_buf(&bufs[0], DSV_PACKET_HDR_SIZE);
     BitWriter bw{bufs[0].data, 0};
     put_packet_hdr(bw, DSV_PT_EOS);
@@ -2132,10 +2213,73 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
     Job jb;
     memset(&jb, 0, sizeof(jb));
     jb.enc = enc;
-    jb.frame = frame;
     jb.bufs = bufs;
-    enc_batch(&jb, 1);
+    if (!Coalescer<Job>::enabled()) {
+        jb.frame = frame;
+        enc_batch(&jb, 1);
+        return jb.nbuf;
+    }
+    // The calling thread does what is its own: the picture, whatever its strides, is packed into this encoder's pinned
+    // staging block (concurrent callers pack side by side; the step then uploads every picture asynchronously) and released
+    // (dsv_encoder.c:1457).  The step itself is shared with whoever else is calling right now (batch.h: Coalescer).
+    bind_device();
+    if (!enc->ref) {
+        enc->ref = new EncImpl();
+    }
+    EncImpl *im = (EncImpl *) enc->ref;
+    const int fmt = enc->vidmeta.subsamp, w = enc->vidmeta.width, h = enc->vidmeta.height;
+    const int hs = DSV_FORMAT_H_SHIFT(fmt), vs = DSV_FORMAT_V_SHIFT(fmt);
+    const int pw[3] = {w, (w + (1 << hs) - 1) >> hs, (w + (1 << hs) - 1) >> hs}, ph[3] = {h, (h + (1 << vs) - 1) >> vs, (h + (1 << vs) - 1) >> vs};
+    const size_t pbytes = (size_t) pw[0] * ph[0] + 2 * (size_t) pw[1] * ph[1];
+    if (im->h_pack_bytes != pbytes) {
+        if (im->h_pack) {
+            pinned_pool_release(im->h_pack);
+        }
+        im->h_pack = (uint8_t *) pinned_pool_take(pbytes);
+        im->h_pack_bytes = pbytes;
+    }
+    uint8_t *dst = im->h_pack;
+    for (int c = 0; c < 3; c++) {
+        const DSV_PLANE *sp = &frame->planes[c];
+        const int cw = sp->w < pw[c] ? sp->w : pw[c], rows = sp->h < ph[c] ? sp->h : ph[c];
+        for (int y = 0; y < ph[c]; y++, dst += pw[c]) {
+            if (y < rows) {
+                memcpy(dst, sp->data + (size_t) y * sp->stride, (size_t) cw);
+                if (cw < pw[c]) {
+                    memset(dst + cw, 0, (size_t) (pw[c] - cw));
+                }
+            } else {
+                memset(dst, 0, (size_t) pw[c]);
+            }
+        }
+    }
+    dsv_frame_ref_dec(frame);
+    jb.host_planar = im->h_pack;
+    jb.from_frame = true;
+    // what a lockstep step must agree on (enc_batch checks it again): picture geometry, block size, pyramid depth, psy switch
+    unsigned long long key = 1469598103934665603ull;
+    for (unsigned long long v : {(unsigned long long) w, (unsigned long long) h, (unsigned long long) fmt, (unsigned long long) (unsigned) enc->block_size_override_x,
+                                 (unsigned long long) (unsigned) enc->block_size_override_y, (unsigned long long) enc->pyramid_levels, (unsigned long long) enc->do_psy}) {
+        key = (key ^ v) * 1099511628211ull;
+    }
+    g_enc_queue.submit(jb, key, enc, enc_batch);
     return jb.nbuf;
+}
+
+/* what the submit queue of dsv_enc did so far: [0] calls, [1] lockstep steps they were run as, [2] the largest step, [3] total
+ * microseconds leaders spent waiting for expected callers; reset != 0 clears the counts afterwards */
+void dsv2hip_enc_queue_stats(unsigned long long *out4, int reset)
+{
+    Coalescer<Job>::Stats st = g_enc_queue.stats();
+    if (out4) {
+        out4[0] = st.calls;
+        out4[1] = st.steps;
+        out4[2] = st.largest;
+        out4[3] = st.waited_us;
+    }
+    if (reset) {
+        g_enc_queue.reset_stats();
+    }
 }
 
 /* same as dsv_enc for a packed planar 8-bit picture (Y, then U, then V, no padding) that is

@@ -1184,7 +1184,21 @@ static int g_hme_rows = getenv("DSV2_HME_ROWS") ? atoi(getenv("DSV2_HME_ROWS")) 
 // picture under the other wavefronts' feet -- 11 % of the search's span in the four-group bench (5 590 -> 5 990 frames/s on
 // the same box).  Both forms are run against the reference at the benchmarked operating point
 // (tests/test_gpu_operating_point.py), tools/stress_hme.sh repeats the stage test under each.
-static int g_hme_fence = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 0;
+// Hardware assumption (advisor, round 3): the fence-free hand-off is message passing over two locations with relaxed agent-scope
+// atomics -- outside what the HSA / LLVM memory model promises.  It holds on gfx950 (and gfx942) because an agent-scope (sc1)
+// store is written through to the memory side of the per-XCD L2s and is complete when vmcnt drains, an sc1 load is answered from
+// there, and a wavefront issues its loads in order behind the poll's wave-scope fence.  Any other architecture gets both fences.
+static int hme_fence_mode()
+{
+    static const int mode = [] {
+        if (getenv("DSV2_HME_FENCE")) {
+            return atoi(getenv("DSV2_HME_FENCE"));
+        }
+        return device_arch_is("gfx950") || device_arch_is("gfx942") ? 0 : 3;
+    }();
+    return mode;
+}
+#define g_hme_fence hme_fence_mode()
 // issue priority of the search wavefronts while they work on a block (s_setprio; 0 while they wait for the row above)
 static int g_hme_prio = getenv("DSV2_HME_PRIO") ? atoi(getenv("DSV2_HME_PRIO")) & 3 : 0;
 

@@ -252,7 +252,9 @@ __device__ __forceinline__ void block(const SideJob &J, int nbh, int idx, Walk &
 
 } // namespace
 
-// grid = streams; dynamic LDS: none (static images)
+// grid = streams; dynamic LDS: none (static images).  The six images plus the per-thread scan arrays are ~70 KB of static LDS:
+// this kernel is written for the 160 KB of a gfx950 CU (a 64 KB part would need the scan arrays folded into the image).
+static_assert(SIDE_IMG_BYTES + 25 * kThreads * 4 < 150 * 1024, "k_side_info: static LDS beyond a gfx950 CU");
 __global__ __launch_bounds__(kThreads) void k_side_info(const SideJob *__restrict__ tab, int nbh, int nbv)
 {
     __shared__ uint32_t img[SIDE_IMG_BYTES / 4 + 2];

@@ -97,15 +97,25 @@ def gather_segments(dist, rank, world, my_segments, device="cpu", chunk=CHUNK):
         total = totals[r]
         if not total:
             continue
-        flat = np.empty(total, dtype=np.uint8)
+        # the rank's payload is its segments back to back: (start in that flat order, length, segment id); every received
+        # piece is dropped straight into the output at the offsets of the segments it overlaps (no second host copy)
+        spans, off = [], 0
+        for s, n in tables[r]:
+            spans.append((off, int(n), int(s)))
+            off += int(n)
+        k = 0
         for a in range(0, total, chunk):
             n = min(total, a + chunk) - a
             view = rbuf[:n]
             dist.recv(view, src=r)
-            flat[a:a + n] = view.cpu().numpy()
-        off = 0
-        for s, n in tables[r]:
-            s, n = int(s), int(n)
-            out[offset[s]:offset[s] + n] = flat[off:off + n]
-            off += n
+            piece = view.cpu().numpy()
+            while k < len(spans) and spans[k][0] + spans[k][1] <= a:
+                k += 1
+            j = k
+            while j < len(spans) and spans[j][0] < a + n:
+                s0, sn, sid = spans[j]
+                lo, hi = max(s0, a), min(s0 + sn, a + n)
+                if hi > lo:
+                    out[offset[sid] + (lo - s0):offset[sid] + (hi - s0)] = piece[lo - a:hi - a]
+                j += 1
     return memoryview(out)

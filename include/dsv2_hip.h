@@ -394,6 +394,15 @@ void dsv2hip_host_free(void *p);
  * and fn[k] are exactly what dsv_dec(decs[k], &bufs[k], &out[k], &fn[k]) would have produced (packets are
  * consumed the same way).  All pictures of a step run through one set of kernel launches. */
 int dsv2hip_dec_batch(int n, DSV_DECODER **decs, DSV_BUF *bufs, DSV_FRAME **out, DSV_FNUM *fn, int *ret);
+/* Submit queue behind dsv_enc / dsv_dec.  The reference's interface is one synchronous call per frame
+ * (dsv_encoder.h:190-199, dsv_decoder.h:54-61); its own parallel recipe is one encoder per process
+ * (parallel_encode_yuv.sh:31-52).  Threads that each loop dsv_enc (or dsv_dec) on an instance of their own are run
+ * TOGETHER: calls that arrive within a bounded window (10 % of the last step, 100 us .. 2 ms; DSV2_COALESCE_US) and agree
+ * on the picture geometry share one lockstep step, each call still returning when its own frame is finished, with the
+ * packets dsv_enc alone would have produced.  DSV2_COALESCE=0 turns the queue off.  The stats calls report what it did:
+ * out4[0] calls, [1] lockstep steps they ran as, [2] largest step, [3] microseconds leaders waited for expected callers. */
+void dsv2hip_enc_queue_stats(unsigned long long *out4, int reset);
+void dsv2hip_dec_queue_stats(unsigned long long *out4, int reset);
 /* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
  * off at any time (resets the totals).  dsv2hip_prof_read fills 9 entries (ingest+pyramid, HME,
  * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend, and -- inside HME -- the level-0

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libdsv2ref.so")
-ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+ORACLE_SO = os.environ.get("DSV2_ORACLE_SO", os.path.join(ROOT, "oracle", "liboracle.so"))  # (make -C oracle asan-test points it at the sanitizer build)
 # DSV2HIP_LIB selects another build of the same library (e.g. the phase-clock build of tools/hme_phase_prof.py)
 HIP_SO = os.environ.get("DSV2HIP_LIB") or os.path.join(ROOT, "digital-subband-video-2_amd", "libdsv2hip.so")
 REF_CLI = os.path.join(ROOT, "oracle", "_ref", "dsv2_ref")

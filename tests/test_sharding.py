@@ -18,6 +18,14 @@ from conftest import load_pkg  # noqa: E402
 W, H, GOP, NFRAMES = 176, 144, 4, 14
 
 
+def _free_port():
+    """a port the kernel says is free right now (as bench.spawn_ranks does), not a guess from the pid"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def encode_segment(seg):
     from codec_run import encode_stream
     pkg = load_pkg()
@@ -47,7 +55,7 @@ def _worker(rank, world, port, outdir):
 def test_two_rank_gather_equals_sequential_per_segment(tmp_path):
     from codec_run import decode_stream
     world = 2
-    port = 29500 + (os.getpid() % 1000)
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     got = open(tmp_path / "gathered.dsv", "rb").read()
     nseg = (NFRAMES + GOP - 1) // GOP
@@ -96,7 +104,7 @@ def test_gather_unpadded_chunked(tmp_path, nseg, chunk):
     """uneven segment lengths (one of them empty), a rank without segments, payloads split over several transfers"""
     import numpy as np
     world = 2
-    port = 29500 + ((os.getpid() + 7 * nseg + chunk) % 1000)
+    port = _free_port()
     mp.spawn(_gather_worker, args=(world, port, str(tmp_path), nseg, chunk), nprocs=world, join=True)
     want = b"".join(np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8).tobytes() for s in range(nseg))
     assert open(tmp_path / "g.bin", "rb").read() == want
