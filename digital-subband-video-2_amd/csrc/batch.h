@@ -148,8 +148,9 @@ class WorkerPool {
 //   * the first caller to arrive becomes the LEADER; it waits -- bounded: `window` -- until the callers it can expect have
 //     arrived (those seen within the last 100 ms under this key, less the ones inside a running step), takes them, runs the
 //     batch on its own thread, and hands every caller its results; each call still returns when ITS frame is done;
-//   * with many callers (>= 2 * kMinSplit) a leader takes only its share (1 / groups), the rest elect the next leader at once:
-//     two or more steps then run side by side, one's host phases and latency-bound kernels under another's;
+//   * a few callers run one step at a time (a caller that arrives while it runs joins the next one); with many callers
+//     (>= 2 * kMinSplit) a leader takes only its share (1 / groups) and up to `groups` steps run side by side, one's host
+//     phases and latency-bound kernels under another's;
 //   * a single caller finds nobody to wait for and runs at once: the plain dsv_enc path.
 // DSV2_COALESCE=0 turns it off, DSV2_COALESCE_US sets the longest wait (default 10 % of the last step, 100 us .. 2 ms),
 // DSV2_COALESCE_GROUPS the number of concurrent steps a crowd is split into (default 2).
@@ -176,8 +177,11 @@ template <class JobT> class Coalescer {
             if (me.done) {
                 return;
             }
-            if (!me.taken && !collecting_) {
-                break; // nobody is collecting: this caller leads
+            // nobody is collecting and this key may start another step: this caller leads.  (A few callers run ONE step at
+            // a time: whoever arrives while it runs waits for it, and the step after it takes everybody -- callers that start
+            // out of phase fall into step after one round instead of each running alone for ever.)
+            if (!me.taken && !collecting_ && steps_running(key) < max_steps(key, clock::now())) {
+                break;
             }
             cv_.wait(lk);
         }
@@ -316,6 +320,18 @@ template <class JobT> class Coalescer {
         return c;
     }
     bool busy(const void *) { return !running_.empty(); } // (callers inside a step do not age out while steps are running)
+    int steps_running(unsigned long long key)
+    {
+        int c = 0;
+        for (const Running &r : running_) {
+            c += r.key == key;
+        }
+        return c;
+    }
+    int max_steps(unsigned long long key, std::chrono::steady_clock::time_point now)
+    {
+        return live(key, now) >= 2 * kMinSplit ? std::max(1, groups_) : 1;
+    }
     int inflight(unsigned long long key)
     {
         int c = 0;

@@ -5,11 +5,23 @@
 #include <sys/prctl.h>
 #include <time.h>
 
+#include <chrono>
 #include <mutex>
 
 namespace dsv2 {
 
 thread_local long long t_launch_count = 0;
+
+// DSV2_STARTUP_TRACE=1: milliseconds since the library was loaded at a few points of a process's first step (what a short-lived
+// caller -- one CLI process per closed-GOP segment, parallel_encode_yuv.sh:31-52 -- pays before its first packet)
+static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+void startup_mark(const char *what)
+{
+    static const bool on = getenv("DSV2_STARTUP_TRACE") != nullptr;
+    if (on) {
+        fprintf(stderr, "[dsv2hip startup] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count(), what);
+    }
+}
 
 
 [[noreturn]] void fatal(const char *what, const char *file, int line)

@@ -167,6 +167,7 @@ void ingest_batch16(hipStream_t s, const IngestJob *d_jobs, int n, int total_row
 void ensure_device();
 void set_default_device(int ordinal);
 void bind_device(); // ensure_device + hipSetDevice(default ordinal) for the calling thread
+void startup_mark(const char *what); // DSV2_STARTUP_TRACE
 int device_status(); // 0 = usable HIP device present
 bool device_arch_is(const char *prefix); // the default device's gcnArchName starts with `prefix`
 

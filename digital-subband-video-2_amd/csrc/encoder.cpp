@@ -1478,7 +1478,16 @@ void enc_batch(Job *jobs, int n)
         set_wait_fine(n <= fine_max);
     }
     const int kAuxStreams = kAuxStreamsEnv >= 0 ? kAuxStreamsEnv : (n < 12 ? 1 : 0);
+    static bool first_step = true; // (DSV2_STARTUP_TRACE only; a benign race)
+    const bool trace_startup = first_step;
+    first_step = false;
+    if (trace_startup) {
+        startup_mark("first step entered");
+    }
     bind_device();
+    if (trace_startup) {
+        startup_mark("device bound (HIP runtime up)");
+    }
     t_clock.start();
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
@@ -1495,9 +1504,15 @@ void enc_batch(Job *jobs, int n)
         phase_p0(jb);
     }
     t_clock.lap(0);
+    if (trace_startup) {
+        startup_mark("encoder instances allocated");
+    }
     StageProf &prof = jobs[0].im->dev.prof;
     ScratchLease lease;
     BatchScratch &sc = *lease.sc;
+    if (trace_startup) {
+        startup_mark("batch scratch + streams ready");
+    }
     // The step's kernels run on a stream that belongs to the batch scratch (made once, see ScratchPool::acquire), not on one
     // of the encoders': a step starts and ends with that stream drained, so which stream carried an encoder's previous step
     // does not matter.  (DSV2_SCRATCH_STREAM=0: the first encoder's stream, created with the instance: A/B.)
@@ -2093,6 +2108,9 @@ void enc_batch(Job *jobs, int n)
         }
     }
     parallel_for(n, [&](int k) { g_task_cpu.run(2, [&] { phase_h2(jobs[k]); }); });
+    if (trace_startup) {
+        startup_mark("first step done");
+    }
     t_clock.lap(7);
     t_clock.done(n);
 }
