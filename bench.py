@@ -96,6 +96,9 @@ def parse():
                     help="pictures parked in HBM before the clock starts (kernel-side figure; NOT the SURVEY 8d metric)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for exercising the N>1 path "
                                                       "on a box with fewer GPUs than ranks, together with DSV2_FORCE_DEVICE)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the segment gather even with ONE rank "
+                    "(exercises RCCL init + collectives on a single GPU)")
+    ap.add_argument("--no-multi-rank", action="store_true", help="skip the 8-ranks-on-one-GPU leg")
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--gen-procs", type=int, default=-1,
                     help="helper processes that generate the synthetic pictures (default: the usable cores, 1 under a profiler: "
@@ -702,7 +705,12 @@ def main():
     import torch
     import dsvabi as A
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            so = socket.socket()
+            so.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(so.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+            so.close()
         import torch.distributed as dist_
         dist = dist_
         if args.backend == "nccl":
@@ -779,9 +787,27 @@ def main():
         whole = pkg.sharding.gather_segments(dist, rank, world, segs, device=xdev)
         gather_s = time.perf_counter() - t_g
         total_bytes = len(whole) if rank == 0 else 0
+        # every segment of the gathered buffer against what its rank produced: (length, md5) tables exchanged beside the payload
+        import hashlib
+        mine_tab = {sid: (len(b), hashlib.md5(b).hexdigest()) for sid, b in segs.items()}
+        tabs = [None] * world
+        dist.all_gather_object(tabs, mine_tab)
+        gather_ok = None
+        if rank == 0:
+            at, good, nseg = 0, 0, 0
+            for sid in sorted(k for t in tabs for k in t):
+                ln, md = next(t[sid] for t in tabs if sid in t)
+                good += int(hashlib.md5(whole[at:at + ln]).hexdigest() == md)
+                at += ln
+                nseg += 1
+            gather_ok = {"segments": nseg, "segments_verified": good, "bytes": at}
+            if good != nseg or at != len(whole):
+                sys.stderr.write("[bench] gathered segment bytes DIFFER from what the ranks produced (%d of %d ok)\n" % (good, nseg))
+                sys.exit(8)
         del whole, segs
     else:
         total_bytes = sum(len(p) for s in range(S) for fr in run.out[s] for p in fr)
+        gather_ok = None
     elapsed = float(t_max.item())
     frames_total, intra_total, pairs_total = (int(x) for x in counts.tolist())
 
@@ -825,7 +851,8 @@ def main():
                    "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2), "mpix_per_s": round(fps * W_ * H_ / 1e6, 1),
                    "stream_bytes_total": total_bytes, "host_cpus_usable": ncpu, "host_cores_pinned": args.host_cores or None,
                    "host_threads": int(os.environ["DSV2_HOST_THREADS"]),
-                   "final_gather_s": round(gather_s, 3) if gather_s is not None else None,
+                   "final_gather_s": round(gather_s, 3) if gather_s is not None else None, "final_gather_check": gather_ok,
+                   "exchange_backend": (args.backend if dist is not None else None),
                    "setup_s": {"generate_pictures": round(t_gen, 1)}},
         "parity_checked": {"twin_pairs_equal": pairs_total, "twin_pairs": pairs_total,
                            "note": "twins = same input, different lockstep group (and GOP phase), compared frame by frame over the run"},
@@ -918,6 +945,9 @@ def main():
     # ---- does the host side fit the cores an 8-GPU node leaves per rank?  The headline again, pinned to 2 cores ----
     if extras and not args.no_host_share and not args.only_batch_curve and not args.only_api_legs and args.host_cores <= 0:
         result["host_share"] = host_share(args, 2, fps)
+
+    if extras and not args.no_multi_rank and not args.only_batch_curve and not args.only_api_legs and args.host_cores <= 0:
+        result["multi_rank_one_gpu"] = multi_rank_one_gpu(args, fps)
 
     # ---- parity, part 2 + CPU baselines: the real reference (oracle/_ref) on the host cores ----
     rc = 0
@@ -1310,6 +1340,45 @@ def api_process_leg(vids, W_, H_, QP, GOP):
     finally:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def multi_rank_one_gpu(args, fps_one_rank):
+    """What one GPU can prove about the N > 1 path (the 1 -> 8 curve itself needs an 8-GPU node and is the driver's to measure):
+    (a) EIGHT ranks of this bench sharing this one GPU (DSV2_FORCE_DEVICE=0), 96 streams and 2 host cores each -- the whole
+    multi-rank code path (rank spawn, per-rank streams, barrier + max-over-ranks timing, the ordered segment gather over gloo,
+    every gathered segment verified) with the aggregate beside the one-rank 768-stream figure; (b) ONE rank forced through the
+    distributed path on RCCL (--backend nccl): process-group init, all_reduce, all_gather and the gather on the hardware."""
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-profile", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    env.pop("DSV2_HOST_THREADS", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def sub(cmd, env2, key):
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env2)
+            j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            c = j["config"]
+            return {"value": j["value"], "unit": "frames/s", "ranks": j["n_gpus"], "streams_per_rank": c["streams_per_gpu"], "groups_per_rank": c["groups"],
+                    "steps": j["steps"], "ms_per_step": j["ms_per_step"], "exchange_backend": c.get("exchange_backend"), "final_gather_s": c.get("final_gather_s"),
+                    "final_gather_check": c.get("final_gather_check"), "twin_pairs_equal": j["parity_checked"]["twin_pairs_equal"],
+                    "twin_pairs": j["parity_checked"]["twin_pairs"], "host_cores_per_rank": c.get("host_cores_pinned"), "rc": r.returncode}
+        except Exception as e:  # noqa: BLE001
+            return {"error": repr(e), "leg": key}
+
+    e8 = dict(env, DSV2_FORCE_DEVICE="0", GPU_MAX_HW_QUEUES="2")
+    a = sub(base + ["--gpus", "8", "--backend", "gloo", "--streams", "96", "--groups", "1", "--host-cores", "2", "--steps", "24", "--warmup", "4"], e8, "eight_ranks")
+    if "value" in a:
+        a["ratio_to_one_rank_768_streams"] = round(a["value"] / fps_one_rank, 3)
+        a["note"] = "8 processes x 96 streams on ONE GPU (DSV2_FORCE_DEVICE=0), gloo exchange, 2 host cores per rank; aggregate over the ranks, max-over-ranks time"
+    out["eight_ranks_one_gpu_gloo"] = a
+    b = sub(base + ["--gpus", "1", "--force-dist", "--backend", "nccl", "--streams", "96", "--groups", "1", "--steps", "8", "--warmup", "2"], env, "one_rank_rccl")
+    if "value" in b:
+        b["note"] = "one rank through the distributed path on RCCL: init_process_group(nccl), all_reduce, all_gather and the segment gather executed on the GPU"
+    out["one_rank_rccl_path"] = b
+    out["scaling_1_to_8_gpus"] = "unmeasured here: needs an 8-GPU node (the driver's SCALE run)"
+    return out
 
 
 def host_share(args, cores, fps_unrestricted):
