@@ -1550,6 +1550,39 @@ HME_ROWS_B(1)
 HME_ROWS_B(2)
 HME_ROWS_B(3)
 HME_ROWS_B(4)
+
+// PERSISTENT form of the fast kernels (round 4; DSV2_HME_PERSIST = workgroups per launch, 0 = the launch-per-row forms above).
+// amdgpu_waves_per_eu(W, W) caps the search at W wavefronts per SIMD by PADDING every wavefront's register allocation until a
+// (W + 1)th does not fit: at W = 2 a search wavefront that needs 113 registers holds 176, two of them 352 of the SIMD's 512,
+// and every other kernel of the step -- the other lockstep groups' streaming kernels, whose bandwidth is their bytes in
+// flight, i.e. their resident wavefronts -- lives in the 160 that are left (three wavefronts of 48 registers per SIMD where
+// eight run when the GPU is theirs: predict, quantiser, level-1 transforms took 2.6 - 3.6 x their exclusive time beside a
+// search).  Here the cap is the LAUNCH: `P` workgroups (default 2 048 = two per SIMD) that each walk row after row -- the
+// tickets of take_row already hand rows to whoever asks -- compiled for four wavefronts per SIMD, i.e. with the 120 registers
+// the routine needs: two resident search wavefronts leave 272.  A row still only waits for a lower ticket, which a RUNNING
+// worker holds (a worker takes its next ticket after finishing its row), so the progress argument is unchanged.
+#define HME_ROWS_P(NAME, LEVEL_EXPR, ...)                                                                                \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void NAME(                               \
+        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts, int nstreams, int nrows)          \
+    {                                                                                                                    \
+        __shared__ FastLds S;                                                                                            \
+        for (;;) {                                                                                                       \
+            const RowTicket t_ = take_row(tab, LEVEL_EXPR, nstreams, nrows, parts);                                      \
+            if (t_.row < 0) {                                                                                            \
+                return;                                                                                                  \
+            }                                                                                                            \
+            hme_row<__VA_ARGS__>(tab[t_.stream], t_.row, LEVEL_EXPR, nbx, nrows, allow_fast, S);                         \
+            __syncthreads();                                                                                             \
+        }                                                                                                                \
+    }
+HME_ROWS_P(k_hme_rows_p_fast_l0, 0, true, 0)
+HME_ROWS_P(k_hme_rows_p_fast_l0_444, 0, true, 0, 0)
+HME_ROWS_P(k_hme_rows_p_fast_lx, level, true, 1)
+HME_ROWS_P(k_hme_rows_p_fast_l0_pre, 0, true, 0, 1, true)
+HME_ROWS_P(k_hme_rows_p_fast_l0_444_pre, 0, true, 0, 0, true)
+HME_ROWS_P(k_hme_rows_p_fast_lx_pre, level, true, 1, 1, true)
+static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 2048;
+static int g_hme_persist_lx = getenv("DSV2_HME_PERSIST_LX") ? atoi(getenv("DSV2_HME_PERSIST_LX")) : g_hme_persist;
 static int g_hme_xcd = getenv("DSV2_HME_XCD") && atoi(getenv("DSV2_HME_XCD")) >= 1 ? atoi(getenv("DSV2_HME_XCD")) : 8; // ticket partitions (take_row): 8 XCDs on MI355X; 1 = chip-wide tickets
 static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 2;
 static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
@@ -2188,6 +2221,13 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             if (prof && level == 0) {
                 prof->begin(s, ST_HME_L0);
             }
+            const int persist = level == 0 ? g_hme_persist : g_hme_persist_lx;
+            if (persist > 0 && (fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
+                auto pk = level == 0 ? (g.a.hshift == 0 ? (pre ? k_hme_rows_p_fast_l0_444_pre : k_hme_rows_p_fast_l0_444) : (pre ? k_hme_rows_p_fast_l0_pre : k_hme_rows_p_fast_l0))
+                                     : (pre ? k_hme_rows_p_fast_lx_pre : k_hme_rows_p_fast_lx);
+                DSV2_LAUNCH(pk, dim3(std::min(persist, n * nby)), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1) | (g_hme_prio << 3),
+                            n < g_hme_xcd ? n : g_hme_xcd, n, nby);
+            } else
             DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1) | (g_hme_prio << 3), n < g_hme_xcd ? n : g_hme_xcd);
             if (prof && level == 0) {
                 prof->end(s, ST_HME_L0, n, 1);
