@@ -270,6 +270,11 @@ def mk_params(meta, w, h, isP, lossless=0, do_psy=0xff, effort=10, temporal_mc=0
     return p
 
 
+def format_shifts(subsamp):
+    """(horizontal, vertical) chroma shift of a DSV_SUBSAMP_* code (dsv.h: DSV_FORMAT_H_SHIFT / _V_SHIFT)"""
+    return (subsamp >> 2) & 3, subsamp & 3
+
+
 def mk_meta(w, h, subsamp, fps=(30, 1), inter_sharpen=1):
     m = META()
     m.width, m.height, m.subsamp = w, h, subsamp

@@ -55,6 +55,10 @@ class Scene:
         self.w, self.h, self.subsamp = w, h, subsamp
         v = pkg.synth.SynthVideo(w, h, "420" if subsamp == A.SUBSAMP_420 else "444", seed=seed)
         cur, prev = v.frame(t), v.frame(t - 1)
+        if subsamp not in (A.SUBSAMP_420, A.SUBSAMP_444):  # 4:2:2, 4:1:1 ...: the 4:4:4 picture's chroma decimated to the format's grid
+            hs, vs = A.format_shifts(subsamp)
+            cur = (cur[0], cur[1][::1 << vs, ::1 << hs].copy(), cur[2][::1 << vs, ::1 << hs].copy())
+            prev = (prev[0], prev[1][::1 << vs, ::1 << hs].copy(), prev[2][::1 << vs, ::1 << hs].copy())
         rng = np.random.RandomState(seed)
         deg = [np.clip((p.astype(np.int32) // 6) * 6 + 3 + rng.randint(-1, 2, size=p.shape), 0, 255).astype(np.uint8)
                for p in prev]

@@ -24,6 +24,8 @@ def run_lib(lib, sc, quant, effort, skip_thresh=0):
     (640, 360, A.SUBSAMP_420, 5, 172, 3, True),
     (1280, 720, A.SUBSAMP_420, 6, 172, 10, True),
     (1920, 1080, A.SUBSAMP_420, 7, 172, 10, True),
+    (640, 360, A.SUBSAMP_422, 8, 172, 10, True),     # 4:2:2: the general block routine at level 0
+    (3840, 2160, A.SUBSAMP_420, 9, 172, 10, True),   # 32 x 32 blocks (dsv_encoder.c:1203-1211)
 ])
 def test_hme_matches_reference(w, h, subsamp, seed, quant, effort, prev):
     ref, hip = A.load_ref(), A.load_hip()
