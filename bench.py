@@ -730,11 +730,15 @@ def main():
     effort = int(os.environ.get("DSV2_BENCH_EFFORT", "10"))  # (experiments only: the headline is effort 10)
     align = not args.no_phase_align
     mix = None if args.no_mix else MIX
+    torch.cuda.synchronize()
+    hbm_free0 = torch.cuda.mem_get_info()[0]
     run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, args.groups, vids[:NV], not args.no_stagger, args.device_resident,
                     seeds=seeds, phase_align=align, mix=mix, timed_from=(GOP if not args.no_stagger else 0) + Wm, timed_steps=K)
     G = run.G
     hip.dsv2hip_prof_enable(0)
     run.run(run.R + Wm)                   # untimed: GOP-phase pre-roll + warm-up (allocations, clocks)
+    torch.cuda.synchronize()
+    hbm_per_instance = (hbm_free0 - torch.cuda.mem_get_info()[0]) / S  # every instance has coded intra and inter pictures by now
     import resource
     thr0 = thread_cpu() if os.environ.get("DSV2_BENCH_THREADS") else None
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
@@ -847,6 +851,7 @@ def main():
                    "content_classes": classes,
                    "input": "pinned_host" if not args.device_resident else "device_resident", "h2d_bytes_per_step_per_gpu": 0 if args.device_resident else S * run.P,
                    "distinct_videos_per_gpu": NV, "unique_frames_per_video": NF,
+                   "hbm_bytes_per_instance": int(hbm_per_instance), "hbm_bytes_instances_total": int(hbm_per_instance * S),
                    "ms_per_frame_p50": round(step_ms[len(step_ms) // 2], 3) if step_ms else None,
                    "group_time_inside_library": in_call_share,
                    "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2), "mpix_per_s": round(fps * W_ * H_ / 1e6, 1),

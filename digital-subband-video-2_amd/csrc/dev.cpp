@@ -280,8 +280,29 @@ void SbtScratch::ensure(size_t n, size_t n_ll)
     elems_ll = n_ll;
 }
 
+void SbtScratch::borrow(int32_t *base, size_t n, size_t n_ll)
+{
+    release();
+    if (n_ll == 0 || n_ll > n) {
+        n_ll = n;
+    }
+    const size_t a = (n + 3) & ~(size_t) 3, b = (n_ll + 3) & ~(size_t) 3;
+    t[2] = base;
+    t[0] = base + a;
+    t[1] = base + a + b;
+    elems = n;
+    elems_ll = n_ll;
+    borrowed = true;
+}
+
 void SbtScratch::release()
 {
+    if (borrowed) {
+        t[0] = t[1] = t[2] = nullptr;
+        elems = elems_ll = 0;
+        borrowed = false;
+        return;
+    }
     for (int i = 0; i < 3; i++) {
         if (t[i]) {
             HIPCHK(hipFree(t[i]));

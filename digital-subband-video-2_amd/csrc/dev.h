@@ -93,6 +93,10 @@ struct SbtScratch {
     // with the plane's row stride: (ceil(h / 2) + 1) rows of it suffice -- n_ll elements (0: as large as t[2]).
     void ensure(size_t n, size_t n_ll = 0);
     void release();
+    // the three images laid out in memory the caller owns (base: 16-byte aligned, scratch_elems(n, n_ll) int32): t[2], t[0], t[1]
+    bool borrowed = false;
+    void borrow(int32_t *base, size_t n, size_t n_ll);
+    static size_t scratch_elems(size_t n, size_t n_ll) { return ((n + 3) & ~(size_t) 3) + 2 * ((n_ll + 3) & ~(size_t) 3); }
 };
 inline size_t sbt_ll_elems(int cw, int ch) { return (size_t) cw * (size_t) ((ch + 1) / 2 + 1); }
 
