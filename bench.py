@@ -51,7 +51,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 STAGES = ["ingest_pyramid", "hme", "predict_subtract", "fwd_sbt", "quant_compact", "inv_sbt", "recon_filters", "extend", "hme_level0"]
 NST = len(STAGES)
 # dominant-kernel name per stage (rocprofv3 --kernel-trace name prefix)
-STAGE_KERNEL = {"hme": "k_hme_rows_b_*", "hme_level0": "k_hme_rows_b_fast_l0_pre_w2", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
+STAGE_KERNEL = {"hme": "k_hme_rows_b_*", "hme_level0": "k_hme_rows_p_fast_l0_pre", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
                 "quant_compact": "k_quant_level", "recon_filters": "k_inter_filters", "predict_subtract": "k_predict_w",
                 "ingest_pyramid": "k_extend/k_ds2x", "extend": "k_extend"}
 HBM_PEAK_GBS = 8000.0
@@ -884,9 +884,17 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             same = (pt.get("stage") == dom and pt.get("streams_per_gpu") == S and pt.get("groups") == G and pt.get("kernel") == STAGE_KERNEL[dom]
                     and bool(pt.get("stagger", False)) == bool(run.R) and bool(pt.get("phase_aligned", False)) == run.phase_aligned)
-            if same:
+            # ... and only for the KERNEL they were taken on: the committed figure carries a hash of the search's sources
+            import hashlib
+            hh = hashlib.sha256()
+            for fn in ("hme.hip", "hme_fast.h", "hme.h", "blockstat.h", "dev.h"):
+                hh.update(open(os.path.join(ROOT, "digital-subband-video-2_amd", "csrc", fn), "rb").read())
+            fresh = pt.get("kernel_source_sha16") == hh.hexdigest()[:16]
+            if same and fresh:
                 traffic = pt.get("bytes_per_launch")
                 traffic_source = "committed PMC passes, not this run: " + pt.get("source", "profiles/pmc_traffic.json")
+            elif same:
+                traffic_source = "profiles/pmc_traffic.json is STALE (taken on other search sources: kernel_source_sha16 differs): not quoted"
         except (OSError, ValueError):
             pass
         result["roofline"] = {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom,
