@@ -1472,11 +1472,15 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     {
         const unsigned long long em = __ballot(exist);
         const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16); // both components are int16 by now
+        // one round per DISTINCT vector, not per list entry (a block has ~15 - 25 entries and ~3.5 distinct vectors): the lowest
+        // lane that still holds an unclassified entry keeps it, every other entry with that vector is a duplicate of it
         bool dup = false;
-        for (unsigned long long rest = em; rest; rest &= rest - 1) {
+        for (unsigned long long rest = em; rest;) {
             const int m = __ffsll((long long) rest) - 1;
             const int km = __builtin_amdgcn_readlane(key, m);
-            dup = dup || (m < lane && km == key);
+            const bool same = exist && km == key;
+            dup = dup || (same && lane != m);
+            rest &= ~__ballot(same);
         }
         const bool keep = exist && !dup;
         const unsigned long long km = __ballot(keep);
