@@ -19,6 +19,8 @@ trace)
     gzip -c $out/trace/*/*_kernel_trace.csv > $out/kernel_trace.csv.gz
     rm -rf $out/trace ;;
 pmc)
+    # (the figure is only valid for the search sources it was measured on: their hash is taken HERE, not when summarising)
+    cat digital-subband-video-2_amd/csrc/{hme.hip,hme_fast.h,hme.h,blockstat.h,dev.h} | sha256sum | cut -c1-16 > $out/kernel_source_sha16.txt
     for c in FETCH_SIZE WRITE_SIZE; do
         timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$L0" --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 6 --warmup 3 --gen-procs 1 --no-cpu-baseline --no-profile --no-extras > /dev/null 2> $out/pmc_$c.err
         cp $out/pmc_$c/*/*_counter_collection.csv $out/pmc_$c.csv

@@ -126,7 +126,7 @@ def pmc_part(traced):
                 % (fetch, write, per_launch / 1e6, per_launch / (4.0 * N * pics), pics, 4.0 * N * pics / 1e6))
     json.dump({"stage": "hme_level0", "kernel": L0 + "_pre", "streams_per_gpu": traced["config"]["streams_per_gpu"], "groups": groups, "stagger": True,
                "phase_aligned": bool(traced["config"].get("phase_aligned_groups")), "bytes_per_launch": round(per_launch),
-               "kernel_source_sha16": kernel_source_hash(),
+               "kernel_source_sha16": open(os.path.join(src, "kernel_source_sha16.txt")).read().strip(),
                "source": "profiles/r04_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
@@ -169,7 +169,7 @@ def insts_part():
 
 have = lambda f: os.path.exists(os.path.join(src, f))
 traced = trace_part() if have("kernel_trace.csv.gz") else None
-if traced and have("pmc_FETCH_SIZE.csv"):
+if traced and have("pmc_FETCH_SIZE.csv") and have("kernel_source_sha16.txt"):
     pmc_part(traced)
 if have("excl_kernel_stats.csv"):
     excl_part()
