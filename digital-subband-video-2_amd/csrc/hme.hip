@@ -219,8 +219,8 @@ __device__ __forceinline__ bool invalid_block(const DPlane &f, int bx, int by, i
 // row-pipelined kernel those were stored by other workgroups of the same launch, possibly on another
 // XCD whose L2 is not coherent with ours: the first 8 bytes of a DSV_MV ({x,y}, flags -- all a
 // neighbour ever looks at) are therefore stored and loaded as ONE agent-scope 8-byte access
-// (write-through store, L1-bypassing load); a per-row progress word published after the store has
-// drained orders them.  In the launch-per-front kernels the same accessors are merely redundant.
+// (write-through store, L1-bypassing load); a head reads kMvPending until that one store has written it (wait_heads
+// below).  In the launch-per-front kernels the same accessors are merely redundant.
 struct MvHead {
     int x, y;
     uint32_t all, flags;
@@ -1167,35 +1167,25 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     }
 }
 
+// (shared with hme_fast.h: the hand-off through the vector heads, see wait_heads below)
+constexpr int kHmeErrWord = 7;                              // counters[7]: a row gave up waiting (the host turns it into a fatal error)
+constexpr unsigned long long kHmeSpinLimit = 400000000ull;  // 100 MHz ticks = 4 s
+constexpr unsigned long long kMvPending = ~0ull;            // a head the search has not stored yet (k_hme_clear_b)
+
 #include "hme_fast.h"
 
 // DSV2_HME_FAST=0 forces the generic per-block routine (A/B checks); default: fast path on
 static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
 // DSV2_HME_ROWS=0 falls back to one launch per anti-diagonal front in the batched driver
 static int g_hme_rows = getenv("DSV2_HME_ROWS") ? atoi(getenv("DSV2_HME_ROWS")) : 1;
-// DSV2_HME_FENCE: bit 0 = an agent-scope ACQUIRE fence behind every row hand-off poll, bit 1 = an agent-scope RELEASE before
-// every publication.  Default 0 since round 3.  Neither is needed by the protocol: everything a wavefront reads that another
-// wavefront of the SAME launch wrote -- the progress words and the 8-byte vector heads -- is read by agent-scope atomic
-// loads (sc1: coherent for the location itself, no stale L1 / per-XCD L2 line can answer them), written by agent-scope
-// atomic stores that the producer has drained (s_waitcnt vmcnt(0)) before it publishes, and the vector loads are
-// control-dependent on the poll (a wavefront does not issue them before the poll's value is back).  Nothing else a block
-// reads is written during the launch (parent-level and previous-frame fields, pictures: earlier launches).  What the
-// acquire cost: `s_waitcnt vmcnt(0); buffer_inv sc1` in front of every block, i.e. the CU's L1 emptied 8 160 times a
-// picture under the other wavefronts' feet -- 11 % of the search's span in the four-group bench (5 590 -> 5 990 frames/s on
-// the same box).  Both forms are run against the reference at the benchmarked operating point
-// (tests/test_gpu_operating_point.py), tools/stress_hme.sh repeats the stage test under each.
-// Hardware assumption (advisor, round 3): the fence-free hand-off is message passing over two locations with relaxed agent-scope
-// atomics -- outside what the HSA / LLVM memory model promises.  It holds on gfx950 (and gfx942) because an agent-scope (sc1)
-// store is written through to the memory side of the per-XCD L2s and is complete when vmcnt drains, an sc1 load is answered from
-// there, and a wavefront issues its loads in order behind the poll's wave-scope fence.  Any other architecture gets both fences.
+// DSV2_HME_FENCE (either bit): an agent-scope acquire + release fence in front of every block of the row pipeline.  Default 0:
+// since round 4 nothing in the hand-off depends on the order in which two locations become visible -- a consumer validates
+// every head it reads on its own (kMvPending until the one atomic store that writes it), the left neighbour comes out of
+// registers, and the level epilogue reads the field behind an acquire-release counter (hme_row).  The variants stay as
+// parity cases of the tests (tests/test_gpu_operating_point.py, tools/stress_hme.sh).
 static int hme_fence_mode()
 {
-    static const int mode = [] {
-        if (getenv("DSV2_HME_FENCE")) {
-            return atoi(getenv("DSV2_HME_FENCE"));
-        }
-        return device_arch_is("gfx950") || device_arch_is("gfx942") ? 0 : 3;
-    }();
+    static const int mode = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 0;
     return mode;
 }
 #define g_hme_fence hme_fence_mode()
@@ -1269,10 +1259,10 @@ __global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ t
 // grid = (streams, block rows); one wavefront walks one block row of one stream left to right (which row: see take_ticket
 // below -- tickets run row-major ACROSS streams, so by the time row j of any stream is taken its row j-1 is well under way
 // and few resident wavefronts sit spinning).  Block (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and
-// (bi, bj-1), (bi-1, bj-1) of the row above, so a row only ever waits for the progress word of the row above it: a slow
+// (bi, bj-1), (bi-1, bj-1) of the row above, so a row only ever waits for heads of the row above it: a slow
 // block delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front does.  Every spin
 // is bounded by the wall clock and reports through counters[7] and the host's pinned counter block.
-constexpr int kHmeErrWord = 7, kHmeTicket = 8 /* 8 .. 13: one ticket counter per pyramid level */, kHmeProgress = 16;
+constexpr int kHmeTicket = 8 /* 8 .. 13: one ticket counter per pyramid level */, kHmeProgress = 16;
 constexpr int kHmeExhausted = 14; // level 0: ticket partitions whose last row has been handed out (counter block of stream 0)
 constexpr int kHmeHostTail = 12;  // ... and the word of the pinned host counter block that says "all of them" (hme.h)
 
@@ -1332,13 +1322,22 @@ __device__ __forceinline__ RowTicket take_row(const HmeDev *tab, int level, int 
     }
     return RowTicket{-1, -1};
 }
-constexpr unsigned long long kHmeSpinLimit = 400000000ull; // 100 MHz ticks = 4 s
-
-__device__ __forceinline__ bool wait_row_progress(const unsigned *word, unsigned need, int *err)
+// ---- hand-off through the vector heads themselves (round 4) -------------------------------------------------------------
+// The grid points of every level's field start a search as kMvPending (k_hme_clear_b); a block's 8-byte head is written once,
+// as ONE agent-scope atomic store.  A consumer reads the heads it needs -- its top and top-left neighbours -- as agent-scope
+// atomic loads and retries while either still reads pending: every location is validated on its own, so the hand-off needs
+// no ordering BETWEEN locations (until round 3: a per-row progress word published behind a drained store -- message passing
+// over two locations with relaxed atomics, which only the hardware's treatment of sc1 accesses made safe) and the producer
+// no longer drains its store and publishes after every block (a memory round trip per block).  No real head equals the
+// pattern: its flag word would need all 32 bits set.
+__device__ __forceinline__ bool wait_heads(const DSV_MV *top, const DSV_MV *top_left, int *err)
 {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long *p = (const unsigned long long *) (lane == 1 ? top_left : top);
     unsigned long long t0 = 0;
     for (unsigned spins = 0;; spins++) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) {
+        unsigned long long v = lane < 2 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (!__any(v == kMvPending)) {
             return true;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -1398,7 +1397,6 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
 {
     const int level = LV == 0 ? 0 : level_rt;
     int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
-    unsigned *progress = (unsigned *) uni_ptr(c.counters) + kHmeProgress;
     int j = bj << level;
     const HmeCtx x = make_ctx(c, level);
 #ifdef DSV2_HME_PROF
@@ -1412,8 +1410,13 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
 #endif
     int pcx = 0, pcy = 0; // where the previous block of this row ended up: centre of the next block's LDS windows
     RowAcc acc;           // this row's share of the frame's counters (flushed behind the loop)
+    const int step_ = 1 << level;
     for (int bi = 0; bi < nbx; bi++) {
-        if (bj > 0 && !wait_row_progress(&progress[bj - 1], (unsigned) bi + 1, &c.counters[kHmeErrWord])) {
+        const DSV_MV *top_ = x.mvf.cur + (bi << level) + (j - step_) * x.a.nbh;
+        // (the fast routine validates the two heads inside its own load round -- no round trip of its own for the hand-off --
+        // and reports through acc.failed; blocks of the general routine wait here)
+        const bool pre_wait = !FAST_ONLY && !((allow_fast & 1) && fast_path_ok(c, level, bi << level, j));
+        if (bj > 0 && pre_wait && !wait_heads(top_, bi > 0 ? top_ - step_ : top_, &c.counters[kHmeErrWord])) {
             // the row above never got there (or another row gave up): tell the host directly -- the level's
             // epilogue, which normally delivers the counters, will not run because this row does not arrive
             if (c.host_counters && (threadIdx.x & 63) == 0) {
@@ -1430,8 +1433,8 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
             __builtin_amdgcn_s_setprio(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // no neighbour load may move above the poll
-        if (allow_fast & 2) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (allow_fast & 6) { // (DSV2_HME_FENCE, either bit: an agent-scope acquire + release around every hand-off -- parity variants)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         }
         __syncthreads();                                       // LDS scratch of the previous block is dead
         int i = bi << level;
@@ -1440,14 +1443,18 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         } else if constexpr (!FAST_ONLY) {
             hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
             pcx = pcy = 0;
+            acc.have_left = false; // (its head is in memory, drained below, not in `acc`)
         }
-        if (allow_fast & 4) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (acc.failed) { // a neighbour's head never arrived (bounded spin inside the block routine)
+            if (c.host_counters && (threadIdx.x & 63) == 0) {
+                __hip_atomic_store(&c.host_counters[kHmeErrWord], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
         }
-        // the vector was stored write-through by lane 0: drain it, then publish
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((threadIdx.x & 63) == 0) {
-            __hip_atomic_store(&progress[bj], (unsigned) bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (!FAST_ONLY) {
+            // the general routine reads its LEFT neighbour back from memory (the fast one carries it in registers): this
+            // wavefront's own store has to have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (allow_fast & 24) {
             __builtin_amdgcn_s_setprio(0);
@@ -1467,7 +1474,8 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
     // arrival of this row; its vectors and counter updates were drained above
     int done = 0;
     if ((threadIdx.x & 63) == 0) {
-        done = __hip_atomic_fetch_add(&c.counters[kHmeRowsDone], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (release: this row's heads and counter sums; acquire: the last row to arrive reads every row's heads in the epilogue)
+        done = __hip_atomic_fetch_add(&c.counters[kHmeRowsDone], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     }
     done = __builtin_amdgcn_readfirstlane(done);
     if (done == nby - 1) {
@@ -1620,6 +1628,16 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
     return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (level > 1 || (!(bw & 1) && !(bh & 1)));
 }
 
+__global__ __launch_bounds__(256) void k_hme_clear_one(DSV_MV *field, int nwords, int nbh, int level)
+{
+    uint32_t *p = (uint32_t *) field;
+    const int gmask = (1 << level) - 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) {
+        const int e = i >> 2, bx = e % nbh, by = e / nbh;
+        p[i] = ((i & 2) == 0 && ((bx | by) & gmask) == 0) ? 0xffffffffu : 0u;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
 {
     __shared__ FastLds S;
@@ -1635,8 +1653,11 @@ __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ 
         level = (int) blockIdx.z;
     }
     uint32_t *p = (uint32_t *) c.mvf[level];
+    const int nbh = c.a.nbh, gmask = (1 << level) - 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) {
-        p[i] = 0;
+        // a block of this level's grid: its head (words 0, 1 of the record) reads "pending" until the search stores it
+        const int e = i >> 2, bx = e % nbh, by = e / nbh;
+        p[i] = ((i & 2) == 0 && ((bx | by) & gmask) == 0) ? 0xffffffffu : 0u;
     }
     if (clear_counters && first && blockIdx.x == 0 && threadIdx.x < 16) {
         c.counters[threadIdx.x] = 0;
@@ -2283,7 +2304,7 @@ int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
     for (int level = hp.pyr_levels; level >= 0; level--) {
         int step = 1 << level;
         int nbx = (hp.a.nbh + step - 1) / step, nby = (hp.a.nbv + step - 1) / step;
-        HIPCHK(hipMemsetAsync(f.mvf[level], 0, nb * sizeof(DSV_MV), s));
+        DSV2_LAUNCH(k_hme_clear_one, dim3((unsigned) ((nb * 4 + 2047) / 2048)), dim3(256), 0, s, f.mvf[level], (int) (nb * 4), hp.a.nbh, level);
         if (g_hme_rows) {
             DSV2_LAUNCH(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, ((uniform_geometry(f, hp.pyr_levels) ? g_hme_fast : 0) & 1) | (g_hme_fence << 1));
             nlaunch++;

@@ -761,6 +761,11 @@ struct NbPre {
 // four atomics per block they sat in front of every block's drain-and-publish.
 struct RowAcc {
     int intra = 0, ndiff = 0, elig = 0, err = 0;
+    // the 8-byte head ({x, y}, flags) this wavefront stored for the previous block of its row: the next block's LEFT neighbour
+    // (wave-uniform; read back from registers, not from memory: the store need not have landed)
+    unsigned long long left_head = 0;
+    bool have_left = false; // (false: the routine reads the left neighbour from memory -- launch per front, or behind a block of the general routine)
+    bool failed = false;    // a top / top-left head stayed pending beyond the spin limit: the row gives up (hme_row reports it)
     __device__ __forceinline__ void flush(int *counters)
     {
         if ((threadIdx.x & 63) == 0) {
@@ -1234,6 +1239,9 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     if (lane == 0) {
         st_mv_final(c, out, mv);
     }
+    acc.left_head = (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.u.all) |
+                    ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.flags) << 32);
+    acc.have_left = true;
     acc.intra += is_intra;
     acc.ndiff += add_ndiff;
     acc.elig += best > 0 ? 1 : 0;
@@ -1361,6 +1369,31 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         typedef const __attribute__((address_space(1))) unsigned long long *gu64p_t;
         ov = *(gu32p_t) op;
         unsigned long long head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Row pipeline: the top / top-left heads may not have been stored yet -- they read kMvPending until they are (hme.hip:
+        // wait_heads).  Validated HERE, inside the block's first load round: in the usual case (the row above is ahead) the
+        // hand-off costs no memory round trip of its own.  (Launch per front: never pending.)
+        {
+            const bool mine = nb_ok && lane != 3;
+            unsigned long long t0 = 0;
+            for (unsigned spins = 0; __any(mine && head == kMvPending); spins++) {
+                __builtin_amdgcn_s_sleep(8);
+                head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((spins & 1023u) == 1023u) {
+                    const unsigned long long now = wall_clock64();
+                    int *err = &c.counters[kHmeErrWord];
+                    if (t0 == 0) {
+                        t0 = now;
+                    } else if (now - t0 > kHmeSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc.failed = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (lane == 3 && acc.have_left) { // the left neighbour is the block this wavefront has just finished: its head is still in registers
+            head = acc.left_head;
+        }
         nbv.all = (uint32_t) head;
         nbv.flags = (uint32_t) (head >> 32);
         nbv.x = (int) (int16_t) (nbv.all & 0xffffu);
@@ -1650,6 +1683,9 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         if (lane == 0) {
             st_mv(out, mv);
         }
+        acc.left_head = (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.u.all) |
+                        ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.flags) << 32);
+        acc.have_left = true;
         return;
     }
     if constexpr (LV <= 0) {
