@@ -31,6 +31,10 @@ struct McJob {
     MCParams p;
     FilterParams f;
     Planes3 ref, pred, res;
+    // predict + subtract: where the SOURCE pixels are read (null: from `res`, which then holds a copy of the source and is
+    // overwritten in place -- the single-call seam); same strides as `res` (planes of dframe_alloc).  The batch encoder points
+    // this at the padded source picture itself: no copy of the source into the working picture for P pictures.
+    const uint8_t *src[3] = {nullptr, nullptr, nullptr};
 };
 
 inline int spatial_psy_factor_host(int bw, int bh, int nbh, int nbv, int sub) { return spatial_psy_factor(bw, bh, nbh, nbv, sub); }

@@ -385,7 +385,8 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
             int m = (g & (gw - 1)) * 4, n = g >> lgw;
             gbr_t r = (gbr_t) rbase + (ptrdiff_t) n * rp.stride + m;
             // every load of the group up front (explicit global accesses), so that they share one round trip
-            const uint32_t sv4 = *(gw32_t) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
+            const uint8_t *srcd = (MODE == MC_SUBTRACT && jb.src[c]) ? jb.src[c] : sp.data;
+            const uint32_t sv4 = *(gw32_t) (srcd + (ptrdiff_t) (y + n) * sp.stride + (x + m));
             int pv[4];
             if (intra) {
                 uint32_t v = ((gur_t) r)->v;
@@ -517,7 +518,11 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
         return;
     }
     const bool noxmit = (flags & (1u << DSV_MV_BIT_NOXMITC)) != 0;
-    const uint32_t sv4 = *(gw32_t) (sdata + (ptrdiff_t) (y + n) * sp1.stride + (x + m));
+    const uint8_t *srcd = sdata;
+    if (MODE == MC_SUBTRACT && jb.src[1]) {
+        srcd = v_plane ? jb.src[2] : jb.src[1];
+    }
+    const uint32_t sv4 = *(gw32_t) (srcd + (ptrdiff_t) (y + n) * sp1.stride + (x + m));
     int pv[4];
     if (intra) {
         const uint32_t v = ((gur_t) r)->v;

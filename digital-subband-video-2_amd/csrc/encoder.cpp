@@ -1879,7 +1879,7 @@ void enc_batch(Job *jobs, int n)
     sc.ensure_stage(slot * (i_jobs.size() + 1));
     const CopyJob *d_mvcopy;
     CopyJob *h_mvcopy = sc.tabs.take<CopyJob>((size_t) n, &d_mvcopy);
-    int nP = 0, nI = 0, n_rext = 0, n_mvcopy = 0, n_slots = 0;
+    int nP = 0, nI = 0, n_rext = 0, n_mvcopy = 0, n_slots = 0, n_copy = 0;
     bool any_filter = false;
     for (int i = 0; i < n; i++) {
         int k = order[(size_t) i];
@@ -1888,8 +1888,12 @@ void enc_batch(Job *jobs, int n)
         PicSet &cur = dv.pics[jb.im->cur], &ref = dv.pics[jb.im->cur ^ 1];
         const DSV_PARAMS *p = &jb.d.params;
         size_t nb = dv.nblocks();
-        // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292)
-        h_copy[i] = CopyJob{cur.src.alloc, cur.recon.alloc, cur.src.bytes};
+        // the working ("residual") picture starts as a copy of the padded source (dsv_encoder.c:1292) -- of an INTRA picture:
+        // its forward transform reads the working picture.  A P picture's predict + subtract reads the source itself and
+        // writes the residual over every block of the working picture (McJob::src), so nothing needs copying there.
+        if (!p->has_ref) {
+            h_copy[n_copy++] = CopyJob{cur.src.alloc, cur.recon.alloc, cur.src.bytes};
+        }
         cur.recon_pyr_valid = false;
         const uint8_t *d_bd = dv.d_blockdata; // P: formed on the device (k_side_info)
         if (!p->has_ref) {                      // I: the host coders' flag bytes, staged and shipped with one copy
@@ -1906,6 +1910,7 @@ void enc_batch(Job *jobs, int n)
             mj.ref.p[c] = ref.recon.p[c];
             mj.pred.p[c] = dv.pred.p[c];
             mj.res.p[c] = cur.recon.p[c];
+            mj.src[c] = cur.src.p[c].data;
         }
         if (p->has_ref) {
             // the motion field as transmitted (written into cur.d_final_mvs by k_side_info): used by MC now and as temporal
@@ -1966,7 +1971,7 @@ void enc_batch(Job *jobs, int n)
         HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, slot * (size_t) n_slots, hipMemcpyHostToDevice, bs));
     }
     copy_linear_batch(bs, d_mvcopy, n_mvcopy, mv_bytes);
-    copy_linear_batch(bs, d_copy, n, dv0.pics[0].src.bytes);
+    copy_linear_batch(bs, d_copy, n_copy, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
     mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv);
     prof.end(bs, ST_PREDICT, nP);
