@@ -14,8 +14,10 @@
 
 #include "batch.h"
 #include "codec.h"
+#include "dec_parse.h"
 
 using namespace dsv2;
+using namespace dsv2::decparse;
 
 namespace {
 
@@ -24,191 +26,13 @@ struct DecImpl {
     bool ready = false;
     int cur = 0;
     bool have_ref = false;
-    std::vector<DSV_MV> mvs;
-    std::vector<uint8_t> blockdata;
+    SideBufs side;                  // per-block flag bytes and vectors as parsed (dec_parse.h)
+    std::vector<DSV_MV> &mvs = side.mvs;
+    std::vector<uint8_t> &blockdata = side.blockdata;
     std::vector<uint32_t> pos;
     std::vector<int32_t> val;
     bool out420p = false; // deliver every picture as 4:2:0 (the CLI's -out420p, util.c:79-153, done by the GPU on the way out)
 };
-
-inline int sar(int v, int s) { return v < 0 ? ~(~v >> s) : v >> s; }
-inline int sar_r(int v, int s) { return sar(v + (1 << (s - 1)), s); }
-
-int mv_pred1(int left, int top, int topleft)
-{
-    int dif = left + top - topleft;
-    return abs(dif - left) < abs(dif - top) ? left : top;
-}
-
-void movec_pred(const DSV_MV *v, int nbh, int x, int y, int *px, int *py) // dsv.c:375
-{
-    int vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
-    if (x > 0) {
-        vx[0] = v[y * nbh + x - 1].u.mv.x;
-        vy[0] = v[y * nbh + x - 1].u.mv.y;
-    }
-    if (y > 0) {
-        vx[1] = v[(y - 1) * nbh + x].u.mv.x;
-        vy[1] = v[(y - 1) * nbh + x].u.mv.y;
-    }
-    if (x > 0 && y > 0) {
-        vx[2] = v[(y - 1) * nbh + x - 1].u.mv.x;
-        vy[2] = v[(y - 1) * nbh + x - 1].u.mv.y;
-    }
-    *px = mv_pred1(vx[0], vx[1], vx[2]);
-    *py = mv_pred1(vy[0], vy[1], vy[2]);
-}
-
-int neighbordif(const DSV_MV *v, int nbh, int x, int y) // dsv.c:404-447
-{
-    const DSV_MV *c = &v[x + y * nbh];
-    int cx = c->u.mv.x, cy = c->u.mv.y, lx = cx, ly = cy, tx = cx, ty = cy;
-    if (abs(cx) < 2 && abs(cy) < 2) {
-        return 0;
-    }
-    if (x > 0) {
-        const DSV_MV *m = c - 1;
-        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
-            lx = m->u.mv.x;
-            ly = m->u.mv.y;
-        }
-    }
-    if (y > 0) {
-        const DSV_MV *m = c - nbh;
-        if (m->u.all && !(m->flags & (1u << DSV_MV_BIT_SKIP))) {
-            tx = m->u.mv.x;
-            ty = m->u.mv.y;
-        }
-    }
-    return (abs(lx - cx) + abs(ly - cy) + abs(tx - cx) + abs(ty - cy)) / 3;
-}
-
-enum { ST_STABLE = 0, ST_MAINTAIN, ST_RINGING, ST_MODE, ST_EPRM, ST_MAX };
-
-int read_packet_hdr(BitReader &br) // dsv_decoder.c:21
-{
-    unsigned c0 = br.get_bits(8), c1 = br.get_bits(8), c2 = br.get_bits(8), c3 = br.get_bits(8);
-    if (c0 != 'D' || c1 != 'S' || c2 != 'V' || c3 != '2') {
-        return -1;
-    }
-    br.get_bits(8); /* minor version */
-    int type = (int) br.get_bits(8);
-    br.get_bits(32);
-    br.get_bits(32);
-    return type;
-}
-
-void read_meta(DSV_DECODER *d, BitReader &br) // dsv_decoder.c:51
-{
-    DSV_META *m = &d->vidmeta;
-    m->width = (int) br.get_ueg();
-    m->height = (int) br.get_ueg();
-    m->subsamp = (int) br.get_ueg();
-    m->fps_num = (int) br.get_ueg();
-    m->fps_den = (int) br.get_ueg();
-    m->aspect_num = (int) br.get_ueg();
-    m->aspect_den = (int) br.get_ueg();
-    m->inter_sharpen = (int) br.get_ueg();
-    m->reserved = br.get_bit() ? (int) br.get_bits(15) : 0;
-}
-
-// a byte-aligned, length-prefixed sub-stream: returns a reader positioned on it and skips it
-BitReader take_sub(BitReader &br, const uint8_t *base)
-{
-    br.align();
-    unsigned len = br.get_ueg();
-    br.align();
-    if (br.pos > br.limit) {
-        br.seek(br.pos);
-    }
-    BitReader sub{base + br.byte_pos(), 0};
-    sub.wide = br.wide;
-    sub.limit = br.limit - br.pos; // a sub-stream may be read up to the end of the packet, as in the reference
-    br.seek((uint64_t) br.pos + (uint64_t) len * 8);
-    return sub;
-}
-
-void read_stability(DecImpl *im, BitReader &br, const uint8_t *base, int isP, const int *stats) // dsv_decoder.c:176
-{
-    RleReader r;
-    r.br = take_sub(br, base);
-    int shift = isP ? 2 : 0; /* DSV_SKIP_BIT : DSV_STABLE_BIT */
-    for (size_t i = 0; i < im->blockdata.size(); i++) {
-        int bit = r.get();
-        if (stats[ST_STABLE]) {
-            bit = !bit;
-        }
-        im->blockdata[i] = (uint8_t) (bit << shift);
-    }
-}
-
-void read_intra_meta(DecImpl *im, BitReader &br, const uint8_t *base, const int *stats) // dsv_decoder.c:201
-{
-    RleReader rr, rm;
-    rr.br = take_sub(br, base);
-    rm.br = take_sub(br, base);
-    for (size_t i = 0; i < im->blockdata.size(); i++) {
-        int bitr = rr.get(), bitm = rm.get();
-        if (stats[ST_RINGING]) {
-            bitr = !bitr;
-        }
-        if (stats[ST_MAINTAIN]) {
-            bitm = !bitm;
-        }
-        im->blockdata[i] |= (uint8_t) ((bitm << 1) | (bitr << 3));
-    }
-}
-
-void read_motion(DecImpl *im, BitReader &br, const uint8_t *base, const int *stats) // dsv_decoder.c:81
-{
-    const CodecDev &dv = im->dev;
-    br.align();
-    RleReader mode, eprm;
-    mode.br = take_sub(br, base);
-    BitReader mvx = take_sub(br, base), mvy = take_sub(br, base), sbim = take_sub(br, base);
-    eprm.br = take_sub(br, base);
-    DSV_MV *mvs = im->mvs.data();
-    for (int j = 0; j < dv.nbv; j++) {
-        for (int i = 0; i < dv.nbh; i++) {
-            int idx = i + j * dv.nbh;
-            DSV_MV *mv = &mvs[idx];
-            if (im->blockdata[idx] & DSV_IS_SKIP) {
-                mv->flags |= 1u << DSV_MV_BIT_SKIP;
-                mv->u.all = 0;
-                im->blockdata[idx] |= DSV_IS_STABLE;
-                continue;
-            }
-            int m = mode.get(), e = eprm.get();
-            if (stats[ST_MODE]) {
-                m = !m;
-            }
-            if (stats[ST_EPRM]) {
-                e = !e;
-            }
-            mv->flags = (m ? (1u << DSV_MV_BIT_INTRA) : 0u) | (e ? (1u << DSV_MV_BIT_EPRM) : 0u);
-            im->blockdata[idx] &= (uint8_t) ~DSV_IS_STABLE;
-            im->blockdata[idx] |= (uint8_t) (e << 5);
-            int px, py;
-            movec_pred(mvs, dv.nbh, i, j, &px, &py);
-            if (m) {
-                px = sar_r(px, 2);
-                py = sar_r(py, 2);
-            }
-            mv->u.mv.x = (int16_t) (mvx.get_seg() + px);
-            mv->u.mv.y = (int16_t) (mvy.get_seg() + py);
-            if (m) {
-                mv->u.mv.x = (int16_t) (mv->u.mv.x * 4);
-                mv->u.mv.y = (int16_t) (mv->u.mv.y * 4);
-                mv->submask = sbim.get_bit() ? DSV_MASK_ALL_INTRA : (uint8_t) sbim.get_bits(4);
-                mv->dc = sbim.get_bit() ? (uint16_t) (sbim.get_bits(8) | DSV_SRC_DC_PRED) : 0;
-                im->blockdata[idx] |= DSV_IS_INTRA;
-            }
-            if (neighbordif(mvs, dv.nbh, i, j) > 8) {
-                im->blockdata[idx] |= DSV_IS_STABLE;
-            }
-        }
-    }
-}
 
 // ---- lockstep batch engine ------------------------------------------------------------------------
 // One step decodes ONE packet on each of n decoder instances (dsv_dec is the n = 1 case):
@@ -334,7 +158,9 @@ struct DecClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep decode s
 };
 thread_local DecClock t_dec_clock;
 
-// phase A: everything dsv_dec does before it touches the device (dsv_decoder.c:393-503)
+// phase A: everything dsv_dec does before it touches the device (dsv_decoder.c:393-503).  The bit parsing itself is
+// dec_parse.h (device-free: fuzzed on the CPU under AddressSanitizer by tests/parser_fuzz.cpp); here: the private copy of
+// the packet, the device instance of the stream's geometry, the pinned mirrors the device reads.
 void dec_parse(DecJob &jb)
 {
     DSV_DECODER *d = jb.d;
@@ -352,51 +178,17 @@ void dec_parse(DecJob &jb)
     BitReader br{pkt, 0};
     br.wide = true;
     br.limit = (buffer->len + 8) * 8; // reads stop here; the copy is zero for 56 more bytes (see BitReader)
-    int type = read_packet_hdr(br);
-    if (type == -1) {
-        jb.ret = DSV_DEC_ERROR;
-        return;
-    }
-    if (!(type & DSV_PT_PIC)) {
-        jb.ret = DSV_DEC_ERROR;
-        if (type == DSV_PT_META) {
-            read_meta(d, br);
-            d->got_metadata = 1;
-            jb.ret = DSV_DEC_GOT_META;
-        } else if (type == DSV_PT_EOS) {
-            jb.ret = DSV_DEC_EOS;
-        }
-        return;
-    }
-    if (!d->got_metadata) {
-        jb.ret = DSV_DEC_OK; /* picture before any metadata: skipped (dsv_decoder.c:436) */
+    PictureHead hd;
+    const int rc = parse_head(br, d, hd);
+    if (rc != kParsePicture) {
+        jb.ret = rc;
         return;
     }
     const DSV_META *meta = &d->vidmeta;
-    jb.has_ref = type & 1;
-    jb.is_ref = (type & 0x6) == 0x6;
-
-    br.align();
-    jb.fno = br.get_bits(32);
-    br.align();
-    unsigned ew = br.get_ueg(), eh = br.get_ueg(); // log2 of the block size - 4: 0 or 1 (checked before it becomes a shift count)
-    if (ew > 1 || eh > 1 || br.overrun) {
-        jb.ret = DSV_DEC_ERROR;
-        return;
-    }
-    int blk_w = 16 << ew, blk_h = 16 << eh;
-    // the metadata is untrusted: only geometries the device pipeline can allocate and run are accepted (the reference
-    // would pass anything on to calloc); a hostile packet must come back as an error, not take the process down
-    {
-        const int ss = meta->subsamp;
-        const bool known = ss == DSV_SUBSAMP_444 || ss == DSV_SUBSAMP_422 || ss == DSV_SUBSAMP_420 || ss == DSV_SUBSAMP_411 ||
-                           ss == DSV_SUBSAMP_410 || ss == DSV_SUBSAMP_UYVY;
-        if (!known || meta->width < 16 || meta->height < 16 || meta->width > 16384 || meta->height > 16384 || (meta->width & 1) ||
-            (meta->height & 1)) {
-            jb.ret = DSV_DEC_ERROR;
-            return;
-        }
-    }
+    jb.has_ref = hd.has_ref;
+    jb.is_ref = hd.is_ref;
+    jb.fno = hd.fno;
+    const int blk_w = hd.blk_w, blk_h = hd.blk_h;
     bind_device();
     DecImpl *im = (DecImpl *) d->ref;
     if (!im) {
@@ -417,57 +209,24 @@ void dec_parse(DecJob &jb)
         im->ready = true;
     }
     CodecDev &dv = im->dev;
-    size_t nb = dv.nblocks();
-
-    br.align();
-    int stats[ST_MAX] = {0, 0, 0, 0, 0};
-    stats[ST_STABLE] = (int) br.get_bit();
-    if (!jb.has_ref) {
-        stats[ST_MAINTAIN] = (int) br.get_bit();
-        stats[ST_RINGING] = (int) br.get_bit();
-    } else {
-        stats[ST_MODE] = (int) br.get_bit();
-        stats[ST_EPRM] = (int) br.get_bit();
-    }
-    jb.do_filter = (int) br.get_bit();
-    jb.quant = (int) br.get_bits(DSV_MAX_QP_BITS);
-    jb.lossless = jb.quant == 1;
-    if (br.get_bit()) {
-        br.get_bits(15);
-    }
-    br.align();
-
-    im->blockdata.assign(nb, 0);
-    read_stability(im, br, pkt, jb.has_ref, stats);
-    if (jb.has_ref) {
-        im->mvs.assign(nb, DSV_MV{});
-        read_motion(im, br, pkt, stats);
-    } else {
-        read_intra_meta(im, br, pkt, stats);
-    }
-    br.align();
-
-    // the three planes' symbols, one after the other in the decoder's list
-    size_t cap = (size_t) dv.scan[0].base[10] + (size_t) dv.scan[1].base[10] + (size_t) dv.scan[2].base[10];
-    if (im->pos.size() < cap) {
-        im->pos.resize(cap);
-        im->val.resize(cap);
-    }
-    size_t at = 0;
+    PictureBody body;
+    parse_body(br, pkt, hd.has_ref, dv.nbh, dv.nbv, dv.scan, im->side, im->pos, im->val, body);
+    jb.do_filter = body.do_filter;
+    jb.quant = body.quant;
+    jb.lossless = body.lossless;
     for (int c = 0; c < 3; c++) {
-        jb.sym_first[c] = at;
-        jb.LL[c] = 0;
-        jb.ok[c] = entropy_decode_plane(br, &jb.LL[c], im->pos.data() + at, im->val.data() + at, jb.seg[c], dv.scan[c]);
-        if (jb.ok[c] <= 0) { /* "decoding error in plane": the residual plane stays zero (dsv_decoder.c:516-523) */
-            jb.seg[c][0] = jb.seg[c][1] = jb.seg[c][2] = jb.seg[c][3] = 0;
+        jb.sym_first[c] = body.sym_first[c];
+        jb.LL[c] = body.LL[c];
+        jb.ok[c] = body.ok[c];
+        for (int k = 0; k < 4; k++) {
+            jb.seg[c][k] = body.seg[c][k];
         }
-        at += (size_t) (jb.seg[c][0] + jb.seg[c][1] + jb.seg[c][2] + jb.seg[c][3]);
     }
-    jb.nsym = at;
+    jb.nsym = body.nsym;
     // the device reads the symbols straight from pinned host memory (each is read exactly once)
-    dv.ensure_host_syms(at);
-    memcpy(dv.h_pos, im->pos.data(), at * sizeof(uint32_t));
-    memcpy(dv.h_val, im->val.data(), at * sizeof(int32_t));
+    dv.ensure_host_syms(body.nsym);
+    memcpy(dv.h_pos, im->pos.data(), body.nsym * sizeof(uint32_t));
+    memcpy(dv.h_val, im->val.data(), body.nsym * sizeof(int32_t));
     *jb.fn = jb.fno;
     if (jb.has_ref && !im->have_ref) {
         jb.ret = DSV_DEC_ERROR; /* reference frame not found (dsv_decoder.c:535) */

@@ -112,26 +112,7 @@ static int hfquant(const QuantCfg &c, int q, int s, int l) // hzcc.c:108
     return q > 8 ? q : 8;
 }
 
-void make_scan(ScanGeom *g, int w, int h) // scan order of hzcc.c:264-342
-{
-    int k = 1;
-    g->w = w;
-    g->h = h;
-    g->off[0] = 0;
-    g->sw[0] = h_dimat(0, w);
-    g->sh[0] = h_dimat(0, h);
-    for (int l = 0; l < 3; l++) {
-        for (int s = 1; s <= 3; s++, k++) {
-            g->off[k] = h_subband_off(l, s, w, h);
-            g->sw[k] = h_dimat(l, w);
-            g->sh[k] = h_dimat(l, h);
-        }
-    }
-    g->base[0] = 0;
-    for (k = 0; k < 10; k++) {
-        g->base[k + 1] = g->base[k] + g->sw[k] * g->sh[k];
-    }
-}
+// (make_scan: scan.cpp -- host geometry without any device code, shared with the CPU-side parser fuzzing harness)
 
 // ---- device arithmetic ------------------------------------------------------------
 struct LevelArgs {
