@@ -62,6 +62,7 @@ struct CodecDev {
     int32_t *coefs[3] = {nullptr, nullptr, nullptr};
     int32_t *qv = nullptr; // dense quantised values of the 3 planes, concatenated (encoder: inside `work`, see init)
     int32_t *work = nullptr; // encoder: ONE block for the transform scratch of all planes and the dense quantised values
+    DevArena arena;          // encoder: the one device allocation everything below lives in (dev.h)
     size_t qv_off[4] = {0, 0, 0, 0};
     ScanGeom scan[3];
     SbtScratch scratch;        // luma (and, one plane at a time, any plane of the single-stream calls)

@@ -6,6 +6,8 @@
 // ~95 MB, so thousands of instances fit in 288 GB -- concurrency is bounded by CUs, not memory.
 #include "codec.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include <atomic>
@@ -153,9 +155,42 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     alive = true;
     coef_dims(format, w, h, cw, ch);
     size_t nb = nblocks();
+    // encoder: everything this function (and the entropy buffers) allocates on the device comes out of ONE block, sized here
+    // from the same formulas the allocations use, plus slack; what does not fit falls back to an allocation of its own
+    static const bool use_arena = !(getenv("DSV2_ARENA") && atoi(getenv("DSV2_ARENA")) == 0);
+    if (encoder && use_arena) {
+        // (the same sizes the allocations below ask for; 256 bytes of alignment for each of the ~100 pieces)
+        size_t est = 0;
+        est += 2 * (2 * dframe_bytes(format, w, h) + nb * sizeof(DSV_MV));
+        for (int l = 0; l < pyr_levels; l++) {
+            int lw = (w + (1 << (l + 1)) - 1) >> (l + 1), lh = (h + (1 << (l + 1)) - 1) >> (l + 1);
+            est += 4 * dframe_bytes(format, lw, lh);
+        }
+        est += dframe_bytes(format, w, h); // pred
+        size_t ncoef = 0, nscan = 0;
+        for (int c = 0; c < 3; c++) {
+            ScanGeom g;
+            make_scan(&g, cw[c], ch[c]);
+            ncoef += (size_t) cw[c] * ch[c];
+            nscan += (size_t) g.base[10];
+        }
+        est += ncoef * sizeof(int32_t); // coefficient planes
+        {
+            const size_t lum = SbtScratch::scratch_elems((size_t) cw[0] * ch[0], sbt_ll_elems(cw[0], ch[0]));
+            const size_t chr = SbtScratch::scratch_elems((size_t) cw[1] * ch[1], sbt_ll_elems(cw[1], ch[1]));
+            est += std::max(std::max(lum, 2 * chr), (nscan + 3) & ~(size_t) 3) * sizeof(int32_t); // work block
+        }
+        est += nscan * 8 + ((nscan + 1023) / 1024) * 8 + 4;                                  // compaction lists, tile counts
+        est += nscan + ((nscan + 1023) / 1024 + 3) * (256 * 2 + 2 + 4 + 4) + (4u << 20) + 64 + 64; // entropy coder (EntBuffers::ensure)
+        est += nb * (1 + sizeof(DSV_MV) + 2) + (size_t) (pyr_levels + 1) * nb * sizeof(DSV_MV);
+        est += hme_counter_words(nbv) * sizeof(int) + hme_src_stats_bytes(nbh, nbv) + 16;
+        est += 128 * 256;
+        arena.create(est);
+    }
+    DevArenaScope arena_scope(encoder && use_arena ? &arena : nullptr);
     for (int i = 0; i < 2; i++) {
         dframe_alloc(&pics[i].recon, format, w, h);
-        HIPCHK(hipMalloc((void **) &pics[i].d_final_mvs, nb * sizeof(DSV_MV)));
+        HIPCHK(dev_alloc((void **) &pics[i].d_final_mvs, nb * sizeof(DSV_MV)));
         dev_zero(pics[i].d_final_mvs, nb * sizeof(DSV_MV));
         if (encoder) {
             dframe_alloc(&pics[i].src, format, w, h);
@@ -170,7 +205,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     qv_off[0] = 0;
     for (int c = 0; c < 3; c++) {
         size_t n = (size_t) cw[c] * ch[c];
-        HIPCHK(hipMalloc((void **) &coefs[c], n * sizeof(int32_t)));
+        HIPCHK(dev_alloc((void **) &coefs[c], n * sizeof(int32_t)));
         dev_zero(coefs[c], n * sizeof(int32_t));
         make_scan(&scan[c], cw[c], ch[c]);
         qv_off[c + 1] = qv_off[c] + (size_t) scan[c].base[10];
@@ -185,30 +220,33 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         const size_t n0 = (size_t) cw[0] * ch[0], l0 = sbt_ll_elems(cw[0], ch[0]), n1 = (size_t) cw[1] * ch[1], l1 = sbt_ll_elems(cw[1], ch[1]);
         const size_t lum = SbtScratch::scratch_elems(n0, l0), chr = SbtScratch::scratch_elems(n1, l1);
         const size_t elems = std::max(std::max(lum, 2 * chr), (qv_off[3] + 3) & ~(size_t) 3);
-        HIPCHK(hipMalloc((void **) &work, elems * sizeof(int32_t)));
+        HIPCHK(dev_alloc((void **) &work, elems * sizeof(int32_t)));
         scratch.borrow(work, n0, l0);
         scratch_uv[0].borrow(work, n1, l1);
         scratch_uv[1].borrow(work + chr, n1, l1);
         qv = work;
         comp.ensure(qv_off[3]);
+        // (the plane sections of the packet assembled on the GPU: 4 MB section buffer, 1 MB pinned mirror -- far above any 1080p
+        // picture at sane quality; larger ones are fetched by a copy)
+        ent.ensure(qv_off[3], 4u << 20, 1u << 20);
     } else {
-        HIPCHK(hipMalloc((void **) &qv, qv_off[3] * sizeof(int32_t)));
+        HIPCHK(dev_alloc((void **) &qv, qv_off[3] * sizeof(int32_t)));
         scratch.ensure((size_t) cw[0] * ch[0], sbt_ll_elems(cw[0], ch[0]));
     }
-    HIPCHK(hipMalloc((void **) &d_blockdata, nb));
+    HIPCHK(dev_alloc((void **) &d_blockdata, nb));
     dev_zero(d_blockdata, nb);
-    HIPCHK(hipMalloc((void **) &d_mvs_stage, nb * sizeof(DSV_MV)));
+    HIPCHK(dev_alloc((void **) &d_mvs_stage, nb * sizeof(DSV_MV)));
     dev_zero(d_mvs_stage, nb * sizeof(DSV_MV));
     for (int l = 0; l <= pyr_levels; l++) {
-        HIPCHK(hipMalloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
+        HIPCHK(dev_alloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
     }
-    HIPCHK(hipMalloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
-    HIPCHK(hipMalloc(&d_src_stats, hme_src_stats_bytes(nbh, nbv)));
+    HIPCHK(dev_alloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
+    HIPCHK(dev_alloc(&d_src_stats, hme_src_stats_bytes(nbh, nbv)));
     for (int i = 0; i < 2; i++) {
-        HIPCHK(hipMalloc((void **) &d_intra_map[i], nb));
+        HIPCHK(dev_alloc((void **) &d_intra_map[i], nb));
         dev_zero(d_intra_map[i], nb);
     }
-    HIPCHK(hipMalloc((void **) &d_ll, 4 * sizeof(int32_t)));
+    HIPCHK(dev_alloc((void **) &d_ll, 4 * sizeof(int32_t)));
     h_frame_bytes = 0;
     for (int c = 0; c < 3; c++) {
         h_frame_bytes += (size_t) pred.p[c].w * pred.p[c].h;
@@ -242,12 +280,12 @@ void CodecDev::ensure_dev_syms(size_t n)
         return;
     }
     if (d_sym_pos) {
-        HIPCHK(hipFree(d_sym_pos));
-        HIPCHK(hipFree(d_sym_val));
+        dev_release(d_sym_pos);
+        dev_release(d_sym_val);
     }
     size_t cap = n + n / 4 + 4096;
-    HIPCHK(hipMalloc((void **) &d_sym_pos, cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &d_sym_val, cap * sizeof(int32_t)));
+    HIPCHK(dev_alloc((void **) &d_sym_pos, cap * sizeof(uint32_t)));
+    HIPCHK(dev_alloc((void **) &d_sym_val, cap * sizeof(int32_t)));
     sym_cap = cap;
 }
 
@@ -276,17 +314,17 @@ void CodecDev::destroy()
             dframe_free(&pics[i].src_pyr[l]);
             dframe_free(&pics[i].recon_pyr[l]);
         }
-        HIPCHK(hipFree(pics[i].d_final_mvs));
+        dev_release(pics[i].d_final_mvs);
     }
     dframe_free(&pred);
     for (int c = 0; c < 3; c++) {
-        HIPCHK(hipFree(coefs[c]));
+        dev_release(coefs[c]);
     }
     if (work) {
-        HIPCHK(hipFree(work));
+        dev_release(work);
         work = nullptr;
     } else {
-        HIPCHK(hipFree(qv));
+        dev_release(qv);
     }
     qv = nullptr;
     scratch.release();
@@ -294,25 +332,25 @@ void CodecDev::destroy()
     scratch_uv[1].release();
     comp.release();
     ent.release();
-    HIPCHK(hipFree(d_blockdata));
-    HIPCHK(hipFree(d_mvs_stage));
+    dev_release(d_blockdata);
+    dev_release(d_mvs_stage);
     for (int l = 0; l <= DSV_MAX_PYRAMID_LEVELS; l++) {
         if (d_mvf[l]) {
-            HIPCHK(hipFree(d_mvf[l]));
+            dev_release(d_mvf[l]);
         }
     }
-    HIPCHK(hipFree(d_counters));
-    HIPCHK(hipFree(d_src_stats));
+    dev_release(d_counters);
+    dev_release(d_src_stats);
     for (int i = 0; i < 2; i++) {
         if (d_intra_map[i]) {
-            HIPCHK(hipFree(d_intra_map[i]));
+            dev_release(d_intra_map[i]);
             d_intra_map[i] = nullptr;
         }
     }
-    HIPCHK(hipFree(d_ll));
+    dev_release(d_ll);
     if (d_sym_pos) {
-        HIPCHK(hipFree(d_sym_pos));
-        HIPCHK(hipFree(d_sym_val));
+        dev_release(d_sym_pos);
+        dev_release(d_sym_val);
     }
     HIPCHK(hipHostFree(h_frame));
     HIPCHK(hipHostFree(h_mvs));
@@ -328,6 +366,7 @@ void CodecDev::destroy()
         HIPCHK(hipStreamDestroy(stream));
         stream = nullptr;
     }
+    arena.destroy(); // (last: the releases above skipped everything that lives inside it)
 }
 
 MCParams CodecDev::mc_params(int temporal_mc, int lossless) const

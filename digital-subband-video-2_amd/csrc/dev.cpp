@@ -6,6 +6,7 @@
 #include <time.h>
 
 #include <chrono>
+#include <map>
 #include <mutex>
 
 namespace dsv2 {
@@ -93,10 +94,83 @@ void coef_dims(int format, int w, int h, int cw[3], int ch[3]) // frame.c:30-60
     ch[1] = ch[2] = c_h;
 }
 
+// ---- one device block per codec instance (dev.h: DevArena) ----
+static thread_local DevArena *t_arena = nullptr;
+static std::mutex g_arena_mu;
+static std::map<uintptr_t, size_t> g_arenas; // live blocks: base -> bytes
+
+void DevArena::create(size_t bytes)
+{
+    HIPCHK(hipMalloc((void **) &base, bytes));
+    HIPCHK(hipMemset(base, 0, bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    cap = bytes;
+    used = 0;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    g_arenas[(uintptr_t) base] = bytes;
+}
+
+void DevArena::destroy()
+{
+    if (!base) {
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        g_arenas.erase((uintptr_t) base);
+    }
+    HIPCHK(hipFree(base));
+    base = nullptr;
+    cap = used = 0;
+}
+
+DevArenaScope::DevArenaScope(DevArena *a) : prev(t_arena) { t_arena = a; }
+DevArenaScope::~DevArenaScope() { t_arena = prev; }
+
+hipError_t dev_alloc(void **p, size_t bytes)
+{
+    DevArena *a = t_arena;
+    if (a && a->base) {
+        const size_t off = (a->used + 255) & ~(size_t) 255;
+        if (off + bytes <= a->cap) {
+            *p = a->base + off;
+            a->used = off + bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && a && a->base) { // (the estimate of the block was short: this piece lives on its own, zeroed like the block)
+        HIPCHK(hipMemset(*p, 0, bytes));
+        HIPCHK(hipStreamSynchronize(nullptr));
+    }
+    return e;
+}
+
+static bool in_live_arena(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.upper_bound((uintptr_t) p);
+    if (it == g_arenas.begin()) {
+        return false;
+    }
+    --it;
+    return (uintptr_t) p < it->first + it->second;
+}
+
+void dev_release(void *p)
+{
+    if (p && !in_live_arena(p)) {
+        HIPCHK(hipFree(p));
+    }
+}
+
 // hipMemset is asynchronous to the host and runs on the null stream, which the codec's non-blocking
 // streams do not wait for: finish it before anything may be enqueued on those streams
 void dev_zero(void *p, size_t bytes)
 {
+    if (t_arena && t_arena->base && in_live_arena(p)) {
+        return; // (the block was zeroed when it was made)
+    }
     HIPCHK(hipMemset(p, 0, bytes));
     HIPCHK(hipStreamSynchronize(nullptr));
 }
@@ -171,6 +245,18 @@ void event_wait(hipEvent_t ev)
     }
 }
 
+size_t dframe_bytes(int format, int w, int h)
+{
+    int hs = DSV_FORMAT_H_SHIFT(format), vs = DSV_FORMAT_V_SHIFT(format);
+    int cw = (w + (1 << hs) - 1) >> hs, ch = (h + (1 << vs) - 1) >> vs;
+    int pw[3] = {w, cw, cw}, ph[3] = {h, ch, ch};
+    size_t off = 0;
+    for (int c = 0; c < 3; c++) {
+        off += (size_t) ((pw[c] + 2 * kBorder + 15) & ~15) * (size_t) (ph[c] + 2 * kBorder);
+    }
+    return off + 4096;
+}
+
 void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-113, always bordered
 {
     ensure_device();
@@ -192,7 +278,7 @@ void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-1
     }
     f->bytes = off;
     // slack after the last plane: block reads may run a few bytes past the final border row
-    HIPCHK(hipMalloc((void **) &f->alloc, off + 4096));
+    HIPCHK(dev_alloc((void **) &f->alloc, off + 4096));
     dev_zero(f->alloc, off + 4096);
     for (int c = 0; c < 3; c++) {
         f->p[c].data = f->alloc + f->plane_off[c] + (size_t) f->p[c].stride * kBorder + kBorder;
@@ -202,7 +288,7 @@ void dframe_alloc(DFrame *f, int format, int w, int h) // layout of frame.c:63-1
 void dframe_free(DFrame *f)
 {
     if (f->alloc) {
-        HIPCHK(hipFree(f->alloc));
+        dev_release(f->alloc);
         f->alloc = nullptr;
     }
 }

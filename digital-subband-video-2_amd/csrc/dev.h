@@ -66,7 +66,26 @@ struct BlockMap {
     int nbh, nbv;
 };
 
-void dev_zero(void *p, size_t bytes); // synchronous zero fill of device memory
+void dev_zero(void *p, size_t bytes); // synchronous zero fill of device memory (nothing inside an arena scope: the arena is zeroed once)
+// One device allocation per codec instance (round 4).  Inside an arena scope (DevArenaScope on the calling thread) dev_alloc
+// hands out 256-byte aligned pieces of ONE hipMalloc'd block -- an encoder instance made ~75 allocations, each a driver call
+// when it is made and a device-synchronising one when it is freed: what a short-lived process (one CLI process per closed-GOP
+// segment) pays before its first packet and again on its way out.  A request the block cannot hold falls back to hipMalloc;
+// dev_release frees only what does not lie inside a live arena (the block itself is freed by its owner).
+struct DevArena {
+    uint8_t *base = nullptr;
+    size_t cap = 0, used = 0;
+    void create(size_t bytes); // hipMalloc + zero fill + registration
+    void destroy();
+};
+struct DevArenaScope {
+    DevArenaScope(DevArena *a);
+    ~DevArenaScope();
+    DevArena *prev;
+};
+hipError_t dev_alloc(void **p, size_t bytes);
+void dev_release(void *p);
+size_t dframe_bytes(int format, int w, int h); // device bytes dframe_alloc asks for
 void event_wait(hipEvent_t ev);        // ... for a recorded event
 void set_wait_fine(bool fine);         // this thread's waits poll at 20 us (small batches: DSV2_WAIT_FINE_MAX) instead of up to 120 us
 void stream_wait(hipStream_t s);       // host wait for the stream to drain: sleeps between completion queries (dev.cpp: 10 - 120 us apart), no busy spin

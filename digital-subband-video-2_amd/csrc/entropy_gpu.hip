@@ -700,14 +700,14 @@ void EntBuffers::ensure(size_t nsym_cap, uint32_t out_bytes, uint32_t host_bytes
         return;
     }
     size_t nch = (nsym_cap + kEntChunk - 1) / kEntChunk + 3;
-    HIPCHK(hipMalloc((void **) &tables, nch * kStates * sizeof(uint16_t)));
-    HIPCHK(hipMalloc((void **) &chunk_vk, nch * sizeof(uint16_t)));
-    HIPCHK(hipMalloc((void **) &chunk_bits, nch * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &chunk_off, nch * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &ksym, nsym_cap));
+    HIPCHK(dev_alloc((void **) &tables, nch * kStates * sizeof(uint16_t)));
+    HIPCHK(dev_alloc((void **) &chunk_vk, nch * sizeof(uint16_t)));
+    HIPCHK(dev_alloc((void **) &chunk_bits, nch * sizeof(uint32_t)));
+    HIPCHK(dev_alloc((void **) &chunk_off, nch * sizeof(uint32_t)));
+    HIPCHK(dev_alloc((void **) &ksym, nsym_cap));
     out_cap = (out_bytes + 15u) & ~15u;
-    HIPCHK(hipMalloc((void **) &out, out_cap + 64));
-    HIPCHK(hipMalloc((void **) &info, 16 * sizeof(int)));
+    HIPCHK(dev_alloc((void **) &out, out_cap + 64));
+    HIPCHK(dev_alloc((void **) &info, 16 * sizeof(int)));
     host_cap = (host_bytes + 15u) & ~15u;
     HIPCHK(hipHostMalloc((void **) &host_out, host_cap, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &host_info, 16 * sizeof(int), hipHostMallocDefault));
@@ -718,13 +718,13 @@ void EntBuffers::release()
     if (!tables) {
         return;
     }
-    HIPCHK(hipFree(tables));
-    HIPCHK(hipFree(chunk_vk));
-    HIPCHK(hipFree(chunk_bits));
-    HIPCHK(hipFree(chunk_off));
-    HIPCHK(hipFree(ksym));
-    HIPCHK(hipFree(out));
-    HIPCHK(hipFree(info));
+    dev_release(tables);
+    dev_release(chunk_vk);
+    dev_release(chunk_bits);
+    dev_release(chunk_off);
+    dev_release(ksym);
+    dev_release(out);
+    dev_release(info);
     HIPCHK(hipHostFree(host_out));
     HIPCHK(hipHostFree(host_info));
     tables = nullptr;

@@ -680,12 +680,12 @@ void Compactor::ensure(size_t n)
     }
     release();
     size_t ntiles = (n + kTile - 1) / kTile;
-    HIPCHK(hipMalloc((void **) &tile_count, ntiles * sizeof(int)));
+    HIPCHK(dev_alloc((void **) &tile_count, ntiles * sizeof(int)));
     dev_zero(tile_count, ntiles * sizeof(int));
-    HIPCHK(hipMalloc((void **) &tile_base, ntiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **) &d_total, sizeof(int)));
-    HIPCHK(hipMalloc((void **) &d_pos, n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &d_val, n * sizeof(int32_t)));
+    HIPCHK(dev_alloc((void **) &tile_base, ntiles * sizeof(int)));
+    HIPCHK(dev_alloc((void **) &d_total, sizeof(int)));
+    HIPCHK(dev_alloc((void **) &d_pos, n * sizeof(uint32_t)));
+    HIPCHK(dev_alloc((void **) &d_val, n * sizeof(int32_t)));
     HIPCHK(hipHostMalloc((void **) &h_total, sizeof(int), hipHostMallocDefault));
     cap = n;
 }
@@ -695,11 +695,11 @@ void Compactor::release()
     if (!cap) {
         return;
     }
-    HIPCHK(hipFree(tile_count));
-    HIPCHK(hipFree(tile_base));
-    HIPCHK(hipFree(d_total));
-    HIPCHK(hipFree(d_pos));
-    HIPCHK(hipFree(d_val));
+    dev_release(tile_count);
+    dev_release(tile_base);
+    dev_release(d_total);
+    dev_release(d_pos);
+    dev_release(d_val);
     HIPCHK(hipHostFree(h_total));
     cap = 0;
 }
