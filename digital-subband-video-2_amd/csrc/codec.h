@@ -93,7 +93,9 @@ struct CodecDev {
     int32_t *h_val = nullptr;
     size_t h_sym_cap = 0;
 
-    void init(int format, int w, int h, int blk_w, int blk_h, int pyr_levels, bool encoder);
+    // list_symbols: symbols the compaction lists (and the entropy coder's per-symbol buffers) hold at first; 0 = every coefficient
+    // (the worst case: lossless).  A picture that has more is worked out again into enlarged lists (encoder.cpp: redo_overflow).
+    void init(int format, int w, int h, int blk_w, int blk_h, int pyr_levels, bool encoder, size_t list_symbols = 0);
     void destroy();
     void ensure_host_syms(size_t n);
     void ensure_dev_syms(size_t n);

@@ -141,7 +141,16 @@ void block_geometry(int w, int h, int ovx, int ovy, int *blk_w, int *blk_h, int 
     *nbv = (h + bh - 1) / bh;
 }
 
-void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr_levels_, bool encoder)
+// Section buffer of the GPU entropy coder: 4 bits per coefficient (1.5 MB at 1080p: a 370 Mbit/s stream at 30 pictures a second),
+// at least 1 MB; 4 MB or that, whichever is more, for streams whose lists are sized for the worst case (lossless).  A picture
+// that does not fit raises the coder's "no room" flag and is coded on the host.
+static uint32_t ent_out_bytes(size_t list_symbols, size_t ncoef)
+{
+    const size_t half = (ncoef / 2 + 65535) & ~(size_t) 65535;
+    return (uint32_t) std::max<size_t>(list_symbols >= ncoef ? (4u << 20) : (1u << 20), half);
+}
+
+void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr_levels_, bool encoder, size_t list_symbols)
 {
     ensure_device();
     format = format_;
@@ -180,8 +189,9 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
             const size_t chr = SbtScratch::scratch_elems((size_t) cw[1] * ch[1], sbt_ll_elems(cw[1], ch[1]));
             est += std::max(std::max(lum, 2 * chr), (nscan + 3) & ~(size_t) 3) * sizeof(int32_t); // work block
         }
-        est += nscan * 8 + ((nscan + 1023) / 1024) * 8 + 4;                                  // compaction lists, tile counts
-        est += nscan + ((nscan + 1023) / 1024 + 3) * (256 * 2 + 2 + 4 + 4) + (4u << 20) + 64 + 64; // entropy coder (EntBuffers::ensure)
+        const size_t nlist = list_symbols && list_symbols < nscan ? list_symbols : nscan;
+        est += nlist * 8 + ((nscan + 1023) / 1024) * 8 + 4;                                  // compaction lists, tile counts
+        est += ((nlist + 1023) / 1024 + 3) * (1024 + 256 * 2 + 2 + 4 + 4 + 8) + ent_out_bytes(nlist, nscan) + 64 + 128; // entropy coder (EntBuffers::ensure)
         est += nb * (1 + sizeof(DSV_MV) + 2) + (size_t) (pyr_levels + 1) * nb * sizeof(DSV_MV);
         est += hme_counter_words(nbv) * sizeof(int) + hme_src_stats_bytes(nbh, nbv) + 16;
         est += 128 * 256;
@@ -225,10 +235,10 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         scratch_uv[0].borrow(work, n1, l1);
         scratch_uv[1].borrow(work + chr, n1, l1);
         qv = work;
-        comp.ensure(qv_off[3]);
+        comp.ensure_lists(qv_off[3], list_symbols ? list_symbols : qv_off[3]);
         // (the plane sections of the packet assembled on the GPU: 4 MB section buffer, 1 MB pinned mirror -- far above any 1080p
         // picture at sane quality; larger ones are fetched by a copy)
-        ent.ensure(qv_off[3], 4u << 20, 1u << 20);
+        ent.ensure(comp.list_cap, ent_out_bytes(comp.list_cap, qv_off[3]), 1u << 20);
     } else {
         HIPCHK(dev_alloc((void **) &qv, qv_off[3] * sizeof(int32_t)));
         scratch.ensure((size_t) cw[0] * ch[0], sbt_ll_elems(cw[0], ch[0]));

@@ -955,11 +955,23 @@ struct BatchScratch { // pinned + device memory for the job tables, the step's H
             HIPCHK(hipEventCreateWithFlags(&copy_done, hipEventDisableTiming));
         }
     }
+    // working picture of a picture whose symbols are worked out a second time (redo_overflow: its compaction lists were too short)
+    DFrame redo;
+    DFrame &redo_frame(int format, int w, int h)
+    {
+        if (redo.alloc && (redo.format != format || redo.w != w || redo.h != h)) {
+            dframe_free(&redo);
+        }
+        if (!redo.alloc) {
+            dframe_alloc(&redo, format, w, h);
+        }
+        return redo;
+    }
     TableArena tabs;
     int cap = 0;
     void ensure(int n)
     {
-        tabs.reserve((size_t) n * 8192 + 65536);
+        tabs.reserve((size_t) n * 12288 + 65536); // (the last 4 KB a stream: the tables of a redone picture, enc_batch)
         if (n <= cap) {
             return;
         }
@@ -1083,7 +1095,17 @@ void ensure_ready(DSV_ENCODER *enc, EncImpl *im)
         }
         enc->pyramid_levels = clampi(lvls, 3, DSV_MAX_PYRAMID_LEVELS);
     }
-    im->dev.init(enc->vidmeta.subsamp, w, h, bw, bh, enc->pyramid_levels, true);
+    // Compaction lists: HALF the worst case to begin with -- a detail-rich 1080p intra picture at qp 60 has a symbol for 33 % of
+    // its coefficients, its P pictures for 5 % -- and the worst case at once for lossless streams, where nearly every coefficient
+    // is a symbol.  DSV2_COMPACT_CAP (symbols) forces a figure (tests: so small that pictures overflow and take the redo path).
+    size_t list_syms = 0;
+    if (enc->quality != DSV_RC_QUAL_MAX) {
+        const long forced = getenv("DSV2_COMPACT_CAP") ? atol(getenv("DSV2_COMPACT_CAP")) : -1; // (read per instance: tests set it)
+        const int fmt = enc->vidmeta.subsamp;
+        const size_t ncoef = (size_t) w * h + 2 * (size_t) ((w + (1 << DSV_FORMAT_H_SHIFT(fmt)) - 1) >> DSV_FORMAT_H_SHIFT(fmt)) * ((h + (1 << DSV_FORMAT_V_SHIFT(fmt)) - 1) >> DSV_FORMAT_V_SHIFT(fmt));
+        list_syms = forced >= 0 ? (size_t) forced : std::max<size_t>(65536, ncoef / 2);
+    }
+    im->dev.init(enc->vidmeta.subsamp, w, h, bw, bh, enc->pyramid_levels, true, list_syms);
     im->ready = true;
     im->mvs.assign((size_t) nbh * nbv, DSV_MV{});
     enc->stability = (struct DSV_STAB_ACC *) dsv_alloc((int) (sizeof(struct DSV_STAB_ACC) * (size_t) nbh * nbv));
@@ -1469,6 +1491,7 @@ static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV
 static const int kAuxStreamsEnv = getenv("DSV2_AUX_STREAMS") ? atoi(getenv("DSV2_AUX_STREAMS")) : -1;
 static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") && atoi(getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK")) != 0; // (tests)
 // the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
+static std::atomic<long> g_list_growths{0}; // pictures that had more symbols than their stream's compaction lists (dsv2hip_enc_list_growths)
 static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV2_FUSED_COUNT")) == 0);
 
 void enc_batch(Job *jobs, int n)
@@ -1950,8 +1973,8 @@ void enc_batch(Job *jobs, int n)
         if (kGpuEntropy) {
             // the symbols stay in HBM; what comes back is the finished plane sections (pinned mirror: 1 MB, far above
             // any 1080p picture at sane quality -- larger ones are fetched by a copy)
-            dv.ent.ensure(dv.qv_off[3], 4u << 20, 1u << 20);
-            h_ent[i] = dv.ent.job(dv.comp.d_pos, dv.comp.d_val, sc.d_totals + i, sc.d_ll + 3 * i);
+            dv.ent.ensure(dv.comp.list_cap, 4u << 20, 1u << 20);
+            h_ent[i] = dv.ent.job(dv.comp.d_pos, dv.comp.d_val, sc.d_totals + i, sc.d_ll + 3 * i, dv.comp.list_cap);
         } else {
             dv.ensure_host_syms(dv.qv_off[3] / 8); // P pictures fit; the first intra picture grows it (one fallback copy)
             h_comp[i].host_pos = dv.h_pos;
@@ -2049,6 +2072,7 @@ void enc_batch(Job *jobs, int n)
     stream_wait(bs);
     t_clock.lap(5);
     bool late_copy = false;
+    const bool force_redo = getenv("DSV2_COMPACT_REDO") && atoi(getenv("DSV2_COMPACT_REDO"));
     for (int k = 0; k < n; k++) {
         Job &jb = jobs[k];
         CodecDev &dv = jb.im->dev;
@@ -2059,7 +2083,63 @@ void enc_batch(Job *jobs, int n)
         }
         jb.gpu_bytes = nullptr;
         bool need_syms = !kGpuEntropy;
-        if (kGpuEntropy) {
+        // More symbols than this stream's compaction lists hold (they start at a quarter of the worst case): the lists are
+        // enlarged to the worst case for good, and this picture's symbols worked out again -- predict + subtract (or the source
+        // copy of an intra picture) into a spare working picture, forward transform, quantiser, compaction: the same kernels
+        // on the same operands, so the same symbols -- which the host then codes.  The reconstruction is untouched.
+        const bool overflow = (size_t) jb.nsym > dv.comp.list_cap || force_redo; // (DSV2_COMPACT_REDO=1: every picture, a test switch)
+        if (overflow) {
+            if (getenv("DSV2_BATCH_TRACE")) {
+                fprintf(stderr, "[batch] stream %d: %d symbols > compaction lists of %zu: redone\n", k, jb.nsym, dv.comp.list_cap);
+            }
+            const bool isP = jb.d.params.has_ref, lossless = jb.d.params.lossless;
+            PicSet &cur = dv.pics[jb.im->cur];
+            g_list_growths += (size_t) jb.nsym > dv.comp.list_cap;
+            dv.comp.grow_lists(dv.qv_off[3]);
+            if (kGpuEntropy) {
+                dv.ent.ensure(dv.comp.list_cap, 4u << 20, 1u << 20);
+            }
+            DFrame &tmp = sc.redo_frame(dv.format, dv.w, dv.h);
+            const McJob *d_m2;
+            McJob *h_m2 = sc.tabs.take<McJob>(1, &d_m2);
+            const CopyJob *d_c2;
+            CopyJob *h_c2 = sc.tabs.take<CopyJob>(1, &d_c2);
+            const PlaneJob *d_y2, *d_uv2;
+            PlaneJob *h_y2 = sc.tabs.take<PlaneJob>(1, &d_y2), *h_uv2 = sc.tabs.take<PlaneJob>(2, &d_uv2);
+            const CompactJob *d_k2;
+            CompactJob *h_k2 = sc.tabs.take<CompactJob>(1, &d_k2);
+            if (isP) {
+                *h_m2 = sc.h_mc[ti]; // (P pictures lead the sorted order: table slot = index among the P jobs)
+                for (int c = 0; c < 3; c++) {
+                    h_m2->res.p[c] = tmp.p[c];
+                }
+            } else {
+                *h_c2 = CopyJob{cur.src.alloc, tmp.alloc, cur.src.bytes};
+            }
+            *h_y2 = h_py[ti];
+            h_y2->pic = tmp.p[0];
+            for (int c = 1; c < 3; c++) {
+                h_uv2[c - 1] = h_pc[2 * ti + c - 1];
+                h_uv2[c - 1].pic = tmp.p[c];
+            }
+            dv.ensure_host_syms((size_t) jb.nsym);
+            *h_k2 = dv.comp.job(dv.qv, dv.qv_off[3]);
+            h_k2->total = sc.d_totals + ti;
+            sc.tabs.upload(bs);
+            if (isP) {
+                mc_sub_pred_batch(bs, d_m2, 1, nbh, nbv);
+            } else {
+                copy_linear_batch(bs, d_c2, 1, cur.src.bytes);
+            }
+            sbt_forward_jobs(bs, d_y2, 1, dv.cw[0], dv.ch[0], 0, isP, lossless, nbh, nbv);
+            sbt_forward_jobs(bs, d_uv2, 2, dv.cw[1], dv.ch[1], 1, isP, lossless, nbh, nbv);
+            quant_jobs(bs, d_y2, 1, dv.quant_cfg(0, isP, lossless, do_psy, nullptr));
+            quant_jobs(bs, d_uv2, 2, dv.quant_cfg(1, isP, lossless, do_psy, nullptr));
+            compact_jobs(bs, d_k2, 1, dv.qv_off[3], kFusedCount);
+            need_syms = true;
+            late_copy = true;
+        }
+        if (kGpuEntropy && !overflow) {
             const int *info = dv.ent.host_info;
             if ((info[0] & ENT_FALLBACK_MASK) || kEntForceFallback) {
                 need_syms = true; // (state outside the tabulated range / no room: code this picture on the host)
@@ -2081,7 +2161,7 @@ void enc_batch(Job *jobs, int n)
             }
         }
         // the symbols are needed on the host: copied when the mirror did not hold them (always so with the GPU coder on)
-        if (need_syms && jb.nsym > 0 && (kGpuEntropy || (size_t) jb.nsym > dv.h_sym_cap)) {
+        if (need_syms && jb.nsym > 0 && (kGpuEntropy || overflow || (size_t) jb.nsym > dv.h_sym_cap)) {
             if (getenv("DSV2_BATCH_TRACE")) {
                 fprintf(stderr, "[batch] stream %d: %d symbols > pinned mirror of %zu, copying\n", k, jb.nsym, dv.h_sym_cap);
             }
@@ -2291,6 +2371,8 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
 
 /* what the submit queue of dsv_enc did so far: [0] calls, [1] lockstep steps they were run as, [2] the largest step, [3] total
  * microseconds leaders spent waiting for expected callers; reset != 0 clears the counts afterwards */
+long dsv2hip_enc_list_growths(void) { return g_list_growths.load(); }
+
 void dsv2hip_enc_queue_stats(unsigned long long *out4, int reset)
 {
     Coalescer<Job>::Stats st = g_enc_queue.stats();

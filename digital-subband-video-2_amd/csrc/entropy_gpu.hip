@@ -8,19 +8,26 @@
 // floored at 0).  Everything else -- run lengths, code words, code lengths -- is a pure function of a symbol, its
 // predecessor's position and the vk it meets.  The state is made parallel exactly, with no speculation:
 //
-//   1 k_ent_planes   per stream: where each plane's symbols start in the compacted (position, value) list
+//   1 k_ent_planes   per stream: where each plane's symbols start in the compacted (position, value) list, and how many of
+//                    each plane's symbols are coded without the state (the LL prefix)
 //   2 k_ent_tables   per chunk of 1024 symbols: the chunk's TRANSFER FUNCTION vk_in -> vk_out as a 256-entry table,
 //                    by walking all 256 start states through the chunk at once (two states per lane in packed 16-bit
-//                    arithmetic against one threshold per symbol, staged in LDS; one wavefront alone once all
-//                    trajectories have joined two neighbouring values)
-//   3 k_ent_chain    per plane: vk at the start of every chunk by following the tables (one lookup per chunk, the
-//                    tables staged 32 chunks at a time in LDS)
-//   4 k_ent_ks       per chunk, one wavefront: one lane walks the chunk's thresholds (staged in LDS) from its now known
-//                    start state; the lanes turn the states into k of every symbol and the chunk's total code length
+//                    arithmetic against one threshold per symbol, staged in LDS) UNTIL all trajectories have joined two
+//                    neighbouring values (m, m + 1) -- some 250 symbols: the states above every threshold march down
+//                    together.  Leaves each symbol's threshold as a byte (T >> 3) for the two walks below.
+//   2b k_ent_pair    the rest of the chunk is the walk of that ONE pair: a lane per chunk, 64 chunks a wavefront
+//                    (round 4: until then one wavefront per chunk walked it with 63 lanes idle)
+//   3 k_ent_chain    per plane: vk at the start of every chunk by following the tables (one lookup per chunk -- and the
+//                    pair's result where the chunk's trajectories had joined --, the tables staged 32 chunks at a time in LDS)
+//   4 k_ent_walk     a lane per chunk again: the walk from the chunk's now known start state, the state every symbol meets
+//                    written over its threshold byte
+//   4b k_ent_bits    per chunk, a lane per symbol: the states into Rice parameters and the chunk's total code length
 //   5 k_ent_layout   per stream: exclusive scan of the chunk lengths, byte layout of the three plane sections
 //   6 k_ent_zero / k_ent_emit   every symbol ORs its code words into an LDS image of its chunk at its bit offset; the
 //                    image leaves as whole words (only a chunk's first and last word are ORed into the zeroed output)
 //   7 k_ent_out      the finished bytes and their sizes to pinned host memory
+//
+// (DSV2_ENT_LANES=0 selects the round-3 form of steps 2 and 4: k_ent_tables walking the pair itself, k_ent_ks.)
 //
 // A state beyond 255 (k >= 32 at damp 3, never seen on real pictures) or a plane that outgrows its buffer raises a
 // flag; the host then codes that picture from the symbol list as before (entropy.cpp) -- same bytes either way.
@@ -33,7 +40,8 @@ namespace {
 constexpr int kStates = 256;
 
 // info words (device and, mirrored, pinned host)
-enum { EI_FLAGS = 0, EI_PSTART = 1 /* 1..3 */, EI_N = 4, EI_PBYTES = 5 /* 5..7 */, EI_TOTAL = 8, EI_NCH = 9 /* 9..11 */, EI_SYMBIT = 12 /* 12..14 */ };
+enum { EI_FLAGS = 0, EI_PSTART = 1 /* 1..3 */, EI_N = 4, EI_PBYTES = 5 /* 5..7 */, EI_TOTAL = 8, EI_NCH = 9 /* 9..11 */, EI_SYMBIT = 12 /* 12..14 */,
+       EI_NSKIP = 16 /* 16..18: device only */, EI_WORDS = 32 };
 
 __device__ __forceinline__ uint64_t spread32(uint32_t x) // bit i -> bit 2i
 {
@@ -124,10 +132,12 @@ __global__ __launch_bounds__(64) void k_ent_planes(const EntJob *__restrict__ ta
 {
     const EntJob &J = tab[blockIdx.x];
     const int lane = threadIdx.x;
-    const int N = *J.total;
+    const int Nall = *J.total;
+    const bool over = Nall > J.list_cap; // more symbols than the lists hold: nothing of this picture is coded here (flag 16)
+    const int N = over ? 0 : Nall;
     int res = 0;
-    if (lane == 1 || lane == 2) { // first symbol whose position lies in plane `lane`
-        uint32_t key = (uint32_t) g.qv_off[lane];
+    if (lane >= 1 && lane <= 5) { // 1, 2: first symbol whose position lies in plane `lane`; 3..5: first of plane lane - 3 behind its LL region
+        uint32_t key = lane <= 2 ? (uint32_t) g.qv_off[lane] : (uint32_t) (g.qv_off[lane - 3] + g.base[lane - 3][1]);
         int lo = 0, hi = N;
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(64) void k_ent_planes(const EntJob *__restrict__ ta
     int p1 = __shfl(res, 1, 64), p2 = __shfl(res, 2, 64);
     if (lane == 0) {
         int *I = J.info;
-        I[EI_FLAGS] = 0;
+        I[EI_FLAGS] = over ? ENT_LIST_OVERFLOW : 0;
         I[EI_PSTART + 0] = 0;
         I[EI_PSTART + 1] = p1;
         I[EI_PSTART + 2] = p2;
@@ -150,6 +160,10 @@ __global__ __launch_bounds__(64) void k_ent_planes(const EntJob *__restrict__ ta
         I[EI_NCH + 0] = (p1 + kEntChunk - 1) / kEntChunk;
         I[EI_NCH + 1] = (p2 - p1 + kEntChunk - 1) / kEntChunk;
         I[EI_NCH + 2] = (N - p2 + kEntChunk - 1) / kEntChunk;
+    }
+    if (lane >= 3 && lane <= 5) { // symbols of the plane that are coded without the adaptive state: a prefix of its list
+        const int c = lane - 3, first = c == 0 ? 0 : (c == 1 ? p1 : p2);
+        J.info[EI_NSKIP + c] = res - first;
     }
 }
 
@@ -189,6 +203,9 @@ __device__ __forceinline__ uint32_t rice_threshold(int32_t v, int seg) // T of a
     return (uint32_t) bitlen(rice_u(v)) << (3 + (seg - 1) / 3);
 }
 
+constexpr uint32_t kNotJoined = 0xffffffffu;
+
+template <bool kLanes> // kLanes: stop where the trajectories have joined (k_ent_pair walks on), leave the threshold bytes behind
 __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__restrict__ tab, EntGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t sT[kEntChunk];
@@ -213,17 +230,22 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
 #pragma unroll
         for (int j = 0; j < kEntChunk / (kStates / 2); j++) {
             int s = j * (kStates / 2) + tid;
-            uint32_t t = 0;
+            uint32_t t = 0, tc = 0;
             if (s < cnt) {
                 int seg = seg_of(g, c, J.pos[first + s] - off);
                 if (seg > 0) {
-                    t = rice_threshold(J.val[first + s], seg) - 1u; // T - 1 in -1 .. 1023
+                    t = rice_threshold(J.val[first + s], seg); // T in 0 .. 1024, a multiple of 8
+                    tc = t >> 3;
+                    t = t - 1u;
                     t = (t & 0xffffu) | (t << 16);
                 } else {
                     nskip_mine++;
                 }
             }
             sT[s] = t;
+            if (kLanes) { // (chunk-major, whole chunks: the walks read on behind a plane's last symbol)
+                J.ksym[(size_t) (ps.cbase + lc) * kEntChunk + s] = (uint8_t) tc;
+            }
         }
         if (nskip_mine) {
             atomicAdd(&s_nskip, nskip_mine);
@@ -280,7 +302,11 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
                 }
             }
         }
-        if (joined) {
+        if (kLanes) {
+            if (tid == 0) {
+                J.chunk_join[ps.cbase + lc] = make_uint2(joined ? (uint32_t) m | ((uint32_t) (4 * q) << 16) : kNotJoined, 0u);
+            }
+        } else if (joined) {
             if (tid < 64) { // the pair (m, m + 1), the same five instructions a symbol, ONE wavefront
                 pk16 x = (pk16){(short) m, (short) (m + 1)};
                 for (; q < qend; q++) {
@@ -310,15 +336,64 @@ __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__rest
     }
 }
 
+// ---- 2b ---------------------------------------------------------------------------------------------------
+// The pair (m, m + 1) a chunk's trajectories had joined at symbol q0, walked to the chunk's end: a lane per chunk.  Lane l's
+// thresholds are 1 KB apart from lane l + 1's: a load of 16 bytes a lane brings 16 symbols, fetched one group ahead.
+// (A plane's last chunk is walked over its zero padding: its transfer function is never used.)
+__device__ __forceinline__ uint32_t tm1_splat(uint32_t w, int b) // byte b of w = T >> 3: (T - 1) in both halves
+{
+    const uint32_t t = (((w >> (8 * b)) & 0xffu) << 3) - 1u;
+    return (t & 0xffffu) * 0x10001u;
+}
+
+__global__ __launch_bounds__(64) void k_ent_pair(const EntJob *__restrict__ tab)
+{
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.z;
+    const PlaneSpan ps = plane_span(J.info, c);
+    for (int lc = blockIdx.x * 64 + threadIdx.x; lc - (int) threadIdx.x < ps.nch; lc += gridDim.x * 64) {
+        const bool live = lc < ps.nch;
+        const uint32_t jn = live ? J.chunk_join[ps.cbase + lc].x : kNotJoined;
+        const bool joined = jn != kNotJoined;
+        const int m = (int) (jn & 0xffffu), q0 = joined ? (int) (jn >> 16) : kEntChunk; // (q0: a multiple of 4)
+        int g0 = q0 >> 4;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            g0 = min(g0, __shfl_xor(g0, o, 64));
+        }
+        g0 = __builtin_amdgcn_readfirstlane(g0);
+        if (g0 >= kEntChunk / 16) {
+            continue;
+        }
+        const uint4 *src = (const uint4 *) (J.ksym + (size_t) (ps.cbase + (live ? lc : 0)) * kEntChunk);
+        pk16 x = (pk16){(short) m, (short) (m + 1)};
+        uint4 cur = src[g0];
+        for (int gq = g0; gq < kEntChunk / 16; gq++) {
+            const uint4 nxt = src[min(gq + 1, kEntChunk / 16 - 1)];
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const pk16 y = pk_step(x, tm1_splat(w[k >> 2], k & 3));
+                x = 16 * gq + k >= q0 ? y : x;
+            }
+            cur = nxt;
+        }
+        if (live && joined) {
+            J.chunk_join[ps.cbase + lc].y = (uint32_t) (uint16_t) x.x | ((uint32_t) (uint16_t) x.y << 16);
+        }
+    }
+}
+
 // ---- 3 ----------------------------------------------------------------------------------------------------
 // One wavefront per plane (grid = (3, streams)).  A link of the chain is one table lookup, but each waits for the one
 // before it: straight from global memory that is a memory round trip per chunk (~1.4 us under load, 250 chunks a luma
 // plane).  So the wavefront stages the tables of 32 chunks at a time in LDS (one coalesced round trip for 16 KB) and lane
 // 0 follows the chain through them there.
 constexpr int kChainBatch = 32;
-__global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab)
+__global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab, int lanes)
 {
     __shared__ __attribute__((aligned(16))) uint16_t st[kChainBatch * kStates];
+    __shared__ uint2 sj[kChainBatch];
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.x;
     const PlaneSpan ps = plane_span(J.info, c);
@@ -332,11 +407,18 @@ __global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab
         for (int i = lane; i < nb * (kStates * 2 / 16); i += 64) {
             dst[i] = src[i];
         }
+        if (lane < nb) {
+            sj[lane] = lanes ? J.chunk_join[ps.cbase + base + lane] : make_uint2(kNotJoined, 0u);
+        }
         __syncthreads();
         if (lane == 0) {
             for (int k = 0; k < nb; k++) {
                 J.chunk_vk[ps.cbase + base + k] = (uint16_t) vk;
                 vk = st[k * kStates + vk];
+                const uint2 jn = sj[k];
+                if (jn.x != kNotJoined) { // the table holds where the start state stood when all had joined m, m + 1: k_ent_pair took those on
+                    vk = vk == (int) (jn.x & 0xffffu) ? (int) (jn.y & 0xffffu) : (int) (jn.y >> 16);
+                }
                 if (vk >= kStates) {
                     ovf = true;
                     vk = kStates - 1;
@@ -464,6 +546,129 @@ __global__ __launch_bounds__(64) void k_ent_ks(const EntJob *__restrict__ tab, E
     }
 }
 
+// ---- 4 (round 4) ------------------------------------------------------------------------------------------
+// The walk from the chunk's known start state, a lane per chunk: the state each symbol meets goes back over its threshold byte
+// as vk >> 3 (all a Rice parameter needs: k = vk >> (3 + damp); vk <= 1024).  Symbols of the LL prefix (a plane's first nskip)
+// are stepped over.
+__global__ __launch_bounds__(64) void k_ent_walk(const EntJob *__restrict__ tab)
+{
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.z;
+    const PlaneSpan ps = plane_span(J.info, c);
+    const int nskip = J.info[EI_NSKIP + c];
+    for (int lc = blockIdx.x * 64 + threadIdx.x; lc - (int) threadIdx.x < ps.nch; lc += gridDim.x * 64) {
+        const bool live = lc < ps.nch;
+        const int s0 = live ? min(max(nskip - lc * kEntChunk, 0), kEntChunk) : kEntChunk; // first symbol of the chunk that moves the state
+        // groups of 16 symbols: the wavefront starts at g0, and from g1 on every live lane steps every symbol
+        int g0 = live ? s0 >> 4 : kEntChunk / 16, g1 = live ? (s0 + 15) >> 4 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            g0 = min(g0, __shfl_xor(g0, o, 64));
+            g1 = max(g1, __shfl_xor(g1, o, 64));
+        }
+        g0 = __builtin_amdgcn_readfirstlane(g0);
+        g1 = __builtin_amdgcn_readfirstlane(g1);
+        uint4 *buf = (uint4 *) (J.ksym + (size_t) (ps.cbase + (live ? lc : 0)) * kEntChunk);
+        int vk = live ? (int) J.chunk_vk[ps.cbase + lc] : 0;
+        if (g0 >= kEntChunk / 16) {
+            continue;
+        }
+        uint4 cur = buf[g0];
+        for (int gq = g0; gq < kEntChunk / 16; gq++) {
+            const uint4 nxt = buf[min(gq + 1, kEntChunk / 16 - 1)];
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t o4[4];
+            if (gq < g1) { // some lane's prefix ends in here
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int T = (int) (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) << 3);
+                    const int met = vk;
+                    const int nv = vk < T ? vk + 1 : max(vk - 1, 0);
+                    vk = 16 * gq + k >= s0 ? nv : vk;
+                    o4[k >> 2] = (k & 3) ? (o4[k >> 2] | ((uint32_t) (met >> 3) << (8 * (k & 3)))) : (uint32_t) (met >> 3);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int T = (int) (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) << 3);
+                    const int met = vk;
+                    vk = vk < T ? vk + 1 : max(vk - 1, 0);
+                    o4[k >> 2] = (k & 3) ? (o4[k >> 2] | ((uint32_t) (met >> 3) << (8 * (k & 3)))) : (uint32_t) (met >> 3);
+                }
+            }
+            if (live) {
+                buf[gq] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            }
+            cur = nxt;
+        }
+    }
+}
+
+// ---- 4b ---------------------------------------------------------------------------------------------------
+// per chunk, a lane per symbol (four a thread): the Rice parameter of every symbol from the state it met, the chunk's code length
+__global__ __launch_bounds__(256) void k_ent_bits(const EntJob *__restrict__ tab, EntGeom g)
+{
+    __shared__ unsigned long long wsum[4];
+    const EntJob &J = tab[blockIdx.y];
+    const int c = blockIdx.z;
+    const PlaneSpan ps = plane_span(J.info, c);
+    const uint32_t off = (uint32_t) g.qv_off[c];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
+        const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
+        const int s0 = threadIdx.x * 4;
+        unsigned long long bits = 0;
+        bool bad = false;
+        if (s0 < cnt) {
+            const uint32_t st4 = *(const uint32_t *) (J.ksym + (size_t) (ps.cbase + lc) * kEntChunk + s0);
+            const int i0 = first + s0;
+            uint32_t prev_end = i0 > ps.first ? J.pos[i0 - 1] - off + 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (s0 + j < cnt) {
+                    const uint32_t p = J.pos[i0 + j] - off;
+                    const int32_t v = J.val[i0 + j];
+                    const int seg = seg_of(g, c, p);
+                    bits += (unsigned) ueg_len(p - prev_end);
+                    prev_end = p + 1u;
+                    if (seg == 0) {
+                        const uint32_t a = (uint32_t) (v < 0 ? -v : v);
+                        bits += (unsigned) ueg_len(a - 1u) + 1u;
+                    } else {
+                        const uint32_t u = rice_u(v);
+                        int kk = (int) ((st4 >> (8 * j)) & 0xffu) >> ((seg - 1) / 3);
+                        if (kk >= 32) { // a state no real picture reaches (a long run of 16-bit values): the host codes it
+                            bad = true;
+                            kk = 31;
+                        }
+                        bits += (unsigned long long) (u >> kk) + (unsigned) (kk + 1);
+                    }
+                }
+            }
+        }
+        if (bad) {
+            atomicOr(&J.info[EI_FLAGS], 1);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bits += (unsigned long long) __shfl_xor((long long) bits, o, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            wsum[wv] = bits;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bits = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (bits >= (1ull << 24)) { // 16 Kbit per symbol on average: not a picture (and keeps the 32-bit scans below exact)
+                atomicOr(&J.info[EI_FLAGS], 4);
+                bits = 0;
+            }
+            J.chunk_bits[ps.cbase + lc] = (uint32_t) bits;
+        }
+    }
+}
+
 // ---- 5 ----------------------------------------------------------------------------------------------------
 // byte layout of one plane section (hzcc.c:586-613): 32-bit length | SEG(DC) | pad | 24-bit count | codes | pad | 0x55
 __global__ __launch_bounds__(64) void k_ent_layout(const EntJob *__restrict__ tab)
@@ -530,7 +735,7 @@ __global__ __launch_bounds__(256) void k_ent_zero(const EntJob *__restrict__ tab
 // average) ORs every code word into global memory as before.
 constexpr int kEmitWords = 4096;
 
-__global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g, unsigned img_words)
+__global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g, unsigned img_words, int lanes)
 {
     __shared__ unsigned wsum[4];
     __shared__ uint32_t img[kEmitWords + 2];
@@ -593,7 +798,8 @@ __global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab
                     vl[j]++;
                 } else { // adaptive Rice (bs.c:237) with the parameter found by k_ent_ks
                     uint32_t u = rice_u(v);
-                    int kk = J.ksym[first + s0 + j];
+                    // (the parameter k_ent_ks left, or the state >> 3 k_ent_walk left in the chunk-major bytes)
+                    int kk = lanes ? min((int) J.ksym[(size_t) (ps.cbase + lc) * kEntChunk + s0 + j] >> ((seg - 1) / 3), 31) : (int) J.ksym[first + s0 + j];
                     lead[j] = kk < 32 ? u >> kk : 0u;
                     vc[j] = (1ull << kk) | (kk < 32 ? (uint64_t) (u & (uint32_t) ((1ull << kk) - 1ull)) : (uint64_t) u);
                     vl[j] = kk + 1;
@@ -696,18 +902,23 @@ EntGeom ent_geom(const size_t qv_off[4], const ScanGeom scan[3])
 
 void EntBuffers::ensure(size_t nsym_cap, uint32_t out_bytes, uint32_t host_bytes)
 {
-    if (tables) {
+    if (tables && nsym_cap <= this->nsym_cap) {
         return;
     }
+    if (tables) { // grown: the lists of this stream were enlarged (a picture had more symbols than they held)
+        release();
+    }
+    this->nsym_cap = nsym_cap;
     size_t nch = (nsym_cap + kEntChunk - 1) / kEntChunk + 3;
     HIPCHK(dev_alloc((void **) &tables, nch * kStates * sizeof(uint16_t)));
     HIPCHK(dev_alloc((void **) &chunk_vk, nch * sizeof(uint16_t)));
     HIPCHK(dev_alloc((void **) &chunk_bits, nch * sizeof(uint32_t)));
     HIPCHK(dev_alloc((void **) &chunk_off, nch * sizeof(uint32_t)));
-    HIPCHK(dev_alloc((void **) &ksym, nsym_cap));
+    HIPCHK(dev_alloc((void **) &chunk_join, nch * sizeof(uint2)));
+    HIPCHK(dev_alloc((void **) &ksym, nch * kEntChunk)); // (chunk-major: whole chunks)
     out_cap = (out_bytes + 15u) & ~15u;
     HIPCHK(dev_alloc((void **) &out, out_cap + 64));
-    HIPCHK(dev_alloc((void **) &info, 16 * sizeof(int)));
+    HIPCHK(dev_alloc((void **) &info, EI_WORDS * sizeof(int)));
     host_cap = (host_bytes + 15u) & ~15u;
     HIPCHK(hipHostMalloc((void **) &host_out, host_cap, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &host_info, 16 * sizeof(int), hipHostMallocDefault));
@@ -722,6 +933,7 @@ void EntBuffers::release()
     dev_release(chunk_vk);
     dev_release(chunk_bits);
     dev_release(chunk_off);
+    dev_release(chunk_join);
     dev_release(ksym);
     dev_release(out);
     dev_release(info);
@@ -730,17 +942,19 @@ void EntBuffers::release()
     tables = nullptr;
 }
 
-EntJob EntBuffers::job(const uint32_t *pos, const int32_t *val, const int *total, const int32_t *ll) const
+EntJob EntBuffers::job(const uint32_t *pos, const int32_t *val, const int *total, const int32_t *ll, size_t list_cap) const
 {
     EntJob j;
     j.pos = pos;
     j.val = val;
     j.total = total;
+    j.list_cap = (int) (list_cap < nsym_cap ? list_cap : nsym_cap);
     j.ll = ll;
     j.tables = tables;
     j.chunk_vk = chunk_vk;
     j.chunk_bits = chunk_bits;
     j.chunk_off = chunk_off;
+    j.chunk_join = (uint2 *) chunk_join;
     j.ksym = ksym;
     j.out = out;
     j.out_cap = out_cap;
@@ -757,15 +971,26 @@ void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom 
         return;
     }
     const int slots = chunk_slots < 1 ? 1 : chunk_slots;
+    // round 4: the single-trajectory walks run a lane per chunk (k_ent_pair, k_ent_walk); DSV2_ENT_LANES=0: a wavefront per chunk
+    static const int lanes = !(getenv("DSV2_ENT_LANES") && atoi(getenv("DSV2_ENT_LANES")) == 0);
+    const int wslots = (slots + 63) / 64 < 1 ? 1 : (slots + 63) / 64; // workgroups of 64 chunks per (stream, plane)
     DSV2_LAUNCH(k_ent_planes, dim3(n), dim3(64), 0, s, d_jobs, g);
-    DSV2_LAUNCH(k_ent_tables, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
-    DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs);
-    DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(64), 0, s, d_jobs, g);
+    if (lanes) {
+        DSV2_LAUNCH(k_ent_tables<true>, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
+        DSV2_LAUNCH(k_ent_pair, dim3(wslots, n, 3), dim3(64), 0, s, d_jobs);
+        DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs, 1);
+        DSV2_LAUNCH(k_ent_walk, dim3(wslots, n, 3), dim3(64), 0, s, d_jobs);
+        DSV2_LAUNCH(k_ent_bits, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
+    } else {
+        DSV2_LAUNCH(k_ent_tables<false>, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
+        DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs, 0);
+        DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(64), 0, s, d_jobs, g);
+    }
     DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);
     // (tests shrink the image to send chunks down the global-memory path: DSV2_ENT_EMIT_WORDS)
     static const unsigned img_words = getenv("DSV2_ENT_EMIT_WORDS") ? (unsigned) min(atoi(getenv("DSV2_ENT_EMIT_WORDS")), kEmitWords) : (unsigned) kEmitWords;
-    DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g, img_words);
+    DSV2_LAUNCH(k_ent_emit, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g, img_words, lanes);
     DSV2_LAUNCH(k_ent_out, dim3(8, n), dim3(256), 0, s, d_jobs);
     HIPCHK(hipGetLastError());
 }

@@ -39,11 +39,15 @@ struct CompactJob {
     uint32_t *host_pos;
     int32_t *host_val;
     int host_cap;
+    int list_cap; // symbols pos / val hold: the scatter drops what lies beyond (the count in *total still says how many there were)
 };
 
 // ordered stream compaction of nonzero entries of a dense int32 array
 struct Compactor {
-    size_t cap = 0;
+    size_t cap = 0;      // dense values a compaction may span (tile counters)
+    size_t list_cap = 0; // symbols the lists hold (<= cap): sized by need since round 4, see CodecDev::init
+    void ensure_lists(size_t n, size_t symbols); // (ensure(n) = ensure_lists(n, n))
+    void grow_lists(size_t symbols);             // new, larger lists (contents dropped)
     int *tile_count = nullptr, *tile_base = nullptr, *d_total = nullptr;
     uint32_t *d_pos = nullptr;
     int32_t *d_val = nullptr;

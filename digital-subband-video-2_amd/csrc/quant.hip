@@ -664,8 +664,10 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
     for (int k = threadIdx.x; k < total; k += 256) {
         uint32_t p = spos[k];
         int32_t v = sval[k];
-        out_pos[tb + k] = p;
-        out_val[tb + k] = v;
+        if (tb + k < J.list_cap) { // (a picture with more symbols than the lists hold: the host sees it in *total and has it redone)
+            out_pos[tb + k] = p;
+            out_val[tb + k] = v;
+        }
         if (tb + k < host_cap) {
             host_pos[tb + k] = p;
             host_val[tb + k] = v;
@@ -673,21 +675,38 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
     }
 }
 
-void Compactor::ensure(size_t n)
+void Compactor::ensure(size_t n) { ensure_lists(n, n); }
+
+void Compactor::ensure_lists(size_t n, size_t symbols)
 {
     if (n <= cap) {
         return;
     }
     release();
+    symbols = symbols < n ? symbols : n;
     size_t ntiles = (n + kTile - 1) / kTile;
     HIPCHK(dev_alloc((void **) &tile_count, ntiles * sizeof(int)));
     dev_zero(tile_count, ntiles * sizeof(int));
     HIPCHK(dev_alloc((void **) &tile_base, ntiles * sizeof(int)));
     HIPCHK(dev_alloc((void **) &d_total, sizeof(int)));
-    HIPCHK(dev_alloc((void **) &d_pos, n * sizeof(uint32_t)));
-    HIPCHK(dev_alloc((void **) &d_val, n * sizeof(int32_t)));
+    HIPCHK(dev_alloc((void **) &d_pos, symbols * sizeof(uint32_t)));
+    HIPCHK(dev_alloc((void **) &d_val, symbols * sizeof(int32_t)));
     HIPCHK(hipHostMalloc((void **) &h_total, sizeof(int), hipHostMallocDefault));
     cap = n;
+    list_cap = symbols;
+}
+
+void Compactor::grow_lists(size_t symbols)
+{
+    symbols = symbols < cap ? symbols : cap;
+    if (symbols <= list_cap) {
+        return;
+    }
+    dev_release(d_pos); // (inside the instance's arena: stays there unused; outside: freed)
+    dev_release(d_val);
+    HIPCHK(hipMalloc((void **) &d_pos, symbols * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &d_val, symbols * sizeof(int32_t)));
+    list_cap = symbols;
 }
 
 void Compactor::release()
@@ -707,7 +726,7 @@ void Compactor::release()
 CompactJob Compactor::job(const int32_t *qv, size_t n)
 {
     ensure(n);
-    return CompactJob{qv, (int) n, tile_count, tile_base, d_total, d_pos, d_val, nullptr, nullptr, 0};
+    return CompactJob{qv, (int) n, tile_count, tile_base, d_total, d_pos, d_val, nullptr, nullptr, 0, (int) list_cap};
 }
 
 void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)

@@ -52,8 +52,10 @@ print("BAD", bad)
 # code words straight into global memory, 40 mixes both paths (short chunks in LDS, long ones not)
 # DSV2_SIDE_FORCE_FALLBACK: the per-block side information of every P picture is coded by the host (the path a frame takes whose
 # sub-streams do not fit the device coder's images), from the field the device finalised
+# DSV2_ENT_LANES=0: the round-3 form of the state walks (a wavefront per chunk: k_ent_tables<false>, k_ent_ks) instead of a lane
+# per chunk (k_ent_pair, k_ent_walk, k_ent_bits)
 @pytest.mark.parametrize("env", [{"DSV2_GPU_ENTROPY_FORCE_FALLBACK": "1"}, {"DSV2_GPU_ENTROPY": "0"}, {"DSV2_ENT_EMIT_WORDS": "8"},
-                                 {"DSV2_ENT_EMIT_WORDS": "40"}, {"DSV2_SIDE_FORCE_FALLBACK": "1"}])
+                                 {"DSV2_ENT_EMIT_WORDS": "40"}, {"DSV2_SIDE_FORCE_FALLBACK": "1"}, {"DSV2_ENT_LANES": "0"}])
 def test_host_coder_paths(env):
     r = subprocess.run([sys.executable, "-c", _CHILD % os.path.dirname(os.path.abspath(__file__))], env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, text=True, timeout=600)
