@@ -237,6 +237,69 @@ struct __attribute__((packed)) U32u {
     uint32_t v;
 };
 
+// ---- packed 16-bit forms of the sub-pel taps (two pixels an instruction) -------------------------------------------------
+// Exact: a 4-tap sum is at most 20 * 2 * 340 and a blended one 2 * that + 32, inside 16 bits with sign (the reference keeps the
+// intermediate row in int16 as well, bmc.c:702-760).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_of(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t u32_of(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 spl16s(int v) { return (s16x2){(short) v, (short) v}; }
+
+struct SubpelAxis { // one axis of a quarter-pel vector, wave-uniform: tap = k1 (b + c) - k2 (a + d); out = (wf tap + wb b + wc c + 32) >> 6
+    s16x2 k1, k2, wf, wb, wc;
+};
+__device__ __forceinline__ SubpelAxis subpel_axis(int frac, bool soft)
+{
+    SubpelAxis a;
+    a.k1 = spl16s(soft ? 19 : 20); // dsv_internal.h:130-133
+    a.k2 = spl16s(soft ? 3 : 4);
+    a.wf = spl16s(frac == 0 ? 0 : (frac == 2 ? 2 : 1)); // bmc.c:702-715
+    a.wb = spl16s(frac == 0 ? 64 : (frac == 1 ? 32 : 0));
+    a.wc = spl16s(frac == 3 ? 32 : 0);
+    return a;
+}
+__device__ __forceinline__ s16x2 subpel_pk(const SubpelAxis &A, s16x2 a, s16x2 b, s16x2 c, s16x2 d)
+{
+    const s16x2 f = A.k1 * (b + c) - A.k2 * (a + d);
+    return (A.wf * f + A.wb * b + A.wc * c + spl16s(32)) >> spl16s(6);
+}
+
+// residual (MC_SUBTRACT) or reconstruction (MC_RECONSTRUCT) of four pixels, two an instruction: s4 = the four source / residual
+// bytes, p01 / p23 = the prediction (0..255 in 16-bit halves); `flat` = a block whose residual is not transmitted (128)
+template <int MODE>
+__device__ __forceinline__ uint32_t resid4_pk(uint32_t s4, s16x2 p01, s16x2 p23, bool lossless, bool flat, bool eprm, bool plain)
+{
+    const s16x2 s01 = pk_of(__builtin_amdgcn_perm(0u, s4, 0x0c010c00u)), s23 = pk_of(__builtin_amdgcn_perm(0u, s4, 0x0c030c02u));
+    const s16x2 lo = spl16s(0), hi = spl16s(255);
+    s16x2 o01, o23;
+    if (MODE == MC_SUBTRACT) { // residual_px (bmc.c:1015-1050)
+        if (lossless) {
+            o01 = (s01 - p01 + spl16s(128)) & hi;
+            o23 = (s23 - p23 + spl16s(128)) & hi;
+        } else if (flat) {
+            return 0x80808080u;
+        } else if (eprm) {
+            o01 = __builtin_elementwise_min(__builtin_elementwise_max((s01 - p01 + spl16s(256)) >> spl16s(1), lo), hi);
+            o23 = __builtin_elementwise_min(__builtin_elementwise_max((s23 - p23 + spl16s(256)) >> spl16s(1), lo), hi);
+        } else {
+            o01 = __builtin_elementwise_min(__builtin_elementwise_max(s01 - p01 + spl16s(128), lo), hi);
+            o23 = __builtin_elementwise_min(__builtin_elementwise_max(s23 - p23 + spl16s(128), lo), hi);
+        }
+    } else { // recon_px (bmc.c:953-983)
+        if (lossless) {
+            o01 = (p01 + s01 - spl16s(128)) & hi;
+            o23 = (p23 + s23 - spl16s(128)) & hi;
+        } else if (plain) {
+            o01 = __builtin_elementwise_min(__builtin_elementwise_max(p01 + s01 - spl16s(128), lo), hi);
+            o23 = __builtin_elementwise_min(__builtin_elementwise_max(p23 + s23 - spl16s(128), lo), hi);
+        } else {
+            o01 = __builtin_elementwise_min(__builtin_elementwise_max(p01 + (s01 - spl16s(128)) * spl16s(2), lo), hi);
+            o23 = __builtin_elementwise_min(__builtin_elementwise_max(p23 + (s23 - spl16s(128)) * spl16s(2), lo), hi);
+        }
+    }
+    return __builtin_amdgcn_perm(u32_of(o23), u32_of(o01), 0x06040200u);
+}
+
 struct WaveLds {
     alignas(4) uint8_t win[35 * 36];
     int16_t hz[35 * 32];
@@ -344,8 +407,9 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
                 const int k0 = lane, k1 = lane + 64 < total ? lane + 64 : 0;
                 const int r0 = (int) (((unsigned) k0 * ndw_inv) >> 16), c0 = k0 - r0 * ndw;
                 const int r1 = (int) (((unsigned) k1 * ndw_inv) >> 16), c1 = k1 - r1 * ndw;
-                uint32_t d0 = ((gu32_t) (gbase + (ptrdiff_t) r0 * rp.stride + 4 * c0))->v;
-                uint32_t d1 = ((gu32_t) (gbase + (ptrdiff_t) r1 * rp.stride + 4 * c1))->v;
+                // (per-lane offsets in 32 bits from a wave-uniform base: a 24-bit multiply instead of a 64-bit multiply-add)
+                uint32_t d0 = ((gu32_t) (gbase + (__mul24(r0, rp.stride) + 4 * c0)))->v;
+                uint32_t d1 = ((gu32_t) (gbase + (__mul24(r1, rp.stride) + 4 * c1)))->v;
                 if (k0 < total) {
                     win32[r0 * 9 + c0] = d0;
                 }
@@ -359,11 +423,27 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
                 }
             }
             wave_lds_sync();
-            for (int idx = lane; idx < wh * bw; idx += 64) {
-                int r = idx >> lbw, m = idx & (bw - 1);
-                const uint8_t *q = &L.win[r * 36 + m];
-                int a = q[0], b = q[1], cc = q[2], d = q[3];
-                L.hz[r * 32 + m] = (int16_t) qp_blend(hp_tap(a, b, cc, d, soft_x), b, cc, fx);
+            if (CC == 0) { // 16x16: four pixels of a window row per lane (19 rows x 4 groups: two rounds), two pixels an instruction
+                const SubpelAxis AX = subpel_axis(fx, soft_x);
+#pragma unroll
+                for (int rnd = 0; rnd < 2; rnd++) {
+                    const int it = lane + 64 * rnd, r = it >> 2, g = it & 3;
+                    if (rnd == 0 || it < 19 * 4) {
+                        const uint32_t w0 = win32[r * 9 + g], w1 = win32[r * 9 + g + 1]; // bytes B0..B7; output k takes Bk..Bk+3
+                        const s16x2 p01 = pk_of(__builtin_amdgcn_perm(w1, w0, 0x0c010c00u)), p12 = pk_of(__builtin_amdgcn_perm(w1, w0, 0x0c020c01u)),
+                                    p23 = pk_of(__builtin_amdgcn_perm(w1, w0, 0x0c030c02u)), p34 = pk_of(__builtin_amdgcn_perm(w1, w0, 0x0c040c03u)),
+                                    p45 = pk_of(__builtin_amdgcn_perm(w1, w0, 0x0c050c04u)), p56 = pk_of(__builtin_amdgcn_perm(w1, w0, 0x0c060c05u));
+                        const s16x2 o01 = subpel_pk(AX, p01, p12, p23, p34), o23 = subpel_pk(AX, p23, p34, p45, p56);
+                        *(uint2 *) &L.hz[r * 32 + 4 * g] = make_uint2(u32_of(o01), u32_of(o23));
+                    }
+                }
+            } else {
+                for (int idx = lane; idx < wh * bw; idx += 64) {
+                    int r = idx >> lbw, m = idx & (bw - 1);
+                    const uint8_t *q = &L.win[r * 36 + m];
+                    int a = q[0], b = q[1], cc = q[2], d = q[3];
+                    L.hz[r * 32 + m] = (int16_t) qp_blend(hp_tap(a, b, cc, d, soft_x), b, cc, fx);
+                }
             }
             wave_lds_sync();
         } else if (c != 0 && !intra) {
@@ -383,10 +463,10 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
         typedef __attribute__((address_space(1))) uint32_t *gw32_t;
         for (int g = lane; g < ngroups; g += 64) {
             int m = (g & (gw - 1)) * 4, n = g >> lgw;
-            gbr_t r = (gbr_t) rbase + (ptrdiff_t) n * rp.stride + m;
+            gbr_t r = (gbr_t) rbase + (__mul24(n, rp.stride) + m);
             // every load of the group up front (explicit global accesses), so that they share one round trip
             const uint8_t *srcd = (MODE == MC_SUBTRACT && jb.src[c]) ? jb.src[c] : sp.data;
-            const uint32_t sv4 = *(gw32_t) (srcd + (ptrdiff_t) (y + n) * sp.stride + (x + m));
+            const uint32_t sv4 = *(gw32_t) (srcd + ((ptrdiff_t) y * sp.stride + x) + (__mul24(n, sp.stride) + m));
             int pv[4];
             if (intra) {
                 uint32_t v = ((gur_t) r)->v;
@@ -396,6 +476,17 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
                     bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
                     pv[k4] = fill ? (dcq[k] & 0xff) : (int) ((v >> (8 * k4)) & 0xff);
                 }
+            } else if (subpel_luma && CC == 0) { // four rows of the intermediate image, two pixels an instruction
+                const SubpelAxis AY = subpel_axis(fy, soft_y);
+                const uint2 t0 = *(const uint2 *) &L.hz[n * 32 + m], t1 = *(const uint2 *) &L.hz[(n + 1) * 32 + m],
+                            t2 = *(const uint2 *) &L.hz[(n + 2) * 32 + m], t3 = *(const uint2 *) &L.hz[(n + 3) * 32 + m];
+                const s16x2 lo = spl16s(0), hi = spl16s(255);
+                const s16x2 o01 = __builtin_elementwise_min(__builtin_elementwise_max(subpel_pk(AY, pk_of(t0.x), pk_of(t1.x), pk_of(t2.x), pk_of(t3.x)), lo), hi);
+                const s16x2 o23 = __builtin_elementwise_min(__builtin_elementwise_max(subpel_pk(AY, pk_of(t0.y), pk_of(t1.y), pk_of(t2.y), pk_of(t3.y)), lo), hi);
+                pv[0] = o01.x;
+                pv[1] = o01.y;
+                pv[2] = o23.x;
+                pv[3] = o23.y;
             } else if (subpel_luma) {
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {
@@ -419,28 +510,12 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
                     pv[k4] = (int) ((v >> (8 * k4)) & 0xff);
                 }
             }
-            gw32_t dpx = (gw32_t) (dp.data + (ptrdiff_t) (y + n) * dp.stride + (x + m));
-            gw32_t spx = (gw32_t) (sp.data + (ptrdiff_t) (y + n) * sp.stride + (x + m));
-            uint32_t out = 0;
-#pragma unroll
-            for (int k4 = 0; k4 < 4; k4++) {
-                int s1 = (int) ((sv4 >> (8 * k4)) & 0xff), o;
-                if (MODE == MC_SUBTRACT) { // residual_px (bmc.c:1015-1050)
-                    if (p.lossless) {
-                        o = (s1 - pv[k4] + 128) & 0xff;
-                    } else if (!intra && (skip || noxmit)) {
-                        o = 128;
-                    } else {
-                        o = eprm ? clamp_u8((s1 - pv[k4] + 256) >> 1) : clamp_u8(s1 - pv[k4] + 128);
-                    }
-                } else { // recon_px (bmc.c:953-983)
-                    bool plain = !eprm || (!intra && skip);
-                    o = p.lossless ? ((pv[k4] + s1 - 128) & 0xff) : (plain ? clamp_u8(pv[k4] + s1 - 128) : clamp_u8(pv[k4] + (s1 - 128) * 2));
-                }
-                out |= (uint32_t) o << (8 * k4);
-            }
+            gw32_t dpx = (gw32_t) (dp.data + ((ptrdiff_t) y * dp.stride + x) + (__mul24(n, dp.stride) + m));
+            gw32_t spx = (gw32_t) (sp.data + ((ptrdiff_t) y * sp.stride + x) + (__mul24(n, sp.stride) + m));
+            const s16x2 p01 = (s16x2){(short) pv[0], (short) pv[1]}, p23 = (s16x2){(short) pv[2], (short) pv[3]};
+            const uint32_t out = resid4_pk<MODE>(sv4, p01, p23, p.lossless, !intra && (skip || noxmit), eprm, !eprm || (!intra && skip));
             if (MODE == MC_SUBTRACT) {
-                *dpx = (uint32_t) pv[0] | ((uint32_t) pv[1] << 8) | ((uint32_t) pv[2] << 16) | ((uint32_t) pv[3] << 24);
+                *dpx = __builtin_amdgcn_perm(u32_of(p23), u32_of(p01), 0x06040200u);
                 *spx = out;
             } else {
                 *dpx = out;
@@ -486,7 +561,7 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
     typedef const __attribute__((address_space(1))) uint8_t *gbr_t;
     typedef const __attribute__((address_space(1))) U32u *gur_t;
     typedef __attribute__((address_space(1))) uint32_t *gw32_t;
-    gbr_t r = (gbr_t) rbase + (ptrdiff_t) n * rp1.stride + m;
+    gbr_t r = (gbr_t) rbase + (__mul24(n, rp1.stride) + m);
     int dcq[4] = {0, 0, 0, 0};
     if (intra) { // quadrant means of the reference block (bmc.c:845-900); a transmitted DC is luma only
         const uint32_t v = ((gur_t) r)->v;
@@ -522,7 +597,7 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
     if (MODE == MC_SUBTRACT && jb.src[1]) {
         srcd = v_plane ? jb.src[2] : jb.src[1];
     }
-    const uint32_t sv4 = *(gw32_t) (srcd + (ptrdiff_t) (y + n) * sp1.stride + (x + m));
+    const uint32_t sv4 = *(gw32_t) (srcd + ((ptrdiff_t) y * sp1.stride + x) + (__mul24(n, sp1.stride) + m));
     int pv[4];
     if (intra) {
         const uint32_t v = ((gur_t) r)->v;
@@ -533,15 +608,24 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
             pv[k4] = fill ? (dcq[k] & 0xff) : (int) ((v >> (8 * k4)) & 0xff);
         }
     } else if (chroma_frac) {
+        // (f0 a + f1 a' + f2 b + f3 b' + 32) >> 6 with f0 + .. + f3 = 64: at most 64 * 255 + 32, two pixels an instruction
         gbr_t r2 = r + rp1.stride;
         const uint32_t va = ((gur_t) r)->v, vb = ((gur_t) r2)->v; // five pixels of two rows: a dword and a byte each
-        const int a4 = r[4], b4 = r2[4];
-        const int a0 = va & 0xff, a1 = (va >> 8) & 0xff, a2 = (va >> 16) & 0xff, a3 = va >> 24;
-        const int b0 = vb & 0xff, b1 = (vb >> 8) & 0xff, b2 = (vb >> 16) & 0xff, b3 = vb >> 24;
-        pv[0] = ((f0 * a0 + f1 * a1 + f2 * b0 + f3 * b1 + af) >> sf) & 0xff;
-        pv[1] = ((f0 * a1 + f1 * a2 + f2 * b1 + f3 * b2 + af) >> sf) & 0xff;
-        pv[2] = ((f0 * a2 + f1 * a3 + f2 * b2 + f3 * b3 + af) >> sf) & 0xff;
-        pv[3] = ((f0 * a3 + f1 * a4 + f2 * b3 + f3 * b4 + af) >> sf) & 0xff;
+        const uint32_t a4 = r[4], b4 = r2[4];
+        typedef unsigned short q16x2 __attribute__((ext_vector_type(2)));
+        auto uq = [](uint32_t v) { return __builtin_bit_cast(q16x2, v); };
+        const q16x2 a01 = uq(__builtin_amdgcn_perm(a4, va, 0x0c010c00u)), a12 = uq(__builtin_amdgcn_perm(a4, va, 0x0c020c01u)),
+                    a23 = uq(__builtin_amdgcn_perm(a4, va, 0x0c030c02u)), a34 = uq(__builtin_amdgcn_perm(a4, va, 0x0c040c03u));
+        const q16x2 b01 = uq(__builtin_amdgcn_perm(b4, vb, 0x0c010c00u)), b12 = uq(__builtin_amdgcn_perm(b4, vb, 0x0c020c01u)),
+                    b23 = uq(__builtin_amdgcn_perm(b4, vb, 0x0c030c02u)), b34 = uq(__builtin_amdgcn_perm(b4, vb, 0x0c040c03u));
+        const q16x2 F0 = (q16x2){(unsigned short) f0, (unsigned short) f0}, F1 = (q16x2){(unsigned short) f1, (unsigned short) f1},
+                    F2 = (q16x2){(unsigned short) f2, (unsigned short) f2}, F3 = (q16x2){(unsigned short) f3, (unsigned short) f3},
+                    AF = (q16x2){(unsigned short) af, (unsigned short) af}, SH = (q16x2){(unsigned short) sf, (unsigned short) sf};
+        const q16x2 o01 = (F0 * a01 + F1 * a12 + F2 * b01 + F3 * b12 + AF) >> SH, o23 = (F0 * a23 + F1 * a34 + F2 * b23 + F3 * b34 + AF) >> SH;
+        pv[0] = o01.x;
+        pv[1] = o01.y;
+        pv[2] = o23.x;
+        pv[3] = o23.y;
     } else {
         const uint32_t v = ((gur_t) r)->v;
 #pragma unroll
@@ -549,29 +633,12 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
             pv[k4] = (int) ((v >> (8 * k4)) & 0xff);
         }
     }
-    gw32_t dpx = (gw32_t) (ddata + (ptrdiff_t) (y + n) * dp1.stride + (x + m));
-    gw32_t spx = (gw32_t) (sdata + (ptrdiff_t) (y + n) * sp1.stride + (x + m));
-    uint32_t out = 0;
-#pragma unroll
-    for (int k4 = 0; k4 < 4; k4++) {
-        const int s1 = (int) ((sv4 >> (8 * k4)) & 0xff);
-        int o;
-        if (MODE == MC_SUBTRACT) { // residual_px (bmc.c:1015-1050)
-            if (p.lossless) {
-                o = (s1 - pv[k4] + 128) & 0xff;
-            } else if (!intra && (skip || noxmit)) {
-                o = 128;
-            } else {
-                o = eprm ? clamp_u8((s1 - pv[k4] + 256) >> 1) : clamp_u8(s1 - pv[k4] + 128);
-            }
-        } else { // recon_px (bmc.c:953-983)
-            const bool plain = !eprm || (!intra && skip);
-            o = p.lossless ? ((pv[k4] + s1 - 128) & 0xff) : (plain ? clamp_u8(pv[k4] + s1 - 128) : clamp_u8(pv[k4] + (s1 - 128) * 2));
-        }
-        out |= (uint32_t) o << (8 * k4);
-    }
+    gw32_t dpx = (gw32_t) (ddata + ((ptrdiff_t) y * dp1.stride + x) + (__mul24(n, dp1.stride) + m));
+    gw32_t spx = (gw32_t) (sdata + ((ptrdiff_t) y * sp1.stride + x) + (__mul24(n, sp1.stride) + m));
+    const s16x2 p01 = (s16x2){(short) pv[0], (short) pv[1]}, p23 = (s16x2){(short) pv[2], (short) pv[3]};
+    const uint32_t out = resid4_pk<MODE>(sv4, p01, p23, p.lossless, !intra && (skip || noxmit), eprm, !eprm || (!intra && skip));
     if (MODE == MC_SUBTRACT) {
-        *dpx = (uint32_t) pv[0] | ((uint32_t) pv[1] << 8) | ((uint32_t) pv[2] << 16) | ((uint32_t) pv[3] << 24);
+        *dpx = __builtin_amdgcn_perm(u32_of(p23), u32_of(p01), 0x06040200u);
         *spx = out;
     } else {
         *dpx = out;
@@ -602,7 +669,9 @@ template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJ
 {
     __shared__ WaveLds L[4];
     const McJob &jb = tab[blockIdx.z];
-    int w = threadIdx.x >> 6;
+    // (the wavefront's index told to the compiler as wave-uniform: the block's origin, its vector and every base address
+    // then live in scalar registers)
+    const int w = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     int i = (int) blockIdx.x * 4 + w, j = blockIdx.y;
     if (i < jb.p.nbh) {
         predict_block_wave<MODE>(jb, i, j, L[w]);
