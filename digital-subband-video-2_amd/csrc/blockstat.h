@@ -90,6 +90,24 @@ __device__ __forceinline__ unsigned isqrt_u32(unsigned n)
     return r;
 }
 
+// idx -> (x, y) in a w-wide block, for the wave-cooperative loops below: block widths are powers of two except where the
+// picture's edge clips one, and a 32-bit division costs some twenty instructions per pixel
+struct RowSplit {
+    int w, sh;
+    bool p2;
+    __device__ __forceinline__ explicit RowSplit(int w_) : w(w_), sh(31 - __builtin_clz((unsigned) (w_ | 1))), p2((w_ & (w_ - 1)) == 0) {}
+    __device__ __forceinline__ void operator()(int idx, int &x, int &y) const
+    {
+        if (p2) {
+            x = idx & (w - 1);
+            y = idx >> sh;
+        } else {
+            y = idx / w;
+            x = idx - y * w;
+        }
+    }
+};
+
 struct Grad {
     unsigned sh, sv;
     int sum;
@@ -100,8 +118,10 @@ __device__ __forceinline__ Grad ws_gradients(const uint8_t *a, int as, int w, in
     int lane = threadIdx.x & 63;
     unsigned sh = 0, sv = 0;
     int s = 0;
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        int x = idx % w, y = idx / w;
+        int x, y;
+        split(idx, x, y);
         const uint8_t *p = a + (ptrdiff_t) y * as + x;
         int v = p[0];
         s += v;
@@ -122,8 +142,11 @@ __device__ __forceinline__ Grad ws_gradients(const uint8_t *a, int as, int w, in
 __device__ __forceinline__ int ws_abs_dev(const uint8_t *a, int as, int w, int h, int mean)
 {
     int lane = threadIdx.x & 63, v = 0;
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        v += abs((int) a[(ptrdiff_t) (idx / w) * as + (idx % w)] - mean);
+        int x, y;
+        split(idx, x, y);
+        v += abs((int) a[(ptrdiff_t) y * as + x] - mean);
     }
     return wave_sum(v);
 }
@@ -131,8 +154,11 @@ __device__ __forceinline__ int ws_abs_dev(const uint8_t *a, int as, int w, int h
 __device__ __forceinline__ int ws_block_sum(const uint8_t *a, int as, int w, int h)
 {
     int lane = threadIdx.x & 63, v = 0;
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        v += a[(ptrdiff_t) (idx / w) * as + (idx % w)];
+        int x, y;
+        split(idx, x, y);
+        v += a[(ptrdiff_t) y * as + x];
     }
     return wave_sum(v);
 }
@@ -166,8 +192,10 @@ __device__ __forceinline__ int ws_quant_tex(const uint8_t *a, int as, int w, int
 {
     int lane = threadIdx.x & 63;
     unsigned sh = 0, sv = 0;
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        int x = idx % w, y = idx / w;
+        int x, y;
+        split(idx, x, y);
         const uint8_t *p = a + (ptrdiff_t) y * as + x;
         int px = p[0] >> 4;
         int right = (x + 1 < w) ? (p[1] >> 4) : px;
@@ -193,8 +221,11 @@ __device__ __forceinline__ unsigned ws_hist_var(const uint8_t *a, int as, int w,
         hist[lane] = 0;
     }
     __syncthreads();
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        int hi = (int) ((unsigned) a[(ptrdiff_t) (idx / w) * as + (idx % w)] * q16 >> 16);
+        int x, y;
+        split(idx, x, y);
+        int hi = (int) ((unsigned) a[(ptrdiff_t) y * as + x] * q16 >> 16);
         atomicAdd(&hist[min(max(hi, 0), 15)], 1);
     }
     __syncthreads();
@@ -219,8 +250,11 @@ __device__ __forceinline__ int ws_peaks(const uint8_t *a, int as, int w, int h, 
     }
     __syncthreads();
     int w2 = w / 2, h2 = h / 2;
+    const RowSplit split(w2);
     for (int idx = lane; idx < w2 * h2; idx += 64) {
-        const uint8_t *p = a + (ptrdiff_t) (2 * (idx / w2)) * as + 2 * (idx % w2);
+        int x, y;
+        split(idx, x, y);
+        const uint8_t *p = a + (ptrdiff_t) (2 * y) * as + 2 * x;
         int ds = (int) ((unsigned) (p[0] + p[1] + p[as] + p[as + 1] + 2) >> 2);
         int hi = ds * q16 >> 16;
         atomicAdd(&hist[min(hi, 15)], 1);

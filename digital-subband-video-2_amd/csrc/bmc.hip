@@ -2147,7 +2147,7 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
 // chip -- and the launch reserves that for the chroma workgroups too: with the plane as the SLOW grid index all luma sweeps of
 // a 192-picture launch (576 workgroups) are dispatched first and start at once; the short chroma sweeps fill in behind them.
 // (Plane-major order had a fifth of the luma sweeps start when the first chroma sweeps had finished.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
+__device__ __forceinline__ void inter_filters_b_body(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
@@ -2203,6 +2203,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     } else {
         sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
     }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inter_filters_b(const McJob *__restrict__ tab, unsigned lds_bytes)
+{
+    inter_filters_b_body(tab, lds_bytes);
+}
+// 512 threads, still a lane per cell: pictures so wide that more than 256 cell rows are in flight on a front (3840 pixels: 488)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inter_filters_bw(const McJob *__restrict__ tab, unsigned lds_bytes)
+{
+    inter_filters_b_body(tab, lds_bytes);
 }
 
 // the same with a lane pair per luma cell: 512 threads (the chroma workgroups use all of them as block rows)
@@ -2283,7 +2293,7 @@ __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes)
+__device__ __forceinline__ void intra_filter_b_body(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
@@ -2303,6 +2313,9 @@ __global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict_
             [](int, int) {}, []() {});
     }
 }
+
+__global__ __launch_bounds__(256) void k_intra_filter_b(const McJob *__restrict__ tab, unsigned lds_bytes) { intra_filter_b_body(tab, lds_bytes); }
+__global__ __launch_bounds__(512) void k_intra_filter_bw(const McJob *__restrict__ tab, unsigned lds_bytes) { intra_filter_b_body(tab, lds_bytes); }
 
 // the batched filters where the plane-resident ring does not fit (width not a multiple of 4, more cell rows in flight than
 // threads, taller than the LDS): the same fronts through global memory; grid = (n jobs, 3 planes) / (n jobs)
@@ -2453,7 +2466,9 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
 
 // dynamic LDS of the plane-resident luma sweep: one 64-byte ring per pixel row + guard rows (0 = the ring does not fit this
 // picture: the global-memory kernels run).  Host mirror of what the ring sweeps assume (ring_eligible).
-static unsigned ring_lds_bytes(int luma_w, int luma_h)
+// bytes of LDS of the plane-resident sweep, or 0 where it does not fit; *wide: more than 256 cell rows are in flight on a front
+// (the 512-thread lane-per-cell kernels; no lane-pair form for those)
+static unsigned ring_lds_bytes(int luma_w, int luma_h, bool *wide = nullptr)
 {
     // The ring needs more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU): asked for once, only when the ring
     // is selected at all, and a device that refuses (64 KB parts) gets the global-memory kernels instead of an abort.
@@ -2461,7 +2476,8 @@ static unsigned ring_lds_bytes(int luma_w, int luma_h)
         if (getenv("DSV2_FILTER_RING") && atoi(getenv("DSV2_FILTER_RING")) == 0) {
             return 0;
         }
-        const void *ks[4] = {(const void *) k_inter_filters_b, (const void *) k_intra_filter_b, (const void *) k_inter_filters_b2, (const void *) k_intra_filter_b2};
+        const void *ks[6] = {(const void *) k_inter_filters_b, (const void *) k_intra_filter_b, (const void *) k_inter_filters_b2, (const void *) k_intra_filter_b2,
+                             (const void *) k_inter_filters_bw, (const void *) k_intra_filter_bw};
         for (const void *k : ks) {
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
                 (void) hipGetLastError();
@@ -2471,7 +2487,11 @@ static unsigned ring_lds_bytes(int luma_w, int luma_h)
         return 1;
     }();
     size_t b = (size_t) (luma_h + RingView::kGuardRows) * 64;
-    const bool fits = on && (luma_w & 3) == 0 && (luma_h & 3) == 0 && luma_w >= 64 && b <= 150 * 1024 && (luma_w / 4 + 14) / 2 + 1 <= 256;
+    const int rows_in_flight = (luma_w / 4 + 14) / 2 + 1;
+    const bool fits = on && (luma_w & 3) == 0 && (luma_h & 3) == 0 && luma_w >= 64 && b <= 150 * 1024 && rows_in_flight <= 512;
+    if (wide) {
+        *wide = rows_in_flight > 256;
+    }
     return fits ? (unsigned) b : 0u;
 }
 
@@ -2498,9 +2518,12 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
     if (n > 0) {
         DSV2_LAUNCH(k_reconstruct_w, dim3((nbh * blk_w / 16 + 63) / 64, (nbv * blk_h + 3) / 4, 3 * n), dim3(256), 0, s, d_tab);
         if (any_filter) {
-            const unsigned lds = ring_lds_bytes(luma_w, luma_h);
+            bool wide = false;
+            const unsigned lds = ring_lds_bytes(luma_w, luma_h, &wide);
             if (!lds) {
                 DSV2_LAUNCH(k_inter_filters_g, dim3(n, 3), dim3(256), 0, s, d_tab);
+            } else if (wide) {
+                DSV2_LAUNCH(k_inter_filters_bw, dim3(n, 3), dim3(512), lds, s, d_tab, lds);
             } else if (filter_pair(n)) {
                 DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), lds, s, d_tab, lds);
             } else {
@@ -2516,9 +2539,12 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
     if (n > 0) {
         DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
         if (any_filter) {
-            const unsigned lds = ring_lds_bytes(luma_w, luma_h);
+            bool wide = false;
+            const unsigned lds = ring_lds_bytes(luma_w, luma_h, &wide);
             if (!lds) {
                 DSV2_LAUNCH(k_inter_filters_g, dim3(n, 3), dim3(256), 0, s, d_filt);
+            } else if (wide) {
+                DSV2_LAUNCH(k_inter_filters_bw, dim3(n, 3), dim3(512), lds, s, d_filt, lds);
             } else if (filter_pair(n)) {
                 DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), lds, s, d_filt, lds);
             } else {
@@ -2531,9 +2557,12 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_w, int luma_h)
 {
     if (n > 0) {
-        const unsigned lds = ring_lds_bytes(luma_w, luma_h);
+        bool wide = false;
+        const unsigned lds = ring_lds_bytes(luma_w, luma_h, &wide);
         if (!lds) {
             DSV2_LAUNCH(k_intra_filter_g, dim3(n), dim3(256), 0, s, d_tab);
+        } else if (wide) {
+            DSV2_LAUNCH(k_intra_filter_bw, dim3(n), dim3(512), lds, s, d_tab, lds);
         } else if (filter_pair(n)) {
             DSV2_LAUNCH(k_intra_filter_b2, dim3(n), dim3(512), lds, s, d_tab, lds);
         } else {

@@ -2100,6 +2100,8 @@ void enc_batch(Job *jobs, int n)
                 dv.ent.ensure(dv.comp.list_cap, 4u << 20, 1u << 20);
             }
             DFrame &tmp = sc.redo_frame(dv.format, dv.w, dv.h);
+            static_assert(sizeof(McJob) + sizeof(CopyJob) + 3 * sizeof(PlaneJob) + sizeof(CompactJob) + 6 * 16 <= 4096,
+                          "a redone picture's tables outgrow the 4 KB a stream BatchScratch::ensure sets aside for them");
             const McJob *d_m2;
             McJob *h_m2 = sc.tabs.take<McJob>(1, &d_m2);
             const CopyJob *d_c2;

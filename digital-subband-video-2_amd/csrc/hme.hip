@@ -164,8 +164,10 @@ __device__ __forceinline__ unsigned ws_umetr(const uint8_t *a, int as, const uin
 {
     int lane = threadIdx.x & 63, qw = w / 2, qh = h / 2;
     unsigned acc = 0;
+    const RowSplit split(qw);
     for (int q = lane; q < qw * qh; q += 64) {
-        int i = q % qw, j = q / qw;
+        int i, j;
+        split(q, i, j);
         const uint8_t *p = a + (ptrdiff_t) (2 * j) * as + 2 * i, *r = b + (ptrdiff_t) (2 * j) * bs + 2 * i;
         acc += quad_metric(p[0], p[1], p[as], p[as + 1], r[0], r[1], r[bs], r[bs + 1], psy);
     }
@@ -193,8 +195,10 @@ __device__ __forceinline__ unsigned ws_sse(const uint8_t *a, int as, const uint8
     }
     int lane = threadIdx.x & 63;
     unsigned acc = 0;
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        int x = idx % w, y = idx / w;
+        int x, y;
+        split(idx, x, y);
         int d = (int) a[(ptrdiff_t) y * as + x] - (int) b[(ptrdiff_t) y * bs + x];
         acc += (unsigned) (d * d);
     }
@@ -527,6 +531,63 @@ __device__ __forceinline__ int qsample(const uint8_t *h, int X, int Y) // hme.c:
     }
 }
 
+// ---- staging for the general block routine (round 4) ---------------------------------------------------------------------
+// The routine below is the reference's block loop with wave-cooperative primitives that walk a block pixel by pixel: on
+// global memory that is a memory round trip per 64 pixels (16 for one squared error of a 32 x 32 block, some 250 per block).
+// Every operand block is therefore copied into LDS first -- all its dwords in ONE round trip -- and the same primitives run
+// on the copies.  Blocks are at most 32 x 32 (dsv_encoder.c:1203-1211; checked by hme_run_batch).
+struct GenLds {
+    alignas(4) uint8_t src[32 * 32];   // the source block, pitch 32
+    alignas(4) uint8_t ref[34 * 36];   // a reference block, or one with a one-pixel rim (sub-pel search), pitch 36
+    alignas(4) uint8_t aux[32 * 32];   // the sub-pel search's source window; the reference block at zero motion (skip test)
+    alignas(4) uint8_t cs[2][32 * 32]; // chroma: source,
+    alignas(4) uint8_t cr[2][32 * 32]; //         reference at the vector,
+    alignas(4) uint8_t cz[2][32 * 32]; //         reference at zero motion
+    // the candidate list and the parent vectors (wave-uniform values: every lane stores the same ones); as arrays of a lane's
+    // own they were indexed at run time and lived in scratch memory -- the library's only scratch
+    Vec2 cands[40], lc[16], inl[16];
+};
+
+template <int PITCH> __device__ __forceinline__ void stage_block(uint8_t *dst, const uint8_t *g, int gs, int w, int h)
+{
+    typedef const __attribute__((address_space(1))) uint8_t *gb_t;
+    typedef const __attribute__((address_space(1))) U32u *gu32_t;
+    const int lane = threadIdx.x & 63;
+    const int nd = w >> 2, tail = w & 3, per_row = nd + (tail ? 1 : 0), total = per_row * h; // <= 9 x 34 dwords: five a lane
+    const unsigned inv = (65536u + (unsigned) per_row - 1u) / (unsigned) per_row;             // idx / per_row for idx < 4096
+    __syncthreads(); // the previous tenant's readers are done
+    uint32_t v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int idx = lane + 64 * k;
+        v[k] = 0;
+        if (idx < total) {
+            const int r = (int) (((unsigned) idx * inv) >> 16), cc = idx - r * per_row;
+            gb_t q = (gb_t) g + (ptrdiff_t) r * gs + 4 * cc;
+            if (cc < nd) {
+                v[k] = ((gu32_t) q)->v;
+            } else { // a row's last one to three pixels: nothing is read beyond the block
+                v[k] = q[0];
+                if (tail > 1) {
+                    v[k] |= (uint32_t) q[1] << 8;
+                }
+                if (tail > 2) {
+                    v[k] |= (uint32_t) q[2] << 16;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int idx = lane + 64 * k;
+        if (idx < total) {
+            const int r = (int) (((unsigned) idx * inv) >> 16), cc = idx - r * per_row;
+            *(uint32_t *) (dst + r * PITCH + 4 * cc) = v[k];
+        }
+    }
+    __syncthreads();
+}
+
 // one quad per lane: the 16x16 source window against the block sampled at quarter-pel offset (tx, ty) (hme.c:244)
 __device__ __forceinline__ unsigned ws_qpsad(const uint8_t *a, int as, const uint8_t *h, int tx, int ty, const Psy &psy)
 {
@@ -539,7 +600,7 @@ __device__ __forceinline__ unsigned ws_qpsad(const uint8_t *a, int as, const uin
     return metric_return(wave_sum(acc), 16, 16);
 }
 
-__device__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely,
+__device__ __forceinline__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, GenLds &G, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely,
                                 unsigned best, int bx, int by, int bw, int bh, const Psy &psy) // hme.c:1051
 {
     const DPlane &src = c.src[0], &ref = c.ref[0];
@@ -550,14 +611,20 @@ __device__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, const CostCtx &
     unsigned yarea = (unsigned) (bw * bh);
     unsigned quad[4];
     const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
+    // the four neighbours of the full-pel position out of ONE staged copy of the block with a one-pixel rim (the caller has
+    // checked a rim of four: invalid_block(.., 4)); the source block sits in G.src
+    stage_block<36>(G.ref, at(ref, bx + fpelx - 1, by + fpely - 1), ref.stride, bw + 2, bh + 2);
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        quad[n] = ws_sse(at(src, bx, by), src.stride, at(ref, bx + fpelx + dxs[n], by + fpely + dys[n]), ref.stride, bw, bh);
+        quad[n] = ws_sse(G.src, 32, G.ref + (1 + dys[n]) * 36 + (1 + dxs[n]), 36, bw, bh);
     }
     int area_ratio = (int) (8 * 256 / yarea), iarea_ratio = (int) (8 * yarea / 256);
     best = best * (unsigned) area_ratio >> 3;
     int xx = bx + ((bw >> 1) - 8), yy = by + ((bh >> 1) - 8);
-    const uint8_t *srcw = at(src, xx, yy);
+    // (the 16 x 16 source window is centred on the block and reaches beyond a clipped one: staged from the plane, not from G.src)
+    stage_block<32>(G.aux, at(src, xx, yy), src.stride, 16, 16);
+    const uint8_t *srcw = G.aux;
+    const int srcw_stride = 32;
     build_hpel(lds, load_hpel_window(at(ref, xx + fpelx - 1, yy + fpely - 1), ref.stride));
 
     int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
@@ -592,7 +659,7 @@ __device__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, const CostCtx &
         if (((t0 | t1) & 1) && c.effort < 8) {
             continue;
         }
-        unsigned score = ws_qpsad(srcw, src.stride, lds.h, t0, t1, psy);
+        unsigned score = ws_qpsad(srcw, srcw_stride, lds.h, t0, t1, psy);
         score += (unsigned) mv_cost(cc, fpelx * 4 + t0, fpely * 4 + t1, 0);
         if (best > score) {
             best = score;
@@ -607,46 +674,50 @@ __device__ unsigned subpixel_me(const HmeDev &c, SubpelLds &lds, const CostCtx &
 }
 
 // ---- mode decision helpers -----------------------------------------------------------------------
-__device__ void ws_yuv_max_subblock_err(unsigned out[3], const HmeDev &c, int bx, int by, int brx, int bry, int bw, int bh, int cbx,
-                                        int cby, int cbrx, int cbry, int cbw, int cbh, const Psy &psy) // hme.c:369
+// (operands: staged copies -- luma source / reference, and the two chroma planes' source / reference blocks, pitch 32 unless said)
+__device__ __forceinline__ void ws_yuv_max_subblock_err(unsigned out[3], const uint8_t *ys, int yss, const uint8_t *yr, int yrs, int bw, int bh,
+                                        const uint8_t (*cs)[32 * 32], const uint8_t (*cr)[32 * 32], int cbw, int cbh, const Psy &psy) // hme.c:369
 {
-    for (int z = 0; z < 3; z++) {
+#pragma unroll
+    for (int z = 0; z < 3; z++) { // (unrolled: out[z] indexed at run time would put the caller's array in scratch memory)
         const uint8_t *sp, *rp;
         int ss, rs, w, h;
         if (z == 0) {
-            sp = at(c.src[0], bx, by);
-            ss = c.src[0].stride;
-            rp = at(c.ref[0], brx, bry);
-            rs = c.ref[0].stride;
+            sp = ys;
+            ss = yss;
+            rp = yr;
+            rs = yrs;
             w = bw / 2;
             h = bh / 2;
         } else {
-            sp = at(c.srcc[z - 1], cbx, cby);
-            ss = c.srcc[z - 1].stride;
-            rp = at(c.refc[z - 1], cbrx, cbry);
-            rs = c.refc[z - 1].stride;
+            sp = cs[z - 1];
+            ss = 32;
+            rp = cr[z - 1];
+            rs = 32;
             w = cbw / 2;
             h = cbh / 2;
         }
         unsigned mx = 0;
         for (int k = 0; k < 4; k++) {
             int f = (k & 1) ? w : 0, g = (k & 2) ? h : 0;
-            unsigned e = ws_umetr(sp + f + (ptrdiff_t) g * ss, ss, rp + f + (ptrdiff_t) g * rs, rs, w, h, psy);
+            unsigned e = ws_umetr(sp + f + g * ss, ss, rp + f + g * rs, rs, w, h, psy);
             mx = max(mx, e);
         }
         out[z] = mx;
     }
 }
 
-__device__ void ws_calc_eprm(const uint8_t *src, int ss, const uint8_t *mvr, int rs, int avg_src, int avg_ref, int w, int h, int &eprmi,
+__device__ __forceinline__ void ws_calc_eprm(const uint8_t *src, int ss, const uint8_t *mvr, int rs, int avg_src, int avg_ref, int w, int h, int &eprmi,
                              int &eprmd, int &eprmr) // hme.c:452
 {
     int lane = threadIdx.x & 63;
     int ci = 0, cd = 0, cr = 0;
     avg_src -= 128;
     avg_ref -= 128;
+    const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
-        int x = idx % w, y = idx / w;
+        int x, y;
+        split(idx, x, y);
         int s = src[(ptrdiff_t) y * ss + x];
         cr |= ((s - (int) mvr[(ptrdiff_t) y * rs + x]) + 128) & ~0xff;
         ci |= (s - avg_ref) & ~0xff;
@@ -657,13 +728,15 @@ __device__ void ws_calc_eprm(const uint8_t *src, int ss, const uint8_t *mvr, int
     eprmr = __any(cr != 0) ? 1 : 0;
 }
 
-__device__ void ws_err_intra(const uint8_t *a, int as, const uint8_t *b, int bs, int avg_sb, int avg_src, int w, int h,
+__device__ __forceinline__ void ws_err_intra(const uint8_t *a, int as, const uint8_t *b, int bs, int avg_sb, int avg_src, int w, int h,
                              unsigned &intra_err, unsigned &intrasrc_err, unsigned &inter_err, const Psy &psy, int ratio) // hme.c:839
 {
     int lane = threadIdx.x & 63, qw = w / 2, qh = h / 2;
     unsigned isb = 0, isrc = 0, inter = 0;
+    const RowSplit split(qw);
     for (int q = lane; q < qw * qh; q += 64) {
-        int i = q % qw, j = q / qw;
+        int i, j;
+        split(q, i, j);
         const uint8_t *p = a + (ptrdiff_t) (2 * j) * as + 2 * i, *r = b + (ptrdiff_t) (2 * j) * bs + 2 * i;
         int a1 = p[0], a2 = p[1], a3 = p[as], a4 = p[as + 1];
         int b1 = r[0], b2 = r[1], b3 = r[bs], b4 = r[bs + 1];
@@ -690,7 +763,7 @@ __device__ void ws_err_intra(const uint8_t *a, int as, const uint8_t *b, int bs,
 
 __device__ __forceinline__ int ws_plane_avg(const DPlane &p, int x, int y, int w, int h) { return ws_block_avg(at(p, x, y), p.stride, w, h); }
 
-__device__ void test_subblock_intra_y(const HmeDev &c, const DSV_MV *refmv, DSV_MV &mv, const uint8_t *srcd, int ss, const uint8_t *refd,
+__device__ __forceinline__ void test_subblock_intra_y(const HmeDev &c, const DSV_MV *refmv, DSV_MV &mv, const uint8_t *srcd, int ss, const uint8_t *refd,
                                       int rs, int detail_src, int avg_src, int neidif, unsigned ratio, int bw, int bh) // hme.c:891
 {
     int sbw = bw / 2, sbh = bh / 2, nsub = 0;
@@ -738,8 +811,8 @@ __device__ void test_subblock_intra_y(const HmeDev &c, const DSV_MV *refmv, DSV_
     }
 }
 
-__device__ void test_subblock_intra_c(const HmeDev &c, DSV_MV &mv, unsigned mad, unsigned detail_src, unsigned avg_src, int cbx, int cby,
-                                      int cbmx, int cbmy, int cbw, int cbh) // hme.c:987
+__device__ __forceinline__ void test_subblock_intra_c(const HmeDev &c, DSV_MV &mv, unsigned mad, unsigned detail_src, unsigned avg_src,
+                                      const uint8_t (*cs)[32 * 32], const uint8_t (*cr)[32 * 32], int cbw, int cbh) // hme.c:987
 {
     int sbw = cbw / 2, sbh = cbh / 2;
     if (c.effort < 6) {
@@ -755,10 +828,10 @@ __device__ void test_subblock_intra_c(const HmeDev &c, DSV_MV &mv, unsigned mad,
         if (mv.submask & (1 << k)) {
             continue;
         }
-        int us = ws_plane_avg(c.srcc[0], cbx + f, cby + g, sbw, sbh);
-        int vs = ws_plane_avg(c.srcc[1], cbx + f, cby + g, sbw, sbh);
-        int um = ws_plane_avg(c.refc[0], cbmx + f, cbmy + g, sbw, sbh);
-        int vm = ws_plane_avg(c.refc[1], cbmx + f, cbmy + g, sbw, sbh);
+        int us = ws_block_avg(cs[0] + f + g * 32, 32, sbw, sbh);
+        int vs = ws_block_avg(cs[1] + f + g * 32, 32, sbw, sbh);
+        int um = ws_block_avg(cr[0] + f + g * 32, 32, sbw, sbh);
+        int vm = ws_block_avg(cr[1] + f + g * 32, 32, sbw, sbh);
         unsigned dif = (unsigned) (SQR(us - um) + SQR(vs - vm)) * avg_ramp >> 8;
         if (dif > thr) {
             mv.submask |= (uint8_t) (1 << k);
@@ -784,7 +857,8 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     const DSV_MV *parent = level < c.pyr_levels ? c.mvf[level + 1] : nullptr;
     DSV_MV *out = &mvf[i + j * nxb];
     DSV_MV mv = {};
-    Vec2 cands[MAXC];
+    __shared__ GenLds G;
+    Vec2 *cands = G.cands;
     int n = 0;
 
     int bx = (i * y_w) >> level, by = (j * y_h) >> level;
@@ -795,20 +869,23 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         return;
     }
     int bw = min(src.w - bx, y_w), bh = min(src.h - by, y_h);
-    const uint8_t *sblk = at(src, bx, by);
+    // the source block, staged once (every primitive below reads it out of LDS); reference blocks are staged per evaluation
+    stage_block<32>(G.src, at(src, bx, by), src.stride, bw, bh);
+    const uint8_t *sblk = G.src;
+    const int sblk_s = 32;
     cands[n++] = Vec2{0, 0};
     int motion_bias = y_w * y_h;
     unsigned var_src = 0, avg_src = 0;
     Psy psy = {2, 1, 0};
     int lax = 0, lay = 0;
     if (level <= 1) {
-        var_src = (unsigned) ws_block_detail(sblk, src.stride, bw, bh, avg_src);
+        var_src = (unsigned) ws_block_detail(sblk, sblk_s, bw, bh, avg_src);
         int tvar = (int) (var_src + SQR(var_src >> 10));
         tvar = (8 * tvar * c.quant >> 9) / (bw * bh);
         if (tvar) {
-            int hvar = (int) ws_hist_var(sblk, src.stride, bw, bh, hist);
-            int qtex = ws_quant_tex(sblk, src.stride, bw, bh);
-            int npeaks = ws_peaks(sblk, src.stride, bw, bh, (int) avg_src, hist);
+            int hvar = (int) ws_hist_var(sblk, sblk_s, bw, bh, hist);
+            int qtex = ws_quant_tex(sblk, sblk_s, bw, bh);
+            int npeaks = ws_peaks(sblk, sblk_s, bw, bh, (int) avg_src, hist);
             motion_bias += tvar * (hvar - qtex) * npeaks;
         }
         motion_bias = max(motion_bias, 0) / (2 + (abs(gx) + abs(gy)));
@@ -827,7 +904,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         unsigned parent_mask = ~(((unsigned) step << 1) - 1);
         int pi = (int) ((unsigned) i & parent_mask), pj = (int) ((unsigned) j & parent_mask);
         int sumx = 0, sumy = 0, npar = 0;
-        Vec2 lc[16], inl[16];
+        Vec2 *lc = G.lc, *inl = G.inl;
         for (int m = 0; m < 9; m++) {
             int x = pi + pt[2 * m] * step, y = pj + pt[2 * m + 1] * step;
             if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
@@ -908,7 +985,8 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         if (invalid_block(ref, bx + dx, by + dy, bw, bh, 0)) {
             continue;
         }
-        score = ws_hier_metr(level, sblk, src.stride, at(ref, bx + dx, by + dy), ref.stride, bw, bh, psy);
+        stage_block<36>(G.ref, at(ref, bx + dx, by + dy), ref.stride, bw, bh);
+        score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
         if (dx == 0 && dy == 0) {
             score_zero = score;
         }
@@ -927,7 +1005,8 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
     {
-        unsigned zoscore = ws_metr(sblk, src.stride, at(ogr, bx, by), ogr.stride, bw, bh, psy);
+        stage_block<36>(G.ref, at(ogr, bx, by), ogr.stride, bw, bh);
+        unsigned zoscore = ws_metr(sblk, sblk_s, G.ref, 36, bw, bh, psy);
         if (abs(dx) <= 1 && abs(dy) <= 1) {
             qthresh *= 2;
         }
@@ -949,10 +1028,13 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
                 if (invalid_block(ref, bx + tvx, by + tvy, bw, bh, 0)) {
                     continue;
                 }
-                score = ws_hier_metr(level, sblk, src.stride, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh, psy);
-                if (k >= 1) {
-                    metr[k - 1] = score;
-                }
+                stage_block<36>(G.ref, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh);
+                score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
+                // (selects, not metr[k - 1]: an array indexed at run time lives in scratch memory)
+                metr[0] = k == 1 ? score : metr[0];
+                metr[1] = k == 2 ? score : metr[1];
+                metr[2] = k == 3 ? score : metr[2];
+                metr[3] = k == 4 ? score : metr[3];
                 if (level == 0 && !tvx && !tvy && score <= qthresh) {
                     dx = tvx;
                     dy = tvy;
@@ -977,7 +1059,8 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
             if (invalid_block(ref, bx + tvx, by + tvy, bw, bh, 0)) {
                 break;
             }
-            score = ws_hier_metr(level, sblk, src.stride, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh, psy);
+            stage_block<36>(G.ref, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh);
+            score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
             score += (unsigned) mv_cost(cc, tvx * step * 4, tvy * step * 4, level);
             if (best > score) {
                 best = score;
@@ -1007,7 +1090,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     unsigned best_fp = best;
     if (c.effort >= 4) {
         if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
-            best = subpixel_me(c, lds, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, psy);
+            best = subpixel_me(c, lds, G, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, psy);
             if (sx || sy) {
                 fpelx = lax;
                 fpely = lay;
@@ -1015,7 +1098,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
             }
         }
         if (!found_sub && !good_enough && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
-            best = subpixel_me(c, lds, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, psy);
+            best = subpixel_me(c, lds, G, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, psy);
         }
     }
     mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
@@ -1025,14 +1108,17 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     if ((mv.u.mv.x | mv.u.mv.y) & 3) {
         ratio = (best << 5) / (best_fp + !best_fp);
     }
-    const uint8_t *ogrd = at(c.ogr[0], bx + fpelx, by + fpely);
-    const uint8_t *refd = at(ref0, bx + fpelx, by + fpely);
-    unsigned ogrerr = ws_metr(sblk, src.stride, ogrd, c.ogr[0].stride, bw, bh, psy);
+    // the original-reference block at the vector, then -- for everything that follows -- the reference block there
+    stage_block<36>(G.ref, at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, bw, bh);
+    unsigned ogrerr = ws_metr(sblk, sblk_s, G.ref, 36, bw, bh, psy);
+    stage_block<36>(G.ref, at(ref0, bx + fpelx, by + fpely), ref0.stride, bw, bh);
+    const uint8_t *refd = G.ref;
+    const int refd_s = 36;
     unsigned ogrmad = (ogrerr + yarea / 2) / yarea;
     ogrmad = ogrmad * ratio >> 5;
     unsigned mad = (best + yarea / 2) / yarea;
     unsigned avg_ref;
-    unsigned var_ref = (unsigned) ws_block_detail(refd, ref0.stride, bw, bh, avg_ref);
+    unsigned var_ref = (unsigned) ws_block_detail(refd, refd_s, bw, bh, avg_ref);
     int dv = (int) min(ratio, 32u);
     int ipolvar = (int) ((var_src * (unsigned) dv + var_ref * (unsigned) (32 - dv)) >> 5);
     dv = abs((int) var_src - ipolvar);
@@ -1044,13 +1130,18 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
     int cbmx = cbx + sarx(fpelx, hs), cbmy = cby + sarx(fpely, vs);
     int cbw = bw >> hs, cbh = bh >> vs;
     unsigned chroma_ratio = (unsigned) ((cbw * cbh) << 4) / yarea;
-    int uavg_src = ws_plane_avg(c.srcc[0], cbx, cby, cbw, cbh), vavg_src = ws_plane_avg(c.srcc[1], cbx, cby, cbw, cbh);
-    int uavg_ref = ws_plane_avg(c.refc[0], cbmx, cbmy, cbw, cbh), vavg_ref = ws_plane_avg(c.refc[1], cbmx, cbmy, cbw, cbh);
+    // the chroma blocks: source and reference at the vector (staged copies, pitch 32)
+    for (int z = 0; z < 2; z++) {
+        stage_block<32>(G.cs[z], at(c.srcc[z], cbx, cby), c.srcc[z].stride, cbw, cbh);
+        stage_block<32>(G.cr[z], at(c.refc[z], cbmx, cbmy), c.refc[z].stride, cbw, cbh);
+    }
+    int uavg_src = ws_block_avg(G.cs[0], 32, cbw, cbh), vavg_src = ws_block_avg(G.cs[1], 32, cbw, cbh);
+    int uavg_ref = ws_block_avg(G.cr[0], 32, cbw, cbh), vavg_ref = ws_block_avg(G.cr[1], 32, cbw, cbh);
     ChromaPsy cpsy = chroma_analysis((int) avg_src, uavg_src, vavg_src);
     unsigned avg_y_dif = (unsigned) abs((int) avg_src - (int) avg_ref);
     unsigned avg_c_dif = (unsigned) AVG2(abs(uavg_src - uavg_ref), abs(vavg_src - vavg_ref));
     int eprmi, eprmd, eprmr;
-    ws_calc_eprm(sblk, src.stride, refd, ref0.stride, (int) avg_src, (int) avg_ref, bw, bh, eprmi, eprmd, eprmr);
+    ws_calc_eprm(sblk, sblk_s, refd, refd_s, (int) avg_src, (int) avg_ref, bw, bh, eprmi, eprmd, eprmr);
     bool oob;
     {
         int px = i * y_w + sarx(mv.u.mv.x, 2), py = j * y_h + sarx(mv.u.mv.y, 2);
@@ -1078,7 +1169,12 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         if (good_enough) {
             sth *= 2;
         }
-        ws_yuv_max_subblock_err(zsub, c, bx, by, bx, by, bw, bh, cbx, cby, cbx, cby, cbw, cbh, psy);
+        // (against the reference at ZERO motion: luma into G.aux, chroma into G.cz)
+        stage_block<32>(G.aux, at(ref0, bx, by), ref0.stride, bw, bh);
+        for (int z = 0; z < 2; z++) {
+            stage_block<32>(G.cz[z], at(c.refc[z], cbx, cby), c.refc[z].stride, cbw, cbh);
+        }
+        ws_yuv_max_subblock_err(zsub, sblk, sblk_s, G.aux, 32, bw, bh, G.cs, G.cz, cbw, cbh, psy);
         unsigned cth = chroma_ratio * sth * max(skipt, 1u) >> 5;
         zsub[0] = zsub[0] * ratio >> 5;
         zsub[1] = zsub[1] * ratio >> 5;
@@ -1098,7 +1194,7 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
             if (y_prereq || c_prereq) {
                 unsigned bsub[3], xth = skipt * yarea;
                 int carea = 4 * cbw * cbh;
-                ws_yuv_max_subblock_err(bsub, c, bx, by, bx + fpelx, by + fpely, bw, bh, cbx, cby, cbmx, cbmy, cbw, cbh, psy);
+                ws_yuv_max_subblock_err(bsub, sblk, sblk_s, refd, refd_s, bw, bh, G.cs, G.cr, cbw, cbh, psy);
                 xth += (unsigned) ipolvar;
                 xth = (unsigned) max((int) xth - ((int) yarea * neidif * 2), 0);
                 xth = xth * (unsigned) c.quant >> 12;
@@ -1109,8 +1205,8 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
                 if (y_prereq && bsub[0] < 4 * xth) {
                     mv.flags |= 1u << DSV_MV_BIT_NOXMITY;
                 }
-                int utex = (int) ws_block_tex(at(c.srcc[0], cbx, cby), c.srcc[0].stride, cbw, cbh);
-                int vtex = (int) ws_block_tex(at(c.srcc[1], cbx, cby), c.srcc[1].stride, cbw, cbh);
+                int utex = (int) ws_block_tex(G.cs[0], 32, cbw, cbh);
+                int vtex = (int) ws_block_tex(G.cs[1], 32, cbw, cbh);
                 c_prereq = c_prereq && (utex > carea || vtex > carea);
                 xth = chroma_ratio * xth >> 4;
                 if (c_prereq && bsub[1] < xth && bsub[2] < xth) {
@@ -1122,8 +1218,8 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
             }
         }
         const DSV_MV *refmv = c.ref_mvf ? &c.ref_mvf[i + j * nxb] : nullptr;
-        test_subblock_intra_y(c, refmv, mv, sblk, src.stride, refd, ref0.stride, ipolvar, (int) avg_src, neidif, ratio, bw, bh);
-        test_subblock_intra_c(c, mv, mad, (unsigned) (ipolvar / (bw * bh)), avg_src, cbx, cby, cbmx, cbmy, cbw, cbh);
+        test_subblock_intra_y(c, refmv, mv, sblk, sblk_s, refd, refd_s, ipolvar, (int) avg_src, neidif, ratio, bw, bh);
+        test_subblock_intra_c(c, mv, mad, (unsigned) (ipolvar / (bw * bh)), avg_src, G.cs, G.cr, cbw, cbh);
         if (!(mv.flags & (1u << DSV_MV_BIT_NOXMITY))) {
             mv.err = (uint16_t) mad;
             add_err = (int) mad;
@@ -2153,6 +2249,9 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         return 0;
     }
     const HmeParams &g = hp[0];
+    if (g.a.blk_w > 32 || g.a.blk_h > 32) { // (the general block routine stages its operand blocks in LDS: GenLds)
+        fatal("motion search: blocks larger than 32 x 32 (dsv_encoder.c:1203-1211 makes 16 or 32)", __FILE__, __LINE__);
+    }
     // a call that starts the search: job table, clears, source pre-pass
     const bool from_top = (phases & HME_PREPARE) && (level_hi < 0 || level_hi >= g.pyr_levels);
     if (level_hi < 0 || level_hi > g.pyr_levels) {
@@ -2275,6 +2374,9 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
 
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
 {
+    if (hp.a.blk_w > 32 || hp.a.blk_h > 32) {
+        fatal("motion search: blocks larger than 32 x 32 (dsv_encoder.c:1203-1211 makes 16 or 32)", __FILE__, __LINE__);
+    }
     int nlaunch = 0;
     HmeDev c;
     c.a = hp.a;

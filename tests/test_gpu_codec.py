@@ -32,7 +32,7 @@ CASES = [
     ("cif_abr", 352, 288, A.SUBSAMP_420, 6, dict(qp=50, gop=12, rc_mode=1, bitrate=600000)),
     ("720p_ip", 1280, 720, A.SUBSAMP_420, 4, dict(qp=60, gop=48)),
     ("1080p_ip", 1920, 1080, A.SUBSAMP_420, 3, dict(qp=60, gop=48)),
-    ("2160p_ip", 3840, 2160, A.SUBSAMP_420, 2, dict(qp=60, gop=48)),  # 32x32 blocks: general ME routine, global-memory filter sweep
+    ("2160p_ip", 3840, 2160, A.SUBSAMP_420, 2, dict(qp=60, gop=48)),  # 32x32 blocks: general ME routine (operands staged in LDS), 512-thread ring sweep of the filters
 ]
 
 
