@@ -160,6 +160,23 @@ __device__ __forceinline__ unsigned quad_metric(int a1, int a2, int a3, int a4, 
 
 // ---- wave-cooperative block primitives (all 64 lanes call with identical arguments) ----------
 
+// quad_metric on two packed quads (bytes: top-left, top-right, bottom-left, bottom-right): UAVG4 of four absolute differences is
+// (sad + 2) >> 2, a quad's texture the sad against itself rotated by one sample, its sum the sad against zero
+struct __attribute__((packed)) U16g { // possibly unaligned 16-bit load
+    uint16_t v;
+};
+struct __attribute__((packed)) U32g { // possibly unaligned 32-bit load
+    uint32_t v;
+};
+__device__ __forceinline__ unsigned quad_metric_pk(uint32_t a, uint32_t b, const Psy &psy)
+{
+    const uint32_t ra = (a >> 8) | (a << 24), rb = (b >> 8) | (b << 24);
+    int se = (int) ((__builtin_amdgcn_sad_u8(a, b, 0u) + 2) >> 2);
+    int ta = (int) ((__builtin_amdgcn_sad_u8(a, ra, 0u) + 2) >> 2), tb = (int) ((__builtin_amdgcn_sad_u8(b, rb, 0u) + 2) >> 2);
+    int s0 = (int) ((__builtin_amdgcn_sad_u8(a, 0u, 0u) + 2) >> 2), s1 = (int) ((__builtin_amdgcn_sad_u8(b, 0u, 0u) + 2) >> 2);
+    return (unsigned) (sq24(se) << psy.err_weight) + (unsigned) (sq24(ta - tb) << psy.tex_weight) + (unsigned) (sq24(s0 - s1) << psy.avg_weight);
+}
+
 __device__ __forceinline__ unsigned ws_umetr(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h, const Psy &psy)
 {
     int lane = threadIdx.x & 63, qw = w / 2, qh = h / 2;
@@ -169,7 +186,10 @@ __device__ __forceinline__ unsigned ws_umetr(const uint8_t *a, int as, const uin
         int i, j;
         split(q, i, j);
         const uint8_t *p = a + (ptrdiff_t) (2 * j) * as + 2 * i, *r = b + (ptrdiff_t) (2 * j) * bs + 2 * i;
-        acc += quad_metric(p[0], p[1], p[as], p[as + 1], r[0], r[1], r[bs], r[bs + 1], psy);
+        // a quad = two 16-bit loads per operand (round 4: eight byte loads and the metric sample by sample until then)
+        const uint32_t qa = (uint32_t) ((const U16g *) p)->v | ((uint32_t) ((const U16g *) (p + as))->v << 16);
+        const uint32_t qb = (uint32_t) ((const U16g *) r)->v | ((uint32_t) ((const U16g *) (r + bs))->v << 16);
+        acc += quad_metric_pk(qa, qb, psy);
     }
     return wave_sum(acc);
 }
@@ -195,6 +215,17 @@ __device__ __forceinline__ unsigned ws_sse(const uint8_t *a, int as, const uint8
     }
     int lane = threadIdx.x & 63;
     unsigned acc = 0;
+    if ((w & 3) == 0) { // four pixels a lane and step: sum (a - b)^2 = a.a + b.b - 2 a.b as three byte dot products
+        const int w4 = w >> 2;
+        const RowSplit split(w4);
+        for (int idx = lane; idx < w4 * h; idx += 64) {
+            int x, y;
+            split(idx, x, y);
+            const uint32_t va = ((const U32g *) (a + (ptrdiff_t) y * as + 4 * x))->v, vb = ((const U32g *) (b + (ptrdiff_t) y * bs + 4 * x))->v;
+            acc += __builtin_amdgcn_udot4(va, va, 0u, false) + __builtin_amdgcn_udot4(vb, vb, 0u, false) - 2u * __builtin_amdgcn_udot4(va, vb, 0u, false);
+        }
+        return wave_sum(acc);
+    }
     const RowSplit split(w);
     for (int idx = lane; idx < w * h; idx += 64) {
         int x, y;
@@ -1022,14 +1053,27 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
         while (again && !good_enough) {
             int tvx, tvy;
             again = false;
+            // the positions of one round -- the centre, its four neighbours, then one diagonal -- lie inside the block at the
+            // centre with a one-pixel rim: where all four neighbours are valid positions (so the rim is inside the padded
+            // plane) it is staged ONCE and every position of the round read out of it
+            const bool rim = !invalid_block(ref, bx + dx - 1, by + dy, bw, bh, 0) && !invalid_block(ref, bx + dx + 1, by + dy, bw, bh, 0) &&
+                             !invalid_block(ref, bx + dx, by + dy - 1, bw, bh, 0) && !invalid_block(ref, bx + dx, by + dy + 1, bw, bh, 0);
+            const int rim_x = dx, rim_y = dy;
+            if (rim) {
+                stage_block<36>(G.ref, at(ref, bx + dx - 1, by + dy - 1), ref.stride, bw + 2, bh + 2);
+            }
             for (int k = 0; k < 5; k++) {
                 tvx = dx + rectx[k];
                 tvy = dy + recty[k];
                 if (invalid_block(ref, bx + tvx, by + tvy, bw, bh, 0)) {
                     continue;
                 }
-                stage_block<36>(G.ref, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh);
-                score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
+                if (rim) {
+                    score = ws_hier_metr(level, sblk, sblk_s, G.ref + (1 + tvy - rim_y) * 36 + (1 + tvx - rim_x), 36, bw, bh, psy);
+                } else {
+                    stage_block<36>(G.ref, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh);
+                    score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
+                }
                 // (selects, not metr[k - 1]: an array indexed at run time lives in scratch memory)
                 metr[0] = k == 1 ? score : metr[0];
                 metr[1] = k == 2 ? score : metr[1];
@@ -1059,8 +1103,12 @@ __device__ void hme_block(const HmeDev &c, int level, int i, int j, int gx, int 
             if (invalid_block(ref, bx + tvx, by + tvy, bw, bh, 0)) {
                 break;
             }
-            stage_block<36>(G.ref, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh);
-            score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
+            if (rim && dx == rim_x && dy == rim_y) {
+                score = ws_hier_metr(level, sblk, sblk_s, G.ref + (1 + tvy - rim_y) * 36 + (1 + tvx - rim_x), 36, bw, bh, psy);
+            } else {
+                stage_block<36>(G.ref, at(ref, bx + tvx, by + tvy), ref.stride, bw, bh);
+                score = ws_hier_metr(level, sblk, sblk_s, G.ref, 36, bw, bh, psy);
+            }
             score += (unsigned) mv_cost(cc, tvx * step * 4, tvy * step * 4, level);
             if (best > score) {
                 best = score;
