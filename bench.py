@@ -1112,7 +1112,7 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     cfgs["c4_1080p_444_lossless"]["round_trip"] = lossless_round_trip(hip, A, r4, vids[NV + 4])
     r4.free()
     # 3840x2160 4:2:0: 32 x 32 blocks (dsv_encoder.c:1203-1211) -- level 0 of the search takes the GENERAL block routine
-    # (csrc/hme.hip k_hme_rows_b_w2: no fast form for 32-pixel blocks yet); every stream from its first (intra) picture
+    # (csrc/hme.hip k_hme_rows_b_w2: hme_block on operands staged in LDS; no fast form for 32-pixel blocks yet); every stream from its first (intra) picture
     r5 = EncodeRun(hip, A, torch, 3840, 2160, "420", 60, 48, 10, min(32, S), min(4, args.groups), vids[NV + 5:NV + 7], False, seeds=[301, 302])
     leg("c_2160p_420_qp60_gop48", r5, 2, 6, 8, {"frames": "P frames 2..7 of each stream; 32 x 32 blocks: general level-0 block routine"})
     r5.free()
