@@ -16,6 +16,7 @@
 //     form a wavefront that is processed concurrently; one workgroup per plane sweeps the fronts
 //     with a workgroup barrier between them (the plane stays in L2 / the CU's L1).
 #include "dev.h"
+#include "prio.h"
 #include "blockstat.h"
 #include "bmc.h"
 #include "hme.h"
@@ -667,6 +668,7 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
 
 template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ WaveLds L[4];
     const McJob &jb = tab[blockIdx.z];
     // (the wavefront's index told to the compiler as wave-uniform: the block's origin, its vector and every base address
@@ -696,6 +698,7 @@ __device__ __forceinline__ uint32_t recon4(uint32_t rv4, uint32_t pv4, bool plai
 // flags of its own block.  Planes come from dframe_alloc: rows and origins are 16-byte aligned.
 __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const McJob &jb = tab[blockIdx.z / 3];
     const MCParams p = jb.p;
     int c = blockIdx.z % 3;
@@ -2149,6 +2152,7 @@ __global__ __launch_bounds__(256) void k_inter_filters(const DSV_MV *__restrict_
 // (Plane-major order had a fifth of the luma sweeps start when the first chroma sweeps had finished.)
 __device__ __forceinline__ void inter_filters_b_body(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
+    DSV2_KERNEL_PRIO();
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
     int c = blockIdx.y; // (the luma sweeps -- the long ones, and the ones that need the LDS -- are dispatched first)
@@ -2218,6 +2222,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // the same with a lane pair per luma cell: 512 threads (the chroma workgroups use all of them as block rows)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inter_filters_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
+    DSV2_KERNEL_PRIO();
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
     int c = blockIdx.y; // (the luma sweeps -- the long ones, and the ones that need the LDS -- are dispatched first)
@@ -2276,6 +2281,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
+    DSV2_KERNEL_PRIO();
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
     const DPlane dp = jb.res.p[0];
@@ -2295,6 +2301,7 @@ __global__ __launch_bounds__(512) void k_intra_filter_b2(const McJob *__restrict
 
 __device__ __forceinline__ void intra_filter_b_body(const McJob *__restrict__ tab, unsigned lds_bytes)
 {
+    DSV2_KERNEL_PRIO();
     extern __shared__ uint8_t dyn_lds[];
     const McJob &jb = tab[blockIdx.x];
     const DPlane dp = jb.res.p[0];

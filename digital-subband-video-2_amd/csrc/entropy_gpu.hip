@@ -32,6 +32,7 @@
 // A state beyond 255 (k >= 32 at damp 3, never seen on real pictures) or a plane that outgrows its buffer raises a
 // flag; the host then codes that picture from the symbol list as before (entropy.cpp) -- same bytes either way.
 #include "entropy_gpu.h"
+#include "prio.h"
 
 namespace dsv2 {
 
@@ -130,6 +131,7 @@ __device__ __forceinline__ int wave_incl_scan_u(unsigned v, int lane)
 // ---- 1 ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_ent_planes(const EntJob *__restrict__ tab, EntGeom g)
 {
+    DSV2_KERNEL_PRIO();
     const EntJob &J = tab[blockIdx.x];
     const int lane = threadIdx.x;
     const int Nall = *J.total;
@@ -208,6 +210,7 @@ constexpr uint32_t kNotJoined = 0xffffffffu;
 template <bool kLanes> // kLanes: stop where the trajectories have joined (k_ent_pair walks on), leave the threshold bytes behind
 __global__ __launch_bounds__(kStates / 2) void k_ent_tables(const EntJob *__restrict__ tab, EntGeom g)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ __attribute__((aligned(16))) uint32_t sT[kEntChunk];
     __shared__ int s_nskip;
     __shared__ int s_rng[2][2];
@@ -348,6 +351,7 @@ __device__ __forceinline__ uint32_t tm1_splat(uint32_t w, int b) // byte b of w 
 
 __global__ __launch_bounds__(64) void k_ent_pair(const EntJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(64) void k_ent_pair(const EntJob *__restrict__ tab)
 constexpr int kChainBatch = 32;
 __global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab, int lanes)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ __attribute__((aligned(16))) uint16_t st[kChainBatch * kStates];
     __shared__ uint2 sj[kChainBatch];
     const EntJob &J = tab[blockIdx.y];
@@ -552,6 +557,7 @@ __global__ __launch_bounds__(64) void k_ent_ks(const EntJob *__restrict__ tab, E
 // are stepped over.
 __global__ __launch_bounds__(64) void k_ent_walk(const EntJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
     const PlaneSpan ps = plane_span(J.info, c);
@@ -608,6 +614,7 @@ __global__ __launch_bounds__(64) void k_ent_walk(const EntJob *__restrict__ tab)
 // per chunk, a lane per symbol (four a thread): the Rice parameter of every symbol from the state it met, the chunk's code length
 __global__ __launch_bounds__(256) void k_ent_bits(const EntJob *__restrict__ tab, EntGeom g)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ unsigned long long wsum[4];
     const EntJob &J = tab[blockIdx.y];
     const int c = blockIdx.z;
@@ -673,6 +680,7 @@ __global__ __launch_bounds__(256) void k_ent_bits(const EntJob *__restrict__ tab
 // byte layout of one plane section (hzcc.c:586-613): 32-bit length | SEG(DC) | pad | 24-bit count | codes | pad | 0x55
 __global__ __launch_bounds__(64) void k_ent_layout(const EntJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const EntJob &J = tab[blockIdx.x];
     const int lane = threadIdx.x;
     int *I = J.info;
@@ -721,6 +729,7 @@ __global__ __launch_bounds__(64) void k_ent_layout(const EntJob *__restrict__ ta
 // ---- 6 ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ent_zero(const EntJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const EntJob &J = tab[blockIdx.y];
     const unsigned words = ((unsigned) J.info[EI_TOTAL] + 16u + 3u) >> 2;
     uint32_t *o = (uint32_t *) J.out;
@@ -737,6 +746,7 @@ constexpr int kEmitWords = 4096;
 
 __global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab, EntGeom g, unsigned img_words, int lanes)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ unsigned wsum[4];
     __shared__ uint32_t img[kEmitWords + 2];
     const EntJob &J = tab[blockIdx.y];
@@ -863,6 +873,7 @@ __global__ __launch_bounds__(256) void k_ent_emit(const EntJob *__restrict__ tab
 // ---- 7 ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ent_out(const EntJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const EntJob &J = tab[blockIdx.y];
     const int *I = J.info;
     unsigned total = (unsigned) I[EI_TOTAL];

@@ -9,6 +9,7 @@
 // truncating mean), replicated across the 32-pixel border; corners average the two
 // adjacent strip ends (frame.c:377-380).
 #include "dev.h"
+#include "prio.h"
 
 namespace dsv2 {
 
@@ -94,6 +95,7 @@ static int extend_items(int w, int h) { return 16 * h + 2 * kBorder * ((w + 3) >
 // tab == nullptr: the single plane `one`; otherwise blockIdx.y indexes a device table of planes
 __global__ __launch_bounds__(256) void k_extend(const DPlane *__restrict__ tab, DPlane one)
 {
+    DSV2_KERNEL_PRIO();
     const DPlane &pl = tab ? tab[blockIdx.y] : one;
     extend_item(pl, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void k_ds2x(const PlanePair *__restrict__ tab,
 // goes sample by sample.
 __global__ __launch_bounds__(256) void k_ds2x4(const PlanePair *__restrict__ tab, PlanePair one)
 {
+    DSV2_KERNEL_PRIO();
     const PlanePair &pp = tab ? tab[blockIdx.z] : one;
     int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     int y = blockIdx.y * 4 + threadIdx.y;
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(256) void k_ingest(const IngestJob *__restrict__ ta
 // load, four rows per workgroup -- an eighth of the workgroups and a quarter of the memory instructions of k_ingest
 __global__ __launch_bounds__(128) void k_ingest16(const IngestJob *__restrict__ tab)
 {
+    DSV2_KERNEL_PRIO();
     const IngestJob &j = tab[blockIdx.y];
     const int x = (int) threadIdx.x * 16;
 #pragma unroll

@@ -14,6 +14,7 @@
 //   scanned size up, hzcc.c:40-57, so adjacent levels overlap by one line).  Dependents
 //   run as a tiny second launch of the pass.
 #include "dev.h"
+#include "prio.h"
 #include "quant.h"
 
 namespace dsv2 {
@@ -276,6 +277,7 @@ __device__ __forceinline__ void count_nonzero(const PlaneJob &J, size_t pos, int
 // LL region: hzcc.c:308-328
 __global__ __launch_bounds__(256) void k_quant_ll(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, int sw, int sh)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = tab ? tab[blockIdx.z] : one;
     int x = blockIdx.x * 64 + threadIdx.x;
     int y = blockIdx.y * 4 + threadIdx.y;
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void k_quant_level(const PlaneJob *__restrict_
 template <int MODE>
 __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
 {
+    DSV2_KERNEL_PRIO();
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int si = blockIdx.z % 3;
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(256) void k_count(const CompactJob *__restrict__ ta
 constexpr int kScanThreads = 256;
 __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const CompactJob *__restrict__ tab, CompactJob one, int reset)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ int wsum[kScanThreads / 64];
     const CompactJob &J = tab ? tab[blockIdx.y] : one;
     const int *tile_count = J.tile_count;
@@ -607,6 +611,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const CompactJob *_
 
 __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ tab, CompactJob one)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ int wsum[4];
     __shared__ uint32_t spos[kTile];
     __shared__ int32_t sval[kTile];

@@ -15,6 +15,7 @@
 // Work mapping: threadIdx.x runs along image x (coalesced rows), 64 x 4 threads per
 // workgroup = 4 wavefronts; grids are >> 256 workgroups on the full-resolution levels.
 #include "dev.h"
+#include "prio.h"
 
 namespace dsv2 {
 
@@ -287,6 +288,7 @@ __device__ __forceinline__ int32_t *img(const PlaneJob &J, int sel) { return sel
 template <int F, bool U8>
 __global__ __launch_bounds__(256) void k_fwd_rows(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     int k = blockIdx.x * 64 + threadIdx.x;
     int j = blockIdx.y * 4 + threadIdx.y;
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256) void k_fwd_rows(const PlaneJob *__restrict__ t
 template <int F>
 __global__ __launch_bounds__(256) void k_fwd_cols(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     int i = blockIdx.x * 64 + threadIdx.x;
     int k = blockIdx.y * 4 + threadIdx.y;
@@ -390,6 +393,7 @@ template <bool U8>
 __global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel,
                                                   int d_sel, int ovf)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     int idx = blockIdx.x * 64 + threadIdx.x;
     int jy = blockIdx.y * 4 + threadIdx.y;
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ t
 // picture's right / bottom edge, and jobs whose images are not 16-byte aligned, go quad by quad.
 __global__ __launch_bounds__(256) void k_fwd_haar_u8x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel, int ovf)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int jy = blockIdx.y * 4 + threadIdx.y;
@@ -546,6 +551,7 @@ template <bool OUT_U8>
 __global__ __launch_bounds__(256) void k_inv_haar(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel,
                                                   int d_sel, int ovf, int filtered, int hdiv)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     int idx = blockIdx.x * 64 + threadIdx.x;
     int jy = blockIdx.y * 4 + threadIdx.y;
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(256) void k_inv_haar(const PlaneJob *__restrict__ t
 __global__ __launch_bounds__(256) void k_inv_haar_u8x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel, int ovf,
                                                        int filtered, int hdiv)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int jy = blockIdx.y * 4 + threadIdx.y;
@@ -654,6 +661,7 @@ __device__ __forceinline__ void fwd_haar_quad_p(const int32_t *src, int ss, int3
 __global__ __launch_bounds__(256) void k_fwd_haar_tail(const PlaneJob *__restrict__ tab, PlaneJob one, int cw, int ch, int l0, int lvls, int lossless,
                                                        int cap_a)
 {
+    DSV2_KERNEL_PRIO();
     extern __shared__ int32_t tail_lds[];
     const PlaneJob &J = pick_job(tab, one);
     int32_t *C = J.coefs;
@@ -729,6 +737,7 @@ __device__ __forceinline__ void inv_haar_quad_p(const int32_t *LLp, int ls, cons
 __global__ __launch_bounds__(256) void k_inv_haar_tail(const PlaneJob *__restrict__ tab, PlaneJob one, int cw, int ch, int l0, int lvls, int lossless,
                                                        int plane_idx, int isP, int cap_a)
 {
+    DSV2_KERNEL_PRIO();
     extern __shared__ int32_t tail_lds[];
     const PlaneJob &J = pick_job(tab, one);
     const int32_t *C = J.coefs;
@@ -759,6 +768,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tail(const PlaneJob *__restric
 template <int F>
 __global__ __launch_bounds__(256) void k_inv_cols(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     int i = blockIdx.x * 64 + threadIdx.x;
     int k = blockIdx.y * 4 + threadIdx.y;
@@ -780,6 +790,7 @@ __global__ __launch_bounds__(256) void k_inv_cols(const PlaneJob *__restrict__ t
 template <int F, bool OUT_U8>
 __global__ __launch_bounds__(256) void k_inv_rows(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel)
 {
+    DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     int k = blockIdx.x * 64 + threadIdx.x;
     int j = blockIdx.y * 4 + threadIdx.y;

@@ -17,6 +17,7 @@
 // is coded by the host from the same field: same bytes either way.  The finalised field and the flag bytes are written to
 // HBM for the kernels that follow, so neither travels through the host any more.
 #include "sideinfo.h"
+#include "prio.h"
 
 #include "dev.h"
 
@@ -257,6 +258,7 @@ __device__ __forceinline__ void block(const SideJob &J, int nbh, int idx, Walk &
 static_assert(SIDE_IMG_BYTES + 25 * kThreads * 4 < 150 * 1024, "k_side_info: static LDS beyond a gfx950 CU");
 __global__ __launch_bounds__(kThreads) void k_side_info(const SideJob *__restrict__ tab, int nbh, int nbv)
 {
+    DSV2_KERNEL_PRIO();
     __shared__ uint32_t img[SIDE_IMG_BYTES / 4 + 2];
     __shared__ int s_ones[3][kThreads], s_lead[3][kThreads], s_trail[3][kThreads], s_rest[3][kThreads];
     __shared__ int s_bits[3][kThreads];        // mvx, mvy, sbim bits per thread
