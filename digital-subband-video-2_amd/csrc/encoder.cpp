@@ -1775,12 +1775,30 @@ void enc_batch(Job *jobs, int n)
         // level-0 launch, was tried: hme_run_batch takes a level range for it; no gain, they slow the holder's launch.)
         stream_wait(bs);
         t_clock.mark("pre-search-drained", n);
+    }
+    // DSV2_COARSE_OUTSIDE: the coarse levels -- five launches that are dependency chains and cannot fill the chip -- run BEFORE the
+    // token is taken, beside whatever level-0 launch holds it; the token then covers the level-0 launch alone.  1: queue for the
+    // token at once (the level-0 launch follows the coarse levels on the stream); 2: when the coarse levels have finished.
+    static const int coarse_outside = getenv("DSV2_COARSE_OUTSIDE") ? atoi(getenv("DSV2_COARSE_OUTSIDE")) : 0;
+    const bool split_levels = searching && coarse_outside && dv0.pyr_levels >= 1;
+    int nfronts_coarse = 0;
+    if (split_levels) {
+        prof.begin(bs, ST_HME);
+        nfronts_coarse = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof, -1, 1, HME_LEVELS);
+        if (coarse_outside >= 2) {
+            stream_wait(bs);
+        }
+        t_clock.mark("coarse-levels", n);
+    }
+    if (searching) {
         token.acquire(); // (released once the search has drained, below)
         t_clock.mark("token", n);
     }
     if (!pjobs.empty()) {
-        prof.begin(bs, ST_HME);
-        int nfronts = hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof, -1, 0, HME_LEVELS);
+        if (!split_levels) {
+            prof.begin(bs, ST_HME);
+        }
+        int nfronts = nfronts_coarse + hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, &prof, split_levels ? 0 : -1, 0, HME_LEVELS);
         prof.end(bs, ST_HME, (int) pjobs.size(), nfronts); // launches = the per-level search kernels
         HIPCHK(hipMemsetAsync(sc.d_bstats, 0, (size_t) n_bsj * BS_WORDS * sizeof(int), bs));
         block_stats_batch(bs, d_bsj, n_bsj, nbh, nbv);
