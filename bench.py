@@ -787,7 +787,13 @@ def main():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         assert pkg.sharding.assign_segments(S * world, world)[rank] == [pkg.sharding.segment_id(rank, world, s) for s in range(S)]
-        segs = {pkg.sharding.segment_id(rank, world, s): run.stream_bytes(s) for s in range(S)}
+        # (host memory bound: rank 0 holds every gathered byte.  When the ranks' output together exceeds DSV2_GATHER_MAX_GB --
+        # 8 ranks x 768 streams x ~100 pictures is ~58 GB -- every rank contributes its first streams only, the same share each)
+        mine_bytes = torch.tensor([sum(len(p) for s in range(S) for fr in run.out[s] for p in fr)], device=xdev, dtype=torch.int64)
+        dist.all_reduce(mine_bytes, op=dist.ReduceOp.SUM)
+        cap = float(os.environ.get("DSV2_GATHER_MAX_GB", "16")) * 1e9
+        S_g = S if int(mine_bytes.item()) <= cap else max(1, int(S * cap / int(mine_bytes.item())))
+        segs = {pkg.sharding.segment_id(rank, world, s): run.stream_bytes(s) for s in range(S_g)}
         t_g = time.perf_counter()
         whole = pkg.sharding.gather_segments(dist, rank, world, segs, device=xdev)
         gather_s = time.perf_counter() - t_g
@@ -805,7 +811,7 @@ def main():
                 good += int(hashlib.md5(whole[at:at + ln]).hexdigest() == md)
                 at += ln
                 nseg += 1
-            gather_ok = {"segments": nseg, "segments_verified": good, "bytes": at}
+            gather_ok = {"segments": nseg, "segments_verified": good, "bytes": at, "segments_of_job": S * world}
             if good != nseg or at != len(whole):
                 sys.stderr.write("[bench] gathered segment bytes DIFFER from what the ranks produced (%d of %d ok)\n" % (good, nseg))
                 sys.exit(8)
