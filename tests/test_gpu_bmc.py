@@ -13,7 +13,7 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
 
 
-@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420)])
+@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (2560, 1440, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420)])
 @pytest.mark.parametrize("lossless,tmc,do_filter,q", [(0, 0, 1, 700), (0, 1, 1, 172), (0, 1, 0, 2500), (1, 0, 1, 1)])
 def test_motion_compensation_and_filters(w, h, subsamp, lossless, tmc, do_filter, q):
     ref, hip = A.load_ref(), A.load_hip()
@@ -52,7 +52,7 @@ def test_motion_compensation_and_filters(w, h, subsamp, lossless, tmc, do_filter
 
 
 # (16384 wide: cell index x block count reaches 2^21, the exact-divide branch of the filters' cell -> block mapping)
-@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420)])
+@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (2560, 1440, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420)])
 @pytest.mark.parametrize("q", [60, 400, 3000])
 def test_intra_filter(w, h, subsamp, q):
     ref, hip = A.load_ref(), A.load_hip()
