@@ -1765,7 +1765,10 @@ void enc_batch(Job *jobs, int n)
     // (only launches that keep the chip's 2 048 search slots full for most of their length take the token: a row-pipelined
     // launch ramps up and down over one picture's critical path, ~2 ms whatever the batch, and launches of a few dozen
     // pictures hide each other's ramps when they overlap)
-    static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 8192;
+    // (Until the end of round 4 the bound was 8 192 rows.  Re-measured with the persistent kernels: 4 groups of 3 264 rows -- 192
+    // streams -- gain 3 % from the token, 6 880 -> 7 090 frames/s, 4 groups of 6 528 rows 3.4 %; at 2 176 rows a group the token
+    // costs 3 %, at 816 it makes no difference.  One and a half sets of the 2 048 persistent workers it is.)
+    static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 3072;
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
     SearchTokenGuard token;
     if (searching) {
