@@ -51,7 +51,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 STAGES = ["ingest_pyramid", "hme", "predict_subtract", "fwd_sbt", "quant_compact", "inv_sbt", "recon_filters", "extend", "hme_level0"]
 NST = len(STAGES)
 # dominant-kernel name per stage (rocprofv3 --kernel-trace name prefix)
-STAGE_KERNEL = {"hme": "k_hme_rows_b_*", "hme_level0": "k_hme_rows_p_fast_l0_pre", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
+STAGE_KERNEL = {"hme": "k_hme_rows_*", "hme_level0": "k_hme_rows_l0", "fwd_sbt": "k_fwd_haar/k_fwd_rows/k_fwd_cols", "inv_sbt": "k_inv_haar/k_inv_cols/k_inv_rows",
                 "quant_compact": "k_quant_level", "recon_filters": "k_inter_filters", "predict_subtract": "k_predict_w",
                 "ingest_pyramid": "k_extend/k_ds2x", "extend": "k_extend"}
 HBM_PEAK_GBS = 8000.0
@@ -133,6 +133,64 @@ def spawn_ranks(args):
     for p in procs:
         rc = max(rc, abs(p.wait()))
     sys.exit(rc)
+
+
+# ---- where a rank's host side should run: the cores and memory node next to ITS GPU --------------------------------------
+def _parse_cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_host_locality(ordinal, sysfs="/sys"):
+    """(pci address, numa node, local cpus) of HIP device `ordinal`, read from sysfs WITHOUT touching the GPU runtime: the KFD
+    topology lists the GPU nodes in the order the runtime enumerates them (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES, when they
+    are plain index lists, select from that order).  None when the box does not expose it."""
+    try:
+        base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split(None, 1) for l in open(os.path.join(base, n, "properties")).read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+                gpus.append("%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v and all(x.strip().isdigit() for x in v.split(",")):
+                gpus = [gpus[int(x)] for x in v.split(",") if int(x) < len(gpus)]
+        addr = gpus[ordinal]
+        dev = os.path.join(sysfs, "bus/pci/devices", addr)
+        node = int(open(os.path.join(dev, "numa_node")).read().strip())
+        cpus = _parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        return addr, node, cpus
+    except (OSError, ValueError, IndexError, KeyError):
+        return None
+
+
+def bind_rank_to_gpu_node(ordinal, world):
+    """sched_setaffinity to the usable cores next to GPU `ordinal` (parallel_encode_yuv.sh's processes run wherever the scheduler
+    puts them; here a rank pins ~0.8 GB of pictures and moves ~25 GB/s over ITS GPU's PCIe link: both want the local node).
+    Must run before anything allocates pinned memory or starts the library's worker pool.  Returns what was done, for the line."""
+    info = {"pci": None, "numa_node": None, "cpus": len(os.sched_getaffinity(0)), "bound": False}
+    loc = gpu_host_locality(ordinal)
+    if loc is None:
+        return info
+    addr, node, cpus = loc
+    info.update(pci=addr, numa_node=node)
+    mine = sorted(cpus & os.sched_getaffinity(0))
+    if world > 1 and mine and os.environ.get("DSV2_NUMA_BIND", "1") != "0":
+        # ranks that share a node share its cores evenly (by position among the GPUs of that node)
+        peers = [o for o in range(world) if (gpu_host_locality(o) or (None, None, None))[1] == node]
+        if len(peers) > 1 and len(mine) >= 2 * len(peers):
+            k, per = peers.index(ordinal), len(mine) // len(peers)
+            mine = mine[k * per:(k + 1) * per]
+        os.sched_setaffinity(0, mine)
+        info.update(cpus=len(mine), bound=True)
+    return info
 
 
 # ---- synthetic pictures (generated in forked helpers BEFORE torch / HIP come up) ---------------------------
@@ -671,8 +729,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
         sys.stderr.write("[bench] --gpus %d but WORLD_SIZE=%d: running %d ranks\n" % (args.gpus, world, world))
-    ncpu_box = usable_cpus()
     local = int(os.environ.get("DSV2_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    # this rank's cores: those next to its GPU (before the picture generators fork, the pictures are pinned, the runtime starts)
+    locality = bind_rank_to_gpu_node(local, world if "DSV2_FORCE_DEVICE" not in os.environ else 1)
+    ncpu_box = usable_cpus()
     extras = not args.no_extras and world == 1
 
     # ---- pictures first: forked generators must not inherit an initialised GPU runtime ----
@@ -686,7 +746,7 @@ def main():
         specs += [(3840, 2160, "420", 301 + k, 10) for k in range(2)]
     t_gen = time.perf_counter()
     under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
-    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(8, ncpu_box // max(1, world))))
+    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(8, ncpu_box // (1 if locality["bound"] else max(1, world)))))
     vids = gen_videos(specs, gen_procs)
     t_gen = time.perf_counter() - t_gen
 
@@ -701,7 +761,7 @@ def main():
     if args.host_cores > 0:
         os.environ.setdefault("DSV2_HOST_THREADS", str(max(2, 2 * ncpu)))
     else:
-        os.environ.setdefault("DSV2_HOST_THREADS", str(min(48, max(8, 3 * ncpu // max(1, world)))))
+        os.environ.setdefault("DSV2_HOST_THREADS", str(min(48, max(8, 3 * ncpu // (1 if locality["bound"] else max(1, world))))))
 
     import torch
     import dsvabi as A
@@ -787,38 +847,41 @@ def main():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         assert pkg.sharding.assign_segments(S * world, world)[rank] == [pkg.sharding.segment_id(rank, world, s) for s in range(S)]
-        # (host memory bound: rank 0 holds every gathered byte.  When the ranks' output together exceeds DSV2_GATHER_MAX_GB --
-        # 8 ranks x 768 streams x ~100 pictures is ~58 GB -- every rank contributes its first streams only, the same share each)
-        mine_bytes = torch.tensor([sum(len(p) for s in range(S) for fr in run.out[s] for p in fr)], device=xdev, dtype=torch.int64)
-        dist.all_reduce(mine_bytes, op=dist.ReduceOp.SUM)
-        cap = float(os.environ.get("DSV2_GATHER_MAX_GB", "16")) * 1e9
-        S_g = S if int(mine_bytes.item()) <= cap else max(1, int(S * cap / int(mine_bytes.item())))
-        segs = {pkg.sharding.segment_id(rank, world, s): run.stream_bytes(s) for s in range(S_g)}
+        # Every segment of the job travels to rank 0 and is checked there against its producer's md5 -- in pieces of at most
+        # 256 MB that rank 0 folds into running digests and drops (sharding.gather_segments_streaming): eight ranks of the
+        # headline produce ~58 GB, which no rank ever holds.  (DSV2_GATHER_OUT=<file>: rank 0 also writes every piece at its
+        # final offset of that file, the `cat` of parallel_encode_yuv.sh:50.)
+        out_path = os.environ.get("DSV2_GATHER_OUT")
+        out_fd = os.open(out_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC) if (rank == 0 and out_path) else -1
+        sink = (lambda sid, base, off, piece: os.pwrite(out_fd, piece, base + off)) if out_fd >= 0 else None
+        chunk = int(float(os.environ.get("DSV2_GATHER_CHUNK_MB", "256")) * (1 << 20))
         t_g = time.perf_counter()
-        whole = pkg.sharding.gather_segments(dist, rank, world, segs, device=xdev)
+        res = pkg.sharding.gather_segments_streaming(dist, rank, world, [pkg.sharding.segment_id(rank, world, s) for s in range(S)],
+                                                     lambda sid: run.stream_bytes((sid - rank) // world), device=xdev, chunk=chunk, sink=sink)
         gather_s = time.perf_counter() - t_g
-        total_bytes = len(whole) if rank == 0 else 0
-        # every segment of the gathered buffer against what its rank produced: (length, md5) tables exchanged beside the payload
-        import hashlib
-        mine_tab = {sid: (len(b), hashlib.md5(b).hexdigest()) for sid, b in segs.items()}
-        tabs = [None] * world
-        dist.all_gather_object(tabs, mine_tab)
+        if out_fd >= 0:
+            os.close(out_fd)
+        total_bytes = res["bytes"] if rank == 0 else 0
         gather_ok = None
         if rank == 0:
-            at, good, nseg = 0, 0, 0
-            for sid in sorted(k for t in tabs for k in t):
-                ln, md = next(t[sid] for t in tabs if sid in t)
-                good += int(hashlib.md5(whole[at:at + ln]).hexdigest() == md)
-                at += ln
-                nseg += 1
-            gather_ok = {"segments": nseg, "segments_verified": good, "bytes": at, "segments_of_job": S * world}
-            if good != nseg or at != len(whole):
-                sys.stderr.write("[bench] gathered segment bytes DIFFER from what the ranks produced (%d of %d ok)\n" % (good, nseg))
+            gather_ok = {"segments": res["segments"], "segments_verified": res["segments_verified"], "bytes": res["bytes"], "segments_of_job": S * world,
+                         "rank0_peak_bytes_held": chunk, "form": "streaming: md5 per segment folded piece by piece, pieces dropped"}
+            if res["segments_verified"] != res["segments"] or res["segments"] != S * world:
+                sys.stderr.write("[bench] gathered segment bytes DIFFER from what the ranks produced (%d of %d ok, job has %d)\n"
+                                 % (res["segments_verified"], res["segments"], S * world))
                 sys.exit(8)
-        del whole, segs
+        # per rank: where its host side ran and what it moved
+        mine_info = {"rank": rank, "gpu": local, "pci": locality["pci"], "numa_node": locality["numa_node"], "cpus": locality["cpus"], "bound": locality["bound"],
+                     "frames_per_s": round(frames_rank / elapsed, 1),
+                     "h2d_GBps": 0.0 if args.device_resident else round(frames_rank * run.P / elapsed / 1e9, 2)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_info)
     else:
         total_bytes = sum(len(p) for s in range(S) for fr in run.out[s] for p in fr)
         gather_ok = None
+        per_rank = [{"rank": 0, "gpu": local, "pci": locality["pci"], "numa_node": locality["numa_node"], "cpus": locality["cpus"], "bound": locality["bound"],
+                     "frames_per_s": round(frames_rank / elapsed, 1),
+                     "h2d_GBps": 0.0 if args.device_resident else round(frames_rank * run.P / elapsed / 1e9, 2)}]
     elapsed = float(t_max.item())
     frames_total, intra_total, pairs_total = (int(x) for x in counts.tolist())
 
@@ -865,6 +928,7 @@ def main():
                    "host_threads": int(os.environ["DSV2_HOST_THREADS"]),
                    "final_gather_s": round(gather_s, 3) if gather_s is not None else None, "final_gather_check": gather_ok,
                    "exchange_backend": (args.backend if dist is not None else None),
+                   "per_rank": per_rank,
                    "setup_s": {"generate_pictures": round(t_gen, 1)}},
         "parity_checked": {"twin_pairs_equal": pairs_total, "twin_pairs": pairs_total,
                            "note": "twins = same input, different lockstep group (and GOP phase), compared frame by frame over the run"},

@@ -146,8 +146,13 @@ class WorkerPool {
 // give the GPU T lockstep steps of ONE picture each.  Here concurrent callers whose jobs can share a step (same key: picture
 // geometry and what else a batch must agree on) are run as ONE lockstep step by whichever of them arrived first:
 //   * the first caller to arrive becomes the LEADER; it waits -- bounded: `window` -- until the callers it can expect have
-//     arrived (those seen within the last 100 ms under this key, less the ones inside a running step), takes them, runs the
-//     batch on its own thread, and hands every caller its results; each call still returns when ITS frame is done;
+//     arrived, takes them, runs the batch on its own thread, and hands every caller its results; each call still returns when
+//     ITS frame is done.  Whom it expects: a call blocks its THREAD, so what can still arrive is one call per other thread
+//     that has driven an instance of this key within the last 100 ms, less the ones inside a running step.  (One thread that
+//     drives several instances in turn -- simulcast renditions, a loop over encoders -- counts once: its other instances
+//     cannot call while this one waits, and the plain path stays the plain path.)  An instance inside a running step does
+//     not age out; one that stopped calling without saying so (paused input, a thread that bailed out) does, after 100 ms,
+//     whatever else is running;
 //   * a few callers run one step at a time (a caller that arrives while it runs joins the next one); with many callers
 //     (>= 2 * kMinSplit) a leader takes only its share (1 / groups) and up to `groups` steps run side by side, one's host
 //     phases and latency-bound kernels under another's;
@@ -167,9 +172,10 @@ template <class JobT> class Coalescer {
         Pending me;
         me.job = &job;
         me.key = key;
+        me.who = who;
         std::unique_lock<std::mutex> lk(mu_);
         const auto now = clock::now();
-        seen(who, key, now);
+        seen(who, key, now, std::this_thread::get_id());
         pending_.push_back(&me);
         st_.calls++;
         cv_.notify_all(); // (a collecting leader counts arrivals)
@@ -223,7 +229,17 @@ template <class JobT> class Coalescer {
             }
             pending_.swap(rest);
         }
-        running_.push_back(Running{key, (int) batch.size()});
+        const unsigned long long step_id = ++step_seq_;
+        {
+            Running r;
+            r.key = key;
+            r.n = (int) batch.size();
+            r.id = step_id;
+            for (Pending *p : batch) {
+                r.whos.push_back(p->who);
+            }
+            running_.push_back(std::move(r));
+        }
         collecting_ = false;
         cv_.notify_all(); // whoever is left elects the next leader
         lk.unlock();
@@ -239,10 +255,20 @@ template <class JobT> class Coalescer {
         last_step_us_ = us;
         st_.steps++;
         st_.largest = std::max<unsigned long long>(st_.largest, batch.size());
-        for (size_t i = 0; i < running_.size(); i++) {
-            if (running_[i].key == key && running_[i].n == (int) batch.size()) {
-                running_.erase(running_.begin() + (ptrdiff_t) i);
-                break;
+        {
+            const auto done_at = clock::now();
+            for (size_t i = 0; i < running_.size(); i++) {
+                if (running_[i].id == step_id) {
+                    for (const void *w : running_[i].whos) { // (the 100 ms start when the step hands its callers back)
+                        for (Recent &r : recent_) {
+                            if (r.who == w) {
+                                r.at = done_at;
+                            }
+                        }
+                    }
+                    running_.erase(running_.begin() + (ptrdiff_t) i);
+                    break;
+                }
             }
         }
         for (size_t i = 0; i < batch.size(); i++) {
@@ -284,42 +310,62 @@ template <class JobT> class Coalescer {
     struct Pending {
         JobT *job = nullptr;
         unsigned long long key = 0;
+        const void *who = nullptr;
         bool taken = false, done = false;
     };
     struct Recent {
         const void *who;
         unsigned long long key;
         std::chrono::steady_clock::time_point at;
+        std::thread::id tid; // the thread that last submitted for this instance
     };
     struct Running {
-        unsigned long long key;
-        int n;
+        unsigned long long key = 0, id = 0;
+        int n = 0;
+        std::vector<const void *> whos; // the instances inside this step
     };
-    void seen(const void *who, unsigned long long key, std::chrono::steady_clock::time_point now)
+    void seen(const void *who, unsigned long long key, std::chrono::steady_clock::time_point now, std::thread::id tid)
     {
         for (Recent &r : recent_) {
             if (r.who == who) {
                 r.key = key;
                 r.at = now;
+                r.tid = tid;
                 return;
             }
         }
-        recent_.push_back(Recent{who, key, now});
+        recent_.push_back(Recent{who, key, now, tid});
     }
+    // callers that can be expected under `key`: the distinct THREADS behind its recently seen instances
     int live(unsigned long long key, std::chrono::steady_clock::time_point now)
     {
-        int c = 0;
+        std::vector<std::thread::id> tids;
         for (size_t i = 0; i < recent_.size();) {
             if (now - recent_[i].at > std::chrono::milliseconds(100) && !busy(recent_[i].who)) {
                 recent_.erase(recent_.begin() + (ptrdiff_t) i); // has not called for 100 ms: no longer expected
                 continue;
             }
-            c += recent_[i].key == key;
+            if (recent_[i].key == key && std::find(tids.begin(), tids.end(), recent_[i].tid) == tids.end()) {
+                tids.push_back(recent_[i].tid);
+            }
             i++;
         }
-        return c;
+        return (int) tids.size();
     }
-    bool busy(const void *) { return !running_.empty(); } // (callers inside a step do not age out while steps are running)
+    bool busy(const void *who) // (an instance inside a running step does not age out: its step may take longer than the 100 ms)
+    {
+        for (const Running &r : running_) {
+            if (std::find(r.whos.begin(), r.whos.end(), who) != r.whos.end()) {
+                return true;
+            }
+        }
+        for (const Pending *p : pending_) { // ... nor one that is waiting right now
+            if (p->who == who) {
+                return true;
+            }
+        }
+        return false;
+    }
     int steps_running(unsigned long long key)
     {
         int c = 0;
@@ -354,6 +400,7 @@ template <class JobT> class Coalescer {
     std::vector<Recent> recent_;
     std::vector<Running> running_;
     bool collecting_ = false;
+    unsigned long long step_seq_ = 0;
     long long last_step_us_ = 0;
     const int groups_ = getenv("DSV2_COALESCE_GROUPS") ? atoi(getenv("DSV2_COALESCE_GROUPS")) : 2;
     Stats st_;

@@ -301,10 +301,11 @@ __device__ __forceinline__ uint32_t resid4_pk(uint32_t s4, s16x2 p01, s16x2 p23,
     return __builtin_amdgcn_perm(u32_of(o23), u32_of(o01), 0x06040200u);
 }
 
-struct WaveLds {
-    alignas(4) uint8_t win[35 * 36];
-    int16_t hz[35 * 32];
+struct WaveLds { // (alignas(16) on both: the packed sub-pel path reads and writes hz rows as 8-byte words, for every wave of L[4])
+    alignas(16) uint8_t win[35 * 36];
+    alignas(16) int16_t hz[35 * 32];
 };
+static_assert(sizeof(WaveLds) % 16 == 0 && offsetof(WaveLds, hz) % 16 == 0, "WaveLds: hz rows must stay 8-byte aligned in every element of an array");
 
 __device__ __forceinline__ void wave_lds_sync()
 {

@@ -74,6 +74,7 @@ struct CodecDev {
     DSV_MV *d_mvf[DSV_MAX_PYRAMID_LEVELS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *d_counters = nullptr;
     void *d_src_stats = nullptr; // hme_src_stats_bytes(): the search's source pre-pass (encoder)
+    void *d_l0_pre = nullptr;    // hme_l0_pre_bytes(): level 0's pre-pass records (encoder)
     uint8_t *d_intra_map[2] = {nullptr, nullptr}; // encoder: running intra map of the GOP (committed / being written), hme.h BlockStatsJob
     int32_t *d_ll = nullptr;
     // decoder-side symbol upload

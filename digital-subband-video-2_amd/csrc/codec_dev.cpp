@@ -193,7 +193,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         est += nlist * 8 + ((nscan + 1023) / 1024) * 8 + 4;                                  // compaction lists, tile counts
         est += ((nlist + 1023) / 1024 + 3) * (1024 + 256 * 2 + 2 + 4 + 4 + 8) + ent_out_bytes(nlist, nscan) + 64 + 128; // entropy coder (EntBuffers::ensure)
         est += nb * (1 + sizeof(DSV_MV) + 2) + (size_t) (pyr_levels + 1) * nb * sizeof(DSV_MV);
-        est += hme_counter_words(nbv) * sizeof(int) + hme_src_stats_bytes(nbh, nbv) + 16;
+        est += hme_counter_words(nbv) * sizeof(int) + hme_src_stats_bytes(nbh, nbv) + hme_l0_pre_bytes(nbh, nbv) + 16 + 256;
         est += 128 * 256;
         arena.create(est);
     }
@@ -252,6 +252,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     }
     HIPCHK(dev_alloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
     HIPCHK(dev_alloc(&d_src_stats, hme_src_stats_bytes(nbh, nbv)));
+    HIPCHK(dev_alloc(&d_l0_pre, hme_l0_pre_bytes(nbh, nbv)));
     for (int i = 0; i < 2; i++) {
         HIPCHK(dev_alloc((void **) &d_intra_map[i], nb));
         dev_zero(d_intra_map[i], nb);
@@ -351,6 +352,7 @@ void CodecDev::destroy()
     }
     dev_release(d_counters);
     dev_release(d_src_stats);
+    dev_release(d_l0_pre);
     for (int i = 0; i < 2; i++) {
         if (d_intra_map[i]) {
             dev_release(d_intra_map[i]);

@@ -5,6 +5,7 @@
 #include <sys/prctl.h>
 #include <time.h>
 
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -127,6 +128,12 @@ void DevArena::destroy()
 DevArenaScope::DevArenaScope(DevArena *a) : prev(t_arena) { t_arena = a; }
 DevArenaScope::~DevArenaScope() { t_arena = prev; }
 
+// allocations an instance arena could not hold (its size is an estimate kept in step with the allocations by hand: CodecDev::init);
+// counted so that drift shows up in the tests (dsv2hip_arena_fallbacks) instead of as a silent extra hipMalloc per instance
+std::atomic<long> g_arena_short{0};
+
+long arena_fallbacks() { return g_arena_short.load(); }
+
 hipError_t dev_alloc(void **p, size_t bytes)
 {
     DevArena *a = t_arena;
@@ -140,6 +147,7 @@ hipError_t dev_alloc(void **p, size_t bytes)
     }
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess && a && a->base) { // (the estimate of the block was short: this piece lives on its own, zeroed like the block)
+        g_arena_short.fetch_add(1);
         HIPCHK(hipMemset(*p, 0, bytes));
         HIPCHK(hipStreamSynchronize(nullptr));
     }

@@ -84,6 +84,7 @@ struct DevArenaScope {
     DevArena *prev;
 };
 hipError_t dev_alloc(void **p, size_t bytes);
+long arena_fallbacks(); // allocations an instance arena could not hold so far (0 unless CodecDev::init's estimate has drifted)
 void dev_release(void *p);
 size_t dframe_bytes(int format, int w, int h); // device bytes dframe_alloc asks for
 void event_wait(hipEvent_t ev);        // ... for a recorded event

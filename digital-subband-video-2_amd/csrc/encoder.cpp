@@ -1741,6 +1741,7 @@ void enc_batch(Job *jobs, int n)
             f.ref_mvf = ref.has_final_mvs ? ref.d_final_mvs : nullptr;
             f.counters = dv.d_counters;
             f.src_stats = dv.d_src_stats;
+            f.l0_pre = dv.d_l0_pre;
             f.host_mvs = nullptr; // (the field reaches the host through k_block_stats_b right behind the search: BlockStatsJob::host_mvs)
             f.host_counters = dv.h_counters;
             dv.h_counters[7] = -1; // overwritten with 0 by the search's last row (1: a row timed out); -1 left = it never finished
@@ -2104,7 +2105,7 @@ void enc_batch(Job *jobs, int n)
         }
         jb.gpu_bytes = nullptr;
         bool need_syms = !kGpuEntropy;
-        // More symbols than this stream's compaction lists hold (they start at a quarter of the worst case): the lists are
+        // More symbols than this stream's compaction lists hold (they start at half the worst case, at least 65 536 symbols: ensure_ready): the lists are
         // enlarged to the worst case for good, and this picture's symbols worked out again -- predict + subtract (or the source
         // copy of an intra picture) into a spare working picture, forward transform, quantiser, compaction: the same kernels
         // on the same operands, so the same symbols -- which the host then codes.  The reconstruction is untouched.
@@ -2395,6 +2396,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
 /* what the submit queue of dsv_enc did so far: [0] calls, [1] lockstep steps they were run as, [2] the largest step, [3] total
  * microseconds leaders spent waiting for expected callers; reset != 0 clears the counts afterwards */
 long dsv2hip_enc_list_growths(void) { return g_list_growths.load(); }
+long dsv2hip_arena_fallbacks(void) { return dsv2::arena_fallbacks(); }
 
 void dsv2hip_enc_queue_stats(unsigned long long *out4, int reset)
 {

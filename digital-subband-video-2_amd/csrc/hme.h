@@ -39,7 +39,8 @@ struct HmeFrames {
     DSV_MV *host_mvs = nullptr;   // batched driver only: pinned host mirror of mvf[0], filled by the search itself
     int *host_counters = nullptr; // batched driver only: pinned host copy of counters[0..7]; word 12 (kHmeHostTailWord) of the FIRST
                                   // stream's block is set when the level-0 launch has handed out its last block row
-    void *src_stats = nullptr; // batched driver only: hme_src_stats_bytes() of device memory for the source pre-pass, or null
+    void *src_stats = nullptr; // hme_src_stats_bytes() of device memory for the source pre-pass, or null (hme_run: allocated per call)
+    void *l0_pre = nullptr;    // hme_l0_pre_bytes() of device memory for level 0's pre-pass records, or null (hme_run: allocated per call)
     int *counters;         // hme_counter_words(nbv) ints. out: [0] nintra [1] ndiff [2] eligible [3] total_err
                            // ([4],[5] global motion, [7] row-pipeline timeout flag, [16..] row progress)
 };
@@ -48,6 +49,8 @@ struct HmeFrames {
 inline size_t hme_counter_words(int nbv) { return 16 + (size_t) nbv; }
 // source statistics of every block of levels 0 and 1, 16 bytes each (k_hme_src_stats_b)
 inline size_t hme_src_stats_bytes(int nbh, int nbv) { return ((size_t) nbh * nbv + (size_t) ((nbh + 1) / 2) * ((nbv + 1) / 2)) * 16; }
+// level 0's pre-pass records (k_hme_l0_pre_b), 256 bytes a block
+inline size_t hme_l0_pre_bytes(int nbh, int nbv) { return (size_t) nbh * nbv * 256; }
 constexpr int kHmeHostTailWord = 12;
 int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp); // returns the number of front launches
 

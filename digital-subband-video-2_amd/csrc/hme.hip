@@ -34,7 +34,8 @@ struct HmeDev {
     int *counters; // [0] nintra [1] ndiff [2] eligible [3] total_err [4] gx [5] gy
     DSV_MV *host_mvs;   // optional pinned host mirror of the level-0 field (written straight over PCIe)
     int *host_counters; // optional pinned host copy of counters[0..7]
-    int4 *stats[2];     // optional: source statistics of every block of levels 0 and 1 (k_hme_src_stats_b), or null
+    int4 *stats[2];     // source statistics of every block of levels 0 and 1 (k_hme_src_stats_b), or null (general routine)
+    uint32_t *l0pre;    // level 0's pre-pass records (k_hme_l0_pre_b: 64 dwords per block), or null (general routine)
 };
 
 // What the blocks of ONE level need, copied out of the job table once per row as wave-uniform scalars: the table
@@ -81,6 +82,7 @@ struct HmeCtx {
     int *counters;
     DSV_MV *host_mvs;
     const int4 *stats; // this level's source statistics or null
+    uint32_t *l0pre;   // level 0's pre-pass records
 };
 
 __device__ __forceinline__ const int4 *src_stats_of(const HmeCtx &c, int) { return c.stats; }
@@ -126,6 +128,7 @@ __device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
     c.counters = uni_ptr(d.counters);
     c.host_mvs = uni_ptr(d.host_mvs);
     c.stats = level <= 1 ? uni_ptr((const int4 *) d.stats[level]) : nullptr;
+    c.l0pre = uni_ptr(d.l0pre);
     return c;
 }
 
@@ -1318,94 +1321,16 @@ constexpr unsigned long long kMvPending = ~0ull;            // a head the search
 
 #include "hme_fast.h"
 
-// DSV2_HME_FAST=0 forces the generic per-block routine (A/B checks); default: fast path on
+// DSV2_HME_FAST=0 forces the general per-block routine at every level (A/B checks, and the parity tests' second opinion)
 static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
-// DSV2_HME_ROWS=0 falls back to one launch per anti-diagonal front in the batched driver
-static int g_hme_rows = getenv("DSV2_HME_ROWS") ? atoi(getenv("DSV2_HME_ROWS")) : 1;
-// DSV2_HME_FENCE (either bit): an agent-scope acquire + release fence in front of every block of the row pipeline.  Default 0:
-// since round 4 nothing in the hand-off depends on the order in which two locations become visible -- a consumer validates
-// every head it reads on its own (kMvPending until the one atomic store that writes it), the left neighbour comes out of
-// registers, and the level epilogue reads the field behind an acquire-release counter (hme_row).  The variants stay as
-// parity cases of the tests (tests/test_gpu_operating_point.py, tools/stress_hme.sh).
-static int hme_fence_mode()
-{
-    static const int mode = getenv("DSV2_HME_FENCE") ? atoi(getenv("DSV2_HME_FENCE")) : 0;
-    return mode;
-}
-#define g_hme_fence hme_fence_mode()
-// issue priority of the search wavefronts while they work on a block (s_setprio; 0 while they wait for the row above)
-static int g_hme_prio = getenv("DSV2_HME_PRIO") ? atoi(getenv("DSV2_HME_PRIO")) & 3 : 0;
-
-// true when hme_block_fast() handles this block (see hme_fast.h preconditions)
-__device__ __forceinline__ bool fast_path_ok(const HmeDev &c, int level, int i, int j)
-{
-    if (c.a.blk_w != 16 || c.a.blk_h != 16 || c.a.hshift != 1 || c.a.vshift != 1) {
-        return false;
-    }
-    const DPlane &src = c.src[level];
-    int bx = (i * 16) >> level, by = (j * 16) >> level;
-    if (bx >= src.w || by >= src.h) {
-        return false;
-    }
-    int bw = min(src.w - bx, 16), bh = min(src.h - by, 16);
-    if (level == 0) {
-        return (bw & 7) == 0 && (bh & 7) == 0;
-    }
-    return level > 1 || (!(bw & 1) && !(bh & 1)); // (the squared-error levels take any clipped size)
-}
-
-// one anti-diagonal front of one level: blockIdx.x enumerates the blocks on the front
-__global__ __launch_bounds__(64) void k_hme_front(HmeDev c, int level, int t, int nbx, int nby, int allow_fast)
-{
-    __shared__ FastLds S;
-    int bj_hi = min(nby - 1, t);
-    int bj = bj_hi - (int) blockIdx.x;
-    int bi = t - bj;
-    if (bj < 0 || bi >= nbx) {
-        return;
-    }
-    int gx = c.counters[4], gy = c.counters[5];
-    int i = bi << level, j = bj << level;
-    if (allow_fast && fast_path_ok(c, level, i, j)) {
-        int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
-        RowAcc acc;
-        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
-        acc.flush(c.counters);
-    } else {
-        hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
-    }
-}
-
-// ---- stream-batched variants: blockIdx.y selects one of n independent streams (same geometry) ----
-__global__ __launch_bounds__(64) void k_hme_front_b(const HmeDev *__restrict__ tab, int level, int t, int nbx, int nby, int allow_fast)
-{
-    __shared__ FastLds S;
-    const HmeDev &c = tab[blockIdx.y];
-    int bj_hi = min(nby - 1, t);
-    int bj = bj_hi - (int) blockIdx.x;
-    int bi = t - bj;
-    if (bj < 0 || bi >= nbx) {
-        return;
-    }
-    int gx = c.counters[4], gy = c.counters[5];
-    int i = bi << level, j = bj << level;
-    if (allow_fast && fast_path_ok(c, level, i, j)) {
-        int pcx = 0, pcy = 0; // (a launch per front has no left neighbour at hand: the windows are centred on the zero vector)
-        RowAcc acc;
-        hme_block_fast<-1>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
-        acc.flush(c.counters);
-    } else {
-        hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
-    }
-}
 
 // ---- row-pipelined level: ONE launch per pyramid level for all streams --------------------------
-// grid = (streams, block rows); one wavefront walks one block row of one stream left to right (which row: see take_ticket
-// below -- tickets run row-major ACROSS streams, so by the time row j of any stream is taken its row j-1 is well under way
-// and few resident wavefronts sit spinning).  Block (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and
-// (bi, bj-1), (bi-1, bj-1) of the row above, so a row only ever waits for heads of the row above it: a slow
-// block delays its own neighbourhood, not a whole anti-diagonal of every stream as a launch per front does.  Every spin
-// is bounded by the wall clock and reports through counters[7] and the host's pinned counter block.
+// One wavefront walks one block row of one stream left to right (which row: see take_row below -- tickets run row-major
+// ACROSS streams, so by the time row j of any stream is taken its row j-1 is well under way and few resident wavefronts
+// sit spinning).  Block (bi, bj) needs (bi-1, bj) -- the same wavefront, earlier -- and (bi, bj-1), (bi-1, bj-1) of the
+// row above, so a row only ever waits for heads of the row above it: a slow block delays its own neighbourhood, not a
+// whole anti-diagonal of every stream as a launch per front would.  Every spin is bounded by the wall clock and reports
+// through counters[7] and the host's pinned counter block.
 constexpr int kHmeTicket = 8 /* 8 .. 13: one ticket counter per pyramid level */, kHmeProgress = 16;
 constexpr int kHmeExhausted = 14; // level 0: ticket partitions whose last row has been handed out (counter block of stream 0)
 constexpr int kHmeHostTail = 12;  // ... and the word of the pinned host counter block that says "all of them" (hme.h)
@@ -1431,7 +1356,7 @@ __device__ __forceinline__ int take_ticket(int *counter)
 // counter block of stream `partition`), and a wavefront takes the next row of ITS XCD's partition (HW_REG_XCC_ID); when that is
 // exhausted it takes from the next partition, so no row is left behind and the tail balances.  Within a partition tickets
 // still run row-major across its streams, and a row's predecessor still holds a lower ticket of the same counter: the
-// progress argument above is unchanged.  DSV2_HME_XCD=0: one partition (the previous behaviour).
+// progress argument above is unchanged.
 struct RowTicket {
     int stream, row;
 };
@@ -1466,14 +1391,13 @@ __device__ __forceinline__ RowTicket take_row(const HmeDev *tab, int level, int 
     }
     return RowTicket{-1, -1};
 }
-// ---- hand-off through the vector heads themselves (round 4) -------------------------------------------------------------
+// ---- hand-off through the vector heads themselves --------------------------------------------------------------------------
 // The grid points of every level's field start a search as kMvPending (k_hme_clear_b); a block's 8-byte head is written once,
 // as ONE agent-scope atomic store.  A consumer reads the heads it needs -- its top and top-left neighbours -- as agent-scope
 // atomic loads and retries while either still reads pending: every location is validated on its own, so the hand-off needs
-// no ordering BETWEEN locations (until round 3: a per-row progress word published behind a drained store -- message passing
-// over two locations with relaxed atomics, which only the hardware's treatment of sc1 accesses made safe) and the producer
-// no longer drains its store and publishes after every block (a memory round trip per block).  No real head equals the
-// pattern: its flag word would need all 32 bits set.
+// no ordering BETWEEN locations and the producer does not drain its store and publish after every block.  No real head equals
+// the pattern: its flag word would need all 32 bits set.  (The fast block routines validate the heads inside their own first
+// load round -- load_neighbour_heads, hme_fast.h; blocks of the general routine wait here.)
 __device__ __forceinline__ bool wait_heads(const DSV_MV *top, const DSV_MV *top_left, int *err)
 {
     const int lane = threadIdx.x & 63;
@@ -1497,8 +1421,6 @@ __device__ __forceinline__ bool wait_heads(const DSV_MV *top, const DSV_MV *top_
     }
 }
 
-// FAST_ONLY: the host has established that every block of this level meets the preconditions of
-// hme_block_fast(); leaving the generic routine out of the kernel more than halves its register need
 constexpr int kHmeRowsDone = 6;
 
 // The last row of a stream to finish closes the level for that stream: global_motion (hme.c:1973) of
@@ -1534,12 +1456,12 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
     }
 }
 
-// LV: 0 / 1 = the launch is known to be level 0 / a coarser level (fast-only kernels: the other half of the block routine
-// is not compiled in), -1 = any level
-template <bool FAST_ONLY, int LV = -1, int CS = 1, bool PRE = false>
-__device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, int allow_fast, FastLds &S)
+// KIND: which block routine walks the row -- the general one (any geometry: blocks up to 32 x 32, any chroma format, odd
+// clipped sizes), the fast one of the coarser levels, or the fast one of level 0 (CS: chroma shift, 1 = 4:2:0, 0 = 4:4:4)
+enum { ROW_GENERAL = 0, ROW_FAST_LX = 1, ROW_FAST_L0 = 2 };
+template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, FastLds &S)
 {
-    const int level = LV == 0 ? 0 : level_rt;
+    const int level = KIND == ROW_FAST_L0 ? 0 : level_rt;
     int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
     int j = bj << level;
     const HmeCtx x = make_ctx(c, level);
@@ -1552,56 +1474,38 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
         S.prof_t = __builtin_amdgcn_s_memtime();
     }
 #endif
-    int pcx = 0, pcy = 0; // where the previous block of this row ended up: centre of the next block's LDS windows
-    RowAcc acc;           // this row's share of the frame's counters (flushed behind the loop)
+    RowAcc acc; // this row's share of the frame's counters (flushed behind the loop) and the left neighbour's head
     const int step_ = 1 << level;
     for (int bi = 0; bi < nbx; bi++) {
-        const DSV_MV *top_ = x.mvf.cur + (bi << level) + (j - step_) * x.a.nbh;
-        // (the fast routine validates the two heads inside its own load round -- no round trip of its own for the hand-off --
-        // and reports through acc.failed; blocks of the general routine wait here)
-        const bool pre_wait = !FAST_ONLY && !((allow_fast & 1) && fast_path_ok(c, level, bi << level, j));
-        if (bj > 0 && pre_wait && !wait_heads(top_, bi > 0 ? top_ - step_ : top_, &c.counters[kHmeErrWord])) {
-            // the row above never got there (or another row gave up): tell the host directly -- the level's
+        if constexpr (KIND == ROW_GENERAL) {
+            const DSV_MV *top_ = x.mvf.cur + (bi << level) + (j - step_) * x.a.nbh;
+            if (bj > 0 && !wait_heads(top_, bi > 0 ? top_ - step_ : top_, &c.counters[kHmeErrWord])) {
+                acc.failed = true;
+            }
+        }
+        HME_MARK(S, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // no neighbour load may move above the poll
+        __syncthreads();                                       // LDS scratch of the previous block is dead
+        int i = bi << level;
+        if (!acc.failed) {
+            if constexpr (KIND == ROW_FAST_L0) {
+                hme_block_l0<CS, SPLIT>(x, i, j, gx, gy, S, acc);
+            } else if constexpr (KIND == ROW_FAST_LX) {
+                hme_block_lx(x, level, i, j, gx, gy, S, acc);
+            } else {
+                hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
+                // the general routine reads its LEFT neighbour back from memory (the fast ones carry it in registers): this
+                // wavefront's own store has to have landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        if (acc.failed) {
+            // a neighbour's head never arrived (bounded spin), or another row gave up: tell the host directly -- the level's
             // epilogue, which normally delivers the counters, will not run because this row does not arrive
             if (c.host_counters && (threadIdx.x & 63) == 0) {
                 __hip_atomic_store(&c.host_counters[kHmeErrWord], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
-        }
-        HME_MARK(S, 0);
-        if ((allow_fast & 24) == 24) {
-            __builtin_amdgcn_s_setprio(3);
-        } else if (allow_fast & 16) {
-            __builtin_amdgcn_s_setprio(2);
-        } else if (allow_fast & 8) {
-            __builtin_amdgcn_s_setprio(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // no neighbour load may move above the poll
-        if (allow_fast & 6) { // (DSV2_HME_FENCE, either bit: an agent-scope acquire + release around every hand-off -- parity variants)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        }
-        __syncthreads();                                       // LDS scratch of the previous block is dead
-        int i = bi << level;
-        if (FAST_ONLY || ((allow_fast & 1) && fast_path_ok(c, level, i, j))) {
-            hme_block_fast<LV, CS, PRE>(x, level, i, j, gx, gy, S, pcx, pcy, acc);
-        } else if constexpr (!FAST_ONLY) {
-            hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
-            pcx = pcy = 0;
-            acc.have_left = false; // (its head is in memory, drained below, not in `acc`)
-        }
-        if (acc.failed) { // a neighbour's head never arrived (bounded spin inside the block routine)
-            if (c.host_counters && (threadIdx.x & 63) == 0) {
-                __hip_atomic_store(&c.host_counters[kHmeErrWord], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            return;
-        }
-        if constexpr (!FAST_ONLY) {
-            // the general routine reads its LEFT neighbour back from memory (the fast one carries it in registers): this
-            // wavefront's own store has to have landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (allow_fast & 24) {
-            __builtin_amdgcn_s_setprio(0);
         }
         HME_MARK(S, 9);
     }
@@ -1627,95 +1531,15 @@ __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, i
     }
 }
 
-// occupancy variants of the batched kernel: amdgpu_waves_per_eu(W, W) both budgets the registers and CAPS the
-// wavefronts of this kernel per SIMD at W (the register allocation is padded accordingly).  The cap matters when
-// several lockstep groups share the GPU: the search is latency-bound and long-lived, and whatever register file it
-// does not hold is where the other groups' streaming kernels run meanwhile.  Measured at 384 streams in 4 groups
-// (fast-path kernel, 121 VGPRs): W = 1: 4 440, W = 2: 4 990, W = 3: 4 690, W = 4: 4 380 frames/s -- although
-// one group alone is fastest at W = 3 or 4.  DSV2_HME_WAVES / DSV2_HME_WAVES_FAST pick the variants.
-#define HME_ROWS_B(W)                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_w##W(                  \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<false>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);                          \
-        }                                                                                                                \
-    }                                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_w##W(          \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<true, 0>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                            \
-        }                                                                                                                \
-    }                                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_444_w##W(      \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<true, 0, 0>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                         \
-        }                                                                                                                \
-    }                                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_w##W(          \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<true, 1>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);                        \
-        }                                                                                                                \
-    }                                                                                                                    \
-    /* the same three with the source statistics guaranteed (k_hme_src_stats4_b / _b ran): no source analysis inside */ \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_pre_w##W(      \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<true, 0, 1, true>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                   \
-        }                                                                                                                \
-    }                                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_l0_444_pre_w##W(  \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, 0, (int) gridDim.x, (int) gridDim.y, parts);                                  \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<true, 0, 0, true>(tab[t_.stream], t_.row, 0, nbx, (int) gridDim.y, allow_fast, S);                   \
-        }                                                                                                                \
-    }                                                                                                                    \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_hme_rows_b_fast_lx_pre_w##W(      \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts)                                   \
-    {                                                                                                                    \
-        __shared__ FastLds S;                                                                                            \
-        const RowTicket t_ = take_row(tab, level, (int) gridDim.x, (int) gridDim.y, parts);                              \
-        if (t_.row >= 0) {                                                                                               \
-            hme_row<true, 1, 1, true>(tab[t_.stream], t_.row, level, nbx, (int) gridDim.y, allow_fast, S);               \
-        }                                                                                                                \
-    }
-HME_ROWS_B(1)
-HME_ROWS_B(2)
-HME_ROWS_B(3)
-HME_ROWS_B(4)
-
-// PERSISTENT form of the fast kernels (round 4; DSV2_HME_PERSIST = workgroups per launch, 0 = the launch-per-row forms above).
-// amdgpu_waves_per_eu(W, W) caps the search at W wavefronts per SIMD by PADDING every wavefront's register allocation until a
-// (W + 1)th does not fit: at W = 2 a search wavefront that needs 113 registers holds 176, two of them 352 of the SIMD's 512,
-// and every other kernel of the step -- the other lockstep groups' streaming kernels, whose bandwidth is their bytes in
-// flight, i.e. their resident wavefronts -- lives in the 160 that are left (three wavefronts of 48 registers per SIMD where
-// eight run when the GPU is theirs: predict, quantiser, level-1 transforms took 2.6 - 3.6 x their exclusive time beside a
-// search).  Here the cap is the LAUNCH: `P` workgroups (default 2 048 = two per SIMD) that each walk row after row -- the
-// tickets of take_row already hand rows to whoever asks -- compiled for four wavefronts per SIMD, i.e. with the 120 registers
-// the routine needs: two resident search wavefronts leave 272.  A row still only waits for a lower ticket, which a RUNNING
-// worker holds (a worker takes its next ticket after finishing its row), so the progress argument is unchanged.
-#define HME_ROWS_P(NAME, LEVEL_EXPR, ...)                                                                                \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void NAME(                               \
-        const HmeDev *__restrict__ tab, int level, int nbx, int allow_fast, int parts, int nstreams, int nrows)          \
+// PERSISTENT kernels: `P` workgroups (default 2 048 = two per SIMD) that each walk row after row -- the tickets of take_row hand
+// rows to whoever asks.  The cap on the search's wavefronts per SIMD is the LAUNCH, not a padded register allocation
+// (amdgpu_waves_per_eu(W, W) caps by padding every wavefront's registers until a (W + 1)th does not fit, and the other
+// lockstep groups' streaming kernels -- whose bandwidth is their bytes in flight, i.e. their resident wavefronts -- then live
+// in what is left).  A row still only waits for a lower ticket, which a RUNNING worker holds (a worker takes its next ticket
+// after finishing its row), so the progress argument is unchanged.
+#define HME_ROWS_P(NAME, WAVES, LEVEL_EXPR, ...)                                                                         \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(                       \
+        const HmeDev *__restrict__ tab, int level, int nbx, int parts, int nstreams, int nrows)                          \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
         for (;;) {                                                                                                       \
@@ -1723,22 +1547,40 @@ HME_ROWS_B(4)
             if (t_.row < 0) {                                                                                            \
                 return;                                                                                                  \
             }                                                                                                            \
-            hme_row<__VA_ARGS__>(tab[t_.stream], t_.row, LEVEL_EXPR, nbx, nrows, allow_fast, S);                         \
+            hme_row<__VA_ARGS__>(tab[t_.stream], t_.row, LEVEL_EXPR, nbx, nrows, S);                                     \
             __syncthreads();                                                                                             \
         }                                                                                                                \
     }
-HME_ROWS_P(k_hme_rows_p_fast_l0, 0, true, 0)
-HME_ROWS_P(k_hme_rows_p_fast_l0_444, 0, true, 0, 0)
-HME_ROWS_P(k_hme_rows_p_fast_lx, level, true, 1)
-HME_ROWS_P(k_hme_rows_p_fast_l0_pre, 0, true, 0, 1, true)
-HME_ROWS_P(k_hme_rows_p_fast_l0_444_pre, 0, true, 0, 0, true)
-HME_ROWS_P(k_hme_rows_p_fast_lx_pre, level, true, 1, 1, true)
+HME_ROWS_P(k_hme_rows_l0, 4, 0, ROW_FAST_L0, 1, false)
+HME_ROWS_P(k_hme_rows_l0_444, 4, 0, ROW_FAST_L0, 0, false)
+HME_ROWS_P(k_hme_rows_l0s, 4, 0, ROW_FAST_L0, 1, true) // ... with the neighbour-independent half from the pre-pass (k_hme_l0_pre_b)
+HME_ROWS_P(k_hme_rows_l0s_444, 4, 0, ROW_FAST_L0, 0, true)
+HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
+HME_ROWS_P(k_hme_rows_general, 2, level, ROW_GENERAL)
 static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 2048;
-static int g_hme_persist_lx = getenv("DSV2_HME_PERSIST_LX") ? atoi(getenv("DSV2_HME_PERSIST_LX")) : g_hme_persist;
-static int g_hme_xcd = getenv("DSV2_HME_XCD") && atoi(getenv("DSV2_HME_XCD")) >= 1 ? atoi(getenv("DSV2_HME_XCD")) : 8; // ticket partitions (take_row): 8 XCDs on MI355X; 1 = chip-wide tickets
-static int g_hme_waves = getenv("DSV2_HME_WAVES") ? atoi(getenv("DSV2_HME_WAVES")) : 2;
-static int g_hme_waves_fast = getenv("DSV2_HME_WAVES_FAST") ? atoi(getenv("DSV2_HME_WAVES_FAST")) : 2;
-static int g_hme_waves_fast_lx = getenv("DSV2_HME_WAVES_FAST_LX") ? atoi(getenv("DSV2_HME_WAVES_FAST_LX")) : g_hme_waves_fast; // levels > 0
+// DSV2_HME_SPLIT: level 0 with its neighbour-independent half in an unordered pre-pass (1) or in place (0); default: by launch size
+// (-1: split below kSplitMaxRows block rows per launch -- few pictures: the chain per block is what the frame waits for -- and in place
+// above -- many pictures: the chip is short of work slots, and the pre-pass costs a quarter more instructions in total)
+static int g_hme_split = getenv("DSV2_HME_SPLIT") ? atoi(getenv("DSV2_HME_SPLIT")) : -1;
+constexpr int kSplitMaxRows = 2048;
+
+// ---- level 0's unordered pre-pass (hme_fast.h: hme_l0_pre_block) --------------------------------------------------------------
+// grid = (ceil(blocks / per_wg), streams); one wavefront works through per_wg blocks.  Runs after the level-1 launch (it reads
+// that level's finished field and its global motion) and before the level-0 launch.
+__global__ __launch_bounds__(64) void k_hme_l0_pre_b(const HmeDev *__restrict__ tab, int nbx, int nby, int per_wg)
+{
+    __shared__ FastLds S;
+    const HmeDev &c = tab[blockIdx.y];
+    const HmeCtx x = make_ctx(c, 0);
+    const int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
+    const int b_end = min(nbx * nby, ((int) blockIdx.x + 1) * per_wg);
+    for (int b = (int) blockIdx.x * per_wg; b < b_end; b++) {
+        const int j = b / nbx, i = b - j * nbx;
+        hme_l0_pre_block(x, i, j, gx, gy, S, x.l0pre + (size_t) b * kL0RecDwords);
+        __syncthreads();
+    }
+}
+
 
 // make_ctx() keeps ONE geometry per level for the source / reference / original-reference luma planes and one for
 // the four chroma planes; frames made by dframe_alloc() always satisfy this, anything else takes the general routine
@@ -1772,22 +1614,6 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
     return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (level > 1 || (!(bw & 1) && !(bh & 1)));
 }
 
-__global__ __launch_bounds__(256) void k_hme_clear_one(DSV_MV *field, int nwords, int nbh, int level)
-{
-    uint32_t *p = (uint32_t *) field;
-    const int gmask = (1 << level) - 1;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) {
-        const int e = i >> 2, bx = e % nbh, by = e / nbh;
-        p[i] = ((i & 2) == 0 && ((bx | by) & gmask) == 0) ? 0xffffffffu : 0u;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_hme_rows(HmeDev c, int level, int nbx, int allow_fast)
-{
-    __shared__ FastLds S;
-    hme_row<false>(c, take_ticket(&c.counters[kHmeTicket + level]), level, nbx, (int) gridDim.x, allow_fast, S);
-}
-
 // level < 0: blockIdx.z enumerates the levels (row pipeline: one clear for the whole search)
 __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
 {
@@ -1810,74 +1636,6 @@ __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ 
         for (int r = threadIdx.x; r < c.a.nbv; r += 256) {
             c.counters[kHmeProgress + r] = 0;
         }
-    }
-}
-
-// global_motion (hme.c:1973): mean vector of the level just finished, scaled up for the next one
-__global__ __launch_bounds__(256) void k_global_motion_b(const HmeDev *__restrict__ tab, int level)
-{
-    __shared__ int sx[4], sy[4];
-    const HmeDev &c = tab[blockIdx.x];
-    int step = 1 << level;
-    int nbx = (c.a.nbh + step - 1) / step, nby = (c.a.nbv + step - 1) / step;
-    int ax = 0, ay = 0;
-    for (int idx = threadIdx.x; idx < nbx * nby; idx += 256) {
-        int i = (idx % nbx) * step, j = (idx / nbx) * step;
-        const DSV_MV *m = &c.mvf[level][i + j * c.a.nbh];
-        ax += m->u.mv.x;
-        ay += m->u.mv.y;
-    }
-    ax = wave_sum(ax);
-    ay = wave_sum(ay);
-    if ((threadIdx.x & 63) == 0) {
-        sx[threadIdx.x >> 6] = ax;
-        sy[threadIdx.x >> 6] = ay;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int nblk = nbx * nby;
-        int tx = sx[0] + sx[1] + sx[2] + sx[3], ty = sy[0] + sy[1] + sy[2] + sy[3];
-        c.counters[4] = nblk ? tx * 2 / nblk : 0;
-        c.counters[5] = nblk ? ty * 2 / nblk : 0;
-    }
-}
-
-// end of the search: the scalars the host controller needs, straight into its pinned memory
-__global__ void k_hme_finish_b(const HmeDev *__restrict__ tab, int n)
-{
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n * 8) {
-        const HmeDev &c = tab[k >> 3];
-        if (c.host_counters) {
-            c.host_counters[k & 7] = c.counters[k & 7];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_global_motion(HmeDev c, int level)
-{
-    __shared__ int sx[4], sy[4];
-    int step = 1 << level;
-    int nbx = (c.a.nbh + step - 1) / step, nby = (c.a.nbv + step - 1) / step;
-    int ax = 0, ay = 0;
-    for (int idx = threadIdx.x; idx < nbx * nby; idx += 256) {
-        int i = (idx % nbx) * step, j = (idx / nbx) * step;
-        const DSV_MV *m = &c.mvf[level][i + j * c.a.nbh];
-        ax += m->u.mv.x;
-        ay += m->u.mv.y;
-    }
-    ax = wave_sum(ax);
-    ay = wave_sum(ay);
-    if ((threadIdx.x & 63) == 0) {
-        sx[threadIdx.x >> 6] = ax;
-        sy[threadIdx.x >> 6] = ay;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int nblk = nbx * nby;
-        int tx = sx[0] + sx[1] + sx[2] + sx[3], ty = sy[0] + sy[1] + sy[2] + sy[3];
-        c.counters[4] = nblk ? tx * 2 / nblk : 0;
-        c.counters[5] = nblk ? ty * 2 / nblk : 0;
     }
 }
 
@@ -2050,7 +1808,6 @@ int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &r
 
 // ---- source statistics ahead of the search (see source_analysis in hme_fast.h) -----------------------------------------
 // grid = (ceil(blocks of level 0 + blocks of level 1, per_wg), streams); one wavefront works through per_wg blocks.
-static int g_hme_prestats = getenv("DSV2_HME_PRESTATS") ? atoi(getenv("DSV2_HME_PRESTATS")) : 1;
 __global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int fb0x, int fb0y,
                                                         int fb1x, int fb1y, int per_wg)
 {
@@ -2285,11 +2042,12 @@ static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
     c.host_mvs = f.host_mvs;
     c.host_counters = f.host_counters;
     c.stats[0] = c.stats[1] = nullptr; // (hme_run_batch sets them when it runs the source pre-pass)
+    c.l0pre = (uint32_t *) f.l0_pre;
 }
 
 size_t hme_table_bytes(int n) { return (size_t) n * sizeof(HmeDev); }
 
-// n independent streams of identical geometry in lockstep: every front is ONE launch for all of them
+// n independent streams of identical geometry in lockstep: every level is ONE launch for all of them
 int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n, void *h_table, void *d_table, StageProf *prof, int level_hi,
                   int level_lo, int phases)
 {
@@ -2313,31 +2071,27 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     }
     const HmeDev *tab = (const HmeDev *) d_table;
     int nlaunch = 0;
-    int fast = g_hme_fast;
+    // The fast block routines: 16 x 16 blocks, one geometry per pyramid level (make_ctx), the source statistics and the level-0
+    // records of the pre-passes (memory for both handed in by the caller).  Anything else takes the general routine.
+    // (A function of the jobs alone: a call that only runs the levels, behind a separate HME_PREPARE call, comes to the same answer.)
+    bool fast = g_hme_fast != 0 && g.a.blk_w == 16 && g.a.blk_h == 16;
     for (int k = 0; k < n; k++) {
-        if (!uniform_geometry(f[k], g.pyr_levels)) {
-            fast &= ~1;
-        }
+        fast = fast && uniform_geometry(f[k], g.pyr_levels) && f[k].src_stats != nullptr && f[k].l0_pre != nullptr;
     }
-    // the source statistics of levels 0 and 1, ahead of the search: whenever the block routine that reads them can run
-    // (a function of the jobs alone: a call that only runs the levels, behind a separate HME_PREPARE call, comes to the same answer)
-    bool pre = g_hme_prestats && (fast & 1) && g.a.blk_w == 16 && g.a.blk_h == 16;
-    for (int k = 0; k < n; k++) {
-        pre = pre && f[k].src_stats != nullptr;
-    }
+    auto fast_level = [&](int level) { return fast && level_all_fast(g.a, f[0].src[level], level); };
+    const bool split = fast_level(0) && (g_hme_split >= 0 ? g_hme_split != 0 : n * g.a.nbv <= kSplitMaxRows);
     if (from_top) {
         const int nb0x = g.a.nbh, nb0y = g.a.nbv, nb1x = g.pyr_levels >= 1 ? (g.a.nbh + 1) / 2 : 0, nb1y = g.pyr_levels >= 1 ? (g.a.nbv + 1) / 2 : 0;
-        if (pre) {
+        if (fast) {
             for (int k = 0; k < n; k++) {
                 ht[k].stats[0] = (int4 *) f[k].src_stats;
                 ht[k].stats[1] = nb1x ? (int4 *) f[k].src_stats + (size_t) nb0x * nb0y : nullptr;
             }
         }
         HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
-        if (pre) {
-            // whole blocks four to a wavefront (DSV2_HME_PRESTATS=2: one block per wavefront everywhere, the form the block
-            // routine itself would run), clipped blocks of the last block row / column one to a wavefront
-            bool four = g_hme_prestats == 1;
+        if (fast) {
+            // whole blocks four to a wavefront, clipped blocks of the last block row / column one to a wavefront
+            bool four = true;
             for (int k = 0; k < n && four; k++) {
                 for (int l = 0; l <= (nb1x ? 1 : 0); l++) {
                     four = four && (((uintptr_t) f[k].src[l].data | (uintptr_t) f[k].ogr[l].data | (uintptr_t) f[k].src[l].stride | (uintptr_t) f[k].ogr[l].stride) & 15) == 0;
@@ -2361,116 +2115,70 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
                 DSV2_LAUNCH(k_hme_src_stats_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, fb0x, fb0y, fb1x, fb1y, per_wg);
             }
         }
-    }
-    int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
-    if (g_hme_rows && from_top) { // one clear for all levels; each level's last row then re-arms the hand-off words itself
+        // one clear for all levels; each level's last row then re-arms the hand-off words itself
+        const int nwords = g.a.nbh * g.a.nbv * (int) (sizeof(DSV_MV) / 4);
         DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n, g.pyr_levels + 1), dim3(256), 0, s, tab, -1, nwords, 1);
     }
+    const int parts = n < 8 ? n : 8; // ticket partitions (take_row): 8 XCDs on MI355X
     for (int level = level_hi; (phases & HME_LEVELS) && level >= level_lo; level--) {
-        int step = 1 << level;
-        int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
-        if (!g_hme_rows) {
-            DSV2_LAUNCH(k_hme_clear_b, dim3((nwords + 2047) / 2048, n), dim3(256), 0, s, tab, level, nwords, level == g.pyr_levels);
+        const int step = 1 << level;
+        const int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
+        const int workers = std::min(g_hme_persist > 0 ? g_hme_persist : 2048, n * nby);
+        if (level == 0 && g.pyr_levels == 0 && split) { // (no level above: the pre-pass has nothing to wait for)
+            DSV2_LAUNCH(k_hme_l0_pre_b, dim3((nbx * nby + 1) / 2, n), dim3(64), 0, s, tab, nbx, nby, 2);
         }
-        if (g_hme_rows) {
-            auto kern = g_hme_waves >= 4 ? k_hme_rows_b_w4 : g_hme_waves == 3 ? k_hme_rows_b_w3 : g_hme_waves == 2 ? k_hme_rows_b_w2 : k_hme_rows_b_w1;
-            if ((fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
-                int w = level == 0 ? g_hme_waves_fast : g_hme_waves_fast_lx;
-#define HME_PICK(base) (w >= 4 ? base##4 : w == 3 ? base##3 : w == 2 ? base##2 : base##1)
-                if (level == 0 && g.a.hshift == 0) {
-                    kern = pre ? HME_PICK(k_hme_rows_b_fast_l0_444_pre_w) : HME_PICK(k_hme_rows_b_fast_l0_444_w);
-                } else if (level == 0) {
-                    kern = pre ? HME_PICK(k_hme_rows_b_fast_l0_pre_w) : HME_PICK(k_hme_rows_b_fast_l0_w);
-                } else {
-                    kern = pre ? HME_PICK(k_hme_rows_b_fast_lx_pre_w) : HME_PICK(k_hme_rows_b_fast_lx_w);
-                }
-#undef HME_PICK
-            }
-            if (prof && level == 0) {
-                prof->begin(s, ST_HME_L0);
-            }
-            const int persist = level == 0 ? g_hme_persist : g_hme_persist_lx;
-            if (persist > 0 && (fast & 1) && level_all_fast(g.a, f[0].src[level], level)) {
-                auto pk = level == 0 ? (g.a.hshift == 0 ? (pre ? k_hme_rows_p_fast_l0_444_pre : k_hme_rows_p_fast_l0_444) : (pre ? k_hme_rows_p_fast_l0_pre : k_hme_rows_p_fast_l0))
-                                     : (pre ? k_hme_rows_p_fast_lx_pre : k_hme_rows_p_fast_lx);
-                DSV2_LAUNCH(pk, dim3(std::min(persist, n * nby)), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1) | (g_hme_prio << 3),
-                            n < g_hme_xcd ? n : g_hme_xcd, n, nby);
-            } else
-            DSV2_LAUNCH(kern, dim3(n, nby), dim3(64), 0, s, tab, level, nbx, (fast & 1) | (g_hme_fence << 1) | (g_hme_prio << 3), n < g_hme_xcd ? n : g_hme_xcd);
-            if (prof && level == 0) {
-                prof->end(s, ST_HME_L0, n, 1);
-            }
-            nlaunch++;
+        if (prof && level == 0) {
+            prof->begin(s, ST_HME_L0);
+        }
+        if (level == 0 && fast_level(0)) {
+            auto pk = g.a.hshift == 0 ? (split ? k_hme_rows_l0s_444 : k_hme_rows_l0_444) : (split ? k_hme_rows_l0s : k_hme_rows_l0);
+            DSV2_LAUNCH(pk, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
+        } else if (level > 0 && fast_level(level)) {
+            DSV2_LAUNCH(k_hme_rows_lx, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else {
-            for (int t = 0; t <= nbx + nby - 2; t++) {
-                int jhi = nby - 1 < t ? nby - 1 : t;
-                int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-                DSV2_LAUNCH(k_hme_front_b, dim3(jhi - jlo + 1, n), dim3(64), 0, s, tab, level, t, nbx, nby, g_hme_fast);
-                nlaunch++;
-            }
+            DSV2_LAUNCH(k_hme_rows_general, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         }
-        if (level != 0 && !g_hme_rows) {
-            DSV2_LAUNCH(k_global_motion_b, dim3(n), dim3(256), 0, s, tab, level);
+        if (prof && level == 0) {
+            prof->end(s, ST_HME_L0, n, 1);
         }
-    }
-    if (!g_hme_rows && level_lo == 0) {
-        DSV2_LAUNCH(k_hme_finish_b, dim3((8 * n + 255) / 256), dim3(256), 0, s, tab, n);
+        nlaunch++;
+        // what of level 0 does not depend on the order of its blocks (hme_fast.h: hme_l0_pre_block): needs level 1's field and its
+        // global motion, nothing else -- so it belongs to the call that runs level 1 (a caller that serialises level-0 launches --
+        // the encoder's search token -- may run the coarser levels, and this with them, outside that)
+        if (level == 1 && split) {
+            const int per_wg = 2;
+            DSV2_LAUNCH(k_hme_l0_pre_b, dim3((g.a.nbh * g.a.nbv + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, g.a.nbh, g.a.nbv, per_wg);
+        }
     }
     HIPCHK(hipGetLastError());
     return nlaunch;
 }
 
-int hme_run(hipStream_t s, const HmeFrames &f, const HmeParams &hp)
+// one search (the per-stage seam, dsv_hme): the batch of one, so that the stage tests exercise the kernels the encoder runs
+int hme_run(hipStream_t s, const HmeFrames &f_in, const HmeParams &hp)
 {
-    if (hp.a.blk_w > 32 || hp.a.blk_h > 32) {
-        fatal("motion search: blocks larger than 32 x 32 (dsv_encoder.c:1203-1211 makes 16 or 32)", __FILE__, __LINE__);
+    HmeFrames f = f_in;
+    void *h_table = nullptr, *d_table = nullptr, *stats = nullptr, *l0pre = nullptr;
+    HIPCHK(hipHostMalloc(&h_table, hme_table_bytes(1), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&d_table, hme_table_bytes(1)));
+    if (f.src_stats == nullptr) {
+        HIPCHK(hipMalloc(&stats, hme_src_stats_bytes(hp.a.nbh, hp.a.nbv)));
+        f.src_stats = stats;
     }
-    int nlaunch = 0;
-    HmeDev c;
-    c.a = hp.a;
-    c.effort = hp.effort;
-    c.lossless = hp.lossless;
-    c.quant = hp.quant;
-    c.skip_block_thresh = hp.skip_block_thresh;
-    c.pyr_levels = hp.pyr_levels;
-    c.psyscale = spatial_psy_factor(hp.a.blk_w, hp.a.blk_h, hp.a.nbh, hp.a.nbv, -1);
-    for (int l = 0; l <= hp.pyr_levels; l++) {
-        c.src[l] = f.src[l];
-        c.ref[l] = f.ref[l];
-        c.ogr[l] = f.ogr[l];
-        c.mvf[l] = f.mvf[l];
+    if (f.l0_pre == nullptr) {
+        HIPCHK(hipMalloc(&l0pre, hme_l0_pre_bytes(hp.a.nbh, hp.a.nbv)));
+        f.l0_pre = l0pre;
     }
-    for (int k = 0; k < 2; k++) {
-        c.srcc[k] = f.srcc[k];
-        c.refc[k] = f.refc[k];
+    const int nlaunch = hme_run_batch(s, &f, &hp, 1, h_table, d_table);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d_table));
+    HIPCHK(hipHostFree(h_table));
+    if (stats) {
+        HIPCHK(hipFree(stats));
     }
-    c.ref_mvf = f.ref_mvf;
-    c.counters = f.counters;
-    c.host_mvs = nullptr;
-    c.host_counters = nullptr;
-    c.stats[0] = c.stats[1] = nullptr;
-    size_t nb = (size_t) hp.a.nbh * hp.a.nbv;
-    HIPCHK(hipMemsetAsync(f.counters, 0, hme_counter_words(hp.a.nbv) * sizeof(int), s));
-    for (int level = hp.pyr_levels; level >= 0; level--) {
-        int step = 1 << level;
-        int nbx = (hp.a.nbh + step - 1) / step, nby = (hp.a.nbv + step - 1) / step;
-        DSV2_LAUNCH(k_hme_clear_one, dim3((unsigned) ((nb * 4 + 2047) / 2048)), dim3(256), 0, s, f.mvf[level], (int) (nb * 4), hp.a.nbh, level);
-        if (g_hme_rows) {
-            DSV2_LAUNCH(k_hme_rows, dim3(nby), dim3(64), 0, s, c, level, nbx, ((uniform_geometry(f, hp.pyr_levels) ? g_hme_fast : 0) & 1) | (g_hme_fence << 1));
-            nlaunch++;
-        } else {
-            for (int t = 0; t <= nbx + nby - 2; t++) {
-                int jhi = nby - 1 < t ? nby - 1 : t;
-                int jlo = t - (nbx - 1) > 0 ? t - (nbx - 1) : 0;
-                DSV2_LAUNCH(k_hme_front, dim3(jhi - jlo + 1), dim3(64), 0, s, c, level, t, nbx, nby, g_hme_fast);
-                nlaunch++;
-            }
-        }
-        if (level != 0 && !g_hme_rows) {
-            DSV2_LAUNCH(k_global_motion, dim3(1), dim3(256), 0, s, c, level);
-        }
+    if (l0pre) {
+        HIPCHK(hipFree(l0pre));
     }
-    HIPCHK(hipGetLastError());
     return nlaunch;
 }
 

@@ -221,93 +221,10 @@ __device__ __forceinline__ int sdiv_fast(int n, int d)
     return n < 0 ? -(int) q : (int) q;
 }
 
-// ---- search windows staged in LDS ------------------------------------------------------------------
-// Every block starts with ONE round of memory traffic: its source quads, its neighbours' vectors and -- by
-// LDS-DMA (global_load_lds: no registers, the data lands in LDS while the source analysis runs) -- the part of
-// the reference picture the search is going to look at: a 48x48 luma window centred on where the block to the
-// left ended up, and at level 0 a 28x28 window of the original reference and two 16x16 chroma windows for the
-// mode decision.  Candidate scoring, every refinement round, the sub-pel search (whose 20x20 filter window and
-// four neighbour blocks are read in place) and the mode-decision operands then come out of LDS (~100 clocks)
-// instead of L2 / HBM (~2 500 clocks under load per dependent round, five to seven rounds per block before).
-// A vector that leaves the window -- a wave-uniform test per phase -- takes that phase's original global path.
-// Window rows are stored as loaded: whole dwords starting at the dword that holds the window's first pixel.
-constexpr int kWinW = 48, kWinH = 48, kWinPitch = 52, kWinMargin = 16; // luma reference window, 13 dwords a row
-constexpr int kOgrW = 28, kOgrPitch = 32, kOgrMargin = 6;               // original-reference window (level 0)
-constexpr int kCwW = 16, kCwPitch = 20, kCwMargin = 4;                  // chroma reference windows (level 0)
-
-#ifndef DSV2_HME_WIN
-#define DSV2_HME_WIN 0
-#endif
-// (without the staged windows -- the default build -- the arrays shrink to one word: 4 KB of LDS per wavefront less)
-constexpr int kWinOn = DSV2_HME_WIN != 0 ? 1 : 0;
-struct WinLds {
-    alignas(16) uint32_t ref[kWinOn ? kWinH * kWinPitch / 4 : 1];
-    uint32_t ogr[kWinOn ? kOgrW * kOgrPitch / 4 : 1];
-    uint32_t chr[2][kWinOn ? kCwW * kCwPitch / 4 : 1];
-    uint32_t csrc[2][kWinOn ? 16 : 1]; // the block's 8x8 source chroma samples (U, V): 8 rows of 2 dwords
-};
-
-// what the windows hold, in plane coordinates (wave-uniform)
-struct Win {
-    int rx, ry; // first pixel of the luma reference window (kWinW x kWinH pixels are guaranteed from here)
-    int ox, oy; // ... of the original-reference window (kOgrW x kOgrW)
-    int cx, cy; // ... of the chroma windows (kCwW x kCwW)
-    bool on;
-};
-
-// ROWS x (PITCH / 4) dwords from `src` (address of the first, 4-byte aligned, dword) into `lds`, row by row.  One
-// instruction moves RPI whole rows (RPI * PITCH / 4 <= 64 lanes), so a lane's offset from the instruction's
-// wave-uniform base is the same in every step: one offset register for the whole window, scalar base arithmetic.
-template <int ROWS, int PITCH, int RPI> __device__ __forceinline__ void win_issue(uint32_t *lds, const uint8_t *src, int stride)
-{
-    typedef __attribute__((address_space(3))) uint32_t *lds_t;
-    typedef const __attribute__((address_space(1))) uint8_t *g_t;
-    const int lane = threadIdx.x & 63;
-    constexpr int PDW = PITCH / 4;
-    static_assert(RPI * PDW <= 64, "win_issue: rows per instruction do not fit a wavefront");
-    const int r = lane / PDW, col = lane - r * PDW;
-    const unsigned voff = (unsigned) (r * stride + col * 4);
-#pragma unroll
-    for (int k = 0; k * RPI < ROWS; k++) {
-        const int rows = ROWS - k * RPI < RPI ? ROWS - k * RPI : RPI;
-        if (lane < rows * PDW) {
-            g_t base = (g_t) src + (size_t) (k * RPI) * (size_t) (unsigned) stride;
-            __builtin_amdgcn_global_load_lds(base + voff, (lds_t) (lds + k * RPI * PDW), 4, 0, 0);
-        }
-    }
-}
-
-// the window's first pixel for a 16-pixel block at `b` displaced by `c`, kept inside the padded plane [-32, dim + 32)
-__device__ __forceinline__ int win_origin(int b, int c, int margin, int span, int dim)
-{
-    return min(max(b + c - margin, -kBorder), dim + kBorder - span);
-}
-
-// is the `bs`-pixel block at plane position p (+ margins before / after) inside a window of `span` pixels starting at w0?
-__device__ __forceinline__ bool win_has(int w0, int span, int p, int bs, int before, int after)
-{
-    return p - before >= w0 && p + bs + after <= w0 + span;
-}
-
-struct __attribute__((packed)) U16l { // possibly unaligned 16-bit LDS read
-    uint16_t v;
-};
-
-// quad (qi, qj) of the block whose first pixel sits `offx` bytes into row `offy` of a window with row pitch PITCH
-template <int PITCH> __device__ __forceinline__ Quad winq(const uint32_t *win, int offx, int offy, int qi, int qj, bool act)
-{
-    const uint8_t *p = (const uint8_t *) win + (offy + 2 * qj) * PITCH + offx + 2 * qi;
-    uint32_t top = ((const U16l *) p)->v, bot = ((const U16l *) (p + PITCH))->v;
-    Quad q;
-    q.w = act ? (top | (bot << 16)) : 0u;
-    return q;
-}
-
 struct FastLds {
     int hist[16];
     int cx[64], cy[64];
     SubpelLds sp;
-    WinLds win;
 #ifdef DSV2_HME_PROF
     unsigned long long prof_t, prof_acc[16];
     int prof_on;
@@ -509,35 +426,26 @@ __device__ __forceinline__ SrcStats source_analysis(const Quad &a, bool act, int
 // smask: bytes of a quad that belong to the block (all four, except in the half quads of an odd last row / column at the
 // squared-error levels)
 template <int NT, class VecFn>
-__device__ __forceinline__ unsigned score_vecs(const FastLds &s, const Win &w, VecFn vec, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
-                                               const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
+__device__ __forceinline__ unsigned score_vecs(VecFn vec, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
+                                               const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu,
+                                               unsigned wanted = 0xffffffffu)
 {
-    // all loads first, back to back (one round trip); a vector that may not be read is replaced by a safe one
+    // all loads first, back to back (one round trip); a vector that may not be read (or is not `wanted`: bit t) is replaced by a safe one
     Quad b[NT];
     bool ok[NT];
     int dxs[NT], dys[NT];
-    bool allin = w.on;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
         int dx, dy;
         vec(t, dx, dy);
-        ok[t] = t < cnt && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
+        ok[t] = t < cnt && ((wanted >> t) & 1u) && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
         dxs[t] = dx;
         dys[t] = dy;
-        allin = allin && (!ok[t] || (win_has(w.rx, kWinW, bx + dx, 16, 0, 0) && win_has(w.ry, kWinH, by + dy, 16, 0, 0)));
     }
-    if (allin) { // every vector of the round points into the staged window
-        const int rxa = w.rx & ~3;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            b[t] = winq<kWinPitch>(s.win.ref, ok[t] ? bx + dxs[t] - rxa : 0, ok[t] ? by + dys[t] - w.ry : 0, qi, qj, act);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; t++) { // the zero vector's block always lies inside the frame
-            b[t] = ldq(at(ref, bx + (ok[t] ? dxs[t] : 0), by + (ok[t] ? dys[t] : 0)), ref.stride, qi, qj, act);
-        }
+    for (int t = 0; t < NT; t++) { // the zero vector's block always lies inside the frame
+        b[t] = ldq(at(ref, bx + (ok[t] ? dxs[t] : 0), by + (ok[t] ? dys[t] : 0)), ref.stride, qi, qj, act);
     }
     constexpr int NR = NT <= 4 ? 4 : (NT <= 8 ? 8 : 16); // width of the joint reduction
     int v[NR];
@@ -556,11 +464,10 @@ __device__ __forceinline__ unsigned score_vecs(const FastLds &s, const Win &w, V
 
 // the same for vectors held in LDS (s.cx / s.cy [first .. first + cnt)): the candidate list
 template <int NT>
-__device__ __forceinline__ unsigned score16(const FastLds &s, const Win &w, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
+__device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
                                             const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
 {
     return score_vecs<NT>(
-        s, w,
         [&](int t, int &dx, int &dy) {
             dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]);
             dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
@@ -584,20 +491,13 @@ __device__ __forceinline__ void quad_err_intra(const Quad &a, const Quad &b, int
     isrc = (unsigned) (sq24(ae) << psy.err_weight) + (unsigned) (sq24(ta) << psy.tex_weight) + (unsigned) (sq24(s0 - dc) << (psy.avg_weight + 1));
 }
 
-// Measured on MI355X (tools/ab_hme.sh, 1080p, 384 streams / 4 groups, and 128 streams / 1 group): with the windows
-// 4 841 / 2 369 frames/s, without 5 015 / 2 511; phase clocks per block 60 200 vs 54 830.  The search is bound by
-// instruction issue, not by memory round trips: a quad out of the byte-addressed LDS window costs more instructions
-// (unaligned 16-bit reads split into byte reads + packing) than the two global_load_ushort it replaces, and the 21
-// LDS-DMA instructions per block are issue slots too.  Kept as a build option (make winlds); off by default.
-#ifndef DSV2_HME_WIN
-#define DSV2_HME_WIN 0
-#endif
-constexpr bool kUseWin = DSV2_HME_WIN != 0; // stage the search windows in LDS (false: every phase reads global memory, the round-1 form)
-constexpr bool kPrefetchSubpelFirst = false; // (measured: no gain once the loads of a phase were batched; costs 12 VGPRs) the first search's loads are issued ahead of candidate scoring (hme_block_fast_t)
-
-// everything a sub-pel search reads from memory: the four neighbouring full-pel blocks, the centred source
-// window and the 20x20 reference window -- twelve loads, one round trip; issued by the search itself or, for
-// the first search (around the parent average, known long before it runs), ahead of candidate scoring
+// ---- sub-pel search (hme.c:1051), in two halves ----------------------------------------------------------------------------
+// subpel_probes(): everything that reads pixels -- the squared errors of the four full-pel neighbours, the 34x34 half-pel image,
+// the seven probes' metrics.  A function of the block, the reference and the full-pel centre alone: for the search around the
+// parent average (known as soon as the level above is done) it runs in the unordered pre-pass (k_hme_l0_pre_b), not in the row
+// pipeline.  subpel_decide(): the comparison of the probes' scores + vector costs with the best full-pel score -- needs the cost
+// predictor (the block's same-level neighbours) and is a few dozen instructions.
+// Probe directions: (pri, sec) in {-1, 0, 1}^2 each, packed two bits per component (value + 1): pri0 | pri1 << 2 | sec0 << 4 | sec1 << 6.
 struct SubpelLoads {
     QuadRaw b4[4];
     QuadRaw awr;
@@ -619,39 +519,34 @@ __device__ __forceinline__ SubpelLoads subpel_issue_loads(const Ctx &c, int fpel
     return L;
 }
 
-// sub-pel search around full-pel vector (fpelx, fpely): hme.c:1051
-template <bool PRELOADED, class Ctx>
-__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const Win &W, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
-                                     int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy, const SubpelLoads &pre)
+// the probe offsets (quarter-pel) of probe n for packed directions `dirs` (all wave-uniform)
+__device__ __forceinline__ void subpel_probe_offset(unsigned dirs, int n, int &t0, int &t1)
+{
+    const int pri0 = (int) (dirs & 3u) - 1, pri1 = (int) ((dirs >> 2) & 3u) - 1, sec0 = (int) ((dirs >> 4) & 3u) - 1, sec1 = (int) ((dirs >> 6) & 3u) - 1;
+    const int diag0 = pri0 + sec0, diag1 = pri1 + sec1;
+    t0 = t1 = 0;
+    if (n == 6) {
+        t0 = pri0 + diag0;
+        t1 = pri1 + diag1;
+    } else if (n < 6) {
+        int v0 = (n >> 1) == 0 ? pri0 : ((n >> 1) == 1 ? sec0 : diag0);
+        int v1 = (n >> 1) == 0 ? pri1 : ((n >> 1) == 1 ? sec1 : diag1);
+        int hp = !(n & 1);
+        t0 = v0 * (1 << hp);
+        t1 = v1 * (1 << hp);
+    }
+}
+
+// returns on every lane L the normalised metric (metric_return) of probe L & 7 (probe 7 does not exist: 0); dirs: see above
+template <class Ctx>
+__device__ __forceinline__ unsigned subpel_probes(const Ctx &c, FastLds &S, int fpelx, int fpely, int bx, int by, int bw, int bh, const Quad &a, bool act, int qi,
+                                                  int qj, const Psy &psy, unsigned &dirs)
 {
     const int lane = threadIdx.x & 63;
-    sub_x = sub_y = 0;
-    if (best == 0) {
-        return best;
-    }
-    HME_COUNT(S, 13, 1);
-    unsigned yarea = (unsigned) (bw * bh);
     int v4[4];
     Quad aw;
-    // whole blocks whose filter window (fpel - 2 ... fpel + 17 both ways, which also holds the four neighbour blocks)
-    // lies inside the staged reference window read everything from LDS; for a whole block the centred 16x16
-    // source window is the block itself
-    const bool inwin = W.on && bw == 16 && bh == 16 && win_has(W.rx, kWinW, bx + fpelx, 16, 2, 2) && win_has(W.ry, kWinH, by + fpely, 16, 2, 2);
-    const int wox = bx + fpelx - (W.rx & ~3), woy = by + fpely - W.ry; // the block at the full-pel vector, in window coordinates
-    if (inwin) {
-        const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
-        aw = a;
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            v4[n] = (int) qsse(a, winq<kWinPitch>(S.win.ref, wox + dxs[n], woy + dys[n], qi, qj, true));
-        }
-    } else {
-        SubpelLoads L;
-        if constexpr (PRELOADED) {
-            L = pre;
-        } else {
-            L = subpel_issue_loads(c, fpelx, fpely, bx, by, bw, bh, qi, qj, act);
-        }
+    {
+        SubpelLoads L = subpel_issue_loads(c, fpelx, fpely, bx, by, bw, bh, qi, qj, act);
         __builtin_amdgcn_sched_barrier(0); // all twelve loads are in flight before the first is waited for
         aw = ldq_finish(L.awr, true);
 #pragma unroll
@@ -659,24 +554,17 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
             v4[n] = act ? (int) qsse(a, ldq_finish(L.b4[n], act)) : 0;
         }
         // park the 20x20 window in LDS now: the registers that hold it are free during the reduction below
-        int lane_ = threadIdx.x & 63;
         uint32_t *win32 = (uint32_t *) S.sp.win;
-        win32[lane_] = L.hw.d0;
-        if (lane_ + 64 < 100) {
-            win32[lane_ + 64] = L.hw.d1;
+        win32[lane] = L.hw.d0;
+        if (lane + 64 < 100) {
+            win32[lane + 64] = L.hw.d1;
         }
     }
     int r4 = reduceN<4>(v4);
     unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
              quad3 = (unsigned) bcastN<4>(r4, 3);
-    int area_ratio = (int) div_nn(8u * 256u, yarea), iarea_ratio = (int) (8 * yarea / 256);
-    best = best * (unsigned) area_ratio >> 3;
-    if (inwin) {
-        build_hpel_at<kWinPitch>(S.sp, (const uint8_t *) S.win.ref + (woy - 2) * kWinPitch + (wox - 2)); // the 20x20 area starts at fpel - 2 (hme.c:1108, :794)
-    } else {
-        __syncthreads();
-        build_hpel_at<20>(S.sp, S.sp.win);
-    }
+    __syncthreads();
+    build_hpel_at<20>(S.sp, S.sp.win);
 
     int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
     unsigned ms1 = quad1, ms2 = quad3;
@@ -693,23 +581,12 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
         sec0 = pri0, sec1 = pri1;
         pri0 = t0, pri1 = t1;
     }
-    int diag0 = pri0 + sec0, diag1 = pri1 + sec1;
-    int tx[8], ty[8], v8[8];
+    dirs = (unsigned) (pri0 + 1) | ((unsigned) (pri1 + 1) << 2) | ((unsigned) (sec0 + 1) << 4) | ((unsigned) (sec1 + 1) << 6);
+    int v8[8];
 #pragma unroll
     for (int n = 0; n < 8; n++) {
-        int t0 = 0, t1 = 0;
-        if (n == 6) {
-            t0 = pri0 + diag0;
-            t1 = pri1 + diag1;
-        } else if (n < 6) {
-            int v0 = (n >> 1) == 0 ? pri0 : ((n >> 1) == 1 ? sec0 : diag0);
-            int v1 = (n >> 1) == 0 ? pri1 : ((n >> 1) == 1 ? sec1 : diag1);
-            int hp = !(n & 1);
-            t0 = v0 * (1 << hp);
-            t1 = v1 * (1 << hp);
-        }
-        tx[n] = t0;
-        ty[n] = t1;
+        int t0, t1;
+        subpel_probe_offset(dirs, n, t0, t1);
         int X = 4 + 8 * qi + t0, Y = 4 + 8 * qj + t1;
         // every lane samples at the same quarter-pel phase (its X, Y differ from the probe offset by multiples of 4)
         const int ph = __builtin_amdgcn_readfirstlane((t0 & 1) | ((t1 & 1) << 1));
@@ -718,22 +595,35 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
         v8[n] = n < 7 ? (int) qmetric(aw, qs, psy) : 0;
     }
     int r8 = reduceN<8>(v8);
-    // lane n finishes probe n: metric_return + vector cost
     unsigned acc = (unsigned) bcastL<8>(r8, lane & 7);
-    int mtx = 0, mty = 0;
+    __syncthreads(); // (the LDS image may be rebuilt by a second search)
+    return metric_return(acc, 16, 16);
+}
+
+// mr: lane n (n < 7) holds the normalised metric of probe n
+__device__ __forceinline__ unsigned subpel_decide(const CostCtx &cc, int effort, unsigned mr, unsigned dirs, int &sub_x, int &sub_y, int fpelx, int fpely,
+                                                  unsigned best, int bw, int bh)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned yarea = (unsigned) (bw * bh);
+    const int area_ratio = (int) div_nn(8u * 256u, yarea), iarea_ratio = (int) (8 * yarea / 256);
+    best = best * (unsigned) area_ratio >> 3;
+    int tx[7], ty[7], mtx = 0, mty = 0;
 #pragma unroll
     for (int n = 0; n < 7; n++) {
-        if ((lane & 7) == n) {
+        subpel_probe_offset(dirs, n, tx[n], ty[n]);
+        if (lane == n) {
             mtx = tx[n];
             mty = ty[n];
         }
     }
-    unsigned sc = metric_return(acc, 16, 16) + (unsigned) mv_cost(cc, fpelx * 4 + mtx, fpely * 4 + mty, 0);
+    // lane n finishes probe n: vector cost
+    unsigned sc = mr + (unsigned) mv_cost(cc, fpelx * 4 + mtx, fpely * 4 + mty, 0);
     int b0 = 0, b1 = 0;
 #pragma unroll
     for (int n = 0; n <= 6; n++) {
-        const int t0 = tx[n], t1 = ty[n]; // (wave-uniform: no need to read them back from the lanes that scored them)
-        if (((t0 | t1) & 1) && c.effort < 8) {
+        const int t0 = tx[n], t1 = ty[n];
+        if (((t0 | t1) & 1) && effort < 8) {
             continue;
         }
         unsigned s = (unsigned) __builtin_amdgcn_readlane((int) sc, n);
@@ -745,8 +635,22 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     }
     sub_x = b0;
     sub_y = b1;
-    __syncthreads();
     return best * (unsigned) iarea_ratio >> 3;
+}
+
+// sub-pel search around full-pel vector (fpelx, fpely), both halves in place: the row pipeline's second search
+template <class Ctx>
+__device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, const CostCtx &cc, int &sub_x, int &sub_y, int fpelx, int fpely, unsigned best,
+                                                     int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, const Psy &psy)
+{
+    sub_x = sub_y = 0;
+    if (best == 0) {
+        return best;
+    }
+    HME_COUNT(S, 13, 1);
+    unsigned dirs;
+    const unsigned mr = subpel_probes(c, S, fpelx, fpely, bx, by, bw, bh, a, act, qi, qj, psy, dirs);
+    return subpel_decide(cc, c.effort, mr, dirs, sub_x, sub_y, fpelx, fpely, best, bw, bh);
 }
 
 // what the candidate load round already fetched and the level-0 tail needs again (wave-uniform)
@@ -806,13 +710,16 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
     dy = abs(tx - cx) + abs(ty - cy);
 }
 
-// level-0 tail of hme_block_fast: sub-pel refinement + mode decision (hme.c:1598-1821)
+// level-0 tail of the block routine: sub-pel refinement + mode decision (hme.c:1598-1821)
+// (sp_done, sp_mr, sp_dirs): the pixel half of the FIRST sub-pel search (around the parent average), from the pre-pass
+// (subpel_probes; sp_done = it was run: effort >= 4 and the block at the parent average has a rim of four inside the padded plane)
 // CS: chroma shift of both axes -- 1 = 4:2:0 (a block's chroma is 8x8: one pixel per lane, its 2x2 quads on lanes 0..31),
 // 0 = 4:4:4 (16x16 like the luma: every lane owns the quad (qi, qj) of U and of V)
-template <int CS, class Ctx>
-__device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, FastLds &S, const Win &W, int &pcx, int &pcy, RowAcc &acc, DSV_MV *mvf, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
+template <int CS, bool SPLIT, class Ctx>
+__device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
-                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, const SubpelLoads &sp_pre)
+                                  unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, bool sp_done, unsigned sp_mr,
+                                  unsigned sp_dirs)
 {
     const int lane = threadIdx.x & 63;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
@@ -827,9 +734,15 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     unsigned best_fp = best;
     if (c.effort >= 4) {
         bool searched_lax = false;
-        if (!invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
+        if (SPLIT ? sp_done : !invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
             searched_lax = true;
-            best = subpixel_me_fast<kPrefetchSubpelFirst>(c, S, W, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
+            if (best_fp != 0) { // (hme.c:1062: a perfect full-pel match is not searched around)
+                if constexpr (SPLIT) {
+                    best = subpel_decide(cc, c.effort, sp_mr, sp_dirs, sx, sy, lax, lay, best_fp, bw, bh);
+                } else {
+                    best = subpixel_me_fast(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+                }
+            }
             if (sx || sy) {
                 fpelx = lax;
                 fpely = lay;
@@ -840,7 +753,7 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
         // first one operand for operand and ends where it did: no sub-pel offset, the same score; it is not run again)
         const bool same_centre = searched_lax && fpelx == lax && fpely == lay;
         if (!found_sub && !good_enough && !same_centre && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
-            best = subpixel_me_fast<false>(c, S, W, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy, sp_pre);
+            best = subpixel_me_fast(c, S, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
         }
     }
     mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
@@ -865,47 +778,24 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
     Quad usq, vsq, umq, vmq, uzq, vzq; // 4:4:4: this lane's quad of the source / reference-at-the-vector / reference-at-zero chroma blocks
     usq.w = vsq.w = umq.w = vmq.w = uzq.w = vzq.w = 0;
     cs.w = cz.w = cm.w = 0;
-    // every operand sits in a staged window when the final vector stayed near the left neighbour's (the usual case)
-    const bool mwin = CS == 1 && W.on && win_has(W.rx, kWinW, bx + fpelx, 16, 0, 0) && win_has(W.ry, kWinH, by + fpely, 16, 0, 0) &&
-                      win_has(W.rx, kWinW, bx, 16, 0, 0) && win_has(W.ry, kWinH, by, 16, 0, 0) &&
-                      win_has(W.ox, kOgrW, bx + fpelx, 16, 0, 0) && win_has(W.oy, kOgrW, by + fpely, 16, 0, 0) &&
-                      win_has(W.cx, kCwW, cbmx, 8, 0, 0) && win_has(W.cy, kCwW, cbmy, 8, 0, 0) && win_has(W.cx, kCwW, cbx, 8, 0, 0) &&
-                      win_has(W.cy, kCwW, cby, 8, 0, 0);
-    if (mwin) {
-        const int rxa = W.rx & ~3, oxa = W.ox & ~3, cxa = W.cx & ~3;
-        r = winq<kWinPitch>(S.win.ref, bx + fpelx - rxa, by + fpely - W.ry, qi, qj, act);
-        rz = winq<kWinPitch>(S.win.ref, bx - rxa, by - W.ry, qi, qj, act);
-        o = winq<kOgrPitch>(S.win.ogr, bx + fpelx - oxa, by + fpely - W.oy, qi, qj, act);
-        const uint8_t *su = (const uint8_t *) S.win.csrc[0], *sv = (const uint8_t *) S.win.csrc[1];
-        us = actc ? su[cyp * 8 + cxp] : 0;
-        vs = actc ? sv[cyp * 8 + cxp] : 0;
-        const uint8_t *wu = (const uint8_t *) S.win.chr[0], *wv = (const uint8_t *) S.win.chr[1];
-        const int mo = (cbmy - W.cy + cyp) * kCwPitch + (cbmx - cxa + cxp);
-        um = actc ? wu[mo] : 0;
-        vm = actc ? wv[mo] : 0;
-        cs = winq<8>(S.win.csrc[cpl], 0, 0, cqi, cqj, actq);
-        cz = winq<kCwPitch>(S.win.chr[cpl], cbx - cxa, cby - W.cy, cqi, cqj, actq);
-        cm = winq<kCwPitch>(S.win.chr[cpl], cbmx - cxa, cbmy - W.cy, cqi, cqj, actq);
+    r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
+    o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
+    rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
+    if constexpr (CS == 1) {
+        us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
+        vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
+        um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
+        vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
+        cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
+        cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
+        cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
     } else {
-        r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
-        o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
-        rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
-        if constexpr (CS == 1) {
-            us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
-            vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
-            um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
-            vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
-            cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
-            cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
-            cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
-        } else {
-            usq = ldq(at(c.srcc[0], cbx, cby), c.srcc[0].stride, qi, qj, act);
-            vsq = ldq(at(c.srcc[1], cbx, cby), c.srcc[1].stride, qi, qj, act);
-            umq = ldq(at(c.refc[0], cbmx, cbmy), c.refc[0].stride, qi, qj, act);
-            vmq = ldq(at(c.refc[1], cbmx, cbmy), c.refc[1].stride, qi, qj, act);
-            uzq = ldq(at(c.refc[0], cbx, cby), c.refc[0].stride, qi, qj, act);
-            vzq = ldq(at(c.refc[1], cbx, cby), c.refc[1].stride, qi, qj, act);
-        }
+        usq = ldq(at(c.srcc[0], cbx, cby), c.srcc[0].stride, qi, qj, act);
+        vsq = ldq(at(c.srcc[1], cbx, cby), c.srcc[1].stride, qi, qj, act);
+        umq = ldq(at(c.refc[0], cbmx, cbmy), c.refc[0].stride, qi, qj, act);
+        vmq = ldq(at(c.refc[1], cbmx, cbmy), c.refc[1].stride, qi, qj, act);
+        uzq = ldq(at(c.refc[0], cbx, cby), c.refc[0].stride, qi, qj, act);
+        vzq = ldq(at(c.refc[1], cbx, cby), c.refc[1].stride, qi, qj, act);
     }
     const int kq = (qi >= (qw >> 1) ? 1 : 0) | (qj >= (qh >> 1) ? 2 : 0);         // luma quadrant of this lane's quad
     const int kc = (cqi >= (cbw >> 2) ? 1 : 0) | (cqj >= (cbh >> 2) ? 2 : 0);      // chroma quadrant of this lane's chroma quad
@@ -1234,8 +1124,6 @@ __device__ __forceinline__ void hme_block_fast_l0(const Ctx &c, int i, int j, Fa
         mv.flags &= ~(1u << DSV_MV_BIT_SIMCMPLX);
     }
     HME_MARK(S, 8);
-    pcx = sarx((int) mv.u.mv.x, 2);
-    pcy = sarx((int) mv.u.mv.y, 2);
     if (lane == 0) {
         st_mv_final(c, out, mv);
     }
@@ -1255,17 +1143,183 @@ __device__ __forceinline__ int tab9(unsigned packed, int k) { return (int) ((pac
 constexpr unsigned kRectX = 0x22149u, kRectY = 0x28095u; // rect[]: {0,1,-1,0,0,-1,1,-1,1} / {0,0,0,1,-1,-1,-1,1,1} (hme.c:1304)
 constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {0,-1,1,0,0,-1,1,1,-1} / {0,0,0,-1,1,-1,1,-1,1} (hme.c:1468)
 
-// FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away
-// (pcx, pcy): in -- where the block to the left ended up (full-pel, this level's pixels), the centre of the staged
-// windows; out -- the same for this block
-// LV: what is known about the level at compile time -- 0: it is level 0; 1: it is a coarser level (the sub-pel search and
-// the mode decision are not even compiled in: a third of the registers); -1: decided at run time
-// PRE: the source statistics of levels 0 and 1 are KNOWN to have been worked out ahead (the batched driver's kernels of that
-// name): the block routine's own source analysis is not even compiled in
-template <bool FULL, int LV, int CS, bool PRE, class Ctx>
-__device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy, RowAcc &acc)
+
+// ---- parent-level half of the candidate list: the average of the parent vectors' inliers (hme.c:1443-1470, find_inliers :1260) ----
+// lanes 16..24 hold the up to nine parent vectors (pvalid).  false: there is none -- the list is then the zero vector alone.
+__device__ __forceinline__ bool parent_average(bool pvalid, int pvx, int pvy, int &lax, int &lay, bool &inl, int &nin)
 {
-    const int level = LV == 0 ? 0 : level_rt;
+    lax = lay = nin = 0;
+    inl = false;
+    const int npar = __popcll(__ballot(pvalid));
+    if (!npar) {
+        return false;
+    }
+    int v2[2] = {pvalid ? pvx : 0, pvalid ? pvy : 0};
+    int r = reduceN<2>(v2);
+    lax = sdiv_fast(bcastN<2>(r, 0), npar);
+    lay = sdiv_fast(bcastN<2>(r, 1), npar);
+    int dist = pvalid ? SQR(pvx - lax) + SQR(pvy - lay) : 0;
+    int avgd = sdiv_fast(wave_sum(dist), npar);
+    int ssd = wave_sum(pvalid ? SQR(dist - avgd) : 0);
+    int thresh = avgd + (int) isqrt_u32((unsigned) sdiv_fast(ssd, npar));
+    inl = pvalid && dist <= thresh;
+    nin = __popcll(__ballot(inl));
+    if (nin) {
+        int w2[2] = {inl ? pvx : 0, inl ? pvy : 0};
+        int r2 = reduceN<2>(w2);
+        lax = sdiv_fast(bcastN<2>(r2, 0), nin);
+        lay = sdiv_fast(bcastN<2>(r2, 1), nin);
+    }
+    return true;
+}
+
+// first-occurrence de-duplication of the per-lane list entries (hme.c:1166): one round per DISTINCT vector, not per entry (a block
+// has ~15 - 25 entries and ~3.5 distinct vectors): the lowest lane that holds an unclassified entry keeps it, every other
+// entry with that vector is a duplicate of it.  key: both components, int16 each.  Returns "this lane's entry is a duplicate".
+__device__ __forceinline__ bool dedup_lanes(bool exist, int key)
+{
+    const int lane = threadIdx.x & 63;
+    bool dup = false;
+    for (unsigned long long rest = __ballot(exist); rest;) {
+        const int m = __ffsll((long long) rest) - 1;
+        const int km = __builtin_amdgcn_readlane(key, m);
+        const bool same = exist && km == key;
+        dup = dup || (same && lane != m);
+        rest &= ~__ballot(same);
+    }
+    return dup;
+}
+
+// ---- full-pel refinement (hme.c:1300): each round scores the 3x3 neighbourhood at once --------------------------------------
+template <bool L0>
+__device__ __forceinline__ void refine_fpel(const DPlane &ref, int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, int level,
+                                            const Psy &psy, uint32_t smask, const CostCtx &cc, unsigned qthresh, int &dx, int &dy, unsigned &best,
+                                            bool &good_enough, FastLds &S)
+{
+    const int lane = threadIdx.x & 63;
+    const int step = 1 << level;
+    unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
+    bool again = true;
+    HME_COUNT(S, 11, 1);
+    while (again && !good_enough) {
+        again = false;
+        HME_COUNT(S, 12, 1);
+        const int rdx = dx, rdy = dy;
+        unsigned raw = score_vecs<9>(
+            [&](int t, int &vx, int &vy) {
+                vx = rdx + tab9(kRectX, t);
+                vy = rdy + tab9(kRectY, t);
+            },
+            9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+        int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
+        bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
+        if (level <= 1) {
+            raw = metric_return(raw, bw, bh);
+        }
+        unsigned full = raw + (unsigned) mv_cost(cc, tx * step * 4, ty * step * 4, level);
+        int cdx = dx, cdy = dy;
+        for (int k = 0; k < 5; k++) {
+            bool vk = __builtin_amdgcn_readlane((int) valid, k) != 0;
+            if (!vk) {
+                continue;
+            }
+            unsigned sk = (unsigned) __builtin_amdgcn_readlane((int) raw, k);
+            int tvx = cdx + tab9(kRectX, k), tvy = cdy + tab9(kRectY, k);
+            if (k == 1) {
+                metr0 = sk;
+            } else if (k == 2) {
+                metr1 = sk;
+            } else if (k == 3) {
+                metr2 = sk;
+            } else if (k == 4) {
+                metr3 = sk;
+            }
+            if (L0 && !tvx && !tvy && sk <= qthresh) {
+                dx = tvx;
+                dy = tvy;
+                best = sk;
+                good_enough = true;
+                break;
+            }
+            unsigned fk = (unsigned) __builtin_amdgcn_readlane((int) full, k);
+            if (best > fk) {
+                best = fk;
+                dx = tvx;
+                dy = tvy;
+                again = true;
+                break;
+            }
+        }
+        if (again || good_enough) {
+            continue;
+        }
+        int sxs = metr0 <= metr1 ? 1 : -1, sys = metr2 <= metr3 ? 1 : -1;
+        int kd = sys < 0 ? (sxs < 0 ? 5 : 6) : (sxs < 0 ? 7 : 8); // index of (sxs, sys) in rect[]
+        bool vd = __builtin_amdgcn_readlane((int) valid, kd) != 0;
+        if (!vd) {
+            break;
+        }
+        unsigned fd = (unsigned) __builtin_amdgcn_readlane((int) full, kd);
+        if (best > fd) {
+            best = fd;
+            dx = cdx + sxs;
+            dy = cdy + sys;
+            again = true;
+        }
+    }
+}
+
+// the 8-byte heads of a block's same-level neighbours: lanes 3 / 4 / 5 load left / top / top-left (coherent loads: the row
+// above may be on another XCD).  Row pipeline: the top / top-left heads may not have been stored yet -- they read kMvPending
+// until they are (hme.hip: wait_heads).  Validated HERE, inside the block's first load round: in the usual case (the row above
+// is ahead) the hand-off costs no memory round trip of its own.  The left neighbour is the block this wavefront has just
+// finished: its head is still in registers (acc.left_head).
+__device__ __forceinline__ MvHead load_neighbour_heads(DSV_MV *mvf, DSV_MV *out, int i, int j, int step, int nxb, int *counters, RowAcc &acc, bool &nb_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const bool need_i = lane != 4, need_j = lane != 3;
+    nb_ok = lane >= 3 && lane <= 5 && (!need_i || i > 0) && (!need_j || j > 0);
+    const DSV_MV *np = nb_ok ? &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb] : out;
+    typedef const __attribute__((address_space(1))) unsigned long long *gu64p_t;
+    unsigned long long head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const bool mine = nb_ok && lane != 3;
+        unsigned long long t0 = 0;
+        for (unsigned spins = 0; __any(mine && head == kMvPending); spins++) {
+            __builtin_amdgcn_s_sleep(8);
+            head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((spins & 1023u) == 1023u) {
+                const unsigned long long now = wall_clock64();
+                int *err = &counters[kHmeErrWord];
+                if (t0 == 0) {
+                    t0 = now;
+                } else if (now - t0 > kHmeSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc.failed = true;
+                    break;
+                }
+            }
+        }
+    }
+    if (lane == 3) {
+        head = acc.left_head;
+    }
+    MvHead nbv;
+    nbv.all = (uint32_t) head;
+    nbv.flags = (uint32_t) (head >> 32);
+    nbv.x = (int) (int16_t) (nbv.all & 0xffffu);
+    nbv.y = (int) (int16_t) (nbv.all >> 16);
+    return nbv;
+}
+
+// ============================================================================================================================
+// Coarser levels (level >= 1): candidate list, best candidate, refinement (hme.c:1373-1597); no sub-pel, no mode decision.
+// FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away.
+// Level 1 reads the source statistics of the pre-pass (c.stats: k_hme_src_stats4_b / _b); the squared-error levels need none.
+// ============================================================================================================================
+template <bool FULL, class Ctx>
+__device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+{
     const int lane = threadIdx.x & 63;
     const int qi = lane & 7, qj = lane >> 3;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
@@ -1277,7 +1331,6 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     DSV_MV mv = {};
 
     const int bx = (i * y_w) >> level, by = (j * y_h) >> level;
-    // (a whole block is 16x16 by definition: as constants its area divisions, metric normalisations and quadrant tests fold away)
     const int bw = FULL ? y_w : min(src.w - bx, y_w), bh = FULL ? y_h : min(src.h - by, y_h);
     const int qw = bw >> 1, qh = bh >> 1;
     // The psy metric works on whole 2x2 quads and drops an odd last row / column (hme.c:136: loops to h / 2, w / 2); the squared
@@ -1290,61 +1343,24 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         act = qi < ((bw + 1) >> 1) && qj < ((bh + 1) >> 1);
         smask = (((bw & 1) && qi == qw) ? 0x00ff00ffu : 0xffffffffu) & (((bh & 1) && qj == qh) ? 0x0000ffffu : 0xffffffffu);
     }
-    const uint8_t *sblk = at(src, bx, by);
-    Quad a = ldq(sblk, src.stride, qi, qj, act);
+    Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
     a.w &= smask;
-    // the block's source statistics, if the driver had them worked out ahead (levels 0 and 1): a scalar load, same round
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
-    const int4 *pre_stats = level <= 1 ? src_stats_of(c, level) : nullptr;
-    const bool have_pre = PRE ? level <= 1 : pre_stats != nullptr;
+    const bool have_pre = level <= 1;
     v4i_t pre_words = {0, 0, 0, 0};
-    Quad o_zero; // for the "good enough" test far below: same load round (its outcome comes with the statistics if they were worked out ahead)
+    Quad o_zero; // for the "good enough" test far below: same load round (level 1: its outcome comes with the statistics)
     o_zero.w = 0;
     if (have_pre) {
-        pre_words = *(cv4i_t) &pre_stats[(i >> level) + (j >> level) * ((nxb + step - 1) >> level)];
+        pre_words = *(cv4i_t) &c.stats[(i >> level) + (j >> level) * ((nxb + step - 1) >> level)];
     } else {
         o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
     }
-    // the same round also stages the search windows in LDS (LDS-DMA, no registers: see WinLds)
-    Win W;
-    W.on = kUseWin;
-    W.rx = W.ry = W.ox = W.oy = W.cx = W.cy = 0;
-    if (kUseWin) {
-        W.rx = win_origin(bx, pcx, kWinMargin, kWinW, src.w);
-        W.ry = win_origin(by, pcy, kWinMargin, kWinH, src.h);
-        win_issue<kWinH, kWinPitch, 4>(S.win.ref, at(ref, W.rx & ~3, W.ry), ref.stride);
-        if (level == 0) {
-            W.ox = win_origin(bx, pcx, kOgrMargin, kOgrW, src.w);
-            W.oy = win_origin(by, pcy, kOgrMargin, kOgrW, src.h);
-            win_issue<kOgrW, kOgrPitch, 8>(S.win.ogr, at(ogr, W.ox & ~3, W.oy), ogr.stride);
-            const DPlane cu = c.refc[0], cv = c.refc[1];
-            W.cx = win_origin((i * 16) >> CS, sarx(pcx, CS), kCwMargin, kCwW, cu.w);
-            W.cy = win_origin((j * 16) >> CS, sarx(pcy, CS), kCwMargin, kCwW, cu.h);
-            win_issue<kCwW, kCwPitch, 12>(S.win.chr[0], at(cu, W.cx & ~3, W.cy), cu.stride);
-            win_issue<kCwW, kCwPitch, 12>(S.win.chr[1], at(cv, W.cx & ~3, W.cy), cv.stride);
-            if (lane < 32) { // the block's own chroma samples: 8 rows x 2 dwords of U (lanes 0..15) and V (16..31)
-                typedef __attribute__((address_space(3))) uint32_t *lds_t;
-                typedef const __attribute__((address_space(1))) uint8_t *g_t;
-                const DPlane sp = c.srcc[(lane >> 4) & 1];
-                __builtin_amdgcn_global_load_lds((g_t) at(sp, i * 8, j * 8) + ((lane & 15) >> 1) * sp.stride + (lane & 1) * 4, (lds_t) &S.win.csrc[0][0], 4, 0, 0);
-            }
-        }
-    }
-
-    // (issued here, ahead of the source analysis, so that its latency is covered by that arithmetic)
-    // ONE load round for every vector the list and the cost predictor read: lanes 3..5 fetch the same-level
-    // neighbours (left, top, top-left; coherent loads, the row above may be on another XCD), lanes 6..14 the
-    // co-located vectors of the previous frame, lanes 16..24 the parent level's.  Lanes without a vector
-    // load this block's own entry and ignore it.
+    // ONE load round for every vector the list reads: lanes 3..5 the same-level neighbours, lanes 6..14 the co-located
+    // vectors of the previous frame, lanes 16..24 the parent level's.  Lanes without a vector load this block's own entry.
     bool nb_ok = false, pvalid = false, tvalid = false;
-    MvHead nbv;
     uint32_t ov;
-    int pvx = 0, pvy = 0;
     {
-        const bool need_i = lane != 4, need_j = lane != 3;
-        nb_ok = lane >= 3 && lane <= 5 && (!need_i || i > 0) && (!need_j || j > 0);
-        const DSV_MV *np = nb_ok ? &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb] : out;
         const DSV_MV *op = out;
         if (parent != nullptr) {
             unsigned parent_mask = ~(((unsigned) step << 1) - 1);
@@ -1366,118 +1382,39 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
             }
         }
         typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
-        typedef const __attribute__((address_space(1))) unsigned long long *gu64p_t;
         ov = *(gu32p_t) op;
-        unsigned long long head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Row pipeline: the top / top-left heads may not have been stored yet -- they read kMvPending until they are (hme.hip:
-        // wait_heads).  Validated HERE, inside the block's first load round: in the usual case (the row above is ahead) the
-        // hand-off costs no memory round trip of its own.  (Launch per front: never pending.)
-        {
-            const bool mine = nb_ok && lane != 3;
-            unsigned long long t0 = 0;
-            for (unsigned spins = 0; __any(mine && head == kMvPending); spins++) {
-                __builtin_amdgcn_s_sleep(8);
-                head = __hip_atomic_load((gu64p_t) np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((spins & 1023u) == 1023u) {
-                    const unsigned long long now = wall_clock64();
-                    int *err = &c.counters[kHmeErrWord];
-                    if (t0 == 0) {
-                        t0 = now;
-                    } else if (now - t0 > kHmeSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        acc.failed = true;
-                        break;
-                    }
-                }
-            }
-        }
-        if (lane == 3 && acc.have_left) { // the left neighbour is the block this wavefront has just finished: its head is still in registers
-            head = acc.left_head;
-        }
-        nbv.all = (uint32_t) head;
-        nbv.flags = (uint32_t) (head >> 32);
-        nbv.x = (int) (int16_t) (nbv.all & 0xffffu);
-        nbv.y = (int) (int16_t) (nbv.all >> 16);
-        pvx = (int) (int16_t) (ov & 0xffffu);
-        pvy = (int) (int16_t) (ov >> 16);
     }
+    const MvHead nbv = load_neighbour_heads(mvf, out, i, j, step, nxb, c.counters, acc, nb_ok);
+    int pvx = (int) (int16_t) (ov & 0xffffu), pvy = (int) (int16_t) (ov >> 16);
     int motion_bias = y_w * y_h;
-    unsigned var_src = 0, avg_src = 0;
+    unsigned var_src = 0;
     Psy psy = {2, 1, 0};
     if (level <= 1) {
-        SrcStats st;
-        if (have_pre) { // (worked out ahead of the search, see source_analysis)
-            st.bias_raw = pre_words.x;
-            st.var_src = (unsigned) pre_words.y;
-            st.avg_src = (unsigned) pre_words.z;
-            st.zoscore = (unsigned) pre_words.w;
-        } else if constexpr (!PRE) {
-            st = source_analysis(a, act, qi, qj, qw, bw, bh, c.quant, S.hist);
-        }
-        var_src = st.var_src;
-        avg_src = st.avg_src;
-        motion_bias = (int) udiv_fast((unsigned) max(st.bias_raw, 0), (unsigned) (2 + (abs(gx) + abs(gy))));
+        var_src = (unsigned) pre_words.y;
+        motion_bias = (int) udiv_fast((unsigned) max(pre_words.x, 0), (unsigned) (2 + (abs(gx) + abs(gy))));
         if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
             motion_bias = 0;
         }
         psy = psy_of_source(var_src, bw, bh, c.quant);
     }
-
-    HME_MARK(S, 1);
     // ---- candidate gathering: lane p owns canonical list position p (hme.c:1443-1528) ----
-    //  0 zero | 1 parent inlier average | 2 predictor (level 0) | 3 left 4 top 5 top-left |
+    //  0 zero | 1 parent inlier average | (2 predictor: level 0 only) | 3 left 4 top 5 top-left |
     //  6..14 temporal | 15 global | 16..24 parent inliers
     int lax = 0, lay = 0;
     bool exist = lane == 0;
     int cxv = 0, cyv = 0;
-    // dsv_movec_pred (dsv.c:375) of this block: at level 0 its operands are the three neighbours just loaded;
-    // at the coarser levels it reads entries between the level's grid points, which are never written (zero)
+    // dsv_movec_pred (dsv.c:375) at the coarser levels reads entries between the level's grid points, which are never written (zero)
     CostCtx cc;
     cc.px = cc.py = 0;
-    if (level == 0) {
-        int v0 = __builtin_amdgcn_readlane((int) nbv.all, 3), v1 = __builtin_amdgcn_readlane((int) nbv.all, 4),
-            v2 = __builtin_amdgcn_readlane((int) nbv.all, 5);
-        v0 = i > 0 ? v0 : 0;
-        v1 = j > 0 ? v1 : 0;
-        v2 = i > 0 && j > 0 ? v2 : 0;
-        cc.px = pred1((int) (int16_t) (v0 & 0xffff), (int) (int16_t) (v1 & 0xffff), (int) (int16_t) (v2 & 0xffff));
-        cc.py = pred1(v0 >> 16, v1 >> 16, v2 >> 16);
-    }
-    HME_MARK(S, 2);
     if (parent != nullptr) {
-        if (!pvalid) {
-            pvx = tvalid ? pvx : 0;
-            pvy = tvalid ? pvy : 0;
-        }
-        int npar = __popcll(__ballot(pvalid));
-        if (npar) {
-            int v2[2] = {pvalid ? pvx : 0, pvalid ? pvy : 0};
-            int r = reduceN<2>(v2);
-            lax = sdiv_fast(bcastN<2>(r, 0), npar);
-            lay = sdiv_fast(bcastN<2>(r, 1), npar);
-            // find_inliers (hme.c:1260)
-            int dist = pvalid ? SQR(pvx - lax) + SQR(pvy - lay) : 0;
-            int avgd = sdiv_fast(wave_sum(dist), npar);
-            int ssd = wave_sum(pvalid ? SQR(dist - avgd) : 0);
-            int thresh = avgd + (int) isqrt_u32((unsigned) sdiv_fast(ssd, npar));
-            bool inl = pvalid && dist <= thresh;
-            int nin = __popcll(__ballot(inl));
-            if (nin) {
-                int w2[2] = {inl ? pvx : 0, inl ? pvy : 0};
-                int r2 = reduceN<2>(w2);
-                lax = sdiv_fast(bcastN<2>(r2, 0), nin);
-                lay = sdiv_fast(bcastN<2>(r2, 1), nin);
-            }
-            HME_MARK(S, 15);
+        bool inl;
+        int nin;
+        if (parent_average(pvalid, pvx, pvy, lax, lay, inl, nin)) {
             // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)
             if (lane == 1) {
                 exist = true;
                 cxv = qp2fp((int16_t) (lax * 4));
                 cyv = qp2fp((int16_t) (lay * 4));
-            } else if (lane == 2 && level == 0) {
-                exist = true;
-                cxv = qp2fp((int16_t) cc.px);
-                cyv = qp2fp((int16_t) cc.py);
             } else if (nb_ok) {
                 exist = true;
                 cxv = qp2fp(nbv.x);
@@ -1499,23 +1436,11 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     }
     cxv = (int) (int16_t) ((int) (int16_t) cxv >> level);
     cyv = (int) (int16_t) ((int) (int16_t) cyv >> level);
-    // first-occurrence de-duplication (hme.c:1166), then ONE order-preserving compaction into LDS.  The comparison walks the
-    // existing entries with scalar reads of the owning lanes (no LDS round trip per entry).
+    // first-occurrence de-duplication, then ONE order-preserving compaction into LDS
     int n;
     {
-        const unsigned long long em = __ballot(exist);
         const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16); // both components are int16 by now
-        // one round per DISTINCT vector, not per list entry (a block has ~15 - 25 entries and ~3.5 distinct vectors): the lowest
-        // lane that still holds an unclassified entry keeps it, every other entry with that vector is a duplicate of it
-        bool dup = false;
-        for (unsigned long long rest = em; rest;) {
-            const int m = __ffsll((long long) rest) - 1;
-            const int km = __builtin_amdgcn_readlane(key, m);
-            const bool same = exist && km == key;
-            dup = dup || (same && lane != m);
-            rest &= ~__ballot(same);
-        }
-        const bool keep = exist && !dup;
+        const bool keep = exist && !dedup_lanes(exist, key);
         const unsigned long long km = __ballot(keep);
         const int nidx = __popcll(km & ((1ull << lane) - 1));
         n = __popcll(km);
@@ -1532,34 +1457,18 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
     }
     cc.q = c.quant;
     cc.b2sr = b2sr_of(c);
-    // loads of the first sub-pel search (around the parent average; hme_block_fast_l0 runs it under this same
-    // condition): in flight from here on, under candidate scoring and refinement
-    SubpelLoads sp_pre;
-    constexpr bool kPrefetchSubpel = kPrefetchSubpelFirst; // costs ~14 VGPRs: see DESIGN 5.2 (register footprint vs co-resident kernels)
-    if (kPrefetchSubpel && level == 0 && c.effort >= 4 && !invalid_block(ref, bx + lax, by + lay, bw, bh, 4)) {
-        sp_pre = subpel_issue_loads(c, lax, lay, bx, by, bw, bh, qi, qj, act);
-    }
-    HME_MARK(S, 2);
-    if (kUseWin) {
-        // the staged windows are read from here on: the LDS-DMA transfers issued at the top of the block must have
-        // landed (the compiler does not order LDS reads behind them)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-
-    HME_COUNT(S, 10, 1);
-    HME_COUNT(S, 14, n);
     // ---- best candidate (hme.c:1530-1557): lane k scores candidate k ----
     int dx, dy;
-    unsigned best, score_zero;
+    unsigned best;
     {
         unsigned raw = 0;
         if (n <= 4) { // the usual case after de-duplication
-            raw = score16<4>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+            raw = score16<4>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
         } else if (n <= 8) {
-            raw = score16<8>(S, W, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+            raw = score16<8>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
         } else {
             for (int first = 0; first < n; first += 16) {
-                unsigned r = score16<16>(S, W, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+                unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
                 if (lane >= first && lane < first + 16) {
                     raw = r;
                 }
@@ -1581,9 +1490,6 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
         unsigned long long hit = __ballot(valid && sc == mn);
         int best_k = (mn != 0xffffffffu && hit) ? (int) __ffsll((long long) hit) - 1 : 0;
         best = mn;
-        bool z_valid = __builtin_amdgcn_readlane((int) valid, 0) != 0;
-        unsigned z_raw = (unsigned) __builtin_amdgcn_readlane((int) raw, 0);
-        score_zero = z_valid ? z_raw : 0xffffffffu;
         dx = __builtin_amdgcn_readfirstlane(S.cx[best_k]);
         dy = __builtin_amdgcn_readfirstlane(S.cy[best_k]);
     }
@@ -1595,121 +1501,469 @@ __device__ __forceinline__ void hme_block_fast_t(const Ctx &c, int level_rt, int
             qthresh *= 2;
         }
         if (zoscore < qthresh) {
-            best = level == 0 ? score_zero : 0;
+            best = 0;
+            dx = dy = 0;
+            good_enough = true;
+        }
+    }
+    if (!good_enough) {
+        refine_fpel<false>(ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask, cc, qthresh, dx, dy, best, good_enough, S);
+    }
+    mv.u.mv.x = (int16_t) (dx * step);
+    mv.u.mv.y = (int16_t) (dy * step);
+    if (lane == 0) {
+        st_mv(out, mv);
+    }
+    acc.left_head = (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.u.all) |
+                    ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.flags) << 32);
+}
+
+template <class Ctx> __device__ __forceinline__ void hme_block_lx(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+{
+    const DPlane &src = c.src[level];
+    int bx = (i * 16) >> level, by = (j * 16) >> level;
+    if (src.w - bx >= 16 && src.h - by >= 16) {
+        hme_block_lx_t<true>(c, level, i, j, gx, gy, S, acc);
+    } else {
+        hme_block_lx_t<false>(c, level, i, j, gx, gy, S, acc);
+    }
+}
+
+// ============================================================================================================================
+// Level 0, first half: what a block's search can know BEFORE its same-level neighbours are known.
+// The row pipeline of the search is serial along a row and down the rows; of a level-0 block's work only the neighbour-derived
+// list entries (predictor, left, top, top-left), the vector COSTS (their predictor is the neighbours' median), the refinement
+// and what follows it depend on that order.  The rest -- the parent level's half of the list (inlier average, inliers), the
+// temporal and global entries, the de-duplicated list's SCORES, and the pixel half of the sub-pel search around the parent
+// average (four squared errors, the 34x34 half-pel image, seven probes) -- is a function of the source, the reference, the
+// level above and the previous frame's field alone: k_hme_l0_pre_b works it out for every block in any order, at full
+// occupancy, right after level 1 has finished, and leaves a 256-byte record per block:
+//   dwords  0..41  21 list entries {key = x | y << 16 (int16 each, full-pel), rf} for canonical positions 0, 1, 6 .. 24
+//                  (entry e = p < 2 ? p : p - 4); rf = kL0Absent: no such entry (or a duplicate of an earlier one), else the
+//                  normalised metric (metric_return: < 2^24) | kL0Invalid if the block at the vector leaves the padded plane
+//   dwords 48..54  normalised metrics of the seven sub-pel probes around the parent average
+//   dword  56      parent average: lax | lay << 16 (int16 each)
+//   dword  57      bit 0: the list is open (a parent level exists and has vectors here: hme.c:1471); bit 1: the sub-pel probes were
+//                  run; bit 2: the co-located vector is valid; bits 8..15: the probes' directions (subpel_probes)
+//   dword  58      the co-located vector of the previous frame's field ({x, y}), for the mode decision (hme.c:896)
+// ============================================================================================================================
+constexpr int kL0RecDwords = 64;
+constexpr uint32_t kL0Absent = 0xffffffffu, kL0Invalid = 0x40000000u, kL0ScoreMask = 0x00ffffffu;
+constexpr unsigned long long kL0PreLanes = 0x1ffffc3ull; // lanes that own a pre-pass entry: 0, 1, 6 .. 24
+
+template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block_t(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, uint32_t *rec)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = lane & 7, qj = lane >> 3;
+    const int nxb = c.a.nbh, nyb = c.a.nbv;
+    const DPlane &src = c.src[0], &ref = c.ref[0];
+    const DSV_MV *parent = c.pyr_levels > 0 ? c.mvf[1] : nullptr;
+    const int bx = i * 16, by = j * 16;
+    const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
+    const int qw = bw >> 1, qh = bh >> 1;
+    const bool act = FULL ? true : (qi < qw && qj < qh);
+    const Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
+    const v4i_t pre_words = *(cv4i_t) &c.stats[i + j * nxb];
+    bool pvalid = false, tvalid = false;
+    uint32_t ov;
+    {
+        const DSV_MV *op = &c.mvf[0][i + j * nxb]; // (lanes without a vector: any readable word)
+        if (parent != nullptr) {
+            const int pi = i & ~1, pj = j & ~1;
+            if (lane >= 16 && lane < 25) {
+                int m = lane - 16;
+                int x = pi + 2 * tab9(kParX, m), y = pj + 2 * tab9(kParY, m);
+                if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
+                    op = &parent[x + y * nxb];
+                    pvalid = true;
+                }
+            } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
+                int k = lane - 6;
+                int rx = i + tab9(kRectX, k), ry = j + tab9(kRectY, k);
+                if (rx >= 0 && ry >= 0 && rx < nxb && ry < nyb) {
+                    op = &c.ref_mvf[rx + ry * nxb];
+                    tvalid = true;
+                }
+            }
+        }
+        typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
+        ov = *(gu32p_t) op;
+    }
+    const int pvx = (int) (int16_t) (ov & 0xffffu), pvy = (int) (int16_t) (ov >> 16);
+    const Psy psy = psy_of_source((unsigned) pre_words.y, bw, bh, c.quant);
+    int lax = 0, lay = 0;
+    bool exist = lane == 0, open = false;
+    int cxv = 0, cyv = 0;
+    if (parent != nullptr) {
+        bool inl;
+        int nin;
+        open = parent_average(pvalid, pvx, pvy, lax, lay, inl, nin);
+        if (open) {
+            if (lane == 1) {
+                exist = true;
+                cxv = qp2fp((int16_t) (lax * 4));
+                cyv = qp2fp((int16_t) (lay * 4));
+            } else if (tvalid) {
+                exist = true;
+                cxv = qp2fp(pvx);
+                cyv = qp2fp(pvy);
+            } else if (lane == 15) {
+                exist = true;
+                cxv = qp2fp((int16_t) (gx * 4));
+                cyv = qp2fp((int16_t) (gy * 4));
+            } else if (lane >= 16 && lane < 25 && nin && inl) {
+                exist = true;
+                cxv = qp2fp((int16_t) (pvx * 4));
+                cyv = qp2fp((int16_t) (pvy * 4));
+            }
+        }
+    }
+    cxv = (int) (int16_t) cxv;
+    cyv = (int) (int16_t) cyv;
+    const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16);
+    const bool keep = exist && !dedup_lanes(exist, key);
+    const unsigned long long km = __ballot(keep);
+    const int nidx = __popcll(km & ((1ull << lane) - 1));
+    const int n = __popcll(km);
+    __syncthreads();
+    if (keep) {
+        S.cx[nidx] = cxv;
+        S.cy[nidx] = cyv;
+    }
+    if (lane >= n) {
+        S.cx[lane] = 0;
+        S.cy[lane] = 0;
+    }
+    __syncthreads();
+    unsigned raw = 0;
+    if (n <= 4) {
+        raw = score16<4>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+    } else if (n <= 8) {
+        raw = score16<8>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+    } else {
+        for (int first = 0; first < n; first += 16) {
+            unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+            if (lane >= first && lane < first + 16) {
+                raw = r;
+            }
+        }
+    }
+    raw = metric_return(raw, bw, bh);                // lane k: list entry k in compacted order
+    raw = (unsigned) __shfl((int) raw, nidx, 64);    // lane p: its own entry
+    uint32_t rf = kL0Absent;
+    if (keep) {
+        rf = (raw & kL0ScoreMask) | (invalid_block(ref, bx + cxv, by + cyv, bw, bh, 0) ? kL0Invalid : 0u);
+    }
+    if ((kL0PreLanes >> lane) & 1ull) {
+        const int e = lane < 2 ? lane : lane - 4;
+        *(uint2 *) (rec + 2 * e) = uint2{(uint32_t) key, rf};
+    }
+    // the pixel half of the sub-pel search around the parent average (hme.c:1598-1612)
+    const bool sp_done = c.effort >= 4 && !invalid_block(ref, bx + lax, by + lay, bw, bh, 4);
+    unsigned dirs = 0;
+    if (sp_done) {
+        const unsigned mr = subpel_probes(c, S, lax, lay, bx, by, bw, bh, a, act, qi, qj, psy, dirs);
+        if (lane < 7) {
+            rec[48 + lane] = mr;
+        }
+    }
+    if (lane == 0) {
+        const bool colo_ok = parent != nullptr && c.ref_mvf != nullptr;
+        uint32_t colo = 0;
+        if (c.ref_mvf != nullptr) {
+            colo = *(const uint32_t *) &c.ref_mvf[i + j * nxb];
+        }
+        *(uint4 *) (rec + 56) = uint4{(uint32_t) (lax & 0xffff) | ((uint32_t) lay << 16),
+                                      (open ? 1u : 0u) | (sp_done ? 2u : 0u) | (colo_ok ? 4u : 0u) | (dirs << 8), colo, 0u};
+    }
+}
+
+template <class Ctx> __device__ __forceinline__ void hme_l0_pre_block(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, uint32_t *rec)
+{
+    const DPlane &src = c.src[0];
+    if (src.w - i * 16 >= 16 && src.h - j * 16 >= 16) {
+        hme_l0_pre_block_t<true>(c, i, j, gx, gy, S, rec);
+    } else {
+        hme_l0_pre_block_t<false>(c, i, j, gx, gy, S, rec);
+    }
+}
+
+// ============================================================================================================================
+// Level 0, second half: the block of the row pipeline.  ONE load round brings the source quads, the pre-pass record and the
+// neighbours' heads; the neighbour-derived entries (positions 2..5) are merged into the list by canonical position (a lane =
+// a position, so "first wins" among equal scores is "lowest lane wins"); an entry whose vector the pre-pass has already scored
+// takes that score, and only a vector nobody has seen costs a load round of its own.
+// CS: chroma shift of both axes (mode decision): 1 = 4:2:0, 0 = 4:4:4.
+// ============================================================================================================================
+// SPLIT: the neighbour-independent half comes from the pre-pass record (k_hme_l0_pre_b); else it is worked out here, in place:
+// one kernel does everything, less work in total (no record, one set of loads) but a longer chain per block.  Which is better
+// depends on what the GPU is short of: with many pictures per launch and several lockstep groups it is work, with a few it is the chain.
+template <bool FULL, int CS, bool SPLIT, class Ctx>
+__device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = lane & 7, qj = lane >> 3;
+    const int nxb = c.a.nbh, nyb = c.a.nbv;
+    const DPlane &src = c.src[0], &ref = c.ref[0];
+    DSV_MV *mvf = c.mvf[0];
+    DSV_MV *out = &mvf[i + j * nxb];
+    DSV_MV mv = {};
+    const int bx = i * 16, by = j * 16;
+    const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
+    const int qw = bw >> 1, qh = bh >> 1;
+    const bool act = FULL ? true : (qi < qw && qj < qh);
+    const Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
+    typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
+    typedef const __attribute__((address_space(1))) uint2v_t *gu2p_t;
+    const v4i_t pre_words = *(cv4i_t) &c.stats[i + j * nxb];
+    const bool pre_lane = ((kL0PreLanes >> lane) & 1ull) != 0;
+    // ---- the block's first load round ----
+    v4i_t hdr = {0, 0, 0, 0};
+    uint2v_t ent = {0u, 0u};
+    unsigned sp_mr = 0;
+    uint32_t ov = 0;
+    bool pvalid = false, tvalid = false;
+    const DSV_MV *parent = nullptr;
+    if constexpr (SPLIT) {
+        const uint32_t *rec = c.l0pre + (size_t) (i + j * nxb) * kL0RecDwords;
+        hdr = *(cv4i_t) (rec + 56);
+        ent = *(gu2p_t) (rec + 2 * (pre_lane ? (lane < 2 ? lane : lane - 4) : 0));
+        sp_mr = *(gu32p_t) (rec + 48 + (lane < 7 ? lane : 0));
+    } else {
+        // lanes 6..14 fetch the co-located vectors of the previous frame, lanes 16..24 the parent level's (hme.c:1443-1528)
+        parent = c.pyr_levels > 0 ? c.mvf[1] : nullptr;
+        const DSV_MV *op = out;
+        if (parent != nullptr) {
+            const int pi = i & ~1, pj = j & ~1;
+            if (lane >= 16 && lane < 25) {
+                int m = lane - 16;
+                int x = pi + 2 * tab9(kParX, m), y = pj + 2 * tab9(kParY, m);
+                if (x >= 0 && x < nxb && y >= 0 && y < nyb) {
+                    op = &parent[x + y * nxb];
+                    pvalid = true;
+                }
+            } else if (lane >= 6 && lane <= 14 && c.ref_mvf != nullptr) {
+                int k = lane - 6;
+                int rx = i + tab9(kRectX, k), ry = j + tab9(kRectY, k);
+                if (rx >= 0 && ry >= 0 && rx < nxb && ry < nyb) {
+                    op = &c.ref_mvf[rx + ry * nxb];
+                    tvalid = true;
+                }
+            }
+        }
+        ov = *(gu32p_t) op;
+    }
+    bool nb_ok = false;
+    const MvHead nbv = load_neighbour_heads(mvf, out, i, j, 1, nxb, c.counters, acc, nb_ok);
+
+    const unsigned var_src = (unsigned) pre_words.y, avg_src = (unsigned) pre_words.z;
+    int motion_bias = (int) udiv_fast((unsigned) max(pre_words.x, 0), (unsigned) (2 + (abs(gx) + abs(gy))));
+    if (var_src <= (unsigned) (8 * bw * bh * c.quant >> 9)) {
+        motion_bias = 0;
+    }
+    const Psy psy = psy_of_source(var_src, bw, bh, c.quant);
+    HME_MARK(S, 1);
+    // dsv_movec_pred (dsv.c:375): the median predictor of the three neighbours just loaded
+    CostCtx cc;
+    {
+        int v0 = __builtin_amdgcn_readlane((int) nbv.all, 3), v1 = __builtin_amdgcn_readlane((int) nbv.all, 4),
+            v2 = __builtin_amdgcn_readlane((int) nbv.all, 5);
+        v0 = i > 0 ? v0 : 0;
+        v1 = j > 0 ? v1 : 0;
+        v2 = i > 0 && j > 0 ? v2 : 0;
+        cc.px = pred1((int) (int16_t) (v0 & 0xffff), (int) (int16_t) (v1 & 0xffff), (int) (int16_t) (v2 & 0xffff));
+        cc.py = pred1(v0 >> 16, v1 >> 16, v2 >> 16);
+    }
+    cc.q = c.quant;
+    cc.b2sr = b2sr_of(c);
+    // ---- the list by canonical position (a lane = a position, so "first wins" among equal scores is "lowest lane wins"):
+    //  0 zero | 1 parent inlier average | 2 predictor | 3 left 4 top 5 top-left | 6..14 temporal | 15 global | 16..24 parent inliers
+    int lax, lay;
+    bool open, sp_done = false, colo_ok;
+    unsigned sp_dirs = 0;
+    uint32_t colo;
+    bool exist;
+    int key;
+    uint32_t rf; // normalised metric of this lane's vector | kL0Invalid, once known
+    if constexpr (SPLIT) {
+        lax = (int) (int16_t) ((uint32_t) hdr.x & 0xffffu);
+        lay = (int) (int16_t) ((uint32_t) hdr.x >> 16);
+        open = (hdr.y & 1) != 0;
+        sp_done = (hdr.y & 2) != 0;
+        colo_ok = (hdr.y & 4) != 0;
+        sp_dirs = ((uint32_t) hdr.y >> 8) & 0xffu;
+        colo = (uint32_t) hdr.z;
+        exist = pre_lane && ent[1] != kL0Absent;
+        key = (int) ent[0];
+        rf = ent[1];
+    } else {
+        const int pvx = (int) (int16_t) (ov & 0xffffu), pvy = (int) (int16_t) (ov >> 16);
+        colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
+        colo_ok = parent != nullptr && c.ref_mvf != nullptr;
+        bool inl = false;
+        int nin = 0;
+        lax = lay = 0;
+        open = parent != nullptr && parent_average(pvalid, pvx, pvy, lax, lay, inl, nin);
+        exist = lane == 0;
+        int cxv = 0, cyv = 0;
+        if (open) { // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)
+            if (lane == 1) {
+                exist = true;
+                cxv = qp2fp((int16_t) (lax * 4));
+                cyv = qp2fp((int16_t) (lay * 4));
+            } else if (tvalid) {
+                exist = true;
+                cxv = qp2fp(pvx);
+                cyv = qp2fp(pvy);
+            } else if (lane == 15) {
+                exist = true;
+                cxv = qp2fp((int16_t) (gx * 4));
+                cyv = qp2fp((int16_t) (gy * 4));
+            } else if (lane >= 16 && lane < 25 && nin && inl) {
+                exist = true;
+                cxv = qp2fp((int16_t) (pvx * 4));
+                cyv = qp2fp((int16_t) (pvy * 4));
+            }
+        }
+        key = ((int) (int16_t) cxv & 0xffff) | (int) ((unsigned) (int) (int16_t) cyv << 16);
+        rf = 0;
+    }
+    if (open && (lane == 2 || nb_ok)) { // the neighbour-derived entries (nb_ok: lanes 3..5 with a neighbour)
+        const int vx = lane == 2 ? (int) (int16_t) cc.px : nbv.x, vy = lane == 2 ? (int) (int16_t) cc.py : nbv.y;
+        const int cxv = (int) (int16_t) qp2fp(vx), cyv = (int) (int16_t) qp2fp(vy);
+        key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16);
+        exist = true;
+        rf = 0;
+    }
+    // first occurrence wins (hme.c:1166)
+    bool keep;
+    unsigned long long want = 0; // lanes whose vector still needs its score
+    if constexpr (SPLIT) {
+        // an entry whose vector the pre-pass has scored further down the list takes that score
+        bool dup = false;
+        for (unsigned long long rest = __ballot(exist); rest;) {
+            const int m = __ffsll((long long) rest) - 1;
+            const int km = __builtin_amdgcn_readlane(key, m);
+            const bool same = exist && km == key;
+            const unsigned long long sm = __ballot(same);
+            dup = dup || (same && lane != m);
+            if (m >= 2 && m <= 5) {
+                const unsigned long long pm = sm & kL0PreLanes;
+                if (pm) {
+                    const uint32_t known = (uint32_t) __builtin_amdgcn_readlane((int) rf, __ffsll((long long) pm) - 1);
+                    rf = lane == m ? known : rf;
+                } else {
+                    want |= 1ull << m;
+                }
+            }
+            rest &= ~sm;
+        }
+        keep = exist && !dup;
+    } else {
+        keep = exist && !dedup_lanes(exist, key);
+        want = __ballot(keep);
+    }
+    const int mx = (int) (int16_t) (key & 0xffff), my = key >> 16;
+    // ONE load round for the vectors nobody has scored yet (SPLIT: usually none), four / eight / sixteen at a time
+    if (want) {
+        HME_COUNT(S, 10, 1);
+        const int nw = __popcll(want);
+        const int widx = __popcll(want & ((1ull << lane) - 1)); // this lane's place among them
+        auto vec_of = [&](unsigned long long rest, int t, int &vx, int &vy) { // the t-th wanted lane's vector (t < nw, else the zero vector)
+            for (int u = 0; u < t; u++) {
+                rest &= rest - 1;
+            }
+            const int k = rest ? __builtin_amdgcn_readlane(key, __ffsll((long long) rest) - 1) : 0;
+            vx = (int) (int16_t) (k & 0xffff);
+            vy = k >> 16;
+        };
+        unsigned raw = 0;
+        if (nw <= 4) {
+            raw = score_vecs<4>([&](int t, int &vx, int &vy) { vec_of(want, t, vx, vy); }, nw, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+        } else if (nw <= 8) {
+            raw = score_vecs<8>([&](int t, int &vx, int &vy) { vec_of(want, t, vx, vy); }, nw, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+        } else {
+            unsigned long long rest = want;
+            for (int first = 0; first < nw; first += 16) {
+                unsigned r = score_vecs<16>([&](int t, int &vx, int &vy) { vec_of(rest, t, vx, vy); }, min(16, nw - first), ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+                if (lane >= first && lane < first + 16) {
+                    raw = r;
+                }
+                for (int u = 0; u < 16 && rest; u++) {
+                    rest &= rest - 1;
+                }
+            }
+        }
+        raw = (unsigned) __shfl((int) raw, widx, 64); // lane k of the round holds entry k: back to the lanes that own the vectors
+        if ((want >> lane) & 1ull) {
+            rf = (metric_return(raw, bw, bh) & kL0ScoreMask) | (invalid_block(ref, bx + mx, by + my, bw, bh, 0) ? kL0Invalid : 0u);
+        }
+    }
+    HME_MARK(S, 2);
+    // ---- best candidate (hme.c:1530-1557) ----
+    int dx, dy;
+    unsigned best, score_zero;
+    {
+        const bool valid = keep && !(rf & kL0Invalid);
+        const unsigned raw = rf & kL0ScoreMask;
+        unsigned sc = raw + (unsigned) mv_cost(cc, mx * 4, my * 4, 0);
+        if (mx == lax && my == lay) {
+            sc = (unsigned) max((int) sc - motion_bias, 0);
+        }
+        if (!valid) {
+            sc = 0xffffffffu;
+        }
+        unsigned mn = wave_min_u(sc);
+        unsigned long long hit = __ballot(valid && sc == mn);
+        int best_k = (mn != 0xffffffffu && hit) ? (int) __ffsll((long long) hit) - 1 : 0;
+        best = mn;
+        bool z_valid = __builtin_amdgcn_readlane((int) valid, 0) != 0;
+        unsigned z_raw = (unsigned) __builtin_amdgcn_readlane((int) raw, 0);
+        score_zero = z_valid ? z_raw : 0xffffffffu;
+        dx = __builtin_amdgcn_readlane(mx, best_k);
+        dy = __builtin_amdgcn_readlane(my, best_k);
+    }
+    unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
+    bool good_enough = false;
+    {
+        const unsigned zoscore = (unsigned) pre_words.w;
+        if (abs(dx) <= 1 && abs(dy) <= 1) {
+            qthresh *= 2;
+        }
+        if (zoscore < qthresh) {
+            best = score_zero;
             dx = dy = 0;
             good_enough = true;
         }
     }
     HME_MARK(S, 3);
-    // ---- refinement (hme.c:1300): each round scores the full 3x3 neighbourhood at once ----
     if (!good_enough) {
-        unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
-        bool again = true;
-        HME_COUNT(S, 11, 1);
-        while (again && !good_enough) {
-            again = false;
-            HME_COUNT(S, 12, 1);
-            const int rdx = dx, rdy = dy;
-            unsigned raw = score_vecs<9>(
-                S, W,
-                [&](int t, int &vx, int &vy) {
-                    vx = rdx + tab9(kRectX, t);
-                    vy = rdy + tab9(kRectY, t);
-                },
-                9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
-            int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
-            bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
-            if (level <= 1) {
-                raw = metric_return(raw, bw, bh);
-            }
-            unsigned full = raw + (unsigned) mv_cost(cc, tx * step * 4, ty * step * 4, level);
-            int cdx = dx, cdy = dy;
-            for (int k = 0; k < 5; k++) {
-                bool vk = __builtin_amdgcn_readlane((int) valid, k) != 0;
-                if (!vk) {
-                    continue;
-                }
-                unsigned sk = (unsigned) __builtin_amdgcn_readlane((int) raw, k);
-                int tvx = cdx + tab9(kRectX, k), tvy = cdy + tab9(kRectY, k);
-                if (k == 1) {
-                    metr0 = sk;
-                } else if (k == 2) {
-                    metr1 = sk;
-                } else if (k == 3) {
-                    metr2 = sk;
-                } else if (k == 4) {
-                    metr3 = sk;
-                }
-                if (level == 0 && !tvx && !tvy && sk <= qthresh) {
-                    dx = tvx;
-                    dy = tvy;
-                    best = sk;
-                    good_enough = true;
-                    break;
-                }
-                unsigned fk = (unsigned) __builtin_amdgcn_readlane((int) full, k);
-                if (best > fk) {
-                    best = fk;
-                    dx = tvx;
-                    dy = tvy;
-                    again = true;
-                    break;
-                }
-            }
-            if (again || good_enough) {
-                continue;
-            }
-            int sxs = metr0 <= metr1 ? 1 : -1, sys = metr2 <= metr3 ? 1 : -1;
-            int kd = sys < 0 ? (sxs < 0 ? 5 : 6) : (sxs < 0 ? 7 : 8); // index of (sxs, sys) in rect[]
-            bool vd = __builtin_amdgcn_readlane((int) valid, kd) != 0;
-            if (!vd) {
-                break;
-            }
-            unsigned fd = (unsigned) __builtin_amdgcn_readlane((int) full, kd);
-            if (best > fd) {
-                best = fd;
-                dx = cdx + sxs;
-                dy = cdy + sys;
-                again = true;
-            }
-        }
+        refine_fpel<true>(ref, bx, by, bw, bh, a, act, qi, qj, 0, psy, 0xffffffffu, cc, qthresh, dx, dy, best, good_enough, S);
     }
     HME_MARK(S, 4);
-    mv.u.mv.x = (int16_t) (dx * step);
-    mv.u.mv.y = (int16_t) (dy * step);
-    if (LV > 0 || level != 0) {
-        pcx = dx;
-        pcy = dy;
-        if (lane == 0) {
-            st_mv(out, mv);
-        }
-        acc.left_head = (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.u.all) |
-                        ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.flags) << 32);
-        acc.have_left = true;
-        return;
-    }
-    if constexpr (LV <= 0) {
+    mv.u.mv.x = (int16_t) dx;
+    mv.u.mv.y = (int16_t) dy;
     NbPre pre;
     pre.l_all = (uint32_t) __builtin_amdgcn_readlane((int) nbv.all, 3);
     pre.l_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 3);
     pre.t_all = (uint32_t) __builtin_amdgcn_readlane((int) nbv.all, 4);
     pre.t_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 4);
-    pre.colo = (uint32_t) __builtin_amdgcn_readlane((int) ov, 6);
-    pre.colo_ok = parent != nullptr && c.ref_mvf != nullptr;
-    hme_block_fast_l0<CS>(c, i, j, S, W, pcx, pcy, acc, mvf, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src,
-                      avg_src, psy, pre, sp_pre);
-    }
+    pre.colo = colo;
+    pre.colo_ok = colo_ok;
+    hme_l0_tail<CS, SPLIT>(c, i, j, S, acc, out, mv, cc, a, act, qi, qj, bx, by, bw, bh, lax, lay, motion_bias, good_enough, best, var_src, avg_src, psy, pre,
+                           sp_done, sp_mr, sp_dirs);
 }
 
-template <int LV, int CS = 1, bool PRE = false, class Ctx>
-__device__ __forceinline__ void hme_block_fast(const Ctx &c, int level_rt, int i, int j, int gx, int gy, FastLds &S, int &pcx, int &pcy, RowAcc &acc)
+template <int CS, bool SPLIT, class Ctx> __device__ __forceinline__ void hme_block_l0(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
-    const int level = LV == 0 ? 0 : level_rt;
-    const DPlane &src = c.src[level];
-    int bx = (i * 16) >> level, by = (j * 16) >> level;
-    if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_fast_t<true, LV, CS, PRE>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
+    const DPlane &src = c.src[0];
+    if (src.w - i * 16 >= 16 && src.h - j * 16 >= 16) {
+        hme_block_l0_t<true, CS, SPLIT>(c, i, j, gx, gy, S, acc);
     } else {
-        hme_block_fast_t<false, LV, CS, PRE>(c, level, i, j, gx, gy, S, pcx, pcy, acc);
+        hme_block_l0_t<false, CS, SPLIT>(c, i, j, gx, gy, S, acc);
     }
 }

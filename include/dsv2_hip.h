@@ -403,11 +403,14 @@ int dsv2hip_dec_batch(int n, DSV_DECODER **decs, DSV_BUF *bufs, DSV_FRAME **out,
  * out4[0] calls, [1] lockstep steps they ran as, [2] largest step, [3] microseconds leaders waited for expected callers. */
 void dsv2hip_enc_queue_stats(unsigned long long *out4, int reset);
 void dsv2hip_dec_queue_stats(unsigned long long *out4, int reset);
-/* Encoder instances size their symbol (compaction) lists by need -- an eighth of the picture's coefficients, the worst case at
- * once for lossless streams -- and enlarge them when a picture has more symbols (its symbols are then worked out a second time
+/* Encoder instances size their symbol (compaction) lists by need -- HALF the picture's coefficients (at least 65 536 symbols), the worst
+ * case at once for lossless streams -- and enlarge them when a picture has more symbols (its symbols are then worked out a second time
  * and coded on the host; the packets are the same).  Number of such enlargements in this process so far: a stream pays at most
  * one.  DSV2_COMPACT_CAP=<symbols> overrides the initial size. */
 long dsv2hip_enc_list_growths(void);
+/* Device allocations that did not fit their instance's one-block arena (the block's size is an estimate): 0 unless the estimate has
+ * drifted from the allocations it stands for. */
+long dsv2hip_arena_fallbacks(void);
 /* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
  * off at any time (resets the totals).  dsv2hip_prof_read fills 9 entries (ingest+pyramid, HME,
  * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend, and -- inside HME -- the level-0

@@ -84,6 +84,93 @@ static Result scenario(int T, int K, const std::vector<int> &keys, int leave_thr
     return r;
 }
 
+// ONE thread drives N instances of one key in turn (simulcast renditions, a loop over encoders): nobody else can arrive while a
+// call blocks that thread, so no call may spend the window waiting for the thread's other instances
+static Result one_thread_many(int N, int K)
+{
+    Coalescer<Job> q;
+    g_mixed = 0;
+    std::vector<int> who(N);
+    int wrong = 0;
+    long long batch_sum = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < K; k++) {
+        for (int n = 0; n < N; n++) {
+            Job j;
+            j.id = n * 1000 + k;
+            j.key = 1;
+            q.submit(j, 1ull, &who[n], step);
+            wrong += j.out != 7 * j.id + 1;
+            batch_sum += j.batch;
+        }
+    }
+    Result r;
+    const auto st = q.stats();
+    r.calls = st.calls;
+    r.steps = st.steps;
+    r.largest = st.largest;
+    r.waited_us = st.waited_us;
+    r.wrong = wrong;
+    r.mixed = g_mixed.load();
+    r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    r.mean_batch = (double) batch_sum / (double) (N * K);
+    return r;
+}
+
+// two callers of one key; one of them STOPS calling without saying so (no forget: paused input, a thread that bailed out) while
+// a long-running step of ANOTHER key keeps the queue busy all the time: after 100 ms the silent one must not be expected any more
+static Result silent_leaver()
+{
+    Coalescer<Job> q;
+    g_mixed = 0;
+    std::vector<int> who(3);
+    std::atomic<int> wrong{0};
+    std::atomic<bool> stop{false};
+    std::thread other([&] { // key 2: back-to-back steps, so that some step is running at every moment
+        int k = 0;
+        while (!stop.load()) {
+            Job j;
+            j.id = 2000 + k++;
+            j.key = 2;
+            q.submit(j, 2ull, &who[2], step);
+        }
+        q.forget(&who[2]);
+    });
+    std::thread quitter([&] {
+        for (int k = 0; k < 3; k++) {
+            Job j;
+            j.id = 1000 + k;
+            j.key = 1;
+            q.submit(j, 1ull, &who[1], step);
+        }
+        // (no forget)
+    });
+    quitter.join();
+    std::this_thread::sleep_for(std::chrono::milliseconds(150)); // the silent instance ages out -- although steps never stop running
+    q.reset_stats();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 40; k++) {
+        Job j;
+        j.id = k;
+        j.key = 1;
+        q.submit(j, 1ull, &who[0], step);
+        wrong += j.out != 7 * j.id + 1;
+    }
+    Result r;
+    const auto st = q.stats();
+    stop = true;
+    other.join();
+    r.calls = st.calls;
+    r.steps = st.steps;
+    r.largest = st.largest;
+    r.waited_us = st.waited_us;
+    r.wrong = wrong.load();
+    r.mixed = g_mixed.load();
+    r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    r.mean_batch = 1;
+    return r;
+}
+
 static void print(const char *name, const Result &r, bool last)
 {
     printf("\"%s\": {\"calls\": %llu, \"steps\": %llu, \"largest\": %llu, \"waited_us\": %llu, \"wrong\": %d, \"mixed\": %d, \"seconds\": %.4f, "
@@ -99,7 +186,9 @@ int main(int argc, char **argv)
     print("four_callers", scenario(4, 40, {1, 1, 1, 1}, -1, 0), false);
     print("sixteen_callers", scenario(16, 30, std::vector<int>(16, 1), -1, 0), false);
     print("two_keys", scenario(6, 30, {1, 1, 1, 2, 2, 2}, -1, 0), false);
-    print("one_leaves", scenario(2, 60, {1, 1}, 1, 5), true);
+    print("one_leaves", scenario(2, 60, {1, 1}, 1, 5), false);
+    print("one_thread_four_instances", one_thread_many(4, 20), false);
+    print("silent_leaver", silent_leaver(), true);
     printf("}\n");
     return 0;
 }

@@ -56,3 +56,21 @@ def test_a_caller_that_left_is_not_waited_for(report):
     # 55 of the 60 calls of the caller that stayed ran after the other had gone: alone, and without spending the window on it
     assert r["steps"] >= 58
     assert r["waited_us"] < 55 * 400
+
+
+def test_one_thread_driving_several_instances_does_not_wait_for_itself(report):
+    """advisor finding (round 4): a single thread that loops over N same-geometry instances slept the window on every call,
+    waiting for instances that only it could have submitted"""
+    r = report["one_thread_four_instances"]
+    assert r["calls"] == 80 and r["steps"] == 80 and r["largest"] == 1
+    assert r["waited_us"] < 80 * 50
+
+
+def test_an_instance_that_went_silent_ages_out_while_other_steps_run(report):
+    """advisor finding (round 4): with steps of any key running back to back nothing ever aged out, and a caller that stopped
+    calling without dsv_*_free / end of stream stayed expected: every leader then spent the full window on it"""
+    r = report["silent_leaver"]
+    assert r["wrong"] == 0
+    own = r["calls"]  # (the other key's calls are counted too: the 40 calls of this key are what must not have waited)
+    assert own >= 40
+    assert r["waited_us"] < 40 * 100

@@ -1,8 +1,8 @@
 """Bit-exactness AT THE BENCHMARKED OPERATING POINT: 1080p 4:2:0 qp=60 gop=48, many streams per lockstep step,
 several lockstep groups running concurrently on one GPU (so the row-pipelined motion search of one group shares
 the chip with the other groups' kernels), repeated in one process.  Every stream must equal the reference
-encode of its input; a second process repeats the run with DSV2_HME_ROWS=0 (launch per anti-diagonal front,
-no dispatch-order assumption) as a cross-check of the row pipeline itself.
+encode of its input; further processes repeat the run with a stage in its other form (general block routine, few
+persistent workers, the filters' other kernels) as a cross-check.
 
 Reference: hme.c:1373-1833 (search order dependencies), parallel_encode_yuv.sh:36-50 (independent streams)."""
 import ctypes as C
@@ -153,14 +153,14 @@ print(json.dumps(T.run_once(hip, frames, 32, 2, pinned)))
 """
 
 
-@pytest.mark.parametrize("env_extra", [{"DSV2_HME_ROWS": "0"}, {"DSV2_HME_XCD": "1"}, {"DSV2_HME_XCD": "3"}, {"DSV2_HME_FENCE": "1"},
-                                       {"DSV2_HME_FENCE": "3"}, {"DSV2_FILTER_PAIR_MAX": "0"}, {"DSV2_FILTER_PAIR_MAX": "100000"}, {"DSV2_HME_PRESTATS": "0"}, {"DSV2_HME_PRESTATS": "2"}, {"DSV2_FILTER_RING": "0"}])
-def test_front_per_launch_form_agrees(env_extra):
-    """the same streams in a process with DSV2_HME_ROWS=0: the search runs one launch per anti-diagonal front; and the row
-    pipeline with chip-wide tickets (one partition) and with three partitions (uneven: the fall-over path takes rows); the
-    in-loop filter's luma sweep with a lane per cell / a lane pair per cell whatever the batch; the search with the source
-    blocks' statistics worked out inside the block routine instead of ahead of it, and ahead of it one block per wavefront
-    everywhere (2) instead of four whole blocks per wavefront; the in-loop filters' global-memory kernels (no LDS ring)"""
+@pytest.mark.parametrize("env_extra", [{"DSV2_HME_FAST": "0"}, {"DSV2_HME_PERSIST": "64"}, {"DSV2_FILTER_PAIR_MAX": "0"}, {"DSV2_FILTER_PAIR_MAX": "100000"},
+                                       {"DSV2_FILTER_RING": "0"}])
+def test_alternative_forms_agree(env_extra):
+    """the same streams in a process where a stage runs its other form: the search with the general block routine at every level
+    (the reference's block loop with wave-cooperative primitives: no pre-passes, no fast routines); the row pipeline with 64
+    persistent workers instead of 2 048 (rows queue for workers: the ticket order is all that keeps it moving); the in-loop
+    filter's luma sweep with a lane per cell / a lane pair per cell whatever the batch; the in-loop filters' global-memory
+    kernels (no LDS ring)"""
     frames = gen_inputs()
     want = reference_digests(frames)
     env = dict(os.environ, **env_extra)

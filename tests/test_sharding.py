@@ -108,3 +108,63 @@ def test_gather_unpadded_chunked(tmp_path, nseg, chunk):
     mp.spawn(_gather_worker, args=(world, port, str(tmp_path), nseg, chunk), nprocs=world, join=True)
     want = b"".join(np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8).tobytes() for s in range(nseg))
     assert open(tmp_path / "g.bin", "rb").read() == want
+
+
+def _stream_worker(rank, world, port, outdir, nseg, chunk, corrupt):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    mine = pkg.sharding.assign_segments(nseg, world)[rank]
+    calls = []
+
+    def seg_bytes(s):
+        calls.append(s)
+        b = np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8)
+        # a producer whose second pass (the one that ships) differs from what it announced: rank 0 must notice
+        if corrupt and s == corrupt and calls.count(s) > 1 and len(b):
+            b[len(b) // 2] ^= 1
+        return b.tobytes()
+
+    fd = os.open(os.path.join(outdir, "s.bin"), os.O_RDWR | os.O_CREAT) if rank == 0 else -1
+    peak = [0]
+
+    def sink(sid, base, off, piece):
+        peak[0] = max(peak[0], len(piece))
+        os.pwrite(fd, piece, base + off)
+
+    res = pkg.sharding.gather_segments_streaming(dist, rank, world, mine, seg_bytes, chunk=chunk, sink=sink if rank == 0 else None)
+    if rank == 0:
+        os.close(fd)
+        import json
+        res["peak_piece"] = peak[0]
+        res.pop("offsets")
+        json.dump(res, open(os.path.join(outdir, "res.json"), "w"))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nseg,chunk", [(2, 9, 1000), (4, 23, 777), (4, 3, 64), (2, 1, 1000)])
+def test_streaming_gather_verifies_every_segment_above_a_tiny_cap(tmp_path, world, nseg, chunk):
+    """the job's bytes exceed the per-transfer cap many times over (the cap stands for rank 0's memory): every segment of the job is
+    gathered, verified against its producer's md5 and written at its final offset; no piece is larger than the cap"""
+    import json
+    import numpy as np
+    port = _free_port()
+    mp.spawn(_stream_worker, args=(world, port, str(tmp_path), nseg, chunk, 0), nprocs=world, join=True)
+    res = json.load(open(tmp_path / "res.json"))
+    want = b"".join(np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8).tobytes() for s in range(nseg))
+    assert res["segments"] == nseg and res["segments_verified"] == nseg and res["bytes"] == len(want)
+    assert res["peak_piece"] <= max(chunk, max((s * 977) % 5000 for s in range(0, nseg, world)))  # (rank 0's own segments arrive whole)
+    assert open(tmp_path / "s.bin", "rb").read() == want
+
+
+def test_streaming_gather_notices_a_corrupted_segment(tmp_path):
+    import json
+    port = _free_port()
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path), 9, 500, 5), nprocs=2, join=True)
+    res = json.load(open(tmp_path / "res.json"))
+    assert res["segments"] == 9 and res["segments_verified"] == 8

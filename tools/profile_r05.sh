@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 profile artefacts (GPU box, repo root; run through gpurun).  Raw output under gpurun_out/prof4/, summarised into
-# profiles/r04_* by tools/summarise_r04.py.  Parts (pick with PARTS="trace pmc excl insts", default all):
+# Round-5 profile artefacts (GPU box, repo root; run through gpurun).  Raw output under gpurun_out/prof5/, summarised into
+# profiles/r05_* by tools/summarise_r05.py.  Parts (pick with PARTS="trace pmc excl insts", default all):
 #   trace  rocprofv3 --kernel-trace --stats of the headline command -> kernel_stats.csv + kernel_trace.csv.gz
 #   pmc    FETCH_SIZE / WRITE_SIZE of the level-0 search launch in the bench's own layout (separate passes)
 #   excl   one lockstep group of 96 streams alone: exclusive kernel durations
@@ -8,10 +8,10 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof4
+out=gpurun_out/prof5
 mkdir -p $out
 parts=${PARTS:-trace pmc excl insts}
-L0=k_hme_rows_p_fast_l0
+L0=k_hme_rows_l0
 for p in $parts; do case $p in
 trace)
     timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras > $out/bench_traced.json 2> $out/trace.err

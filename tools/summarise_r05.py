@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof4 (tools/profile_r04.sh) -> profiles/r04_*.txt, profiles/pmc_traffic.json, profiles/instruction_volume.json.
+"""gpurun_out/prof5 (tools/profile_r05.sh) -> profiles/r05_*.txt, profiles/pmc_traffic.json, profiles/instruction_volume.json.
 
 The timed region of the traced headline is found from the trace itself: its level-0 search launches are the LAST
 steps x groups launches of that kernel (nothing runs behind the headline with --no-extras); rounds 1-3 took "the last 60 % of the
@@ -15,9 +15,9 @@ import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-src = os.path.join(ROOT, "gpurun_out", "prof4")
+src = os.path.join(ROOT, "gpurun_out", "prof5")
 dst = os.path.join(ROOT, "profiles")
-L0 = "k_hme_rows_p_fast_l0"
+L0 = "k_hme_rows_l0"
 N, P = 1920 * 1080, 1920 * 1080 * 3 // 2
 
 
@@ -48,7 +48,7 @@ def trace_part():
     timed = l0[last - steps * groups:last]
     lo, hi = timed[0][0], timed[-1][1]
     span = hi - lo
-    with open(os.path.join(dst, "r04_rocprof_kernel_stats.txt"), "w") as f:
+    with open(os.path.join(dst, "r05_rocprof_kernel_stats.txt"), "w") as f:
         f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras   (MI355X, %d streams / %d groups)\n"
                 % (traced["config"]["streams_per_gpu"], groups))
         f.write("bench line under the profiler: %.1f frames/s, %.2f ms/step; sum of kernel durations over the whole run %.1f ms\n"
@@ -59,7 +59,7 @@ def trace_part():
             f.write("%-78s %8s %12.2f %12.2f %7.2f\n" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                           float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
         d = [(e - s) / 1e3 for s, e, _, _ in timed]
-        f.write("\n%s_pre (level-0 search, the dominant kernel; a persistent launch of 2 048 row workers per lockstep group): the %d launches of the "
+        f.write("\n%s (level-0 search, the dominant kernel; a persistent launch of 2 048 row workers per lockstep group): the %d launches of the "
                 "%d timed steps x %d groups: mean %.1f us, min %.1f, max %.1f -- bench.py HIP-event span of that launch in its profiled steps: %.1f us\n"
                 % (L0, len(d), steps, groups, sum(d) / len(d), min(d), max(d), traced.get("roofline", {}).get("avg_launch_us", float("nan"))))
         f.write("algorithmic bytes of a launch: 4 N x %d pictures = %.0f MB -> %.1f GB/s = %.4f of 8 TB/s\n"
@@ -92,7 +92,7 @@ def trace_part():
         if e2 > s2:
             by[n] += e2 - s2
             cnt[n] += 1
-    with open(os.path.join(dst, "r04_kernel_concurrency.txt"), "w") as f:
+    with open(os.path.join(dst, "r05_kernel_concurrency.txt"), "w") as f:
         f.write("kernel concurrency over the %.1f ms of the headline's TIMED region (%d steps x %d groups, delimited by its own level-0 search launches;\n"
                 "rounds 1-3 analysed 'the last 60 %% of the search span', which is mostly pre-roll + the stage-profile pass: round 3's '0 kernels 19.7 %%' came from there):\n"
                 % (span / 1e6, steps, groups))
@@ -117,17 +117,17 @@ def pmc_part(traced):
     fetch, write = sum(agg["FETCH_SIZE"]) / nl, sum(agg["WRITE_SIZE"]) / max(1, len(agg["WRITE_SIZE"]))
     per_launch = (fetch + write) * 1024.0
     pics = traced["config"]["streams_per_gpu"] // groups
-    with open(os.path.join(dst, "r04_pmc_hme.txt"), "w") as f:
+    with open(os.path.join(dst, "r05_pmc_hme.txt"), "w") as f:
         f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-include-regex %s -- python3 bench.py --steps 6 --warmup 3 "
                 "(the bench's own layout: %d streams, %d groups, staggered GOP phases, content mix)\n" % (L0, traced["config"]["streams_per_gpu"], groups))
         f.write("units: KiB per launch as reported; the search's loads are 2 - 4 bytes per lane, so the gfx950 half-count correction for 16-byte streaming "
                 "reads does not apply.  The %d launches of the 6 timed steps (176 - 192 inter pictures each):\n" % nl)
         f.write("  FETCH_SIZE mean %.1f KiB, WRITE_SIZE mean %.1f KiB -> %.2f MB fetched + written per launch = %.2f x the algorithmic 4 N x %d pictures = %.2f MB\n"
                 % (fetch, write, per_launch / 1e6, per_launch / (4.0 * N * pics), pics, 4.0 * N * pics / 1e6))
-    json.dump({"stage": "hme_level0", "kernel": L0 + "_pre", "streams_per_gpu": traced["config"]["streams_per_gpu"], "groups": groups, "stagger": True,
+    json.dump({"stage": "hme_level0", "kernel": L0, "streams_per_gpu": traced["config"]["streams_per_gpu"], "groups": groups, "stagger": True,
                "phase_aligned": bool(traced["config"].get("phase_aligned_groups")), "bytes_per_launch": round(per_launch),
                "kernel_source_sha16": open(os.path.join(src, "kernel_source_sha16.txt")).read().strip(),
-               "source": "profiles/r04_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"},
+               "source": "profiles/r05_pmc_hme.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 
@@ -136,7 +136,7 @@ def excl_part():
     frames = r["config"]["streams_per_gpu"] * (r["steps"] + r["warmup"])
     rows = [x for x in csv.DictReader(open(os.path.join(src, "excl_kernel_stats.csv"))) if "rocclr_fillBuffer" not in x["Name"]]
     tot = sum(float(x["TotalDurationNs"]) for x in rows)
-    with open(os.path.join(dst, "r04_exclusive_kernel_costs.txt"), "w") as f:
+    with open(os.path.join(dst, "r05_exclusive_kernel_costs.txt"), "w") as f:
         f.write("one lockstep group of 96 streams alone on the GPU (rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 96 --groups 1 --no-stagger --no-mix "
                 "--steps 12 --warmup 2): %.1f frames/s, %.2f ms/step; %d frames traced (1 intra + 13 inter per stream)\n" % (r["value"], r["ms_per_step"], frames))
         f.write("sum of kernel durations %.1f us per frame (set-up memsets left out)\n" % (tot / 1e3 / frames))
@@ -151,7 +151,7 @@ def insts_part():
         agg[short(r["Kernel_Name"])[-44:]][r["Counter_Name"]] += float(r["Counter_Value"])
     names = sorted({c for v in agg.values() for c in v})
     tot = collections.defaultdict(float)
-    with open(os.path.join(dst, "r04_instruction_volume.txt"), "w") as f:
+    with open(os.path.join(dst, "r05_instruction_volume.txt"), "w") as f:
         f.write("rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD, every kernel of: bench.py --streams 32 --groups 1 --steps 4 --warmup 2 --no-stagger\n")
         f.write("wavefront-instructions per frame (1 intra + 5 inter pictures per stream), thousands: %s\n" % names)
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
@@ -163,7 +163,7 @@ def insts_part():
         f.write("  %-46s %s\n" % ("TOTAL (kernels above)", "  ".join("%9.1f" % tot[c] for c in names)))
     json.dump({"vector_per_frame": round(tot["SQ_INSTS_VALU"] * 1e3), "scalar_per_frame": round(tot.get("SQ_INSTS_SALU", 0) * 1e3),
                "mix": "1 intra + 5 inter pictures per stream, 32 streams in one lockstep group",
-               "source": "profiles/r04_instruction_volume.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, every kernel of the run summed)"},
+               "source": "profiles/r05_instruction_volume.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, every kernel of the run summed)"},
               open(os.path.join(dst, "instruction_volume.json"), "w"))
 
 
