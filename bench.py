@@ -106,6 +106,11 @@ def parse():
     return ap.parse_args()
 
 
+def under_profiler_():
+    """rocprofv3's tool library is loaded: picture generation stays in this process (forked children can hang at exit), so the content is the small set"""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+
+
 def usable_cpus():
     """cores this process may actually use: affinity mask and cgroup quota, not os.cpu_count()"""
     n = len(os.sched_getaffinity(0))
@@ -737,7 +742,22 @@ def main():
 
     # ---- pictures first: forked generators must not inherit an initialised GPU runtime ----
     W_, H_, GOP, QP = 1920, 1080, 48, 60
-    NV, NF = (8, 32) if args.streams >= 16 else (max(1, min(4, args.streams // 2)), 24)
+    # Content: 96 distinct videos of 64 unique frames per GPU for the headline (no input shared beyond the twin of a stream and,
+    # at 768 streams, three more streams that start 2 / 4 / 6 frames into the same video) -- 19 GB of pinned pictures per rank,
+    # taken only when the host has room for every rank's share twice over; else 8 x 32 (round 4's content), said on the line.
+    def mem_available():
+        try:
+            return int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
+        except (OSError, StopIteration, ValueError):
+            return 0
+    if args.streams >= 192 and not os.environ.get("DSV2_BENCH_SMALL_CONTENT") and not under_profiler_():
+        NV, NF = 96, 64
+        if mem_available() < 2.2 * world * NV * NF * (W_ * H_ * 3 // 2):
+            NV, NF = 8, 32
+    elif args.streams >= 16:
+        NV, NF = 8, 32
+    else:
+        NV, NF = max(1, min(4, args.streams // 2)), 24
     seeds = [1 + rank * NV + k for k in range(NV)]
     specs = [(W_, H_, "420", seeds[k], NF) for k in range(NV)]
     if extras:
@@ -745,8 +765,8 @@ def main():
         specs += [(W_, H_, "444", 201, 12)]
         specs += [(3840, 2160, "420", 301 + k, 10) for k in range(2)]
     t_gen = time.perf_counter()
-    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
-    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(8, ncpu_box // (1 if locality["bound"] else max(1, world)))))
+    under_profiler = under_profiler_()
+    gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(16, ncpu_box // (1 if locality["bound"] else max(1, world)))))
     vids = gen_videos(specs, gen_procs)
     t_gen = time.perf_counter() - t_gen
 
@@ -1007,6 +1027,13 @@ def main():
     if extras and not args.no_batch_curve and not args.only_api_legs:
         try:
             result["batch_curve"] = batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks)
+            one = next((p for p in result["batch_curve"] if p.get("streams") == 1), None)
+            if one:  # BASELINE.json config 5 as literally written: ONE closed-GOP segment per GPU at a time
+                result["config5_one_stream_per_gpu"] = {
+                    "value": one["value"], "unit": "frames/s per GPU", "ms_per_frame_p50": one["ms_per_frame_p50"],
+                    "note": "one stream alone on the GPU: every frame is the chain coarse search levels -> level 0 -> in-loop filter sweep, "
+                            "the reference's own data dependencies; the headline is the same hardware with 768 such segments in flight "
+                            "(parallel_encode_yuv.sh:31-52 runs as many segments as it has processes)"}
         except Exception as e:  # noqa: BLE001
             result["batch_curve"] = {"error": repr(e)}
     if extras and not args.no_mix and not args.only_batch_curve and not args.only_api_legs:
@@ -1057,8 +1084,8 @@ def reference_phase(result, checks, dec_md5, sel):
     try:
         head = [i for i, c in enumerate(checks) if c.leg == "headline"]
         rest = [i for i, c in enumerate(checks) if c.leg != "headline"]
-        one = rw.go([head[0]], [min(24, checks[head[0]].n)])[0]              # one reference thread, alone on the box
-        one_dec = rw.dec([head[0]], [min(24, checks[head[0]].n)])[0]
+        one = rw.go([head[0]], [min(48, checks[head[0]].n)])[0]              # one reference thread, alone on the box: a whole GOP
+        one_dec = rw.dec([head[0]], [min(48, checks[head[0]].n)])[0]
         allr = rw.go(head, [checks[i].n for i in head])                      # the headline's workers at once
         decr = rw.dec(head, [checks[i].n for i in head]) if dec_md5 else []
         dec_rest = {}
@@ -1172,7 +1199,7 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     leg("c2_720p_420_qp60_gop48", r2, 4, 24, 24, {"input": "pinned_host, staggered GOP phases"})
     r2.free()
     # C3: 1920x1080 4:2:0 -qp=60 -gop=60 (the headline's geometry with the CLI's default GOP)
-    r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=align)
+    r3 = EncodeRun(hip, A, torch, W_, H_, "420", 60, 60, 10, S, args.groups, vids[:min(NV, 8)], not args.no_stagger, seeds=seeds, phase_align=align)
     leg("c3_1080p_420_qp60_gop60", r3, 4, 16, 20, {"input": "pinned_host, staggered GOP phases"})
     r3.free()
     # C4: 1920x1080 4:4:4 lossless (-qp=100), every stream from its first (intra) frame; round trip through the decoder
@@ -1200,7 +1227,7 @@ def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, c
     for S, G in BATCH_POINTS:
         G = min(G, S)
         k = 48
-        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, G, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
+        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, G, vids[:min(NV, 8)], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
                         mix=None if (args.no_mix or S < 20) else MIX, timed_from=(GOP if not args.no_stagger else 0) + 4, timed_steps=k)
         f, e, ms = timed_leg(run, 4, k)
         p, b = run.twins_equal() if S > 1 else (0, 0)
@@ -1220,7 +1247,7 @@ def class_legs(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, ch
     out = {}
     for name in EncodeRun.CLASSES:
         k = 24
-        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, 192, 4, vids[:NV], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
+        run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, 192, 4, vids[:min(NV, 8)], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
                         mix=None if name == "pan" else {name: 10}, timed_from=(GOP if not args.no_stagger else 0) + 4, timed_steps=k)
         f, e, _ = timed_leg(run, 4, k)
         p, b = run.twins_equal()

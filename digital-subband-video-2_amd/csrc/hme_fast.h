@@ -223,7 +223,6 @@ __device__ __forceinline__ int sdiv_fast(int n, int d)
 
 struct FastLds {
     int hist[16];
-    int cx[64], cy[64];
     SubpelLds sp;
 #ifdef DSV2_HME_PROF
     unsigned long long prof_t, prof_acc[16];
@@ -419,33 +418,50 @@ __device__ __forceinline__ SrcStats source_analysis(const Quad &a, bool act, int
     return st;
 }
 
-// scores up to 16 displacement vectors held in LDS (s.cx/cy[first .. first+cnt)) against the
-// register-resident source block; returns on lane k (k < cnt) the raw wave total of vector
-// first+k (SSE for level > 1, psy accumulator otherwise); invalid vectors give 0.
-// vec(t, dx, dy): the t-th displacement vector of the round, wave-uniform
+// ---- scoring rounds: up to 16 displacement vectors against the register-resident source block, ONE load round -----------------
+// The vectors of a round are wave-uniform (dx, dy) pairs (entries beyond `cnt`: the zero vector); on return lane L holds the raw
+// wave total of entry L & (NR - 1), NR = 4 / 8 / 16 (SSE for level > 1, psy accumulator otherwise); a vector whose block leaves
+// the padded plane gives 0.
+// Addressing: a block of the padded plane at any valid position is (plane origin) + a non-negative 32-bit offset, so the loads use
+// ONE wave-uniform base -- the plane's first padded pixel -- plus a vector offset that the hardware adds (scalar base + vector
+// offset form) instead of the wavefront (64-bit scalar arithmetic per vector and a 64-bit vector add per load).
+// safe: every vector of the round is known to lie within +-31 pixels.  The planes carry a 32-pixel border, so such a block is
+// inside the padded plane WHEREVER the block sits: no per-vector bounds test.
 // smask: bytes of a quad that belong to the block (all four, except in the half quads of an odd last row / column at the
 // squared-error levels)
-template <int NT, class VecFn>
-__device__ __forceinline__ unsigned score_vecs(VecFn vec, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
-                                               const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu,
-                                               unsigned wanted = 0xffffffffu)
+template <int NT> struct VecSet {
+    int dx[NT], dy[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ unsigned score_set(const VecSet<NT> &vs, int cnt, bool safe, const DPlane &ref, int bx, int by, int bw, int bh, const Quad &a,
+                                              bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
 {
-    // all loads first, back to back (one round trip); a vector that may not be read (or is not `wanted`: bit t) is replaced by a safe one
+    int ok[NT];
+    if (safe) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            ok[t] = t < cnt;
+        }
+    } else {
+        // valid <=> -32 <= bx + dx and bx + dx + bw < w + 32 (invalid_block, pad 0): one unsigned compare per axis
+        const unsigned lx = (unsigned) (ref.w + 2 * kBorder - bw), ly = (unsigned) (ref.h + 2 * kBorder - bh);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            ok[t] = t < cnt && (unsigned) (bx + kBorder + vs.dx[t]) < lx && (unsigned) (by + kBorder + vs.dy[t]) < ly;
+        }
+    }
+    // all loads first, back to back (one round trip); a vector that may not be read is replaced by the zero vector, whose block
+    // always lies inside the frame
+    gbytes_t base = (gbytes_t) uni_ptr(ref.data - (ptrdiff_t) kBorder * ref.stride - kBorder);
+    const unsigned o0 = (unsigned) ((by + kBorder) * ref.stride + bx + kBorder);
+    const unsigned loff = act ? (unsigned) ((2 * qj) * ref.stride + 2 * qi) : 0u;
     Quad b[NT];
-    bool ok[NT];
-    int dxs[NT], dys[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        // candidate vectors are wave-uniform: as scalars they keep the block address arithmetic on the SALU
-        int dx, dy;
-        vec(t, dx, dy);
-        ok[t] = t < cnt && ((wanted >> t) & 1u) && !invalid_block(ref, bx + dx, by + dy, bw, bh, 0);
-        dxs[t] = dx;
-        dys[t] = dy;
-    }
-#pragma unroll
-    for (int t = 0; t < NT; t++) { // the zero vector's block always lies inside the frame
-        b[t] = ldq(at(ref, bx + (ok[t] ? dxs[t] : 0), by + (ok[t] ? dys[t] : 0)), ref.stride, qi, qj, act);
+        const unsigned o = o0 + (unsigned) (ok[t] ? vs.dy[t] * ref.stride + vs.dx[t] : 0);
+        const uint32_t top = ((gu16_t) (base + (loff + o)))->v, bot = ((gu16_t) (base + (loff + o + (unsigned) ref.stride)))->v;
+        b[t].w = top | (bot << 16);
     }
     constexpr int NR = NT <= 4 ? 4 : (NT <= 8 ? 8 : 16); // width of the joint reduction
     int v[NR];
@@ -462,17 +478,44 @@ __device__ __forceinline__ unsigned score_vecs(VecFn vec, int cnt, const DPlane 
     return (unsigned) bcastL<NR>(r, threadIdx.x & (NR - 1));
 }
 
-// the same for vectors held in LDS (s.cx / s.cy [first .. first + cnt)): the candidate list
-template <int NT>
-__device__ __forceinline__ unsigned score16(const FastLds &s, int first, int cnt, const DPlane &ref, int bx, int by, int bw, int bh,
-                                            const Quad &a, bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
+// the next NT vectors of the lanes in `rest` (lowest lanes first; key = x | y << 16, int16 each), popped off it
+template <int NT> __device__ __forceinline__ VecSet<NT> pop_vecs(unsigned long long &rest, int key)
 {
-    return score_vecs<NT>(
-        [&](int t, int &dx, int &dy) {
-            dx = __builtin_amdgcn_readfirstlane(s.cx[first + t]);
-            dy = __builtin_amdgcn_readfirstlane(s.cy[first + t]);
-        },
-        cnt, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+    VecSet<NT> vs;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int k = 0;
+        if (rest) {
+            k = __builtin_amdgcn_readlane(key, __ffsll((long long) rest) - 1);
+            rest &= rest - 1;
+        }
+        vs.dx[t] = (int) (int16_t) (k & 0xffff);
+        vs.dy[t] = k >> 16;
+    }
+    return vs;
+}
+
+// raw scores of the vectors held (as keys) by the lanes of `mask`, returned on those lanes: four vectors a load round (after
+// de-duplication a list has ~3.5 entries; the rare longer one takes further rounds of the same code)
+__device__ __forceinline__ unsigned score_lanes(unsigned long long mask, int key, const DPlane &ref, int bx, int by, int bw, int bh, const Quad &a, bool act,
+                                                int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = __popcll(mask);
+    const int widx = __popcll(mask & ((1ull << lane) - 1)); // this lane's place among them
+    const int mx = (int) (int16_t) (key & 0xffff), my = key >> 16;
+    const bool mine = ((mask >> lane) & 1ull) != 0;
+    const bool safe = !__any(mine && ((unsigned) (mx + 31) > 62u || (unsigned) (my + 31) > 62u));
+    unsigned long long rest = mask;
+    unsigned raw = 0;
+    for (int first = 0; first < n; first += 4) {
+        const VecSet<4> vs = pop_vecs<4>(rest, key);
+        const unsigned r = (unsigned) __shfl((int) score_set<4>(vs, min(4, n - first), safe, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask), widx & 3, 64);
+        if ((widx >> 2) == (first >> 2)) {
+            raw = r;
+        }
+    }
+    return raw;
 }
 
 // psy accumulator of one 2x2 quad pair for the three predictions compared by err_intra (hme.c:839)
@@ -600,6 +643,153 @@ __device__ __forceinline__ unsigned subpel_probes(const Ctx &c, FastLds &S, int 
     return metric_return(acc, 16, 16);
 }
 
+// ---- the same for a WHOLE 16x16 block, out of registers ------------------------------------------------------------------------
+// The 34x34 half-pel image costs a wavefront ~250 vector instructions, 50 LDS accesses (unaligned: bank conflicts) and two
+// barriers -- and of its 1 156 samples the seven probes read one quadrant's worth.  Which quadrant is known once the four
+// neighbours' squared errors are: with s0 / s1 the signs of the better horizontal / vertical neighbour, every probe is made of
+//   F (x, y)   H (x + s0/2, y)   V (x, y + s1/2)   C (x + s0/2, y + s1/2)            (hme.c:787-835, qsample: AVG2 / AVG4 of those)
+// of the lane's own four pixels.  A lane therefore loads a 6-row x 8-byte PATCH of the reference around its quad -- rows y0 - 2 ..
+// y0 + 3, columns x0 - 2 .. x0 + 5: six loads, which also hold the four neighbour blocks' quads (twelve loads and an LDS round
+// before) -- and filters it in registers: the 5,5,-1,-1 taps along a row as two byte dot products, down the columns in packed
+// 16-bit arithmetic (no intermediate exceeds 26 520).
+typedef short hs16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hs16x2 hpk(uint32_t v) { return __builtin_bit_cast(hs16x2, v); }
+__device__ __forceinline__ uint32_t hu32(hs16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ hs16x2 hspl(int v) { return (hs16x2){(short) v, (short) v}; }
+// 5 (b + c) - (a + d), two columns at once
+__device__ __forceinline__ hs16x2 hpf_pk(hs16x2 a, hs16x2 b, hs16x2 c, hs16x2 d) { return hspl(5) * (b + c) - (a + d); }
+// clamp_u8((v + r) >> s) of both halves, as bytes 0 and 2
+__device__ __forceinline__ uint32_t round_clamp_pk(hs16x2 v, int r, int sft)
+{
+    const hs16x2 t = (v + hspl(r)) >> hspl(sft);
+    return hu32(__builtin_elementwise_min(__builtin_elementwise_max(t, hspl(0)), hspl(255)));
+}
+// bytes k, k + 1 (k = 0 .. 4, a constant) of the 8-byte row {lo, hi} in bytes 0, 1
+__device__ __forceinline__ uint32_t row_bytes(uint32_t lo, uint32_t hi, int k) { return k == 0 ? lo : (k == 4 ? hi : __builtin_amdgcn_alignbit(hi, lo, 8 * k)); }
+// the 2x2 quad whose upper row is {lo0, hi0}, lower row {lo1, hi1}, at byte offset k
+__device__ __forceinline__ uint32_t patch_quad(uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1, int k)
+{
+    return __builtin_amdgcn_perm(row_bytes(lo1, hi1, k), row_bytes(lo0, hi0, k), 0x05040100u);
+}
+// (a + b + 1) >> 1 of four bytes at once
+__device__ __forceinline__ uint32_t avg2_b4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
+__device__ __forceinline__ uint32_t avg4_b4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t m = 0x00ff00ffu;
+    const uint32_t e = ((a & m) + (b & m) + (c & m) + (d & m) + 0x00020002u) >> 2;
+    const uint32_t o = (((a >> 8) & m) + ((b >> 8) & m) + ((c >> 8) & m) + ((d >> 8) & m) + 0x00020002u) >> 2;
+    return (e & m) | ((o & m) << 8);
+}
+
+template <class Ctx>
+__device__ __forceinline__ unsigned subpel_probes_patch(const Ctx &c, int fpelx, int fpely, int bx, int by, const Quad &a, int qi, int qj, const Psy &psy, unsigned &dirs)
+{
+    const int lane = threadIdx.x & 63;
+    const DPlane &ref = c.ref[0];
+    typedef const __attribute__((address_space(1))) uint8_t *gb_t;
+    typedef const __attribute__((address_space(1))) uint2v_t *gu2_t; // (may be unaligned: the hardware splits the access)
+    uint32_t lo[6], hi[6];
+    {
+        gb_t g = (gb_t) at(ref, bx + fpelx - 2, by + fpely - 2);
+        const unsigned off = (unsigned) ((2 * qj) * ref.stride + 2 * qi);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            struct __attribute__((packed)) U2 {
+                uint2v_t v;
+            };
+            const uint2v_t v = ((const __attribute__((address_space(1))) U2 *) (g + off + (unsigned) (r * ref.stride)))->v;
+            lo[r] = v[0];
+            hi[r] = v[1];
+        }
+    }
+    // the four full-pel neighbours (hme.c:1075): (1, 0), (-1, 0), (0, 1), (0, -1); the lane's own quad sits at rows 2, 3, byte 2
+    int v4[4];
+    {
+        Quad n;
+        n.w = patch_quad(lo[2], hi[2], lo[3], hi[3], 3);
+        v4[0] = (int) qsse(a, n);
+        n.w = patch_quad(lo[2], hi[2], lo[3], hi[3], 1);
+        v4[1] = (int) qsse(a, n);
+        n.w = patch_quad(lo[3], hi[3], lo[4], hi[4], 2);
+        v4[2] = (int) qsse(a, n);
+        n.w = patch_quad(lo[1], hi[1], lo[2], hi[2], 2);
+        v4[3] = (int) qsse(a, n);
+    }
+    int r4 = reduceN<4>(v4);
+    unsigned quad0 = (unsigned) bcastN<4>(r4, 0), quad1 = (unsigned) bcastN<4>(r4, 1), quad2 = (unsigned) bcastN<4>(r4, 2),
+             quad3 = (unsigned) bcastN<4>(r4, 3);
+    int pri0 = 0, pri1 = -1, sec0 = -1, sec1 = 0;
+    unsigned ms1 = quad1, ms2 = quad3;
+    if (quad3 >= quad2) {
+        pri1 = 1;
+        ms2 = quad2;
+    }
+    if (quad1 >= quad0) {
+        sec0 = 1;
+        ms1 = quad0;
+    }
+    const int s0 = sec0, s1 = pri1; // the half-sample side of every probe: horizontally, vertically
+    const bool swapped = ms2 > ms1; // the primary direction is the horizontal one
+    if (swapped) {
+        int t0 = sec0, t1 = sec1;
+        sec0 = pri0, sec1 = pri1;
+        pri0 = t0, pri1 = t1;
+    }
+    dirs = (unsigned) (pri0 + 1) | ((unsigned) (pri1 + 1) << 2) | ((unsigned) (sec0 + 1) << 4) | ((unsigned) (sec1 + 1) << 6);
+    // the five rows the vertical taps of both quad rows reach: y0 - 1 .. y0 + 3 (s1 > 0) or y0 - 2 .. y0 + 2; the quad's own rows are T[q0], T[q0 + 1]
+    uint32_t tl[5], th[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        tl[k] = s1 > 0 ? lo[k + 1] : lo[k];
+        th[k] = s1 > 0 ? hi[k + 1] : hi[k];
+    }
+    // horizontal taps: for column x the dword x - 1 .. x + 2; the quad's columns are bytes 2, 3 and the half sample lies on the
+    // s0 side: dword offsets 1, 2 (s0 > 0) or 0, 1 -- as one wave-uniform shift
+    const unsigned sh = s0 > 0 ? 8u : 0u;
+    hs16x2 hz[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t d0 = __builtin_amdgcn_alignbit(th[k], tl[k], sh), d1 = __builtin_amdgcn_alignbit(th[k], tl[k], sh + 8u);
+        const int h0 = (int) __builtin_amdgcn_udot4(d0, 0x00050500u, 0u, false) - (int) __builtin_amdgcn_udot4(d0, 0x01000001u, 0u, false);
+        const int h1 = (int) __builtin_amdgcn_udot4(d1, 0x00050500u, 0u, false) - (int) __builtin_amdgcn_udot4(d1, 0x01000001u, 0u, false);
+        hz[k] = hpk(((uint32_t) h0 & 0xffffu) | ((uint32_t) h1 << 16));
+    }
+    // the quad's columns of the five rows, zero-extended to 16 bits
+    hs16x2 e[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        e[k] = hpk(__builtin_amdgcn_perm(0u, tl[k], 0x0c030c02u));
+    }
+    // samples of the quad's upper / lower pixel row as bytes 0, 2; the rows themselves sit at T[1], T[2] (s1 > 0) or T[2], T[3]
+    const uint32_t h_top = round_clamp_pk(s1 > 0 ? hz[1] : hz[2], 4, 3), h_bot = round_clamp_pk(s1 > 0 ? hz[2] : hz[3], 4, 3);
+    const uint32_t v_top = round_clamp_pk(hpf_pk(e[0], e[1], e[2], e[3]), 4, 3), v_bot = round_clamp_pk(hpf_pk(e[1], e[2], e[3], e[4]), 4, 3);
+    const uint32_t c_top = round_clamp_pk(hpf_pk(hz[0], hz[1], hz[2], hz[3]), 32, 6), c_bot = round_clamp_pk(hpf_pk(hz[1], hz[2], hz[3], hz[4]), 32, 6);
+    const uint32_t Fq = patch_quad(lo[2], hi[2], lo[3], hi[3], 2);
+    const uint32_t Hq = __builtin_amdgcn_perm(h_bot, h_top, 0x06040200u), Vq = __builtin_amdgcn_perm(v_bot, v_top, 0x06040200u),
+                   Cq = __builtin_amdgcn_perm(c_bot, c_top, 0x06040200u);
+    // the seven probes (hme.c:1113-1150): 2 pri, pri, 2 sec, sec, 2 diag, diag, pri + diag
+    const uint32_t A = swapped ? Hq : Vq, B = swapped ? Vq : Hq;
+    uint32_t q[7];
+    q[0] = A;
+    q[1] = avg2_b4(Fq, A);
+    q[2] = B;
+    q[3] = avg2_b4(Fq, B);
+    q[4] = Cq;
+    q[5] = avg4_b4(Fq, Hq, Vq, Cq);
+    q[6] = avg2_b4(A, Cq);
+    int v8[8];
+#pragma unroll
+    for (int n = 0; n < 7; n++) {
+        Quad qs;
+        qs.w = q[n];
+        v8[n] = (int) qmetric(a, qs, psy);
+    }
+    v8[7] = 0;
+    int r8 = reduceN<8>(v8);
+    unsigned acc = (unsigned) bcastL<8>(r8, lane & 7);
+    return metric_return(acc, 16, 16);
+}
+
 // mr: lane n (n < 7) holds the normalised metric of probe n
 __device__ __forceinline__ unsigned subpel_decide(const CostCtx &cc, int effort, unsigned mr, unsigned dirs, int &sub_x, int &sub_y, int fpelx, int fpely,
                                                   unsigned best, int bw, int bh)
@@ -649,7 +839,9 @@ __device__ __forceinline__ unsigned subpixel_me_fast(const Ctx &c, FastLds &S, c
     }
     HME_COUNT(S, 13, 1);
     unsigned dirs;
-    const unsigned mr = subpel_probes(c, S, fpelx, fpely, bx, by, bw, bh, a, act, qi, qj, psy, dirs);
+    // (a whole block -- bw, bh are compile-time 16 in the callers' FULL instantiation -- filters a register patch; a clipped one the LDS image)
+    const unsigned mr = (bw == 16 && bh == 16) ? subpel_probes_patch(c, fpelx, fpely, bx, by, a, qi, qj, psy, dirs)
+                                               : subpel_probes(c, S, fpelx, fpely, bx, by, bw, bh, a, act, qi, qj, psy, dirs);
     return subpel_decide(cc, c.effort, mr, dirs, sub_x, sub_y, fpelx, fpely, best, bw, bh);
 }
 
@@ -733,27 +925,43 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
     }
     unsigned best_fp = best;
     if (c.effort >= 4) {
+        // pass 0: around the parent average; pass 1: around the best full-pel vector -- unless pass 0 found a sub-pel offset, the
+        // full-pel search ended "good enough", or the centre would be the same (a second search around the SAME full-pel vector
+        // repeats the first one operand for operand and ends where it did: no offset, the same score).  ONE copy of the search
+        // in the kernel (a loop the compiler may not unroll: the search is ~700 instructions).
         bool searched_lax = false;
-        if (SPLIT ? sp_done : !invalid_block(ref0, bx + lax, by + lay, bw, bh, 4)) {
-            searched_lax = true;
-            if (best_fp != 0) { // (hme.c:1062: a perfect full-pel match is not searched around)
-                if constexpr (SPLIT) {
+        if constexpr (SPLIT) { // (pass 0's pixel half comes from the pre-pass)
+            if (sp_done) {
+                searched_lax = true;
+                if (best_fp != 0) { // (hme.c:1062: a perfect full-pel match is not searched around)
                     best = subpel_decide(cc, c.effort, sp_mr, sp_dirs, sx, sy, lax, lay, best_fp, bw, bh);
-                } else {
-                    best = subpixel_me_fast(c, S, cc, sx, sy, lax, lay, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+                }
+                if (sx || sy) {
+                    fpelx = lax;
+                    fpely = lay;
+                    found_sub = true;
                 }
             }
-            if (sx || sy) {
-                fpelx = lax;
-                fpely = lay;
-                found_sub = true;
-            }
         }
-        // (a second search around the SAME full-pel vector -- the parent average was also the best candidate -- repeats the
-        // first one operand for operand and ends where it did: no sub-pel offset, the same score; it is not run again)
-        const bool same_centre = searched_lax && fpelx == lax && fpely == lay;
-        if (!found_sub && !good_enough && !same_centre && !invalid_block(ref0, bx + fpelx, by + fpely, bw, bh, 4)) {
-            best = subpixel_me_fast(c, S, cc, sx, sy, fpelx, fpely, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+#pragma unroll 1
+        for (int pass = SPLIT ? 1 : 0; pass < 2; pass++) {
+            const int ccx = pass == 0 ? lax : fpelx, ccy = pass == 0 ? lay : fpely;
+            const bool same_centre = searched_lax && fpelx == lax && fpely == lay;
+            const bool run = (pass == 0 || (!found_sub && !good_enough && !same_centre)) && !invalid_block(ref0, bx + ccx, by + ccy, bw, bh, 4);
+            if (!run) {
+                continue;
+            }
+            if (best_fp != 0) {
+                best = subpixel_me_fast(c, S, cc, sx, sy, ccx, ccy, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
+            }
+            if (pass == 0) {
+                searched_lax = true;
+                if (sx || sy) {
+                    fpelx = lax;
+                    fpely = lay;
+                    found_sub = true;
+                }
+            }
         }
     }
     mv.u.mv.x = (int16_t) (fpelx * 4 + sx);
@@ -780,22 +988,31 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
     cs.w = cz.w = cm.w = 0;
     r = ldq(at(ref0, bx + fpelx, by + fpely), ref0.stride, qi, qj, act);
     o = ldq(at(c.ogr[0], bx + fpelx, by + fpely), c.ogr[0].stride, qi, qj, act);
-    rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
+    // (the zero-motion operands are only looked at by the skip test: hme.c:1686)
+    const bool skip_test = (good_enough || (fpelx | fpely | sx | sy) == 0) && c.skip_block_thresh >= 0 && !c.lossless;
+    rz.w = 0;
+    if (skip_test) {
+        rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
+    }
     if constexpr (CS == 1) {
         us = ldpx(at(c.srcc[0], cbx, cby), cyp * c.srcc[0].stride + cxp, actc);
         vs = ldpx(at(c.srcc[1], cbx, cby), cyp * c.srcc[1].stride + cxp, actc);
         um = ldpx(at(c.refc[0], cbmx, cbmy), cyp * c.refc[0].stride + cxp, actc);
         vm = ldpx(at(c.refc[1], cbmx, cbmy), cyp * c.refc[1].stride + cxp, actc);
         cs = ldq(at(c.srcc[cpl], cbx, cby), c.srcc[cpl].stride, cqi, cqj, actq);
-        cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
+        if (skip_test) {
+            cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
+        }
         cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
     } else {
         usq = ldq(at(c.srcc[0], cbx, cby), c.srcc[0].stride, qi, qj, act);
         vsq = ldq(at(c.srcc[1], cbx, cby), c.srcc[1].stride, qi, qj, act);
         umq = ldq(at(c.refc[0], cbmx, cbmy), c.refc[0].stride, qi, qj, act);
         vmq = ldq(at(c.refc[1], cbmx, cbmy), c.refc[1].stride, qi, qj, act);
-        uzq = ldq(at(c.refc[0], cbx, cby), c.refc[0].stride, qi, qj, act);
-        vzq = ldq(at(c.refc[1], cbx, cby), c.refc[1].stride, qi, qj, act);
+        if (skip_test) {
+            uzq = ldq(at(c.refc[0], cbx, cby), c.refc[0].stride, qi, qj, act);
+            vzq = ldq(at(c.refc[1], cbx, cby), c.refc[1].stride, qi, qj, act);
+        }
     }
     const int kq = (qi >= (qw >> 1) ? 1 : 0) | (qj >= (qh >> 1) ? 2 : 0);         // luma quadrant of this lane's quad
     const int kc = (cqi >= (cbw >> 2) ? 1 : 0) | (cqj >= (cbh >> 2) ? 2 : 0);      // chroma quadrant of this lane's chroma quad
@@ -838,8 +1055,10 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
     int vtex = (int) max((unsigned) bcastN<16>(R, 10), (unsigned) bcastN<16>(R, 11));
     unsigned avg_ref = (unsigned) div_nn(ref_sum, bw * bh);
 
-    // round 2: reference deviation + zero-motion sub-block metrics (skip test operands)
-    {
+    // round 2: reference deviation + -- for the skip test -- the zero-motion sub-block metrics
+    int ref_dev;
+    unsigned zsub[3] = {0u, 0u, 0u};
+    if (skip_test) {
         v[0] = quad_absdev(r, act, (int) avg_ref);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -853,15 +1072,16 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
             }
         }
         v[13] = v[14] = v[15] = 0;
-    }
-    R = reduceN<16>(v);
-    int ref_dev = bcastN<16>(R, 0) >> 1;
-    unsigned zsub[3];
+        R = reduceN<16>(v);
+        ref_dev = bcastN<16>(R, 0) >> 1;
 #pragma unroll
-    for (int z = 0; z < 3; z++) {
-        unsigned m0 = (unsigned) bcastN<16>(R, 1 + 4 * z), m1 = (unsigned) bcastN<16>(R, 2 + 4 * z);
-        unsigned m2 = (unsigned) bcastN<16>(R, 3 + 4 * z), m3 = (unsigned) bcastN<16>(R, 4 + 4 * z);
-        zsub[z] = max(max(m0, m1), max(m2, m3));
+        for (int z = 0; z < 3; z++) {
+            unsigned m0 = (unsigned) bcastN<16>(R, 1 + 4 * z), m1 = (unsigned) bcastN<16>(R, 2 + 4 * z);
+            unsigned m2 = (unsigned) bcastN<16>(R, 3 + 4 * z), m3 = (unsigned) bcastN<16>(R, 4 + 4 * z);
+            zsub[z] = max(max(m0, m1), max(m2, m3));
+        }
+    } else {
+        ref_dev = wave_sum(quad_absdev(r, act, (int) avg_ref)) >> 1;
     }
     int tex_ref = (int) (max(ref_sh, ref_sv) - (unsigned) ref_dev);
     unsigned var_ref = (unsigned) (ref_dev + max(tex_ref, 0));
@@ -905,7 +1125,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
     }
     unsigned skipt = ((unsigned) c.quant * (unsigned) c.quant) >> 19;
     bool skipped = false;
-    if ((good_enough || mv.u.all == 0) && c.skip_block_thresh >= 0 && !c.lossless) {
+    if (skip_test) {
         unsigned sth = skipt * yarea;
         sth += 4 * var_src;
         sth += yarea * (unsigned) c.skip_block_thresh;
@@ -1204,13 +1424,13 @@ __device__ __forceinline__ void refine_fpel(const DPlane &ref, int bx, int by, i
     while (again && !good_enough) {
         again = false;
         HME_COUNT(S, 12, 1);
-        const int rdx = dx, rdy = dy;
-        unsigned raw = score_vecs<9>(
-            [&](int t, int &vx, int &vy) {
-                vx = rdx + tab9(kRectX, t);
-                vy = rdy + tab9(kRectY, t);
-            },
-            9, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+        VecSet<9> vs;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            vs.dx[t] = dx + tab9(kRectX, t);
+            vs.dy[t] = dy + tab9(kRectY, t);
+        }
+        unsigned raw = score_set<9>(vs, 9, (unsigned) (dx + 30) <= 60u && (unsigned) (dy + 30) <= 60u, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
         int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
         bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
         if (level <= 1) {
@@ -1436,46 +1656,19 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
     }
     cxv = (int) (int16_t) ((int) (int16_t) cxv >> level);
     cyv = (int) (int16_t) ((int) (int16_t) cyv >> level);
-    // first-occurrence de-duplication, then ONE order-preserving compaction into LDS
-    int n;
-    {
-        const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16); // both components are int16 by now
-        const bool keep = exist && !dedup_lanes(exist, key);
-        const unsigned long long km = __ballot(keep);
-        const int nidx = __popcll(km & ((1ull << lane) - 1));
-        n = __popcll(km);
-        __syncthreads(); // (the previous block's readers of S.cx / S.cy are done)
-        if (keep) {
-            S.cx[nidx] = cxv;
-            S.cy[nidx] = cyv;
-        }
-        if (lane >= n) { // pad: unused slots hold the zero vector (never selected: masked below)
-            S.cx[lane] = 0;
-            S.cy[lane] = 0;
-        }
-        __syncthreads();
-    }
+    // first-occurrence de-duplication (hme.c:1166); a lane = a canonical list position, so "first wins" among equal scores is
+    // "lowest lane wins" and the list never has to be compacted
+    const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16); // both components are int16 by now
+    const bool keep = exist && !dedup_lanes(exist, key);
     cc.q = c.quant;
     cc.b2sr = b2sr_of(c);
-    // ---- best candidate (hme.c:1530-1557): lane k scores candidate k ----
+    // ---- best candidate (hme.c:1530-1557) ----
     int dx, dy;
     unsigned best;
     {
-        unsigned raw = 0;
-        if (n <= 4) { // the usual case after de-duplication
-            raw = score16<4>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
-        } else if (n <= 8) {
-            raw = score16<8>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
-        } else {
-            for (int first = 0; first < n; first += 16) {
-                unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
-                if (lane >= first && lane < first + 16) {
-                    raw = r;
-                }
-            }
-        }
-        int mx = S.cx[lane], my = S.cy[lane];
-        bool valid = lane < n && !invalid_block(ref, bx + mx, by + my, bw, bh, 0);
+        unsigned raw = score_lanes(__ballot(keep), key, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+        const int mx = cxv, my = cyv;
+        bool valid = keep && !invalid_block(ref, bx + mx, by + my, bw, bh, 0);
         if (level <= 1) {
             raw = metric_return(raw, bw, bh);
         }
@@ -1490,8 +1683,8 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
         unsigned long long hit = __ballot(valid && sc == mn);
         int best_k = (mn != 0xffffffffu && hit) ? (int) __ffsll((long long) hit) - 1 : 0;
         best = mn;
-        dx = __builtin_amdgcn_readfirstlane(S.cx[best_k]);
-        dy = __builtin_amdgcn_readfirstlane(S.cy[best_k]);
+        dx = __builtin_amdgcn_readlane(mx, best_k);
+        dy = __builtin_amdgcn_readlane(my, best_k);
     }
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
@@ -1624,34 +1817,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block
     cyv = (int) (int16_t) cyv;
     const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16);
     const bool keep = exist && !dedup_lanes(exist, key);
-    const unsigned long long km = __ballot(keep);
-    const int nidx = __popcll(km & ((1ull << lane) - 1));
-    const int n = __popcll(km);
-    __syncthreads();
-    if (keep) {
-        S.cx[nidx] = cxv;
-        S.cy[nidx] = cyv;
-    }
-    if (lane >= n) {
-        S.cx[lane] = 0;
-        S.cy[lane] = 0;
-    }
-    __syncthreads();
-    unsigned raw = 0;
-    if (n <= 4) {
-        raw = score16<4>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
-    } else if (n <= 8) {
-        raw = score16<8>(S, 0, n, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
-    } else {
-        for (int first = 0; first < n; first += 16) {
-            unsigned r = score16<16>(S, first, min(16, n - first), ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
-            if (lane >= first && lane < first + 16) {
-                raw = r;
-            }
-        }
-    }
-    raw = metric_return(raw, bw, bh);                // lane k: list entry k in compacted order
-    raw = (unsigned) __shfl((int) raw, nidx, 64);    // lane p: its own entry
+    const unsigned raw = metric_return(score_lanes(__ballot(keep), key, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy), bw, bh);
     uint32_t rf = kL0Absent;
     if (keep) {
         rf = (raw & kL0ScoreMask) | (invalid_block(ref, bx + cxv, by + cyv, bw, bh, 0) ? kL0Invalid : 0u);
@@ -1664,7 +1830,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block
     const bool sp_done = c.effort >= 4 && !invalid_block(ref, bx + lax, by + lay, bw, bh, 4);
     unsigned dirs = 0;
     if (sp_done) {
-        const unsigned mr = subpel_probes(c, S, lax, lay, bx, by, bw, bh, a, act, qi, qj, psy, dirs);
+        const unsigned mr = FULL ? subpel_probes_patch(c, lax, lay, bx, by, a, qi, qj, psy, dirs) : subpel_probes(c, S, lax, lay, bx, by, bw, bh, a, act, qi, qj, psy, dirs);
         if (lane < 7) {
             rec[48 + lane] = mr;
         }
@@ -1710,6 +1876,7 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
     DSV_MV *mvf = c.mvf[0];
     DSV_MV *out = &mvf[i + j * nxb];
     DSV_MV mv = {};
+    HME_COUNT(S, 10, 1);
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
     const int qw = bw >> 1, qh = bh >> 1;
@@ -1868,37 +2035,10 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
         want = __ballot(keep);
     }
     const int mx = (int) (int16_t) (key & 0xffff), my = key >> 16;
-    // ONE load round for the vectors nobody has scored yet (SPLIT: usually none), four / eight / sixteen at a time
+    // ONE load round for the vectors nobody has scored yet (SPLIT: usually none)
     if (want) {
-        HME_COUNT(S, 10, 1);
-        const int nw = __popcll(want);
-        const int widx = __popcll(want & ((1ull << lane) - 1)); // this lane's place among them
-        auto vec_of = [&](unsigned long long rest, int t, int &vx, int &vy) { // the t-th wanted lane's vector (t < nw, else the zero vector)
-            for (int u = 0; u < t; u++) {
-                rest &= rest - 1;
-            }
-            const int k = rest ? __builtin_amdgcn_readlane(key, __ffsll((long long) rest) - 1) : 0;
-            vx = (int) (int16_t) (k & 0xffff);
-            vy = k >> 16;
-        };
-        unsigned raw = 0;
-        if (nw <= 4) {
-            raw = score_vecs<4>([&](int t, int &vx, int &vy) { vec_of(want, t, vx, vy); }, nw, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
-        } else if (nw <= 8) {
-            raw = score_vecs<8>([&](int t, int &vx, int &vy) { vec_of(want, t, vx, vy); }, nw, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
-        } else {
-            unsigned long long rest = want;
-            for (int first = 0; first < nw; first += 16) {
-                unsigned r = score_vecs<16>([&](int t, int &vx, int &vy) { vec_of(rest, t, vx, vy); }, min(16, nw - first), ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
-                if (lane >= first && lane < first + 16) {
-                    raw = r;
-                }
-                for (int u = 0; u < 16 && rest; u++) {
-                    rest &= rest - 1;
-                }
-            }
-        }
-        raw = (unsigned) __shfl((int) raw, widx, 64); // lane k of the round holds entry k: back to the lanes that own the vectors
+        HME_COUNT(S, 14, __popcll(want));
+        const unsigned raw = score_lanes(want, key, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
         if ((want >> lane) & 1ull) {
             rf = (metric_return(raw, bw, bh) & kL0ScoreMask) | (invalid_block(ref, bx + mx, by + my, bw, bh, 0) ? kL0Invalid : 0u);
         }

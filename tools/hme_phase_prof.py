@@ -16,7 +16,7 @@ bench.main()
 lib = ctypes.CDLL(PROF_SO)
 out = (ctypes.c_ulonglong * 16)()
 lib.dsv2hip_debug_hme_prof(out)
-names = ["wait row above", "source analysis", "candidate gather", "candidate score + good-enough", "refinement",
+names = ["wait row above", "first load round", "list + scores", "best candidate + good-enough", "refinement",
          "sub-pel", "mode decision A", "intra sub-block luma", "intra sub-block chroma + rest", "store + publish"]
 tot = float(sum(out[:10])) or 1.0
 for k, nm in enumerate(names):
@@ -26,4 +26,4 @@ if out[15]:
     print(f"(inside candidate gather: parent average + inliers {out[15] / 1e9:.3f} Gticks = {out[15] / tot * 100:.2f} % of the above total)", file=sys.stderr)
 blocks = float(out[10]) or 1.0
 print(f"blocks {out[10]}  refined {out[11] / blocks:.3f}  refinement rounds/block {out[12] / blocks:.3f}  "
-      f"sub-pel searches/block {out[13] / blocks:.3f}  candidates/block {out[14] / blocks:.2f}  ticks/block {tot / blocks:.0f}", file=sys.stderr)
+      f"sub-pel searches/block {out[13] / blocks:.3f}  vectors scored/block {out[14] / blocks:.2f}  ticks/block {tot / blocks:.0f}", file=sys.stderr)
