@@ -99,6 +99,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the segment gather even with ONE rank "
                     "(exercises RCCL init + collectives on a single GPU)")
     ap.add_argument("--no-multi-rank", action="store_true", help="skip the 8-ranks-on-one-GPU leg")
+    ap.add_argument("--decode-too", action="store_true", help="with --no-extras: still run the decode leg on the run's packets (the 2-host-core re-run uses it)")
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--gen-procs", type=int, default=-1,
                     help="helper processes that generate the synthetic pictures (default: the usable cores, 1 under a profiler: "
@@ -661,18 +662,61 @@ def decode_leg(hip, A, run, nsteps, nstreams, groups, check):
             th.join()
         return te - ts
 
+    import resource
     nfr = min(len(run.out[s]) for s in ids_all)
-    warm = min(4, max(1, nfr - nsteps))
+    prof_steps = 4 if nfr >= nsteps + 12 else 0          # a few more steps of the same configuration with stage events on (not timed)
+    warm = min(4, max(1, nfr - nsteps - prof_steps))
     phase(0, warm)
     before = sum(decoded)
-    elapsed = phase(warm, min(nfr, warm + nsteps))
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    elapsed = phase(warm, min(nfr - prof_steps, warm + nsteps))
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
     n = sum(decoded) - before
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+    out = {"value": round(n / elapsed, 2), "unit": "frames/s", "frames": n, "decoders": D, "groups": G,
+           "mpix_per_s": round(n / elapsed * run.w * run.h / 1e6, 1),
+           "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2),
+           "note": "lockstep batch decoder (dsv2hip_dec_batch) over this run's own packets, pictures delivered to host memory as DSV_FRAMEs; "
+                   "host_cpu_cores_busy includes the serial entropy parse of every plane section (hzcc.c:451-585), the one per-coefficient loop "
+                   "the decoder keeps on the host"}
+    if prof_steps:
+        t0 = min(nfr - prof_steps, warm + nsteps)
+        hip.dsv2hip_prof_enable(1)
+        phase(t0, t0 + prof_steps)
+        ms, ln, un, fr = (C.c_double * 16)(), (C.c_longlong * 16)(), (C.c_longlong * 16)(), C.c_longlong(0)
+        hip.dsv2hip_prof_read(ms, ln, C.byref(fr))
+        hip.dsv2hip_prof_read_units(un)
+        hip.dsv2hip_prof_enable(0)
+        nn = run.w * run.h
+        pp = nn * 3 // 2 if run.fmt == "420" else nn * 3
+        # algorithmic bytes of a P picture's decode, 15 P + 2 N: coefficient planes zeroed (4 P) + symbols scattered and dequantised
+        # in place; inverse transform (4 P read, P written); motion-compensated reconstruction (reference P, residual P, picture P)
+        # + in-loop luma filters (2 N); borders and the picture's way into the caller's frame (P read, 2 P written)
+        dbytes = {"quant_compact": 4 * pp, "inv_sbt": 5 * pp, "recon_filters": 3 * pp + 2 * nn, "extend": 3 * pp}
+        dkern = {"quant_compact": "k_zero_linear / k_dequant_level", "inv_sbt": "k_inv_haar_u8x4 / k_inv_haar / k_inv_rows / k_inv_cols",
+                 "recon_filters": "k_predict_w<MC_RECONSTRUCT> / k_inter_filters_b", "extend": "k_extend / k_copy_linear"}
+        per = {}
+        for name in dbytes:
+            i = STAGES.index(name)
+            if un[i]:
+                per[name] = {"ms": ms[i], "launch_groups": fr.value, "units": un[i], "us_per_frame": round(1e3 * ms[i] / un[i], 2),
+                             "GBps": round(dbytes[name] * un[i] / (ms[i] * 1e-3) / 1e9, 1) if ms[i] > 0 else None}
+        if per:
+            dom = max(per, key=lambda k: per[k]["ms"])
+            steps_prof = max(1, fr.value)  # lockstep steps (all groups) the events cover
+            ach = per[dom]["GBps"]
+            out["roofline"] = {"bound": "hbm", "stage": dom, "kernel": dkern[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                               "avg_stage_span_us": round(1e3 * per[dom]["ms"] / steps_prof, 1),
+                               "algorithmic_bytes_per_frame": dbytes[dom], "pictures_per_step_per_group": D // G,
+                               "stage_us_per_frame": {k: v["us_per_frame"] for k, v in per.items()},
+                               "whole_frame_algorithmic_GBps": round((15 * pp + 2 * nn) * out["value"] / 1e9, 1),
+                               "note": "stage spans = HIP events on each group's stream around the stage's launches (%d groups share the GPU: spans of "
+                                       "different groups overlap); kernel durations of the same run: profiles/r05_decode_kernel_stats.txt" % G}
     md5 = {s: [planes_md5(pl) for pl in frames] for s, frames in held.items()}
     for d in decs.values():
         hip.dsv_dec_free(C.byref(d))
-    return {"value": round(n / elapsed, 2), "unit": "frames/s", "frames": n, "decoders": D, "groups": G,
-            "mpix_per_s": round(n / elapsed * run.w * run.h / 1e6, 1),
-            "note": "lockstep batch decoder (dsv2hip_dec_batch) over this run's own packets, pictures delivered to host memory as DSV_FRAMEs"}, md5
+    return out, md5
 
 
 def thread_cpu():
@@ -1010,9 +1054,9 @@ def main():
     # ---- the decoder on this run's packets (N = 1 only) ----
     # (the headline above is complete: whatever goes wrong below is reported beside it, never instead of it)
     dec_md5 = {}
-    if extras and not args.only_batch_curve and not args.only_api_legs:
+    if (extras or args.decode_too) and not args.only_batch_curve and not args.only_api_legs:
         try:
-            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, 256, 4, sel if not args.no_cpu_baseline else [])
+            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, 256, 4, sel if (extras and not args.no_cpu_baseline) else [])
         except Exception as e:  # noqa: BLE001
             result["decode"] = {"error": repr(e)}
     run.free()
@@ -1500,7 +1544,7 @@ def multi_rank_one_gpu(args, fps_one_rank):
 def host_share(args, cores, fps_unrestricted):
     """the headline once more in a fresh process pinned to `cores` host cores (an 8-GPU node's share per rank)"""
     cmd = [sys.executable, os.path.abspath(__file__), "--host-cores", str(cores), "--streams", str(args.streams), "--groups", str(args.groups),
-           "--steps", str(min(args.steps, 24)), "--warmup", str(min(args.warmup, 4)), "--no-extras", "--no-cpu-baseline", "--no-profile"]
+           "--steps", str(min(args.steps, 24)), "--warmup", str(min(args.warmup, 4)), "--no-extras", "--no-cpu-baseline", "--no-profile", "--decode-too"]
     if args.no_stagger:
         cmd.append("--no-stagger")
     if args.no_phase_align:
@@ -1514,6 +1558,7 @@ def host_share(args, cores, fps_unrestricted):
         return {"cores": cores, "value": j["value"], "unit": "frames/s", "ratio_to_unrestricted": round(j["value"] / fps_unrestricted, 3),
                 "host_cpu_cores_busy": j["config"]["host_cpu_cores_busy"], "host_threads": j["config"]["host_threads"], "steps": j["steps"],
                 "twin_pairs_equal": j["parity_checked"]["twin_pairs_equal"], "twin_pairs": j["parity_checked"]["twin_pairs"],
+                "decode": {k: j.get("decode", {}).get(k) for k in ("value", "unit", "decoders", "host_cpu_cores_busy", "error") if k in j.get("decode", {})},
                 "note": "separate process, sched_setaffinity to %d cores before the GPU runtime starts; same workload and timed region" % cores}
     except Exception as e:  # noqa: BLE001
         return {"cores": cores, "error": repr(e)}

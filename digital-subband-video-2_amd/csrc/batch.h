@@ -157,8 +157,8 @@ class WorkerPool {
 //     (>= 2 * kMinSplit) a leader takes only its share (1 / groups) and up to `groups` steps run side by side, one's host
 //     phases and latency-bound kernels under another's;
 //   * a single caller finds nobody to wait for and runs at once: the plain dsv_enc path.
-// DSV2_COALESCE=0 turns it off, DSV2_COALESCE_US sets the longest wait (default 10 % of the last step, 100 us .. 2 ms),
-// DSV2_COALESCE_GROUPS the number of concurrent steps a crowd is split into (default 2).
+// DSV2_COALESCE=0 turns it off, DSV2_COALESCE_US sets the longest wait (default 10 % of the last step, 100 us .. 2 ms); a crowd
+// is split into two concurrent steps.
 template <class JobT> class Coalescer {
   public:
     using RunFn = void (*)(JobT *jobs, int n);
@@ -402,7 +402,7 @@ template <class JobT> class Coalescer {
     bool collecting_ = false;
     unsigned long long step_seq_ = 0;
     long long last_step_us_ = 0;
-    const int groups_ = getenv("DSV2_COALESCE_GROUPS") ? atoi(getenv("DSV2_COALESCE_GROUPS")) : 2;
+    const int groups_ = 2;
     Stats st_;
 };
 

@@ -166,7 +166,7 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
     size_t nb = nblocks();
     // encoder: everything this function (and the entropy buffers) allocates on the device comes out of ONE block, sized here
     // from the same formulas the allocations use, plus slack; what does not fit falls back to an allocation of its own
-    static const bool use_arena = !(getenv("DSV2_ARENA") && atoi(getenv("DSV2_ARENA")) == 0);
+    constexpr bool use_arena = true;
     if (encoder && use_arena) {
         // (the same sizes the allocations below ask for; 256 bytes of alignment for each of the ~100 pieces)
         size_t est = 0;

@@ -135,8 +135,8 @@ struct DecScratchLease {
     ~DecScratchLease() { g_dec_scratch_pool.release(sc); }
 };
 
-struct DecClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep decode step, printed every 16 steps
-    bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+struct DecClock { // DSV2_TRACE=2: wall-clock split of a lockstep decode step, printed every 16 steps
+    bool on = (trace_mode() & 2) != 0;
     double acc[6] = {0};
     int steps = 0;
     std::chrono::steady_clock::time_point t0;
@@ -403,18 +403,33 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
         }
     }
 
+    // (stage spans for bench.py's decode roofline: HIP events on this step's stream when dsv2hip_prof_enable(1) is on -- the
+    // encoder's stage names: QUANT = zero + scatter + dequantise, INV_SBT, RECON_FILTER = intra filter / motion-compensated
+    // reconstruction + in-loop filters, EXTEND = borders + the picture's way into the caller's frame)
+    static thread_local StageProf prof;
     HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, total, hipMemcpyHostToDevice, bs));
     sc.tabs.upload(bs);
+    prof.begin(bs, ST_QUANT);
     zero_linear_batch(bs, d_zero, 3 * n, max_coef_bytes);
     for (const Slice &sl : slices) {
         for (int c = 0; c < 3; c++) {
             dequant_jobs(bs, d_dq[c] + sl.first, sl.count, sl.max_seg[c], dv0.quant_cfg(c, sl.isP, sl.lossless, 0, nullptr));
+        }
+    }
+    prof.end(bs, ST_QUANT, n);
+    prof.begin(bs, ST_INV_SBT);
+    for (const Slice &sl : slices) {
+        for (int c = 0; c < 3; c++) {
             sbt_inverse_jobs(bs, d_pj[c] + sl.first, sl.count, dv0.cw[c], dv0.ch[c], c, sl.isP, sl.lossless, dv0.nbh, dv0.nbv);
         }
     }
+    prof.end(bs, ST_INV_SBT, n);
+    prof.begin(bs, ST_RECON_FILTER);
     zero_linear_batch(bs, d_zfail, n_zfail, max_plane_bytes);
     intra_filter_batch(bs, d_mc_intra, nIf, dv0.w, dv0.h);
     mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter, dv0.w, dv0.h);
+    prof.end(bs, ST_RECON_FILTER, n);
+    prof.begin(bs, ST_EXTEND);
     for (int c = 0; c < 3; c++) {
         const DPlane &pl = dv0.pics[0].recon.p[c];
         copy_planes_batch(bs, d_icopy[c], nI, pl.w, pl.h);
@@ -422,8 +437,10 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     }
     copy_linear_batch(bs, d_out, n_out, dv0.pics[0].recon.bytes);
     to420_batch(bs, d_to420, n_to420, dv0.w, dv0.h);
+    prof.end(bs, ST_EXTEND, n);
     t_dec_clock.lap(2);
     stream_wait(bs);
+    prof.collect();
     t_dec_clock.lap(3);
 
     // phase C: the pictures are already in their output frames
@@ -442,7 +459,7 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
 void dec_batch(DecJob *jobs, int n)
 {
     {
-        static const int fine_max = getenv("DSV2_WAIT_FINE_MAX") ? atoi(getenv("DSV2_WAIT_FINE_MAX")) : 1;
+        constexpr int fine_max = 1;
         set_wait_fine(n <= fine_max); // (dev.cpp: a few streams are a latency chain, their waits poll finely)
     }
     bind_device();
@@ -513,7 +530,7 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn) // d
     // concurrent callers (a decoder per thread) share one lockstep step; dec_batch itself sorts mixed geometries into rounds,
     // so every caller carries the same key
     g_dec_queue.submit(jb, 0, d, dec_batch);
-    if (jb.ret == DSV_DEC_EOS) {
+    if (jb.ret == DSV_DEC_EOS || jb.ret == DSV_DEC_ERROR) { // (a caller that gives up after an error must not stay expected; one that goes on is seen again)
         g_dec_queue.forget(d);
     }
     return jb.ret;

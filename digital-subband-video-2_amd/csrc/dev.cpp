@@ -14,12 +14,18 @@ namespace dsv2 {
 
 thread_local long long t_launch_count = 0;
 
-// DSV2_STARTUP_TRACE=1: milliseconds since the library was loaded at a few points of a process's first step (what a short-lived
+int trace_mode()
+{
+    static const int m = getenv("DSV2_TRACE") ? atoi(getenv("DSV2_TRACE")) : 0;
+    return m;
+}
+
+// DSV2_TRACE=1: milliseconds since the library was loaded at a few points of a process's first step (what a short-lived
 // caller -- one CLI process per closed-GOP segment, parallel_encode_yuv.sh:31-52 -- pays before its first packet)
 static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
 void startup_mark(const char *what)
 {
-    static const bool on = getenv("DSV2_STARTUP_TRACE") != nullptr;
+    static const bool on = (trace_mode() & 1) != 0;
     if (on) {
         fprintf(stderr, "[dsv2hip startup] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count(), what);
     }
@@ -206,11 +212,6 @@ static inline long wait_interval_ns(unsigned tries)
 
 void stream_wait(hipStream_t s)
 {
-    static const bool spin = getenv("DSV2_SPIN_WAIT") && atoi(getenv("DSV2_SPIN_WAIT")) != 0;
-    if (spin) {
-        HIPCHK(hipStreamSynchronize(s));
-        return;
-    }
     static thread_local hipEvent_t ev = nullptr;
     if (!ev) {
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -235,11 +236,6 @@ void stream_wait(hipStream_t s)
 // the same for an event that has been recorded already
 void event_wait(hipEvent_t ev)
 {
-    static const bool spin = getenv("DSV2_SPIN_WAIT") && atoi(getenv("DSV2_SPIN_WAIT")) != 0;
-    if (spin) {
-        HIPCHK(hipEventSynchronize(ev));
-        return;
-    }
     for (unsigned tries = 0;; tries++) {
         hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) {

@@ -191,7 +191,8 @@ void ingest_batch16(hipStream_t s, const IngestJob *d_jobs, int n, int total_row
 void ensure_device();
 void set_default_device(int ordinal);
 void bind_device(); // ensure_device + hipSetDevice(default ordinal) for the calling thread
-void startup_mark(const char *what); // DSV2_STARTUP_TRACE
+int trace_mode();                    // DSV2_TRACE: bit 0 start-up marks, bit 1 wall-clock split of the lockstep steps (bit 2: absolute times, bit 3: every step)
+void startup_mark(const char *what); // DSV2_TRACE=1
 int device_status(); // 0 = usable HIP device present
 bool device_arch_is(const char *prefix); // the default device's gcnArchName starts with `prefix`
 

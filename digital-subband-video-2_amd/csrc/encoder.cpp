@@ -34,6 +34,7 @@ namespace {
 
 struct EncImpl {
     CodecDev dev;
+    bool dead = false; // a step of this instance failed (search time-out, GPU unusable): every later call returns "no packets"
     std::vector<uint8_t> pkt; // picture packet under construction (all zero between frames)
     bool ready = false;
     int cur = 0;          // picture set receiving the current frame
@@ -855,6 +856,7 @@ struct Job {
     DSV_BUF out;
     BitWriter bs;
     int gop_start, forced_intra, ran_hme, inter_filter, nsym;
+    int failed; // phase_h1a: the search did not deliver (1: a row timed out, 2: no counters)
     const int *bstats; // BS_* sums over the search result (pinned, written by k_block_stats_b), P frames only
     const uint8_t *side_out; // P frames: the six side-information sub-streams as coded by k_side_info (pinned), or null
     const int *side_info;    // ... their byte lengths ([1 + sub]) and the fall-back flag ([0])
@@ -1014,8 +1016,7 @@ struct BatchScratch { // pinned + device memory for the job tables, the step's H
 // event on that stream covers every earlier upload on it.
 inline bool use_own_streams()
 {
-    static const bool on = !(getenv("DSV2_SCRATCH_STREAM") && atoi(getenv("DSV2_SCRATCH_STREAM")) == 0);
-    return on;
+    return true;
 }
 
 struct ScratchPool {
@@ -1076,25 +1077,72 @@ struct ScratchLease {
     ~ScratchLease() { g_scratch_pool.release(sc); }
 };
 
+// A step that cannot finish (the search token never comes, a search reports a time-out) fails the CALLS that are part of it --
+// every job of the step returns no packets, its encoder is marked dead -- not the process: the library lives inside somebody
+// else's program (the reference's dsv_enc has no failure path at all; "no packets" is the closest thing its callers handle).
+struct StepFailed {
+    const char *what;
+};
+
+// what the library cannot encode; said once per reason, the call then returns "no packets" (dsv_enc: 0, the batch calls: -1)
+static bool enc_usable(const DSV_ENCODER *enc)
+{
+    if (enc == nullptr) {
+        return false;
+    }
+    const int w = enc->vidmeta.width, h = enc->vidmeta.height;
+    if ((w & 1) || (h & 1) || w < 16 || h < 16) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) {
+            fprintf(stderr, "[dsv2hip] %dx%d: DSV2 needs even picture dimensions of at least 16x16 (dsv_main.c:621, sbt.c:384-388); the call is refused\n", w, h);
+        }
+        return false;
+    }
+    if (enc->ref && ((const EncImpl *) enc->ref)->dead) {
+        return false;
+    }
+    return true;
+}
+
+// the pyramid depth an encoder runs with (dsv_encoder.c:1229-1241): 0 in the public struct means "work it out"
+static int resolved_pyramid_levels(const DSV_ENCODER *enc)
+{
+    if (enc->pyramid_levels != 0) {
+        return enc->pyramid_levels;
+    }
+    const int w = enc->vidmeta.width, h = enc->vidmeta.height;
+    int bw, bh, nbh, nbv;
+    block_geometry(w, h, enc->block_size_override_x, enc->block_size_override_y, &bw, &bh, &nbh, &nbv);
+    int lvls = dsv_lb2((unsigned) (w < h ? w : h));
+    int maxdim = nbh > nbv ? nbh : nbv;
+    while ((1 << lvls) > maxdim) {
+        lvls--;
+    }
+    return clampi(lvls, 3, DSV_MAX_PYRAMID_LEVELS);
+}
+
+// what a lockstep step must agree on: picture geometry, block size, pyramid depth (the RESOLVED one: an encoder's first frame
+// and its later ones, and encoders that were and were not started yet, then share a key), psy switch
+static unsigned long long step_key(const DSV_ENCODER *enc)
+{
+    unsigned long long key = 1469598103934665603ull;
+    for (unsigned long long v : {(unsigned long long) enc->vidmeta.width, (unsigned long long) enc->vidmeta.height, (unsigned long long) enc->vidmeta.subsamp,
+                                 (unsigned long long) (unsigned) enc->block_size_override_x, (unsigned long long) (unsigned) enc->block_size_override_y,
+                                 (unsigned long long) resolved_pyramid_levels(enc), (unsigned long long) enc->do_psy}) {
+        key = (key ^ v) * 1099511628211ull;
+    }
+    return key;
+}
+
 void ensure_ready(DSV_ENCODER *enc, EncImpl *im)
 {
     if (im->ready) {
         return;
     }
     int w = enc->vidmeta.width, h = enc->vidmeta.height;
-    if ((w & 1) || (h & 1) || w < 16 || h < 16) {
-        fatal("DSV2 needs even picture dimensions of at least 16x16 (dsv_main.c:621, sbt.c:384-388)", __FILE__, __LINE__);
-    }
     int bw, bh, nbh, nbv;
     block_geometry(w, h, enc->block_size_override_x, enc->block_size_override_y, &bw, &bh, &nbh, &nbv);
-    if (enc->pyramid_levels == 0) { // dsv_encoder.c:1229-1241
-        int lvls = dsv_lb2((unsigned) (w < h ? w : h));
-        int maxdim = nbh > nbv ? nbh : nbv;
-        while ((1 << lvls) > maxdim) {
-            lvls--;
-        }
-        enc->pyramid_levels = clampi(lvls, 3, DSV_MAX_PYRAMID_LEVELS);
-    }
+    enc->pyramid_levels = resolved_pyramid_levels(enc);
     // Compaction lists: HALF the worst case to begin with -- a detail-rich 1080p intra picture at qp 60 has a symbol for 33 % of
     // its coefficients, its P pictures for 5 % -- and the worst case at once for lossless streams, where nearly every coefficient
     // is a symbol.  DSV2_COMPACT_CAP (symbols) forces a figure (tests: so small that pictures overflow and take the redo path).
@@ -1163,10 +1211,9 @@ void phase_h1a(Job &jb)
     DSV_PARAMS *p = &d->params;
     size_t nb = dv.nblocks();
     if (jb.ran_hme) {
-        if (dv.h_counters[7]) {
-            fatal(dv.h_counters[7] == 1 ? "motion estimation row pipeline timed out (a row waited > 4 s for the row above; DSV2_HME_ROWS=0 selects the launch-per-front form)"
-                                        : "motion estimation did not deliver its counters (search incomplete)",
-                  __FILE__, __LINE__);
+        if (dv.h_counters[7]) { // (a pool thread: the step is failed by enc_batch, behind this phase)
+            jb.failed = dv.h_counters[7] == 1 ? 1 : 2;
+            return;
         }
         int nintra = dv.h_counters[0], ndiff = dv.h_counters[1], eligible = dv.h_counters[2]; // hme.c:1825-1832, 2015
         unsigned total_err = (unsigned) dv.h_counters[3];
@@ -1346,10 +1393,10 @@ void phase_h2(Job &jb)
     }
 }
 
-struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, printed every 16 steps
-    bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+struct PhaseClock { // DSV2_TRACE=2: wall-clock split of a lockstep step, printed every 16 steps
+    bool on = (trace_mode() & 2) != 0;
     // =3: every phase boundary of every step with its absolute time (CLOCK_MONOTONIC, ms) -- lines up the groups' host phases
-    bool abs_on = on && atoi(getenv("DSV2_BATCH_TRACE")) == 3;
+    bool abs_on = (trace_mode() & 4) != 0;
     void mark(const char *what, int n)
     {
         if (!abs_on) return;
@@ -1357,7 +1404,7 @@ struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, 
         clock_gettime(CLOCK_MONOTONIC, &ts);
         fprintf(stderr, "[t %p] %.3f %s n=%d\n", (void *) this, ts.tv_sec * 1e3 + ts.tv_nsec / 1e6, what, n);
     }
-    int every = on && atoi(getenv("DSV2_BATCH_TRACE")) == 2 ? 1 : 16; // =2: print every step
+    int every = (trace_mode() & 8) ? 1 : 16; // bit 3: print every step
     double acc[10] = {0};
     int steps = 0;
     std::chrono::steady_clock::time_point t0;
@@ -1387,11 +1434,11 @@ struct PhaseClock { // DSV2_BATCH_TRACE=1: wall-clock split of a lockstep step, 
 };
 thread_local PhaseClock t_clock;
 
-// DSV2_BATCH_TRACE: CPU time (thread clock) the pool tasks of a host phase consume, summed over the streams of a step
+// DSV2_TRACE bit 1: CPU time (thread clock) the pool tasks of a host phase consume, summed over the streams of a step
 struct TaskCpu {
     std::atomic<long long> ns[3] = {{0}, {0}, {0}};
     std::atomic<long long> tasks{0};
-    bool on = getenv("DSV2_BATCH_TRACE") != nullptr;
+    bool on = (trace_mode() & 2) != 0;
     static long long now()
     {
         timespec ts;
@@ -1425,11 +1472,11 @@ TaskCpu g_task_cpu;
 struct SearchToken {
     std::mutex mu;
     std::condition_variable cv;
-    int free_slots = getenv("DSV2_SEARCH_SLOTS") ? atoi(getenv("DSV2_SEARCH_SLOTS")) : 1;
-    const bool on = free_slots > 0;
+    int free_slots = 1;
+    const bool on = true;
     // first come, first served (DSV2_SEARCH_FIFO=0: whoever the condition variable wakes first): a group that has waited longest
     // searches next, so the groups keep their rotation and none of them falls a step behind the others
-    const bool fifo = !(getenv("DSV2_SEARCH_FIFO") && atoi(getenv("DSV2_SEARCH_FIFO")) == 0);
+    const bool fifo = true;
     unsigned long long next_ticket = 0, serving = 0;
     void acquire()
     {
@@ -1441,7 +1488,7 @@ struct SearchToken {
         // bounded: a holder that never lets go (a search that hangs, a bug between acquire and release) must not park every
         // other lockstep group of the process silently
         if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return free_slots > 0 && (!fifo || serving == mine); })) {
-            fatal("search token not released within 120 s (another lockstep group's motion search never finished)", __FILE__, __LINE__);
+            throw StepFailed{"search token not released within 120 s (another lockstep group's motion search never finished)"};
         }
         if (fifo) {
             serving++;
@@ -1488,20 +1535,36 @@ static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV
 // side streams within a step: bit 0 entropy coder, bit 1 intra filter; unset: the entropy kernels of a SMALL batch (fewer than
 // 12 streams: the step is a chain of latency-bound launches on a mostly idle GPU) run beside inverse transform /
 // reconstruction / filters, a large batch keeps one chain (no throughput gain there, more host work)
-static const int kAuxStreamsEnv = getenv("DSV2_AUX_STREAMS") ? atoi(getenv("DSV2_AUX_STREAMS")) : -1;
+static const int kAuxStreamsEnv = -1;
 static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") && atoi(getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK")) != 0; // (tests)
 // the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
 static std::atomic<long> g_list_growths{0}; // pictures that had more symbols than their stream's compaction lists (dsv2hip_enc_list_growths)
-static const bool kFusedCount = !(getenv("DSV2_FUSED_COUNT") && atoi(getenv("DSV2_FUSED_COUNT")) == 0);
+static const bool kFusedCount = true;
 
+static void enc_batch_step(Job *jobs, int n);
 void enc_batch(Job *jobs, int n)
 {
+    try {
+        enc_batch_step(jobs, n);
+    } catch (const StepFailed &e) {
+        fprintf(stderr, "[dsv2hip] encode step of %d stream(s) FAILED: %s; these encoders return no packets from now on\n", n, e.what);
+        for (int k = 0; k < n; k++) {
+            jobs[k].nbuf = 0;
+            if (jobs[k].enc->ref) {
+                ((EncImpl *) jobs[k].enc->ref)->dead = true;
+            }
+        }
+    }
+}
+
+static void enc_batch_step(Job *jobs, int n)
+{
     {
-        static const int fine_max = getenv("DSV2_WAIT_FINE_MAX") ? atoi(getenv("DSV2_WAIT_FINE_MAX")) : 1;
+        constexpr int fine_max = 1;
         set_wait_fine(n <= fine_max);
     }
     const int kAuxStreams = kAuxStreamsEnv >= 0 ? kAuxStreamsEnv : (n < 12 ? 1 : 0);
-    static bool first_step = true; // (DSV2_STARTUP_TRACE only; a benign race)
+    static bool first_step = true; // (DSV2_TRACE=1 only; a benign race)
     const bool trace_startup = first_step;
     first_step = false;
     if (trace_startup) {
@@ -1627,7 +1690,7 @@ void enc_batch(Job *jobs, int n)
                 HIPCHK(hipEventRecord(sc.copy_done, sc.copy_stream));
             }
         };
-        static const bool upload_early = getenv("DSV2_UPLOAD_EARLY") && atoi(getenv("DSV2_UPLOAD_EARLY")) != 0;
+        constexpr bool upload_early = false;
         if (upload_early) {
             upload_next();
             upload_next = nullptr;
@@ -1769,7 +1832,7 @@ void enc_batch(Job *jobs, int n)
     // (Until the end of round 4 the bound was 8 192 rows.  Re-measured with the persistent kernels: 4 groups of 3 264 rows -- 192
     // streams -- gain 3 % from the token, 6 880 -> 7 090 frames/s, 4 groups of 6 528 rows 3.4 %; at 2 176 rows a group the token
     // costs 3 %, at 816 it makes no difference.  One and a half sets of the 2 048 persistent workers it is.)
-    static const int min_rows = getenv("DSV2_SEARCH_MIN_ROWS") ? atoi(getenv("DSV2_SEARCH_MIN_ROWS")) : 3072;
+    constexpr int min_rows = 3072;
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
     SearchTokenGuard token;
     if (searching) {
@@ -1783,7 +1846,7 @@ void enc_batch(Job *jobs, int n)
     // DSV2_COARSE_OUTSIDE: the coarse levels -- five launches that are dependency chains and cannot fill the chip -- run BEFORE the
     // token is taken, beside whatever level-0 launch holds it; the token then covers the level-0 launch alone.  1: queue for the
     // token at once (the level-0 launch follows the coarse levels on the stream); 2: when the coarse levels have finished.
-    static const int coarse_outside = getenv("DSV2_COARSE_OUTSIDE") ? atoi(getenv("DSV2_COARSE_OUTSIDE")) : 0;
+    constexpr int coarse_outside = 0;
     const bool split_levels = searching && coarse_outside && dv0.pyr_levels >= 1;
     int nfronts_coarse = 0;
     if (split_levels) {
@@ -1819,7 +1882,7 @@ void enc_batch(Job *jobs, int n)
         // stream's completion.)
         volatile int *tail = &jobs[pjobs[0]].im->dev.h_counters[kHmeHostTailWord];
         // DSV2_SEARCH_EARLY_RELEASE: 1 (default) at the tail; 0 when the launch has finished; 2 right after it was enqueued
-        static const int early = getenv("DSV2_SEARCH_EARLY_RELEASE") ? atoi(getenv("DSV2_SEARCH_EARLY_RELEASE")) : 1;
+        constexpr int early = 1;
         if (early == 0) {
             stream_wait(bs);
         } else if (early == 1) {
@@ -1841,6 +1904,12 @@ void enc_batch(Job *jobs, int n)
 
     // ---- H1 ----
     parallel_for(n, [&](int k) { g_task_cpu.run(0, [&] { phase_h1a(jobs[k]); }); });
+    for (int k = 0; k < n; k++) {
+        if (jobs[k].failed) {
+            throw StepFailed{jobs[k].failed == 1 ? "motion estimation row pipeline timed out (a row waited > 4 s for the row above)"
+                                                 : "motion estimation did not deliver its counters (search incomplete)"};
+        }
+    }
     {
         // P frames flipped to intra by the scene-change test: their block analysis is due now
         const IntraJob *d_late;
@@ -2111,7 +2180,7 @@ void enc_batch(Job *jobs, int n)
         // on the same operands, so the same symbols -- which the host then codes.  The reconstruction is untouched.
         const bool overflow = (size_t) jb.nsym > dv.comp.list_cap || force_redo; // (DSV2_COMPACT_REDO=1: every picture, a test switch)
         if (overflow) {
-            if (getenv("DSV2_BATCH_TRACE")) {
+            if (trace_mode() & 2) {
                 fprintf(stderr, "[batch] stream %d: %d symbols > compaction lists of %zu: redone\n", k, jb.nsym, dv.comp.list_cap);
             }
             const bool isP = jb.d.params.has_ref, lossless = jb.d.params.lossless;
@@ -2167,7 +2236,7 @@ void enc_batch(Job *jobs, int n)
             const int *info = dv.ent.host_info;
             if ((info[0] & ENT_FALLBACK_MASK) || kEntForceFallback) {
                 need_syms = true; // (state outside the tabulated range / no room: code this picture on the host)
-                if (getenv("DSV2_BATCH_TRACE")) {
+                if (trace_mode() & 2) {
                     fprintf(stderr, "[batch] stream %d: GPU entropy coder fell back (flags %d)\n", k, info[0]);
                 }
             } else {
@@ -2186,7 +2255,7 @@ void enc_batch(Job *jobs, int n)
         }
         // the symbols are needed on the host: copied when the mirror did not hold them (always so with the GPU coder on)
         if (need_syms && jb.nsym > 0 && (kGpuEntropy || overflow || (size_t) jb.nsym > dv.h_sym_cap)) {
-            if (getenv("DSV2_BATCH_TRACE")) {
+            if (trace_mode() & 2) {
                 fprintf(stderr, "[batch] stream %d: %d symbols > pinned mirror of %zu, copying\n", k, jb.nsym, dv.h_sym_cap);
             }
             dv.ensure_host_syms((size_t) jb.nsym);
@@ -2337,6 +2406,10 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
     if (frame == NULL || bufs == NULL) {
         return 0;
     }
+    if (!enc_usable(enc)) {
+        dsv_frame_ref_dec(frame); // (the reference releases the caller's frame on every path: dsv_encoder.c:1457)
+        return 0;
+    }
     Job jb;
     memset(&jb, 0, sizeof(jb));
     jb.enc = enc;
@@ -2383,13 +2456,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
     dsv_frame_ref_dec(frame);
     jb.host_planar = im->h_pack;
     jb.from_frame = true;
-    // what a lockstep step must agree on (enc_batch checks it again): picture geometry, block size, pyramid depth, psy switch
-    unsigned long long key = 1469598103934665603ull;
-    for (unsigned long long v : {(unsigned long long) w, (unsigned long long) h, (unsigned long long) fmt, (unsigned long long) (unsigned) enc->block_size_override_x,
-                                 (unsigned long long) (unsigned) enc->block_size_override_y, (unsigned long long) enc->pyramid_levels, (unsigned long long) enc->do_psy}) {
-        key = (key ^ v) * 1099511628211ull;
-    }
-    g_enc_queue.submit(jb, key, enc, enc_batch);
+    g_enc_queue.submit(jb, step_key(enc), enc, enc_batch);
     return jb.nbuf;
 }
 
@@ -2416,7 +2483,7 @@ void dsv2hip_enc_queue_stats(unsigned long long *out4, int reset)
  * already resident in device memory: no host->device copy is made */
 int dsv2hip_enc_device_frame(DSV_ENCODER *enc, const void *dev_planar, DSV_BUF *bufs)
 {
-    if (dev_planar == NULL || bufs == NULL) {
+    if (dev_planar == NULL || bufs == NULL || !enc_usable(enc)) {
         return 0;
     }
     Job jb;
@@ -2435,6 +2502,11 @@ int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, 
 {
     if (n <= 0 || !encs || !dev_planar || !bufs || !nbufs) {
         return -1;
+    }
+    for (int k = 0; k < n; k++) { // one geometry per step, every encoder usable: refused as a whole otherwise (nothing was touched)
+        if (!enc_usable(encs[k]) || step_key(encs[k]) != step_key(encs[0])) {
+            return -1;
+        }
     }
     std::vector<Job> jobs((size_t) n);
     for (int k = 0; k < n; k++) {
@@ -2459,6 +2531,11 @@ int dsv2hip_enc_batch_host(int n, DSV_ENCODER **encs, const void *const *host_pl
 {
     if (n <= 0 || !encs || !host_planar || !bufs || !nbufs) {
         return -1;
+    }
+    for (int k = 0; k < n; k++) { // one geometry per step, every encoder usable: refused as a whole otherwise (nothing was touched)
+        if (!enc_usable(encs[k]) || step_key(encs[k]) != step_key(encs[0])) {
+            return -1;
+        }
     }
     std::vector<Job> jobs((size_t) n);
     for (int k = 0; k < n; k++) {

@@ -27,7 +27,6 @@
 //                    image leaves as whole words (only a chunk's first and last word are ORed into the zeroed output)
 //   7 k_ent_out      the finished bytes and their sizes to pinned host memory
 //
-// (DSV2_ENT_LANES=0 selects the round-3 form of steps 2 and 4: k_ent_tables walking the pair itself, k_ent_ks.)
 //
 // A state beyond 255 (k >= 32 at damp 3, never seen on real pictures) or a plane that outgrows its buffer raises a
 // flag; the host then codes that picture from the symbol list as before (entropy.cpp) -- same bytes either way.
@@ -434,120 +433,6 @@ __global__ __launch_bounds__(64) void k_ent_chain(const EntJob *__restrict__ tab
     }
     if (lane == 0 && ovf) {
         atomicOr(&J.info[EI_FLAGS], 1);
-    }
-}
-
-// ---- 4 ----------------------------------------------------------------------------------------------------
-// per chunk: the Rice parameter every symbol is coded with, and the chunk's total code length.  One wavefront per
-// chunk: its lanes stage the thresholds (and sum the code lengths that do not depend on the state), ONE lane walks the
-// adaptive state from the chunk's now known start state -- four dependent instructions a symbol on thresholds that are
-// already in registers, the state each symbol met going back to LDS -- and the lanes turn those states into parameters.
-// The walk wastes 63 lanes but costs what the 256-state walk of step 2 costs, and eight chunks share a SIMD.
-__global__ __launch_bounds__(64) void k_ent_ks(const EntJob *__restrict__ tab, EntGeom g)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t sT[kEntChunk];  // T of every symbol
-    __shared__ __attribute__((aligned(16))) uint16_t sV[kEntChunk];  // the state it met
-    const EntJob &J = tab[blockIdx.y];
-    const int c = blockIdx.z;
-    const PlaneSpan ps = plane_span(J.info, c);
-    const uint32_t off = (uint32_t) g.qv_off[c];
-    const int lane = threadIdx.x;
-    for (int lc = blockIdx.x; lc < ps.nch; lc += gridDim.x) {
-        const int first = ps.first + lc * kEntChunk, cnt = min(kEntChunk, ps.end - first);
-        // symbols lane, lane + 64, ...: run code + state-free value code lengths, thresholds
-        uint32_t u[kEntChunk / 64];
-        unsigned dmask = 0; // two bits a symbol: damp - 3, or 3 = not Rice coded
-        unsigned stat = 0;
-        int nskip_mine = 0;
-#pragma unroll
-        for (int j = 0; j < kEntChunk / 64; j++) {
-            const int s = j * 64 + lane;
-            uint32_t t = 0;
-            unsigned d = 3;
-            u[j] = 0;
-            if (s < cnt) {
-                const int i = first + s;
-                const uint32_t p = J.pos[i] - off;
-                const uint32_t prev_end = i > ps.first ? J.pos[i - 1] - off + 1u : 0u;
-                const int32_t v = J.val[i];
-                const int seg = seg_of(g, c, p);
-                stat += (unsigned) ueg_len(p - prev_end);
-                if (seg == 0) {
-                    uint32_t a = (uint32_t) (v < 0 ? -v : v);
-                    stat += (unsigned) ueg_len(a - 1u) + 1u;
-                    nskip_mine++;
-                } else {
-                    u[j] = rice_u(v);
-                    d = (unsigned) (seg - 1) / 3u;
-                    t = (uint32_t) bitlen(u[j]) << (3 + d);
-                }
-            }
-            dmask |= d << (2 * j);
-            sT[s] = (uint16_t) t;
-        }
-        int nskip = nskip_mine;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            nskip += __shfl_xor(nskip, o, 64);
-            stat += (unsigned) __shfl_xor((int) stat, o, 64);
-        }
-        nskip = __builtin_amdgcn_readfirstlane(nskip);
-        __syncthreads();
-        if (lane == 0) {
-            int vk = J.chunk_vk[ps.cbase + lc];
-            for (int q = nskip >> 3; 8 * q < cnt; q++) {
-                const uint4 t8 = *(const uint4 *) &sT[8 * q];
-                const uint32_t tw[4] = {t8.x, t8.y, t8.z, t8.w};
-                uint32_t vw[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int t0 = (int) (tw[b] & 0xffffu), t1 = (int) (tw[b] >> 16);
-                    const int v0 = vk;
-                    if (8 * q + 2 * b >= nskip) { // (behind the end of the chunk the walk runs on harmlessly)
-                        vk = vk < t0 ? vk + 1 : max(vk - 1, 0);
-                    }
-                    const int v1 = vk;
-                    if (8 * q + 2 * b + 1 >= nskip) {
-                        vk = vk < t1 ? vk + 1 : max(vk - 1, 0);
-                    }
-                    vw[b] = (uint32_t) min(v0, 0xffff) | ((uint32_t) min(v1, 0xffff) << 16);
-                }
-                *(uint4 *) &sV[8 * q] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
-            }
-        }
-        __syncthreads();
-        unsigned long long bits = 0;
-#pragma unroll
-        for (int j = 0; j < kEntChunk / 64; j++) {
-            const int s = j * 64 + lane;
-            const unsigned d = (dmask >> (2 * j)) & 3u;
-            if (s < cnt) {
-                int kk = 0;
-                if (d != 3u) {
-                    kk = (int) sV[s] >> (3 + (int) d);
-                    if (kk >= 32) { // a state no real picture reaches (a long run of 16-bit values): the host codes it
-                        atomicOr(&J.info[EI_FLAGS], 1);
-                        kk = 31;
-                    }
-                    const uint32_t lead = u[j] >> kk;
-                    bits += (unsigned long long) lead + (unsigned) (kk + 1);
-                }
-                J.ksym[first + s] = (uint8_t) kk;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            bits += (unsigned long long) __shfl_xor((long long) bits, o, 64);
-        }
-        if (lane == 0) {
-            bits += stat;
-            if (bits >= (1ull << 24)) { // 16 Kbit per symbol on average: not a picture (and keeps the 32-bit scans below exact)
-                atomicOr(&J.info[EI_FLAGS], 4);
-                bits = 0;
-            }
-            J.chunk_bits[ps.cbase + lc] = (uint32_t) bits;
-        }
-        __syncthreads();
     }
 }
 
@@ -982,21 +867,15 @@ void entropy_gpu_jobs(hipStream_t s, const EntJob *d_jobs, int n, const EntGeom 
         return;
     }
     const int slots = chunk_slots < 1 ? 1 : chunk_slots;
-    // round 4: the single-trajectory walks run a lane per chunk (k_ent_pair, k_ent_walk); DSV2_ENT_LANES=0: a wavefront per chunk
-    static const int lanes = !(getenv("DSV2_ENT_LANES") && atoi(getenv("DSV2_ENT_LANES")) == 0);
+    // the single-trajectory walks run a lane per chunk (k_ent_pair, k_ent_walk)
+    constexpr int lanes = 1;
     const int wslots = (slots + 63) / 64 < 1 ? 1 : (slots + 63) / 64; // workgroups of 64 chunks per (stream, plane)
     DSV2_LAUNCH(k_ent_planes, dim3(n), dim3(64), 0, s, d_jobs, g);
-    if (lanes) {
-        DSV2_LAUNCH(k_ent_tables<true>, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
-        DSV2_LAUNCH(k_ent_pair, dim3(wslots, n, 3), dim3(64), 0, s, d_jobs);
-        DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs, 1);
-        DSV2_LAUNCH(k_ent_walk, dim3(wslots, n, 3), dim3(64), 0, s, d_jobs);
-        DSV2_LAUNCH(k_ent_bits, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
-    } else {
-        DSV2_LAUNCH(k_ent_tables<false>, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
-        DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs, 0);
-        DSV2_LAUNCH(k_ent_ks, dim3(slots, n, 3), dim3(64), 0, s, d_jobs, g);
-    }
+    DSV2_LAUNCH(k_ent_tables<true>, dim3(slots, n, 3), dim3(kStates / 2), 0, s, d_jobs, g);
+    DSV2_LAUNCH(k_ent_pair, dim3(wslots, n, 3), dim3(64), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ent_chain, dim3(3, n), dim3(64), 0, s, d_jobs, 1);
+    DSV2_LAUNCH(k_ent_walk, dim3(wslots, n, 3), dim3(64), 0, s, d_jobs);
+    DSV2_LAUNCH(k_ent_bits, dim3(slots, n, 3), dim3(256), 0, s, d_jobs, g);
     DSV2_LAUNCH(k_ent_layout, dim3(n), dim3(64), 0, s, d_jobs);
     DSV2_LAUNCH(k_ent_zero, dim3(16, n), dim3(256), 0, s, d_jobs);
     // (tests shrink the image to send chunks down the global-memory path: DSV2_ENT_EMIT_WORDS)

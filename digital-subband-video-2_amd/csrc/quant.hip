@@ -364,6 +364,19 @@ __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict
     int32_t *coefs = J.coefs;
     int4 *cell = (int4 *) (coefs + a.off[si] + (size_t) y * c.w + x);
     const int4 cv = *cell;
+    if (MODE == QM_P_PLAIN || MODE == QM_P_PSY) {
+        // A P picture's step is at least 6/8 of the subband's (tmq_for_P) and its dead-zone offset is never negative (hzcc.c:364-380):
+        // a coefficient below 6/8 of the step quantises to zero whatever its parent, its block's flags and vector say.  Most of a
+        // residual's detail coefficients are that small, and they come in runs: a wavefront whose 256 are all below the bound stores
+        // its zeros and is done -- no parent / grandparent / flag / vector loads, no rule evaluation, no divisions, nothing to count.
+        const int zmin = J.qp[a.l][si] * 6 >> 3;
+        const bool small = abs(cv.x) < zmin && abs(cv.y) < zmin && abs(cv.z) < zmin && abs(cv.w) < zmin;
+        if (__all(small)) {
+            *cell = make_int4(0, 0, 0, 0);
+            *(int4 *) (J.qv + a.base[si] + (size_t) y * a.sw + x) = make_int4(0, 0, 0, 0);
+            return;
+        }
+    }
     const int2 pc = *(const int2 *) (coefs + a.par[si] + (size_t) (y >> 1) * c.w + (x >> 1));
     const int gparc = coefs[a.gpar[si] + (size_t) (y >> 2) * c.w + (x >> 2)];
     const int rowb = ((y * a.dby) >> kBlockP) * c.nbh;

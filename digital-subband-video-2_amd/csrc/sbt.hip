@@ -874,11 +874,11 @@ static LevelGeom level_geom(int cw, int ch, int l, int filter, int nbh, int nbv,
 }
 
 // first level of the fused Haar tail (lvls + 1: none): every level from it up is Haar, its LL output and the next one fit in
-// 48 KB of LDS, and at least two levels are fused.  DSV2_SBT_TAIL=0 keeps one launch per level.
+// 48 KB of LDS, and at least two levels are fused.
 constexpr int kTailLdsInts = 12 * 1024;
 static int tail_first_level(int cw, int ch, int plane_idx, int isP, int lossless, int lvls, int *cap_a)
 {
-    static const bool on = !(getenv("DSV2_SBT_TAIL") && atoi(getenv("DSV2_SBT_TAIL")) == 0);
+    constexpr bool on = true;
     int l0 = lvls + 1;
     *cap_a = 0;
     if (!on) {

@@ -9,8 +9,7 @@ import dsvabi as A
 from test_oracle_bmc import CASES, clone, rand_motion
 from test_oracle_sbt import rand_frame
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 @pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (2560, 1440, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420)])

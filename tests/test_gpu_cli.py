@@ -11,8 +11,7 @@ import dsvabi as A
 from conftest import load_pkg
 
 DROPIN = os.path.join(A.ROOT, "oracle", "_ref", "dsv2_dropin")
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not (os.path.exists(A.REF_CLI) and os.path.exists(DROPIN)), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def run(cmd):

@@ -17,8 +17,7 @@ import dsvabi as A
 from codec_run import configure_encoder, encode_stream
 from conftest import load_pkg
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 W, H, GOP, QP, NFRAMES = 1920, 1080, 6, 60, 14
 CLASSES = ("pan", "cut", "static", "fast")

@@ -9,8 +9,7 @@ import dsvabi as A
 from codec_run import decode_stream, encode_stream
 from conftest import load_pkg
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def bind(hip):

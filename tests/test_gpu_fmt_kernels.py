@@ -14,8 +14,7 @@ import dsvabi as A
 from codec_run import configure_encoder, decode_stream, encode_stream
 from test_oracle_fmt import MODES, chroma_dims, orc_to420
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def rand_video(w, h, subsamp, n, seed):

@@ -8,8 +8,7 @@ import pytest
 import dsvabi as A
 from codec_run import decode_stream, encode_stream
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 FMT = {"444": (0x0, 0, 0), "422": (0x4, 1, 0), "420": (0x5, 1, 1), "411": (0x8, 2, 0), "410": (0xA, 2, 2)}
 

@@ -8,8 +8,7 @@ import pytest
 import dsvabi as A
 from hme_common import HME, Scene, assert_fields_equal
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def run_lib(lib, sc, quant, effort, skip_thresh=0):

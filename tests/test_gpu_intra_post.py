@@ -11,8 +11,7 @@ import dsvabi as A
 from test_oracle_intra import ref_intra_flags, synth_frame
 from test_oracle_sbt import rand_frame
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 @pytest.mark.parametrize("w,h,subsamp", [(352, 288, A.SUBSAMP_420), (354, 290, A.SUBSAMP_420), (640, 360, A.SUBSAMP_444),

@@ -20,8 +20,7 @@ import dsvabi as A
 from codec_run import configure_encoder, encode_stream
 from conftest import load_pkg
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 W, H, GOP, QP = 1920, 1080, 48, 60
 NSEED, NFRAMES = 4, 8
@@ -123,7 +122,7 @@ def test_many_streams_concurrent_groups_repeated():
 
 def test_192_pictures_per_launch_with_search_token():
     """the bench's launch size: 192 streams in ONE lockstep group (every kernel launch carries 192 pictures: 13 056 block rows
-    in the level-0 search launch), then 384 streams in two groups of 192 that pass the search token (DSV2_SEARCH_SLOTS) back and
+    in the level-0 search launch), then 384 streams in two groups of 192 that pass the search token back and
     forth; every stream against the reference"""
     hip = A.load_hip()
     bind(hip)

@@ -9,8 +9,7 @@ import dsvabi as A
 from test_oracle_hzcc import CASES, rand_mvs, ref_encode_plane
 from test_oracle_sbt import rand_frame, ref_fwd
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def decode_plane(lib, data, cw, ch, q, plane, isP, params, blockdata):

@@ -8,8 +8,7 @@ import pytest
 import dsvabi as A
 from test_oracle_sbt import CASES, rand_frame, ref_fwd, ref_inv
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def hip_fwd(hip, frame, plane, isP, blockdata, params, cdims):

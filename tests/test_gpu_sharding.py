@@ -14,8 +14,7 @@ import shard_worker as SW
 from codec_run import encode_stream
 from conftest import load_pkg
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(A.REF_SO), reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
 def free_port():

@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage (GPU box): tools/idle_trace.sh <tag> [ENV=VAL ...] -- kernel trace of the headline (12 steps) + tools/idle_analysis.py over it + the
-# host-side phase split of every lockstep group (DSV2_BATCH_TRACE)
+# host-side phase split of every lockstep group (DSV2_TRACE=2)
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/idle
-export DSV2_BATCH_TRACE=${DSV2_BATCH_TRACE:-1}
+export DSV2_TRACE=${DSV2_TRACE:-2}
 timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/idle/$tag -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --no-profile --steps 12 --warmup 4 > gpurun_out/idle/$tag.json 2> gpurun_out/idle/$tag.err
 python3 tools/idle_analysis.py gpurun_out/idle/$tag/*/*_kernel_trace.csv 44 24 > gpurun_out/idle/${tag}_idle.txt
 head -30 gpurun_out/idle/${tag}_idle.txt

@@ -12,6 +12,6 @@ with open("/dev/shm/pp/in.yuv", "wb") as f:
 PY
 EXE=oracle/_ref/dsv2_dropin
 ARGS="-y -inp=$D/in.yuv -w=1920 -h=1080 -fps_num=30 -fps_den=1 -gop=48 -qp=60 -rc_mode=0 -noeos=1"
-for i in 1 2; do DSV2_STARTUP_TRACE=1 $EXE e $ARGS -out=$D/o.dsv -sfr=0 -nfr=3 2>&1 | grep startup; echo; done
-DSV2_STARTUP_TRACE=1 DSV2_HOST_THREADS=2 $EXE e $ARGS -out=$D/o.dsv -sfr=0 -nfr=3 2>&1 | grep startup
+for i in 1 2; do DSV2_TRACE=1 $EXE e $ARGS -out=$D/o.dsv -sfr=0 -nfr=3 2>&1 | grep startup; echo; done
+DSV2_TRACE=1 DSV2_HOST_THREADS=2 $EXE e $ARGS -out=$D/o.dsv -sfr=0 -nfr=3 2>&1 | grep startup
 rm -rf $D

@@ -167,6 +167,32 @@ def insts_part():
               open(os.path.join(dst, "instruction_volume.json"), "w"))
 
 
+def decode_part():
+    """kernels of the decode leg: everything the traced process launched after its last encoder kernel (k_ent_out)"""
+    line = json.loads([l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")][-1])
+    tr = []
+    for r in csv.DictReader(io.TextIOWrapper(gzip.open(os.path.join(src, "decode_kernel_trace.csv.gz")))):
+        tr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+    tr.sort()
+    last_enc = max(e for s, e, n in tr if "k_ent_out" in n)
+    dec = [(s, e, n) for s, e, n in tr if s > last_enc]
+    span = dec[-1][1] - dec[0][0]
+    by, cnt = collections.Counter(), collections.Counter()
+    for s, e, n in dec:
+        by[n] += e - s
+        cnt[n] += 1
+    d = line.get("decode", {})
+    with open(os.path.join(dst, "r05_decode_kernel_stats.txt"), "w") as f:
+        f.write("rocprofv3 --kernel-trace -- python3 bench.py --no-extras --decode-too --streams 256 --groups 4 --steps 24 (tools/profile_decode.sh): the kernels launched\n"
+                "after the last encoder kernel = the decode leg (warm-up, %d timed pictures, the stage-event steps); 256 decoders in 4 lockstep groups\n" % d.get("frames", 0))
+        f.write("decode leg under the profiler: %s frames/s, host_cpu_cores_busy %s; roofline object of the line: %s\n"
+                % (d.get("value"), d.get("host_cpu_cores_busy"), json.dumps(d.get("roofline"))))
+        f.write("span of the decode kernels %.1f ms; kernel time summed %.1f ms (groups overlap)\n\n" % (span / 1e6, sum(by.values()) / 1e6))
+        f.write("%-44s %8s %12s %12s %8s\n" % ("kernel", "calls", "total ms", "avg us", "% span"))
+        for n, v in by.most_common(30):
+            f.write("%-44s %8d %12.2f %12.1f %7.1f%%\n" % (n[:44], cnt[n], v / 1e6, v / cnt[n] / 1e3, 100.0 * v / span))
+
+
 have = lambda f: os.path.exists(os.path.join(src, f))
 traced = trace_part() if have("kernel_trace.csv.gz") else None
 if traced and have("pmc_FETCH_SIZE.csv") and have("kernel_source_sha16.txt"):
@@ -175,4 +201,6 @@ if have("excl_kernel_stats.csv"):
     excl_part()
 if have("insts.csv.gz"):
     insts_part()
+if have("decode_kernel_trace.csv.gz") and have("decode.json"):
+    decode_part()
 print("summarised into", dst)

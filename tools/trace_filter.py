@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Filters DSV2_BATCH_TRACE=2 lines (stdin): prints the steps whose device or host phases stand out."""
+"""Filters DSV2_TRACE=10 lines (stdin): prints the steps whose device or host phases stand out."""
 import re
 import sys
 
