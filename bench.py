@@ -177,6 +177,39 @@ def gpu_host_locality(ordinal, sysfs="/sys"):
         return None
 
 
+def pci_locality(addr, sysfs="/sys"):
+    """(numa node, local cpus) of the PCI device `addr` ("dddd:bb:dd.f"), or None"""
+    try:
+        dev = os.path.join(sysfs, "bus/pci/devices", addr)
+        return int(open(os.path.join(dev, "numa_node")).read().strip()), _parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+    except (OSError, ValueError):
+        return None
+
+
+def bind_rank_late(locality, world, torch, ordinal):
+    """Containers that hide the KFD topology (this pool's do: PermissionError on the GPU nodes' properties) leave the runtime as the
+    only source of a GPU's PCI address.  Asked AFTER it is up -- still ahead of everything that matters: the pinned pictures, the
+    library's worker pool and the lockstep groups' threads are all made later and inherit this thread's cores."""
+    if locality["pci"] is not None:
+        return locality
+    try:
+        pr = torch.cuda.get_device_properties(ordinal)
+        addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except (AttributeError, RuntimeError):
+        return locality
+    loc = pci_locality(addr)
+    locality = dict(locality, pci=addr, source="runtime (KFD topology not readable)")
+    if loc is None:
+        return locality
+    node, cpus = loc
+    locality["numa_node"] = node
+    mine = sorted(cpus & os.sched_getaffinity(0))
+    if world > 1 and mine and os.environ.get("DSV2_NUMA_BIND", "1") != "0":
+        os.sched_setaffinity(0, mine)  # (ranks that share a node share all of its cores here: their positions are not known without the topology)
+        locality.update(cpus=len(mine), bound=True)
+    return locality
+
+
 def bind_rank_to_gpu_node(ordinal, world):
     """sched_setaffinity to the usable cores next to GPU `ordinal` (parallel_encode_yuv.sh's processes run wherever the scheduler
     puts them; here a rank pins ~0.8 GB of pictures and moves ~25 GB/s over ITS GPU's PCIe link: both want the local node).
@@ -843,6 +876,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
+    locality = bind_rank_late(locality, world if "DSV2_FORCE_DEVICE" not in os.environ else 1, torch, local)
     hip = A.load_hip()
     assert hip.dsv2hip_device_ok() == 0, "no HIP device: the product has no CPU path"
     hip.dsv2hip_set_device(local)

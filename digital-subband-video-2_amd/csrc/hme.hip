@@ -1458,7 +1458,7 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
 
 // KIND: which block routine walks the row -- the general one (any geometry: blocks up to 32 x 32, any chroma format, odd
 // clipped sizes), the fast one of the coarser levels, or the fast one of level 0 (CS: chroma shift, 1 = 4:2:0, 0 = 4:4:4)
-enum { ROW_GENERAL = 0, ROW_FAST_LX = 1, ROW_FAST_L0 = 2 };
+enum { ROW_GENERAL = 0, ROW_FAST_LX = 1, ROW_FAST_L0 = 2, ROW_FAST_LX32 = 3 /* the coarser levels' routine for 32 x 32 blocks */ };
 template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, FastLds &S)
 {
     const int level = KIND == ROW_FAST_L0 ? 0 : level_rt;
@@ -1491,7 +1491,9 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
             if constexpr (KIND == ROW_FAST_L0) {
                 hme_block_l0<CS, SPLIT>(x, i, j, gx, gy, S, acc);
             } else if constexpr (KIND == ROW_FAST_LX) {
-                hme_block_lx(x, level, i, j, gx, gy, S, acc);
+                hme_block_lx<1>(x, level, i, j, gx, gy, S, acc);
+            } else if constexpr (KIND == ROW_FAST_LX32) {
+                hme_block_lx<4>(x, level, i, j, gx, gy, S, acc);
             } else {
                 hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
                 // the general routine reads its LEFT neighbour back from memory (the fast ones carry it in registers): this
@@ -1556,6 +1558,7 @@ HME_ROWS_P(k_hme_rows_l0_444, 4, 0, ROW_FAST_L0, 0, false)
 HME_ROWS_P(k_hme_rows_l0s, 4, 0, ROW_FAST_L0, 1, true) // ... with the neighbour-independent half from the pre-pass (k_hme_l0_pre_b)
 HME_ROWS_P(k_hme_rows_l0s_444, 4, 0, ROW_FAST_L0, 0, true)
 HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
+HME_ROWS_P(k_hme_rows_lx32, 2, level, ROW_FAST_LX32) // (36 reference quads live in a refinement round: two wavefronts per SIMD, as the general kernel)
 HME_ROWS_P(k_hme_rows_general, 2, level, ROW_GENERAL)
 static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 2048;
 // DSV2_HME_SPLIT: level 0 with its neighbour-independent half in an unordered pre-pass (1) or in place (0); default: by launch size
@@ -1601,16 +1604,20 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
     // the chroma planes only enter at level 0 (mode decision): 4:2:0 and 4:4:4 have a block routine there, the coarser
     // levels take any format
     const bool c420 = a.hshift == 1 && a.vshift == 1, c444 = a.hshift == 0 && a.vshift == 0;
-    if (a.blk_w != 16 || a.blk_h != 16 || (level == 0 && !c420 && !c444)) {
+    const int bs = a.blk_w;
+    if ((bs != 16 && bs != 32) || a.blk_h != bs || (level == 0 && !c420 && !c444)) {
+        return false;
+    }
+    if (bs == 32 && level < 2) { // (32 x 32 blocks: the squared-error levels so far; levels 0 and 1 need the source pre-pass for that size)
         return false;
     }
     int step = 1 << level;
     int nbx = (a.nbh + step - 1) / step, nby = (a.nbv + step - 1) / step;
-    int lx = (nbx - 1) * 16, ly = (nby - 1) * 16; // origin of the last block column / row
+    int lx = ((nbx - 1) * step * bs) >> level, ly = ((nby - 1) * step * bs) >> level; // origin of the last block column / row
     if (lx >= src.w || ly >= src.h) {
         return false;
     }
-    int bw = src.w - lx < 16 ? src.w - lx : 16, bh = src.h - ly < 16 ? src.h - ly : 16;
+    int bw = src.w - lx < bs ? src.w - lx : bs, bh = src.h - ly < bs ? src.h - ly : bs;
     return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (level > 1 || (!(bw & 1) && !(bh & 1)));
 }
 
@@ -2074,7 +2081,8 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     // The fast block routines: 16 x 16 blocks, one geometry per pyramid level (make_ctx), the source statistics and the level-0
     // records of the pre-passes (memory for both handed in by the caller).  Anything else takes the general routine.
     // (A function of the jobs alone: a call that only runs the levels, behind a separate HME_PREPARE call, comes to the same answer.)
-    bool fast = g_hme_fast != 0 && g.a.blk_w == 16 && g.a.blk_h == 16;
+    const bool b16 = g.a.blk_w == 16 && g.a.blk_h == 16, b32 = g.a.blk_w == 32 && g.a.blk_h == 32;
+    bool fast = g_hme_fast != 0 && (b16 || b32);
     for (int k = 0; k < n; k++) {
         fast = fast && uniform_geometry(f[k], g.pyr_levels) && f[k].src_stats != nullptr && f[k].l0_pre != nullptr;
     }
@@ -2082,14 +2090,14 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     const bool split = fast_level(0) && (g_hme_split >= 0 ? g_hme_split != 0 : n * g.a.nbv <= kSplitMaxRows);
     if (from_top) {
         const int nb0x = g.a.nbh, nb0y = g.a.nbv, nb1x = g.pyr_levels >= 1 ? (g.a.nbh + 1) / 2 : 0, nb1y = g.pyr_levels >= 1 ? (g.a.nbv + 1) / 2 : 0;
-        if (fast) {
+        if (fast && b16) {
             for (int k = 0; k < n; k++) {
                 ht[k].stats[0] = (int4 *) f[k].src_stats;
                 ht[k].stats[1] = nb1x ? (int4 *) f[k].src_stats + (size_t) nb0x * nb0y : nullptr;
             }
         }
         HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
-        if (fast) {
+        if (fast && b16) {
             // whole blocks four to a wavefront, clipped blocks of the last block row / column one to a wavefront
             bool four = true;
             for (int k = 0; k < n && four; k++) {
@@ -2134,7 +2142,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             auto pk = g.a.hshift == 0 ? (split ? k_hme_rows_l0s_444 : k_hme_rows_l0_444) : (split ? k_hme_rows_l0s : k_hme_rows_l0);
             DSV2_LAUNCH(pk, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else if (level > 0 && fast_level(level)) {
-            DSV2_LAUNCH(k_hme_rows_lx, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
+            DSV2_LAUNCH(b32 ? k_hme_rows_lx32 : k_hme_rows_lx, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else {
             DSV2_LAUNCH(k_hme_rows_general, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         }

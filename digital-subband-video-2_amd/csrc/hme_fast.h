@@ -433,10 +433,26 @@ template <int NT> struct VecSet {
     int dx[NT], dy[NT];
 };
 
-template <int NT>
-__device__ __forceinline__ unsigned score_set(const VecSet<NT> &vs, int cnt, bool safe, const DPlane &ref, int bx, int by, int bw, int bh, const Quad &a,
-                                              bool act, int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
+// A lane's share of the source block.  NQ = 1: a 16 x 16 block, the lane (qi, qj) owns its 2x2 quad (qi, qj).  NQ = 4: a
+// 32 x 32 block (dsv_encoder.c:1203-1211: every picture of 2160p and up) as FOUR 16 x 16 quadrants -- quadrant k at (16 (k & 1),
+// 16 (k >> 1)) -- of which the lane owns quad (qi, qj) each: every per-quad primitive of the 16 x 16 routine is used as it is,
+// once per quadrant, with the sums combined before the metric's square root; the mode decision's four sub-block sums are the
+// quadrants' own.  act[k]: the quad takes part in the level's metric (a clipped block's quads beyond its edge do not);
+// smask[k]: bytes of the quad inside the block (all four, except in the half quads of an odd last row / column at the
+// squared-error levels).
+template <int NQ> struct SrcBlk {
+    Quad a[NQ];
+    bool act[NQ];
+    uint32_t smask[NQ];
+    int bx, by, bw, bh, qi, qj;
+};
+// byte offset of quadrant k's origin from the block's, for a plane of row stride `stride`
+__device__ __forceinline__ unsigned quadrant_off(int k, int stride) { return (unsigned) (16 * (k & 1) + 16 * (k >> 1) * stride); }
+
+template <int NT, int NQ>
+__device__ __forceinline__ unsigned score_set(const VecSet<NT> &vs, int cnt, bool safe, const DPlane &ref, const SrcBlk<NQ> &B, int level, const Psy &psy)
 {
+    const int bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
     int ok[NT];
     if (safe) {
 #pragma unroll
@@ -455,13 +471,20 @@ __device__ __forceinline__ unsigned score_set(const VecSet<NT> &vs, int cnt, boo
     // always lies inside the frame
     gbytes_t base = (gbytes_t) uni_ptr(ref.data - (ptrdiff_t) kBorder * ref.stride - kBorder);
     const unsigned o0 = (unsigned) ((by + kBorder) * ref.stride + bx + kBorder);
-    const unsigned loff = act ? (unsigned) ((2 * qj) * ref.stride + 2 * qi) : 0u;
-    Quad b[NT];
+    unsigned loff[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        loff[k] = B.act[k] ? (unsigned) ((2 * B.qj) * ref.stride + 2 * B.qi) + quadrant_off(k, ref.stride) : 0u;
+    }
+    Quad b[NT][NQ];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const unsigned o = o0 + (unsigned) (ok[t] ? vs.dy[t] * ref.stride + vs.dx[t] : 0);
-        const uint32_t top = ((gu16_t) (base + (loff + o)))->v, bot = ((gu16_t) (base + (loff + o + (unsigned) ref.stride)))->v;
-        b[t].w = top | (bot << 16);
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+            const uint32_t top = ((gu16_t) (base + (loff[k] + o)))->v, bot = ((gu16_t) (base + (loff[k] + o + (unsigned) ref.stride)))->v;
+            b[t][k].w = top | (bot << 16);
+        }
     }
     constexpr int NR = NT <= 4 ? 4 : (NT <= 8 ? 8 : 16); // width of the joint reduction
     int v[NR];
@@ -469,9 +492,12 @@ __device__ __forceinline__ unsigned score_set(const VecSet<NT> &vs, int cnt, boo
     for (int t = 0; t < NR; t++) {
         v[t] = 0;
         if (t < NT && ok[t]) { // wave-uniform: the arithmetic of an absent vector is skipped, its (dummy) load was not
-            b[t].w &= smask;
-            int m = (int) (level > 1 ? qsse(a, b[t]) : qmetric(a, b[t], psy));
-            v[t] = act ? m : 0;
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                b[t][k].w &= B.smask[k];
+                int m = (int) (level > 1 ? qsse(B.a[k], b[t][k]) : qmetric(B.a[k], b[t][k], psy));
+                v[t] += B.act[k] ? m : 0;
+            }
         }
     }
     int r = reduceN<NR>(v);
@@ -497,8 +523,8 @@ template <int NT> __device__ __forceinline__ VecSet<NT> pop_vecs(unsigned long l
 
 // raw scores of the vectors held (as keys) by the lanes of `mask`, returned on those lanes: four vectors a load round (after
 // de-duplication a list has ~3.5 entries; the rare longer one takes further rounds of the same code)
-__device__ __forceinline__ unsigned score_lanes(unsigned long long mask, int key, const DPlane &ref, int bx, int by, int bw, int bh, const Quad &a, bool act,
-                                                int qi, int qj, int level, const Psy &psy, uint32_t smask = 0xffffffffu)
+template <int NQ>
+__device__ __forceinline__ unsigned score_lanes(unsigned long long mask, int key, const DPlane &ref, const SrcBlk<NQ> &B, int level, const Psy &psy)
 {
     const int lane = threadIdx.x & 63;
     const int n = __popcll(mask);
@@ -510,7 +536,7 @@ __device__ __forceinline__ unsigned score_lanes(unsigned long long mask, int key
     unsigned raw = 0;
     for (int first = 0; first < n; first += 4) {
         const VecSet<4> vs = pop_vecs<4>(rest, key);
-        const unsigned r = (unsigned) __shfl((int) score_set<4>(vs, min(4, n - first), safe, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask), widx & 3, 64);
+        const unsigned r = (unsigned) __shfl((int) score_set<4, NQ>(vs, min(4, n - first), safe, ref, B, level, psy), widx & 3, 64);
         if ((widx >> 2) == (first >> 2)) {
             raw = r;
         }
@@ -1411,12 +1437,12 @@ __device__ __forceinline__ bool dedup_lanes(bool exist, int key)
 }
 
 // ---- full-pel refinement (hme.c:1300): each round scores the 3x3 neighbourhood at once --------------------------------------
-template <bool L0>
-__device__ __forceinline__ void refine_fpel(const DPlane &ref, int bx, int by, int bw, int bh, const Quad &a, bool act, int qi, int qj, int level,
-                                            const Psy &psy, uint32_t smask, const CostCtx &cc, unsigned qthresh, int &dx, int &dy, unsigned &best,
-                                            bool &good_enough, FastLds &S)
+template <bool L0, int NQ>
+__device__ __forceinline__ void refine_fpel(const DPlane &ref, const SrcBlk<NQ> &B, int level, const Psy &psy, const CostCtx &cc, unsigned qthresh, int &dx,
+                                            int &dy, unsigned &best, bool &good_enough, FastLds &S)
 {
     const int lane = threadIdx.x & 63;
+    const int bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
     const int step = 1 << level;
     unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
     bool again = true;
@@ -1430,7 +1456,7 @@ __device__ __forceinline__ void refine_fpel(const DPlane &ref, int bx, int by, i
             vs.dx[t] = dx + tab9(kRectX, t);
             vs.dy[t] = dy + tab9(kRectY, t);
         }
-        unsigned raw = score_set<9>(vs, 9, (unsigned) (dx + 30) <= 60u && (unsigned) (dy + 30) <= 60u, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+        unsigned raw = score_set<9, NQ>(vs, 9, (unsigned) (dx + 30) <= 60u && (unsigned) (dy + 30) <= 60u, ref, B, level, psy);
         int tx = dx + (lane < 9 ? tab9(kRectX, lane) : 0), ty = dy + (lane < 9 ? tab9(kRectY, lane) : 0);
         bool valid = lane < 9 && !invalid_block(ref, bx + tx, by + ty, bw, bh, 0);
         if (level <= 1) {
@@ -1537,12 +1563,46 @@ __device__ __forceinline__ MvHead load_neighbour_heads(DSV_MV *mvf, DSV_MV *out,
 // FULL: the block is a whole 16x16 one (every lane owns a quad): the per-lane activity tests fold away.
 // Level 1 reads the source statistics of the pre-pass (c.stats: k_hme_src_stats4_b / _b); the squared-error levels need none.
 // ============================================================================================================================
-template <bool FULL, class Ctx>
+// the lane's share of the source block at (bx, by) of `src` for the metric of `level` (see SrcBlk); o (optional): the same quads of another plane
+template <bool FULL, int NQ> __device__ __forceinline__ SrcBlk<NQ> load_src_blk(const DPlane &src, int bx, int by, int bw, int bh, int level, const DPlane *oth, Quad *o)
+{
+    const int lane = threadIdx.x & 63;
+    SrcBlk<NQ> B;
+    B.bx = bx;
+    B.by = by;
+    B.bw = bw;
+    B.bh = bh;
+    B.qi = lane & 7;
+    B.qj = lane >> 3;
+    const int qw = bw >> 1, qh = bh >> 1;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        const int xq = 8 * (k & 1) + B.qi, yq = 8 * (k >> 1) + B.qj; // the quad's place in the block
+        // The psy metric works on whole 2x2 quads and drops an odd last row / column (hme.c:136: loops to h / 2, w / 2); the squared
+        // error of the levels above 1 counts every pixel (hme.c:198).  There an odd row / column is a row / column of HALF quads:
+        // those lanes take part with the bytes outside the block masked off in both operands.
+        B.act[k] = FULL ? true : (xq < qw && yq < qh);
+        B.smask[k] = 0xffffffffu;
+        if (!FULL && level > 1) {
+            B.act[k] = xq < ((bw + 1) >> 1) && yq < ((bh + 1) >> 1);
+            B.smask[k] = (((bw & 1) && xq == qw) ? 0x00ff00ffu : 0xffffffffu) & (((bh & 1) && yq == qh) ? 0x0000ffffu : 0xffffffffu);
+        }
+        B.a[k] = ldq(at(src, bx + 16 * (k & 1), by + 16 * (k >> 1)), src.stride, B.qi, B.qj, B.act[k]);
+        B.a[k].w &= B.smask[k];
+        if (oth != nullptr) {
+            o[k] = ldq(at(*oth, bx + 16 * (k & 1), by + 16 * (k >> 1)), oth->stride, B.qi, B.qj, B.act[k]);
+        }
+    }
+    return B;
+}
+
+template <bool FULL, int NQ, class Ctx>
 __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
     const int lane = threadIdx.x & 63;
     const int qi = lane & 7, qj = lane >> 3;
-    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
+    constexpr int BS = NQ == 4 ? 32 : 16;
+    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = BS, y_h = BS;
     const int step = 1 << level;
     const DPlane &src = c.src[level], &ref = c.ref[level], &ogr = c.ogr[level];
     DSV_MV *mvf = c.mvf[level];
@@ -1552,30 +1612,19 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
 
     const int bx = (i * y_w) >> level, by = (j * y_h) >> level;
     const int bw = FULL ? y_w : min(src.w - bx, y_w), bh = FULL ? y_h : min(src.h - by, y_h);
-    const int qw = bw >> 1, qh = bh >> 1;
-    // The psy metric works on whole 2x2 quads and drops an odd last row / column (hme.c:136: loops to h / 2, w / 2); the squared
-    // error of the levels above 1 counts every pixel (hme.c:198).  There an odd row / column is a row / column of HALF quads:
-    // those lanes take part (`act`) with the bytes outside the block masked off in both operands (`smask`).
-    const bool actM = FULL ? true : (qi < qw && qj < qh);
-    bool act = actM;
-    uint32_t smask = 0xffffffffu;
-    if (!FULL && level > 1) {
-        act = qi < ((bw + 1) >> 1) && qj < ((bh + 1) >> 1);
-        smask = (((bw & 1) && qi == qw) ? 0x00ff00ffu : 0xffffffffu) & (((bh & 1) && qj == qh) ? 0x0000ffffu : 0xffffffffu);
-    }
-    Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
-    a.w &= smask;
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
     const bool have_pre = level <= 1;
     v4i_t pre_words = {0, 0, 0, 0};
-    Quad o_zero; // for the "good enough" test far below: same load round (level 1: its outcome comes with the statistics)
-    o_zero.w = 0;
+    Quad o_zero[NQ]; // for the "good enough" test far below: same load round (level 1: its outcome comes with the statistics)
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        o_zero[k].w = 0;
+    }
     if (have_pre) {
         pre_words = *(cv4i_t) &c.stats[(i >> level) + (j >> level) * ((nxb + step - 1) >> level)];
-    } else {
-        o_zero = ldq(at(ogr, bx, by), ogr.stride, qi, qj, act);
     }
+    const SrcBlk<NQ> B = load_src_blk<FULL, NQ>(src, bx, by, bw, bh, level, have_pre ? nullptr : &ogr, o_zero);
     // ONE load round for every vector the list reads: lanes 3..5 the same-level neighbours, lanes 6..14 the co-located
     // vectors of the previous frame, lanes 16..24 the parent level's.  Lanes without a vector load this block's own entry.
     bool nb_ok = false, pvalid = false, tvalid = false;
@@ -1666,7 +1715,7 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
     int dx, dy;
     unsigned best;
     {
-        unsigned raw = score_lanes(__ballot(keep), key, ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask);
+        unsigned raw = score_lanes<NQ>(__ballot(keep), key, ref, B, level, psy);
         const int mx = cxv, my = cyv;
         bool valid = keep && !invalid_block(ref, bx + mx, by + my, bw, bh, 0);
         if (level <= 1) {
@@ -1689,7 +1738,17 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
     unsigned qthresh = (unsigned) (c.quant * bw * bh >> 11);
     bool good_enough = false;
     {
-        unsigned zoscore = have_pre ? (unsigned) pre_words.w : metric_return(wave_sum(actM ? qmetric(a, o_zero, psy) : 0u), bw, bh);
+        unsigned zoscore = (unsigned) pre_words.w;
+        if (!have_pre) { // (the psy metric of the squared-error levels' "good enough" test: whole quads only)
+            unsigned zp = 0;
+            const int qw = bw >> 1, qh = bh >> 1;
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                const bool whole = FULL || (8 * (k & 1) + qi < qw && 8 * (k >> 1) + qj < qh);
+                zp += whole ? qmetric(B.a[k], o_zero[k], psy) : 0u;
+            }
+            zoscore = metric_return(wave_sum(zp), bw, bh);
+        }
         if (abs(dx) <= 1 && abs(dy) <= 1) {
             qthresh *= 2;
         }
@@ -1700,7 +1759,7 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
         }
     }
     if (!good_enough) {
-        refine_fpel<false>(ref, bx, by, bw, bh, a, act, qi, qj, level, psy, smask, cc, qthresh, dx, dy, best, good_enough, S);
+        refine_fpel<false, NQ>(ref, B, level, psy, cc, qthresh, dx, dy, best, good_enough, S);
     }
     mv.u.mv.x = (int16_t) (dx * step);
     mv.u.mv.y = (int16_t) (dy * step);
@@ -1711,14 +1770,15 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
                     ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) mv.flags) << 32);
 }
 
-template <class Ctx> __device__ __forceinline__ void hme_block_lx(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+template <int NQ, class Ctx> __device__ __forceinline__ void hme_block_lx(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
+    constexpr int BS = NQ == 4 ? 32 : 16;
     const DPlane &src = c.src[level];
-    int bx = (i * 16) >> level, by = (j * 16) >> level;
-    if (src.w - bx >= 16 && src.h - by >= 16) {
-        hme_block_lx_t<true>(c, level, i, j, gx, gy, S, acc);
+    int bx = (i * BS) >> level, by = (j * BS) >> level;
+    if (src.w - bx >= BS && src.h - by >= BS) {
+        hme_block_lx_t<true, NQ>(c, level, i, j, gx, gy, S, acc);
     } else {
-        hme_block_lx_t<false>(c, level, i, j, gx, gy, S, acc);
+        hme_block_lx_t<false, NQ>(c, level, i, j, gx, gy, S, acc);
     }
 }
 
@@ -1754,8 +1814,9 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
     const int qw = bw >> 1, qh = bh >> 1;
-    const bool act = FULL ? true : (qi < qw && qj < qh);
-    const Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
+    const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0, nullptr, nullptr);
+    const bool act = B.act[0];
+    const Quad a = B.a[0];
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
     const v4i_t pre_words = *(cv4i_t) &c.stats[i + j * nxb];
@@ -1817,7 +1878,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block
     cyv = (int) (int16_t) cyv;
     const int key = (cxv & 0xffff) | (int) ((unsigned) cyv << 16);
     const bool keep = exist && !dedup_lanes(exist, key);
-    const unsigned raw = metric_return(score_lanes(__ballot(keep), key, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy), bw, bh);
+    const unsigned raw = metric_return(score_lanes<1>(__ballot(keep), key, ref, B, 0, psy), bw, bh);
     uint32_t rf = kL0Absent;
     if (keep) {
         rf = (raw & kL0ScoreMask) | (invalid_block(ref, bx + cxv, by + cyv, bw, bh, 0) ? kL0Invalid : 0u);
@@ -1880,8 +1941,9 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
     const int qw = bw >> 1, qh = bh >> 1;
-    const bool act = FULL ? true : (qi < qw && qj < qh);
-    const Quad a = ldq(at(src, bx, by), src.stride, qi, qj, act);
+    const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0, nullptr, nullptr);
+    const bool act = B.act[0];
+    const Quad a = B.a[0];
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
     typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
@@ -2038,7 +2100,7 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
     // ONE load round for the vectors nobody has scored yet (SPLIT: usually none)
     if (want) {
         HME_COUNT(S, 14, __popcll(want));
-        const unsigned raw = score_lanes(want, key, ref, bx, by, bw, bh, a, act, qi, qj, 0, psy);
+        const unsigned raw = score_lanes<1>(want, key, ref, B, 0, psy);
         if ((want >> lane) & 1ull) {
             rf = (metric_return(raw, bw, bh) & kL0ScoreMask) | (invalid_block(ref, bx + mx, by + my, bw, bh, 0) ? kL0Invalid : 0u);
         }
@@ -2082,7 +2144,7 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
     }
     HME_MARK(S, 3);
     if (!good_enough) {
-        refine_fpel<true>(ref, bx, by, bw, bh, a, act, qi, qj, 0, psy, 0xffffffffu, cc, qthresh, dx, dy, best, good_enough, S);
+        refine_fpel<true, 1>(ref, B, 0, psy, cc, qthresh, dx, dy, best, good_enough, S);
     }
     HME_MARK(S, 4);
     mv.u.mv.x = (int16_t) dx;
