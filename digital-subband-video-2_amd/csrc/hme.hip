@@ -1320,6 +1320,7 @@ constexpr unsigned long long kHmeSpinLimit = 400000000ull;  // 100 MHz ticks = 4
 constexpr unsigned long long kMvPending = ~0ull;            // a head the search has not stored yet (k_hme_clear_b)
 
 #include "hme_fast.h"
+#include "hme_fast32.h"
 
 // DSV2_HME_FAST=0 forces the general per-block routine at every level (A/B checks, and the parity tests' second opinion)
 static int g_hme_fast = getenv("DSV2_HME_FAST") ? atoi(getenv("DSV2_HME_FAST")) : 1;
@@ -1458,10 +1459,10 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
 
 // KIND: which block routine walks the row -- the general one (any geometry: blocks up to 32 x 32, any chroma format, odd
 // clipped sizes), the fast one of the coarser levels, or the fast one of level 0 (CS: chroma shift, 1 = 4:2:0, 0 = 4:4:4)
-enum { ROW_GENERAL = 0, ROW_FAST_LX = 1, ROW_FAST_L0 = 2, ROW_FAST_LX32 = 3 /* the coarser levels' routine for 32 x 32 blocks */ };
+enum { ROW_GENERAL = 0, ROW_FAST_LX = 1, ROW_FAST_L0 = 2, ROW_FAST_LX32 = 3 /* the coarser levels' routine for 32 x 32 blocks */, ROW_FAST_L0_32 = 4 /* level 0 for 32 x 32 blocks, 4:2:0 */ };
 template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, FastLds &S)
 {
-    const int level = KIND == ROW_FAST_L0 ? 0 : level_rt;
+    const int level = (KIND == ROW_FAST_L0 || KIND == ROW_FAST_L0_32) ? 0 : level_rt;
     int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
     int j = bj << level;
     const HmeCtx x = make_ctx(c, level);
@@ -1490,6 +1491,8 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
         if (!acc.failed) {
             if constexpr (KIND == ROW_FAST_L0) {
                 hme_block_l0<CS, SPLIT>(x, i, j, gx, gy, S, acc);
+            } else if constexpr (KIND == ROW_FAST_L0_32) {
+                hme_block_l0_32(x, i, j, gx, gy, S, acc);
             } else if constexpr (KIND == ROW_FAST_LX) {
                 hme_block_lx<1>(x, level, i, j, gx, gy, S, acc);
             } else if constexpr (KIND == ROW_FAST_LX32) {
@@ -1558,6 +1561,7 @@ HME_ROWS_P(k_hme_rows_l0_444, 4, 0, ROW_FAST_L0, 0, false)
 HME_ROWS_P(k_hme_rows_l0s, 4, 0, ROW_FAST_L0, 1, true) // ... with the neighbour-independent half from the pre-pass (k_hme_l0_pre_b)
 HME_ROWS_P(k_hme_rows_l0s_444, 4, 0, ROW_FAST_L0, 0, true)
 HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
+HME_ROWS_P(k_hme_rows_l0_32, 2, 0, ROW_FAST_L0_32)
 HME_ROWS_P(k_hme_rows_lx32, 2, level, ROW_FAST_LX32) // (36 reference quads live in a refinement round: two wavefronts per SIMD, as the general kernel)
 HME_ROWS_P(k_hme_rows_general, 2, level, ROW_GENERAL)
 static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 2048;
@@ -1608,7 +1612,7 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
     if ((bs != 16 && bs != 32) || a.blk_h != bs || (level == 0 && !c420 && !c444)) {
         return false;
     }
-    if (bs == 32 && level < 2) { // (32 x 32 blocks: the squared-error levels so far; levels 0 and 1 need the source pre-pass for that size)
+    if (bs == 32 && level == 0 && !c420) { // (32 x 32 blocks at level 0: the 4:2:0 routine of hme_fast32.h)
         return false;
     }
     int step = 1 << level;
@@ -1618,6 +1622,9 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
         return false;
     }
     int bw = src.w - lx < bs ? src.w - lx : bs, bh = src.h - ly < bs ? src.h - ly : bs;
+    if (level == 0 && bs == 32) {
+        return (bw & 15) == 0 && (bh & 15) == 0; // (a clipped block's sub-blocks must not straddle a quadrant seam)
+    }
     return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (level > 1 || (!(bw & 1) && !(bh & 1)));
 }
 
@@ -1860,6 +1867,51 @@ __global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict
     }
 }
 
+// ---- the same statistics for 32 x 32 blocks (2160p and up), one block per wavefront ------------------------------------------------
+// The general routine's own formulation (hme_block: wave-cooperative loops over a copy of the block in LDS) -- it runs once per block
+// and in no order, so its cost is not the search's.
+__global__ __launch_bounds__(64) void k_hme_src_stats32_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int per_wg)
+{
+    __shared__ int hist[16];
+    __shared__ alignas(4) uint8_t sblk[32 * 32], oblk[32 * 36];
+    const HmeDev &c = tab[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int n0 = nb0x * nb0y, total = n0 + nb1x * nb1y;
+    const int quant = uni(c.quant);
+    int4 *const out0 = uni_ptr(c.stats[0]), *const out1 = uni_ptr(c.stats[1]);
+    const DPlane src0 = uni(c.src[0]), src1 = uni(c.src[1]), ogr0 = uni(c.ogr[0]), ogr1 = uni(c.ogr[1]);
+    const int b_end = min(total, ((int) blockIdx.x + 1) * per_wg);
+    for (int b = (int) blockIdx.x * per_wg; b < b_end; b++) {
+        const bool l1 = b >= n0;
+        const int e = l1 ? b - n0 : b, nbx = l1 ? nb1x : nb0x;
+        const int bj = e / nbx, bi = e - bj * nbx;
+        const DPlane src = l1 ? src1 : src0, ogr = l1 ? ogr1 : ogr0;
+        const int bx = bi * 32, by = bj * 32;
+        const int bw = min(src.w - bx, 32), bh = min(src.h - by, 32);
+        if (bw <= 0 || bh <= 0) {
+            continue;
+        }
+        stage_block<32>(sblk, at(src, bx, by), src.stride, bw, bh);
+        unsigned avg_src = 0;
+        const unsigned var_src = (unsigned) ws_block_detail(sblk, 32, bw, bh, avg_src);
+        int tvar = (int) (var_src + SQR(var_src >> 10));
+        tvar = (8 * tvar * quant >> 9) / (bw * bh);
+        int bias_raw = 32 * 32;
+        if (tvar) { // hme.c:1405-1417
+            const int hvar = (int) ws_hist_var(sblk, 32, bw, bh, hist);
+            const int qtex = ws_quant_tex(sblk, 32, bw, bh);
+            const int npeaks = ws_peaks(sblk, 32, bw, bh, (int) avg_src, hist);
+            bias_raw += tvar * (hvar - qtex) * npeaks;
+        }
+        stage_block<36>(oblk, at(ogr, bx, by), ogr.stride, bw, bh);
+        const unsigned zoscore = ws_metr(sblk, 32, oblk, 36, bw, bh, psy_of_source(var_src, bw, bh, quant));
+        if (lane == 0) {
+            (l1 ? out1 : out0)[e] = int4{bias_raw, (int) var_src, (int) avg_src, (int) zoscore};
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the same statistics, FOUR whole 16x16 blocks per wavefront -------------------------------------------------------------
 // source_analysis() is written as the block routine needs it: one block per wavefront, a 2x2 quad per lane, full-width
 // reductions -- 330 vector instructions per block, more than the search saves by not running it.  Every quantity in it is an
@@ -2087,16 +2139,20 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         fast = fast && uniform_geometry(f[k], g.pyr_levels) && f[k].src_stats != nullptr && f[k].l0_pre != nullptr;
     }
     auto fast_level = [&](int level) { return fast && level_all_fast(g.a, f[0].src[level], level); };
-    const bool split = fast_level(0) && (g_hme_split >= 0 ? g_hme_split != 0 : n * g.a.nbv <= kSplitMaxRows);
+    const bool split = b16 && fast_level(0) && (g_hme_split >= 0 ? g_hme_split != 0 : n * g.a.nbv <= kSplitMaxRows);
     if (from_top) {
         const int nb0x = g.a.nbh, nb0y = g.a.nbv, nb1x = g.pyr_levels >= 1 ? (g.a.nbh + 1) / 2 : 0, nb1y = g.pyr_levels >= 1 ? (g.a.nbv + 1) / 2 : 0;
-        if (fast && b16) {
+        if (fast) {
             for (int k = 0; k < n; k++) {
                 ht[k].stats[0] = (int4 *) f[k].src_stats;
                 ht[k].stats[1] = nb1x ? (int4 *) f[k].src_stats + (size_t) nb0x * nb0y : nullptr;
             }
         }
         HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
+        if (fast && b32) {
+            const int per_wg = 2, total = nb0x * nb0y + nb1x * nb1y;
+            DSV2_LAUNCH(k_hme_src_stats32_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, per_wg);
+        }
         if (fast && b16) {
             // whole blocks four to a wavefront, clipped blocks of the last block row / column one to a wavefront
             bool four = true;
@@ -2138,7 +2194,9 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         if (prof && level == 0) {
             prof->begin(s, ST_HME_L0);
         }
-        if (level == 0 && fast_level(0)) {
+        if (level == 0 && b32 && fast_level(0)) {
+            DSV2_LAUNCH(k_hme_rows_l0_32, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
+        } else if (level == 0 && fast_level(0)) {
             auto pk = g.a.hshift == 0 ? (split ? k_hme_rows_l0s_444 : k_hme_rows_l0_444) : (split ? k_hme_rows_l0s : k_hme_rows_l0);
             DSV2_LAUNCH(pk, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else if (level > 0 && fast_level(level)) {

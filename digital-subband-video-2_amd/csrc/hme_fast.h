@@ -1564,7 +1564,8 @@ __device__ __forceinline__ MvHead load_neighbour_heads(DSV_MV *mvf, DSV_MV *out,
 // Level 1 reads the source statistics of the pre-pass (c.stats: k_hme_src_stats4_b / _b); the squared-error levels need none.
 // ============================================================================================================================
 // the lane's share of the source block at (bx, by) of `src` for the metric of `level` (see SrcBlk); o (optional): the same quads of another plane
-template <bool FULL, int NQ> __device__ __forceinline__ SrcBlk<NQ> load_src_blk(const DPlane &src, int bx, int by, int bw, int bh, int level, const DPlane *oth, Quad *o)
+template <bool FULL, int NQ>
+__device__ __forceinline__ SrcBlk<NQ> load_src_blk(const DPlane &src, int bx, int by, int bw, int bh, int level, bool with_other, const DPlane &oth, Quad (&o)[NQ])
 {
     const int lane = threadIdx.x & 63;
     SrcBlk<NQ> B;
@@ -1589,11 +1590,16 @@ template <bool FULL, int NQ> __device__ __forceinline__ SrcBlk<NQ> load_src_blk(
         }
         B.a[k] = ldq(at(src, bx + 16 * (k & 1), by + 16 * (k >> 1)), src.stride, B.qi, B.qj, B.act[k]);
         B.a[k].w &= B.smask[k];
-        if (oth != nullptr) {
-            o[k] = ldq(at(*oth, bx + 16 * (k & 1), by + 16 * (k >> 1)), oth->stride, B.qi, B.qj, B.act[k]);
+        if (with_other) {
+            o[k] = ldq(at(oth, bx + 16 * (k & 1), by + 16 * (k >> 1)), oth.stride, B.qi, B.qj, B.act[k]);
         }
     }
     return B;
+}
+template <bool FULL, int NQ> __device__ __forceinline__ SrcBlk<NQ> load_src_blk(const DPlane &src, int bx, int by, int bw, int bh, int level)
+{
+    Quad unused[NQ];
+    return load_src_blk<FULL, NQ>(src, bx, by, bw, bh, level, false, src, unused);
 }
 
 template <bool FULL, int NQ, class Ctx>
@@ -1624,7 +1630,7 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
     if (have_pre) {
         pre_words = *(cv4i_t) &c.stats[(i >> level) + (j >> level) * ((nxb + step - 1) >> level)];
     }
-    const SrcBlk<NQ> B = load_src_blk<FULL, NQ>(src, bx, by, bw, bh, level, have_pre ? nullptr : &ogr, o_zero);
+    const SrcBlk<NQ> B = load_src_blk<FULL, NQ>(src, bx, by, bw, bh, level, !have_pre, ogr, o_zero);
     // ONE load round for every vector the list reads: lanes 3..5 the same-level neighbours, lanes 6..14 the co-located
     // vectors of the previous frame, lanes 16..24 the parent level's.  Lanes without a vector load this block's own entry.
     bool nb_ok = false, pvalid = false, tvalid = false;
@@ -1814,7 +1820,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
     const int qw = bw >> 1, qh = bh >> 1;
-    const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0, nullptr, nullptr);
+    const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0);
     const bool act = B.act[0];
     const Quad a = B.a[0];
     typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -1941,7 +1947,7 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
     const int qw = bw >> 1, qh = bh >> 1;
-    const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0, nullptr, nullptr);
+    const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0);
     const bool act = B.act[0];
     const Quad a = B.a[0];
     typedef int v4i_t __attribute__((ext_vector_type(4)));
