@@ -31,6 +31,8 @@ CONFIGS = [
     dict(name="x_720p_effort3", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=3"]),
     dict(name="x_720p_effort5", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=5"]),
     dict(name="x_720p_effort7", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=7"]),
+    # 32 x 32 blocks (dsv_encoder.c:1203-1211): the four-quadrant block routine
+    dict(name="x_2160p_ip", w=3840, h=2160, fmt="420", seed=16, n=3, flags=["-qp=60", "-gop=48"]),
 ]
 
 
