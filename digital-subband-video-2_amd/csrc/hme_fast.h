@@ -888,6 +888,11 @@ struct RowAcc {
     unsigned long long left_head = 0;
     bool have_left = false; // (false: the routine reads the left neighbour from memory -- launch per front, or behind a block of the general routine)
     bool failed = false;    // a top / top-left head stayed pending beyond the spin limit: the row gives up (hme_row reports it)
+    // Two neighbouring blocks of a row (2 b, 2 b + 1) hang off the SAME parent block, so the parent level's half of the list --
+    // the nine parent vectors' average, their inliers, the inliers' average (hme.c:1443-1470: six divisions, a square root, five
+    // wave reductions) -- is worked out for the even block and kept for the odd one (par_key: the parent's block index, -1: none)
+    int par_key = -1, par_lax = 0, par_lay = 0, par_nin = 0;
+    bool par_open = false, par_inl = false; // (par_inl: per lane)
     __device__ __forceinline__ void flush(int *counters)
     {
         if ((threadIdx.x & 63) == 0) {
@@ -1392,6 +1397,20 @@ constexpr unsigned kParX = 0xa161u, kParY = 0x22215u;   // parent offsets / 2: {
 
 // ---- parent-level half of the candidate list: the average of the parent vectors' inliers (hme.c:1443-1470, find_inliers :1260) ----
 // lanes 16..24 hold the up to nine parent vectors (pvalid).  false: there is none -- the list is then the zero vector alone.
+__device__ __forceinline__ bool parent_average(bool pvalid, int pvx, int pvy, int &lax, int &lay, bool &inl, int &nin);
+// the same through the row's one-entry cache (RowAcc::par_*): `key` names the parent block
+__device__ __forceinline__ bool parent_average_cached(RowAcc &acc, int key, bool pvalid, int pvx, int pvy, int &lax, int &lay, bool &inl, int &nin)
+{
+    if (acc.par_key != key) {
+        acc.par_open = parent_average(pvalid, pvx, pvy, acc.par_lax, acc.par_lay, acc.par_inl, acc.par_nin);
+        acc.par_key = key;
+    }
+    lax = acc.par_lax;
+    lay = acc.par_lay;
+    inl = acc.par_inl;
+    nin = acc.par_nin;
+    return acc.par_open;
+}
 __device__ __forceinline__ bool parent_average(bool pvalid, int pvx, int pvy, int &lax, int &lay, bool &inl, int &nin)
 {
     lax = lay = nin = 0;
@@ -1464,36 +1483,30 @@ __device__ __forceinline__ void refine_fpel(const DPlane &ref, const SrcBlk<NQ> 
         }
         unsigned full = raw + (unsigned) mv_cost(cc, tx * step * 4, ty * step * 4, level);
         int cdx = dx, cdy = dy;
-        for (int k = 0; k < 5; k++) {
-            bool vk = __builtin_amdgcn_readlane((int) valid, k) != 0;
-            if (!vk) {
-                continue;
-            }
-            unsigned sk = (unsigned) __builtin_amdgcn_readlane((int) raw, k);
-            int tvx = cdx + tab9(kRectX, k), tvy = cdy + tab9(kRectY, k);
-            if (k == 1) {
-                metr0 = sk;
-            } else if (k == 2) {
-                metr1 = sk;
-            } else if (k == 3) {
-                metr2 = sk;
-            } else if (k == 4) {
-                metr3 = sk;
-            }
-            if (L0 && !tvx && !tvy && sk <= qthresh) {
-                dx = tvx;
-                dy = tvy;
-                best = sk;
-                good_enough = true;
-                break;
-            }
-            unsigned fk = (unsigned) __builtin_amdgcn_readlane((int) full, k);
-            if (best > fk) {
-                best = fk;
-                dx = tvx;
-                dy = tvy;
-                again = true;
-                break;
+        {
+            // hme.c:1325-1352 walks the centre and its four neighbours in order and leaves at the first one that is "good enough"
+            // (level 0, the zero vector, raw score within the threshold) or improves on the best; the axis scores of the positions it
+            // passed -- that one included -- stick.  Lane k holds position k: the first exit is a ballot, not a five-way unrolled loop.
+            const bool five = lane < 5;
+            const bool ge = L0 && five && valid && tx == 0 && ty == 0 && raw <= qthresh;
+            const bool imp = five && valid && best > full;
+            const unsigned long long gem = __ballot(ge), exm = gem | __ballot(imp);
+            const int first = exm ? __ffsll((long long) exm) - 1 : 5;
+            const unsigned long long seen = __ballot(valid) & ((2ull << first) - 1ull);
+            metr0 = (seen & 2ull) ? (unsigned) __builtin_amdgcn_readlane((int) raw, 1) : metr0;
+            metr1 = (seen & 4ull) ? (unsigned) __builtin_amdgcn_readlane((int) raw, 2) : metr1;
+            metr2 = (seen & 8ull) ? (unsigned) __builtin_amdgcn_readlane((int) raw, 3) : metr2;
+            metr3 = (seen & 16ull) ? (unsigned) __builtin_amdgcn_readlane((int) raw, 4) : metr3;
+            if (exm) {
+                dx = cdx + tab9(kRectX, first);
+                dy = cdy + tab9(kRectY, first);
+                if ((gem >> first) & 1ull) {
+                    best = (unsigned) __builtin_amdgcn_readlane((int) raw, first);
+                    good_enough = true;
+                } else {
+                    best = (unsigned) __builtin_amdgcn_readlane((int) full, first);
+                    again = true;
+                }
             }
         }
         if (again || good_enough) {
@@ -1684,7 +1697,7 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
     if (parent != nullptr) {
         bool inl;
         int nin;
-        if (parent_average(pvalid, pvx, pvy, lax, lay, inl, nin)) {
+        if (parent_average_cached(acc, (int) ((unsigned) i & ~(((unsigned) step << 1) - 1)), pvalid, pvx, pvy, lax, lay, inl, nin)) {
             // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)
             if (lane == 1) {
                 exist = true;
@@ -2042,7 +2055,7 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
         bool inl = false;
         int nin = 0;
         lax = lay = 0;
-        open = parent != nullptr && parent_average(pvalid, pvx, pvy, lax, lay, inl, nin);
+        open = parent != nullptr && parent_average_cached(acc, i & ~1, pvalid, pvx, pvy, lax, lay, inl, nin);
         exist = lane == 0;
         int cxv = 0, cyv = 0;
         if (open) { // every list entry passes through an int16 store and the qpel->fpel rounding (hme.c:1185-1200)

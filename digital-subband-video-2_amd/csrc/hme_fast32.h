@@ -618,7 +618,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_
     const bool colo_ok = parent != nullptr && c.ref_mvf != nullptr;
     bool inl = false;
     int nin = 0, lax = 0, lay = 0;
-    const bool open = parent != nullptr && parent_average(pvalid, pvx, pvy, lax, lay, inl, nin);
+    const bool open = parent != nullptr && parent_average_cached(acc, i & ~1, pvalid, pvx, pvy, lax, lay, inl, nin);
     bool exist = lane == 0;
     int cxv = 0, cyv = 0;
     if (open) {
