@@ -20,9 +20,9 @@ P = N * 3 // 2
 WIDE16 = ("k_inv_haar_u8x4", "k_quant_level4", "k_scatter", "k_reconstruct_w", "k_ingest16", "k_copy_linear", "k_inv_haar_tail", "k_fwd_haar_tail")
 # algorithmic bytes per FRAME by kernel family (P = picture bytes, N = luma pixels); None = no streaming model
 ALGO = [
-    ("k_hme_rows_b_fast_l0", 4 * N, "3 full-size luma planes + chroma (4 N)"),
-    ("k_hme_rows_b_fast_lx", 1 * N, "the coarser pyramid levels of the three lumas (N)"),
-    ("k_hme_src_stats_b", 2.5 * N, "levels 0 and 1 of the source and of the previous source picture (2.5 N)"),
+    ("k_hme_rows_l0", 4 * N, "3 full-size luma planes + chroma (4 N)"),
+    ("k_hme_rows_lx", 1 * N, "the coarser pyramid levels of the three lumas (N)"),
+    ("k_hme_src_stats", 2.5 * N, "levels 0 and 1 of the source and of the previous source picture (2.5 N)"),
     ("k_inter_filters_b", 2 * P, "picture read + written once (2 P)"),
     ("k_intra_filter_b", 2 * N / 14, "luma read + written, intra pictures only (1 in 14 here)"),
     ("k_predict_w", 4 * P, "source + reference read, prediction + residual written (4 P)"),
