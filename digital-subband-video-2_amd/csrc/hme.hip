@@ -1558,6 +1558,7 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
     }
 HME_ROWS_P(k_hme_rows_l0, 4, 0, ROW_FAST_L0, 1, false)
 HME_ROWS_P(k_hme_rows_l0_444, 4, 0, ROW_FAST_L0, 0, false)
+HME_ROWS_P(k_hme_rows_l0_422, 4, 0, ROW_FAST_L0, 2, false)
 HME_ROWS_P(k_hme_rows_l0s, 4, 0, ROW_FAST_L0, 1, true) // ... with the neighbour-independent half from the pre-pass (k_hme_l0_pre_b)
 HME_ROWS_P(k_hme_rows_l0s_444, 4, 0, ROW_FAST_L0, 0, true)
 HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
@@ -1607,9 +1608,9 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
 {
     // the chroma planes only enter at level 0 (mode decision): 4:2:0 and 4:4:4 have a block routine there, the coarser
     // levels take any format
-    const bool c420 = a.hshift == 1 && a.vshift == 1, c444 = a.hshift == 0 && a.vshift == 0;
+    const bool c420 = a.hshift == 1 && a.vshift == 1, c444 = a.hshift == 0 && a.vshift == 0, c422 = a.hshift == 1 && a.vshift == 0;
     const int bs = a.blk_w;
-    if ((bs != 16 && bs != 32) || a.blk_h != bs || (level == 0 && !c420 && !c444)) {
+    if ((bs != 16 && bs != 32) || a.blk_h != bs || (level == 0 && !c420 && !c444 && !(c422 && bs == 16))) {
         return false;
     }
     if (bs == 32 && level == 0 && !c420) { // (32 x 32 blocks at level 0: the 4:2:0 routine of hme_fast32.h)
@@ -2139,7 +2140,8 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         fast = fast && uniform_geometry(f[k], g.pyr_levels) && f[k].src_stats != nullptr && f[k].l0_pre != nullptr;
     }
     auto fast_level = [&](int level) { return fast && level_all_fast(g.a, f[0].src[level], level); };
-    const bool split = b16 && fast_level(0) && (g_hme_split >= 0 ? g_hme_split != 0 : n * g.a.nbv <= kSplitMaxRows);
+    const bool c422 = g.a.hshift == 1 && g.a.vshift == 0;
+    const bool split = b16 && !c422 && fast_level(0) && (g_hme_split >= 0 ? g_hme_split != 0 : n * g.a.nbv <= kSplitMaxRows);
     if (from_top) {
         const int nb0x = g.a.nbh, nb0y = g.a.nbv, nb1x = g.pyr_levels >= 1 ? (g.a.nbh + 1) / 2 : 0, nb1y = g.pyr_levels >= 1 ? (g.a.nbv + 1) / 2 : 0;
         if (fast) {
@@ -2197,7 +2199,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         if (level == 0 && b32 && fast_level(0)) {
             DSV2_LAUNCH(k_hme_rows_l0_32, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else if (level == 0 && fast_level(0)) {
-            auto pk = g.a.hshift == 0 ? (split ? k_hme_rows_l0s_444 : k_hme_rows_l0_444) : (split ? k_hme_rows_l0s : k_hme_rows_l0);
+            auto pk = c422 ? k_hme_rows_l0_422 : g.a.hshift == 0 ? (split ? k_hme_rows_l0s_444 : k_hme_rows_l0_444) : (split ? k_hme_rows_l0s : k_hme_rows_l0);
             DSV2_LAUNCH(pk, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else if (level > 0 && fast_level(level)) {
             DSV2_LAUNCH(b32 ? k_hme_rows_lx32 : k_hme_rows_lx, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);

@@ -278,6 +278,25 @@ __device__ __forceinline__ void quad_grad_partials(const Quad &q, bool act, int 
     }
 }
 
+// the same on a quad grid W lanes wide (W = 4: the 8 x 16 chroma block of 4:2:2 -- 4 x 8 quads on 32 lanes)
+template <int W> __device__ __forceinline__ void quad_grad_partials_w(const Quad &q, bool act, int qi, int qj, int &sum, int &sh, int &sv)
+{
+    int l2 = __shfl_up(q.p2(), 1, 64), l4 = __shfl_up(q.p4(), 1, 64);
+    int u3 = __shfl_up(q.p3(), W, 64), u4 = __shfl_up(q.p4(), W, 64);
+    sum = sh = sv = 0;
+    if (act) {
+        sum = q.p1() + q.p2() + q.p3() + q.p4();
+        sh = abs(q.p2() - q.p1()) + abs(q.p4() - q.p3());
+        sv = abs(q.p3() - q.p1()) + abs(q.p4() - q.p2());
+        if (qi > 0) {
+            sh += abs(q.p1() - l2) + abs(q.p3() - l4);
+        }
+        if (qj > 0) {
+            sv += abs(q.p1() - u3) + abs(q.p2() - u4);
+        }
+    }
+}
+
 __device__ __forceinline__ int quad_absdev(const Quad &q, bool act, int mean)
 {
     return act ? (int) sad4(q.w, rep4(mean)) : 0;
@@ -936,8 +955,9 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
 // level-0 tail of the block routine: sub-pel refinement + mode decision (hme.c:1598-1821)
 // (sp_done, sp_mr, sp_dirs): the pixel half of the FIRST sub-pel search (around the parent average), from the pre-pass
 // (subpel_probes; sp_done = it was run: effort >= 4 and the block at the parent average has a rim of four inside the padded plane)
-// CS: chroma shift of both axes -- 1 = 4:2:0 (a block's chroma is 8x8: one pixel per lane, its 2x2 quads on lanes 0..31),
-// 0 = 4:4:4 (16x16 like the luma: every lane owns the quad (qi, qj) of U and of V)
+// CS: chroma format -- 1 = 4:2:0 (a block's chroma is 8x8: one pixel per lane, its 2x2 quads on lanes 0..31),
+// 0 = 4:4:4 (16x16 like the luma: every lane owns the quad (qi, qj) of U and of V),
+// 2 = 4:2:2 (8 wide, 16 high: 4 x 8 quads a plane -- lanes 0..31 own U's, lanes 32..63 V's)
 template <int CS, bool SPLIT, class Ctx>
 __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
@@ -1004,9 +1024,16 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
 
     HME_MARK(S, 5);
     // ---- operands of the mode decision, one load round ----
-    const int cbx = (i * 16) >> CS, cby = (j * 16) >> CS;   // 16x16 luma blocks
-    const int cbmx = cbx + sarx(fpelx, CS), cbmy = cby + sarx(fpely, CS);
-    const int cbw = bw >> CS, cbh = bh >> CS;
+    constexpr int CSH = CS == 0 ? 0 : 1, CSV = CS == 1 ? 1 : 0; // chroma shifts: horizontal, vertical
+    const int cbx = (i * 16) >> CSH, cby = (j * 16) >> CSV;   // 16x16 luma blocks
+    const int cbmx = cbx + sarx(fpelx, CSH), cbmy = cby + sarx(fpely, CSV);
+    const int cbw = bw >> CSH, cbh = bh >> CSV;
+    // 4:2:2: the lane's chroma quad -- plane c2p, quad (c2i, c2j) of its 4 x 8 grid -- of the source / the reference at the vector / at zero
+    const int c2p = lane >> 5, c2i = lane & 3, c2j = (lane >> 2) & 7;
+    const bool act2 = CS == 2 && c2i < (cbw >> 1) && c2j < (cbh >> 1);
+    const int k2 = (c2i >= (cbw >> 2) ? 1 : 0) | (c2j >= (cbh >> 2) ? 2 : 0); // ... and its sub-block
+    Quad c2s, c2m, c2z;
+    c2s.w = c2m.w = c2z.w = 0;
     const int cxp = lane & 7, cyp = lane >> 3;              // 4:2:0: chroma pixel owned by this lane
     const bool actc = CS == 1 && cxp < cbw && cyp < cbh;
     // 4:2:0: chroma quads for the sub-block metrics: lanes 0..15 U, 16..31 V
@@ -1035,6 +1062,12 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
             cz = ldq(at(c.refc[cpl], cbx, cby), c.refc[cpl].stride, cqi, cqj, actq);
         }
         cm = ldq(at(c.refc[cpl], cbmx, cbmy), c.refc[cpl].stride, cqi, cqj, actq);
+    } else if constexpr (CS == 2) {
+        c2s = ldq(at(c.srcc[c2p], cbx, cby), c.srcc[c2p].stride, c2i, c2j, act2);
+        c2m = ldq(at(c.refc[c2p], cbmx, cbmy), c.refc[c2p].stride, c2i, c2j, act2);
+        if (skip_test) {
+            c2z = ldq(at(c.refc[c2p], cbx, cby), c.refc[c2p].stride, c2i, c2j, act2);
+        }
     } else {
         usq = ldq(at(c.srcc[0], cbx, cby), c.srcc[0].stride, qi, qj, act);
         vsq = ldq(at(c.srcc[1], cbx, cby), c.srcc[1].stride, qi, qj, act);
@@ -1068,6 +1101,19 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
             v[9] = (actc && cyp > 0) ? abs(us - uu) : 0;
             v[10] = (actc && cxp > 0) ? abs(vs - vl) : 0;
             v[11] = (actc && cyp > 0) ? abs(vs - vu) : 0;
+        } else if constexpr (CS == 2) { // the 8 x 16 chroma blocks, quad by quad: U's sums on lanes 0..31, V's on lanes 32..63
+            int cs_, ch_, cv_;
+            quad_grad_partials_w<4>(c2s, act2, c2i, c2j, cs_, ch_, cv_);
+            const int ms_ = act2 ? c2m.p1() + c2m.p2() + c2m.p3() + c2m.p4() : 0;
+            const bool isu = c2p == 0;
+            v[4] = isu ? cs_ : 0;
+            v[5] = isu ? 0 : cs_;
+            v[6] = isu ? ms_ : 0;
+            v[7] = isu ? 0 : ms_;
+            v[8] = isu ? ch_ : 0;
+            v[9] = isu ? cv_ : 0;
+            v[10] = isu ? 0 : ch_;
+            v[11] = isu ? 0 : cv_;
         } else { // pixel sums and first-difference sums of the 16x16 chroma blocks, quad by quad (as for the luma)
             quad_grad_partials(usq, act, qi, qj, 0, 0, v[4], v[8], v[9]);
             quad_grad_partials(vsq, act, qi, qj, 0, 0, v[5], v[10], v[11]);
@@ -1097,6 +1143,9 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
             if constexpr (CS == 1) {
                 v[5 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
                 v[9 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cz, psy) : 0;
+            } else if constexpr (CS == 2) {
+                v[5 + k] = (act2 && c2p == 0 && k2 == k) ? (int) qmetric(c2s, c2z, psy) : 0;
+                v[9 + k] = (act2 && c2p == 1 && k2 == k) ? (int) qmetric(c2s, c2z, psy) : 0;
             } else {
                 v[5 + k] = (act && kq == k) ? (int) qmetric(usq, uzq, psy) : 0;
                 v[9 + k] = (act && kq == k) ? (int) qmetric(vsq, vzq, psy) : 0;
@@ -1192,6 +1241,9 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
                     if constexpr (CS == 1) {
                         v[4 + k] = (actq && cpl == 0 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
                         v[8 + k] = (actq && cpl == 1 && kc == k) ? (int) qmetric(cs, cm, psy) : 0;
+                    } else if constexpr (CS == 2) {
+                        v[4 + k] = (act2 && c2p == 0 && k2 == k) ? (int) qmetric(c2s, c2m, psy) : 0;
+                        v[8 + k] = (act2 && c2p == 1 && k2 == k) ? (int) qmetric(c2s, c2m, psy) : 0;
                     } else {
                         v[4 + k] = (act && kq == k) ? (int) qmetric(usq, umq, psy) : 0;
                         v[8 + k] = (act && kq == k) ? (int) qmetric(vsq, vmq, psy) : 0;
@@ -1322,6 +1374,13 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
                         v[4 * k + 1] = in ? vs : 0;
                         v[4 * k + 2] = in ? um : 0;
                         v[4 * k + 3] = in ? vm : 0;
+                    } else if constexpr (CS == 2) {
+                        const bool in = act2 && k2 == k;
+                        const int ssum = c2s.p1() + c2s.p2() + c2s.p3() + c2s.p4(), msum = c2m.p1() + c2m.p2() + c2m.p3() + c2m.p4();
+                        v[4 * k + 0] = (in && c2p == 0) ? ssum : 0;
+                        v[4 * k + 1] = (in && c2p == 1) ? ssum : 0;
+                        v[4 * k + 2] = (in && c2p == 0) ? msum : 0;
+                        v[4 * k + 3] = (in && c2p == 1) ? msum : 0;
                     } else {
                         bool in = act && kq == k;
                         v[4 * k + 0] = in ? usq.p1() + usq.p2() + usq.p3() + usq.p4() : 0;
