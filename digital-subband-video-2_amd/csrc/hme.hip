@@ -27,6 +27,7 @@ namespace dsv2 {
 struct HmeDev {
     AnalysisParams a;
     int effort, lossless, quant, skip_block_thresh, pyr_levels, psyscale;
+    int b2sr; // dsv_mv_cost's bits-to-SSE ratio (hme.c:163): one value per frame
     DPlane src[6], ref[6], ogr[6];
     DPlane srcc[2], refc[2];
     DSV_MV *mvf[6];
@@ -83,54 +84,67 @@ struct HmeCtx {
     DSV_MV *host_mvs;
     const int4 *stats; // this level's source statistics or null
     uint32_t *l0pre;   // level 0's pre-pass records
+    const HmeDev *self; // the job record all of the above was read from
 };
 
 __device__ __forceinline__ const int4 *src_stats_of(const HmeCtx &c, int) { return c.stats; }
 __device__ __forceinline__ const int4 *src_stats_of(const HmeDev &c, int level) { return c.stats[level]; }
 
-__device__ __forceinline__ HmeCtx make_ctx(const HmeDev &d, int level)
+// The job record is read through the SCALAR cache (constant address space: the record is written by the host before the launch and
+// never during it), so a field costs a fraction of an s_load and no vector register -- and the context can be read AGAIN wherever a
+// phase of a block starts (fenced(), below) instead of being carried through the whole persistent loop in scalar registers the
+// machine does not have (102 per wavefront; the context and what the compiler derives from it up front came to ~380, of which
+// it spilled 280 to vector-register lanes: two v_readlane per use).
+typedef const __attribute__((address_space(4))) HmeDev *HmeDevK;
+template <class T> __device__ __forceinline__ T *from_k(const __attribute__((address_space(4))) void *p) { return (T *) (unsigned long long) p; }
+__device__ __forceinline__ HmeCtx make_ctx(const HmeDev *self, int level)
 {
+    const HmeDev *p = self;
+    asm volatile("" : "+s"(p)); // (the compiler may not merge this read with an earlier one)
+    HmeDevK d = (HmeDevK) (unsigned long long) p;
     HmeCtx c;
-    c.a.width = uni(d.a.width);
-    c.a.height = uni(d.a.height);
-    c.a.blk_w = uni(d.a.blk_w);
-    c.a.blk_h = uni(d.a.blk_h);
-    c.a.nbh = uni(d.a.nbh);
-    c.a.nbv = uni(d.a.nbv);
-    c.a.hshift = uni(d.a.hshift);
-    c.a.vshift = uni(d.a.vshift);
-    c.a.do_psy = uni(d.a.do_psy);
-    c.a.scale = uni(d.a.scale);
-    c.effort = uni(d.effort);
-    c.lossless = uni(d.lossless);
-    c.quant = uni(d.quant);
-    // dsv_mv_cost's bits-to-SSE ratio (hme.c:163): one value per frame, worked out once per wavefront, not per block
-    c.b2sr = (256 * (c.quant * c.quant >> 12) * c.a.blk_w * c.a.blk_h) / (c.a.width * c.a.height);
-    c.skip_block_thresh = uni(d.skip_block_thresh);
-    c.pyr_levels = uni(d.pyr_levels);
-    c.psyscale = uni(d.psyscale);
+    c.self = self;
+    c.a.width = d->a.width;
+    c.a.height = d->a.height;
+    c.a.blk_w = d->a.blk_w;
+    c.a.blk_h = d->a.blk_h;
+    c.a.nbh = d->a.nbh;
+    c.a.nbv = d->a.nbv;
+    c.a.hshift = d->a.hshift;
+    c.a.vshift = d->a.vshift;
+    c.a.do_psy = d->a.do_psy;
+    c.a.scale = d->a.scale;
+    c.effort = d->effort;
+    c.lossless = d->lossless;
+    c.quant = d->quant;
+    c.b2sr = d->b2sr;
+    c.skip_block_thresh = d->skip_block_thresh;
+    c.pyr_levels = d->pyr_levels;
+    c.psyscale = d->psyscale;
     // the source, reference and original-reference pyramids have one geometry per level, and so have the four
     // chroma planes (hme_run_batch checks it): only the data pointers differ, the rest shares scalar registers
-    c.src.lvl = uni(d.src[level]);
-    c.ref.lvl = DPlane{uni_ptr(d.ref[level].data), c.src.lvl.stride, c.src.lvl.w, c.src.lvl.h};
-    c.ogr.lvl = DPlane{uni_ptr(d.ogr[level].data), c.src.lvl.stride, c.src.lvl.w, c.src.lvl.h};
-    c.src.zero = uni(d.src[0]);
-    c.ref.zero = DPlane{uni_ptr(d.ref[0].data), c.src.zero.stride, c.src.zero.w, c.src.zero.h};
-    c.ogr.zero = DPlane{uni_ptr(d.ogr[0].data), c.src.zero.stride, c.src.zero.w, c.src.zero.h};
-    c.srcc.p0 = uni(d.srcc[0]);
-    c.srcc.p1 = DPlane{uni_ptr(d.srcc[1].data), c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
-    c.refc.p0 = DPlane{uni_ptr(d.refc[0].data), c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
-    c.refc.p1 = DPlane{uni_ptr(d.refc[1].data), c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
-    c.mvf.cur = uni_ptr(d.mvf[level]);
-    c.mvf.parent = level < d.pyr_levels ? uni_ptr(d.mvf[level + 1]) : nullptr;
+    c.src.lvl = DPlane{d->src[level].data, d->src[level].stride, d->src[level].w, d->src[level].h};
+    c.ref.lvl = DPlane{d->ref[level].data, c.src.lvl.stride, c.src.lvl.w, c.src.lvl.h};
+    c.ogr.lvl = DPlane{d->ogr[level].data, c.src.lvl.stride, c.src.lvl.w, c.src.lvl.h};
+    c.src.zero = DPlane{d->src[0].data, d->src[0].stride, d->src[0].w, d->src[0].h};
+    c.ref.zero = DPlane{d->ref[0].data, c.src.zero.stride, c.src.zero.w, c.src.zero.h};
+    c.ogr.zero = DPlane{d->ogr[0].data, c.src.zero.stride, c.src.zero.w, c.src.zero.h};
+    c.srcc.p0 = DPlane{d->srcc[0].data, d->srcc[0].stride, d->srcc[0].w, d->srcc[0].h};
+    c.srcc.p1 = DPlane{d->srcc[1].data, c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
+    c.refc.p0 = DPlane{d->refc[0].data, c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
+    c.refc.p1 = DPlane{d->refc[1].data, c.srcc.p0.stride, c.srcc.p0.w, c.srcc.p0.h};
+    c.mvf.cur = d->mvf[level];
+    c.mvf.parent = level < c.pyr_levels ? d->mvf[level + 1] : nullptr;
     c.mvf.level = level;
-    c.ref_mvf = uni_ptr(d.ref_mvf);
-    c.counters = uni_ptr(d.counters);
-    c.host_mvs = uni_ptr(d.host_mvs);
-    c.stats = level <= 1 ? uni_ptr((const int4 *) d.stats[level]) : nullptr;
-    c.l0pre = uni_ptr(d.l0pre);
+    c.ref_mvf = d->ref_mvf;
+    c.counters = d->counters;
+    c.host_mvs = d->host_mvs;
+    c.stats = level <= 1 ? (const int4 *) d->stats[level] : nullptr;
+    c.l0pre = d->l0pre;
     return c;
 }
+// the context read afresh: what a phase of a block starts from (the previous phase's copy, and everything derived from it, dies)
+__device__ __forceinline__ HmeCtx fenced(const HmeCtx &c, int level) { return make_ctx(c.self, level); }
 
 __device__ __forceinline__ int b2sr_of(const HmeCtx &c) { return c.b2sr; }
 __device__ __forceinline__ int b2sr_of(const HmeDev &c) // (the single-call kernels work on the job record itself)
@@ -1344,7 +1358,7 @@ constexpr int kHmeHostTail = 12;  // ... and the word of the pinned host counter
 __device__ __forceinline__ int take_ticket(int *counter)
 {
     int t = 0;
-    if ((threadIdx.x & 63) == 0) {
+    if (hme_lane() == 0) {
         t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return __builtin_amdgcn_readfirstlane(t);
@@ -1378,7 +1392,7 @@ __device__ __forceinline__ RowTicket take_row(const HmeDev *tab, int level, int 
                 // of the first stream's counter block), so that the next lockstep group's search may start filling the
                 // slots this one frees (encoder.cpp: the search token is passed on at that point, not at the launch's end)
                 int done = 0;
-                if ((threadIdx.x & 63) == 0) {
+                if (hme_lane() == 0) {
                     done = __hip_atomic_fetch_add(&tab[0].counters[kHmeExhausted], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (done + 1 == parts && tab[0].host_counters) {
                         __hip_atomic_store(&tab[0].host_counters[kHmeHostTail], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1401,7 +1415,7 @@ __device__ __forceinline__ RowTicket take_row(const HmeDev *tab, int level, int 
 // load round -- load_neighbour_heads, hme_fast.h; blocks of the general routine wait here.)
 __device__ __forceinline__ bool wait_heads(const DSV_MV *top, const DSV_MV *top_left, int *err)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const unsigned long long *p = (const unsigned long long *) (lane == 1 ? top_left : top);
     unsigned long long t0 = 0;
     for (unsigned spins = 0;; spins++) {
@@ -1430,7 +1444,7 @@ constexpr int kHmeRowsDone = 6;
 // before the owner's arrival was counted.
 __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, int nbx, int nby)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     if (level != 0) {
         int step = 1 << level, ax = 0, ay = 0;
         for (int idx = lane; idx < nbx * nby; idx += 64) {
@@ -1465,9 +1479,9 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
     const int level = (KIND == ROW_FAST_L0 || KIND == ROW_FAST_L0_32) ? 0 : level_rt;
     int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
     int j = bj << level;
-    const HmeCtx x = make_ctx(c, level);
+    const HmeCtx x = make_ctx(uni_ptr(&c), level);
 #ifdef DSV2_HME_PROF
-    if ((threadIdx.x & 63) == 0) {
+    if (hme_lane() == 0) {
         S.prof_on = level == 0;
         for (int k = 0; k < 16; k++) {
             S.prof_acc[k] = 0;
@@ -1507,7 +1521,7 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
         if (acc.failed) {
             // a neighbour's head never arrived (bounded spin), or another row gave up: tell the host directly -- the level's
             // epilogue, which normally delivers the counters, will not run because this row does not arrive
-            if (c.host_counters && (threadIdx.x & 63) == 0) {
+            if (c.host_counters && hme_lane() == 0) {
                 __hip_atomic_store(&c.host_counters[kHmeErrWord], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
@@ -1515,7 +1529,7 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
         HME_MARK(S, 9);
     }
 #ifdef DSV2_HME_PROF
-    if ((threadIdx.x & 63) == 0 && S.prof_on) {
+    if (hme_lane() == 0 && S.prof_on) {
         for (int k = 0; k < 16; k++) {
             atomicAdd(&g_hme_prof[k], S.prof_acc[k]);
         }
@@ -1526,7 +1540,7 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // arrival of this row; its vectors and counter updates were drained above
     int done = 0;
-    if ((threadIdx.x & 63) == 0) {
+    if (hme_lane() == 0) {
         // (release: this row's heads and counter sums; acquire: the last row to arrive reads every row's heads in the epilogue)
         done = __hip_atomic_fetch_add(&c.counters[kHmeRowsDone], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1536,14 +1550,19 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
     }
 }
 
-// PERSISTENT kernels: `P` workgroups (default 2 048 = two per SIMD) that each walk row after row -- the tickets of take_row hand
+// PERSISTENT kernels: `P` workgroups (default 3 072 = three per SIMD) that each walk row after row -- the tickets of take_row hand
 // rows to whoever asks.  The cap on the search's wavefronts per SIMD is the LAUNCH, not a padded register allocation
 // (amdgpu_waves_per_eu(W, W) caps by padding every wavefront's registers until a (W + 1)th does not fit, and the other
 // lockstep groups' streaming kernels -- whose bandwidth is their bytes in flight, i.e. their resident wavefronts -- then live
 // in what is left).  A row still only waits for a lower ticket, which a RUNNING worker holds (a worker takes its next ticket
 // after finishing its row), so the progress argument is unchanged.
+#ifdef DSV2_HME_WMAX
+#define HME_WMAX(W) DSV2_HME_WMAX
+#else
+#define HME_WMAX(W) W
+#endif
 #define HME_ROWS_P(NAME, WAVES, LEVEL_EXPR, ...)                                                                         \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(                       \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, HME_WMAX(WAVES)))) void NAME(                       \
         const HmeDev *__restrict__ tab, int level, int nbx, int parts, int nstreams, int nrows)                          \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
@@ -1565,7 +1584,7 @@ HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
 HME_ROWS_P(k_hme_rows_l0_32, 2, 0, ROW_FAST_L0_32)
 HME_ROWS_P(k_hme_rows_lx32, 2, level, ROW_FAST_LX32) // (36 reference quads live in a refinement round: two wavefronts per SIMD, as the general kernel)
 HME_ROWS_P(k_hme_rows_general, 2, level, ROW_GENERAL)
-static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 2048;
+static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 3072;
 // DSV2_HME_SPLIT: level 0 with its neighbour-independent half in an unordered pre-pass (1) or in place (0); default: by launch size
 // (-1: split below kSplitMaxRows block rows per launch -- few pictures: the chain per block is what the frame waits for -- and in place
 // above -- many pictures: the chip is short of work slots, and the pre-pass costs a quarter more instructions in total)
@@ -1579,7 +1598,7 @@ __global__ __launch_bounds__(64) void k_hme_l0_pre_b(const HmeDev *__restrict__ 
 {
     __shared__ FastLds S;
     const HmeDev &c = tab[blockIdx.y];
-    const HmeCtx x = make_ctx(c, 0);
+    const HmeCtx x = make_ctx(uni_ptr(&c), 0);
     const int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
     const int b_end = min(nbx * nby, ((int) blockIdx.x + 1) * per_wg);
     for (int b = (int) blockIdx.x * per_wg; b < b_end; b++) {
@@ -2087,6 +2106,7 @@ static void fill_hme_dev(HmeDev &c, const HmeFrames &f, const HmeParams &hp)
     c.skip_block_thresh = hp.skip_block_thresh;
     c.pyr_levels = hp.pyr_levels;
     c.psyscale = spatial_psy_factor(hp.a.blk_w, hp.a.blk_h, hp.a.nbh, hp.a.nbv, -1);
+    c.b2sr = (256 * (hp.quant * hp.quant >> 12) * hp.a.blk_w * hp.a.blk_h) / (hp.a.width * hp.a.height);
     for (int l = 0; l <= hp.pyr_levels; l++) {
         c.src[l] = f.src[l];
         c.ref[l] = f.ref[l];
@@ -2189,7 +2209,7 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     for (int level = level_hi; (phases & HME_LEVELS) && level >= level_lo; level--) {
         const int step = 1 << level;
         const int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
-        const int workers = std::min(g_hme_persist > 0 ? g_hme_persist : 2048, n * nby);
+        const int workers = std::min(g_hme_persist > 0 ? g_hme_persist : 3072, n * nby);
         if (level == 0 && g.pyr_levels == 0 && split) { // (no level above: the pre-pass has nothing to wait for)
             DSV2_LAUNCH(k_hme_l0_pre_b, dim3((nbx * nby + 1) / 2, n), dim3(64), 0, s, tab, nbx, nby, 2);
         }

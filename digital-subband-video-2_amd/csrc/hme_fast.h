@@ -221,6 +221,17 @@ __device__ __forceinline__ int sdiv_fast(int n, int d)
     return n < 0 ? -(int) q : (int) q;
 }
 
+// The lane number as a value the compiler cannot trace back to threadIdx: every routine asks for its own.  Lane predicates
+// ("lane == 3", "lane < nq") are loop-invariant 64-bit masks; traced, the compiler hoists all of them out of the block loop
+// into scalar registers it does not have, and every use becomes two v_readlane reloads of a spilled pair -- recomputing the
+// compare where it is used is one instruction.
+__device__ __forceinline__ int hme_lane()
+{
+    int l = (int) (threadIdx.x & 63);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 struct FastLds {
     int hist[16];
     SubpelLds sp;
@@ -305,7 +316,7 @@ __device__ __forceinline__ int quad_absdev(const Quad &q, bool act, int mean)
 // hist_var / quant_tex / peaks of the source block from its register-resident quads (hme.c:586-749)
 __device__ int src_hist_var(const Quad &q, bool act, int sum, int w, int h, int *hist)
 {
-    int lane = threadIdx.x & 63;
+    int lane = hme_lane();
     unsigned avg = (unsigned) div_nn(sum, w * h);
     if (avg == 0) {
         avg = 1;
@@ -352,7 +363,7 @@ __device__ int src_quant_tex(const Quad &q, bool act, int qi, int qj, int qw, in
 
 __device__ int src_peaks(const Quad &q, bool act, int bavg, int *hist)
 {
-    int lane = threadIdx.x & 63;
+    int lane = hme_lane();
     int avg = bavg ? bavg : 1;
     int q16 = (int) udiv_fast(8u << 16, (unsigned) avg);
     if (lane < 16) {
@@ -545,7 +556,7 @@ template <int NT> __device__ __forceinline__ VecSet<NT> pop_vecs(unsigned long l
 template <int NQ>
 __device__ __forceinline__ unsigned score_lanes(unsigned long long mask, int key, const DPlane &ref, const SrcBlk<NQ> &B, int level, const Psy &psy)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const int n = __popcll(mask);
     const int widx = __popcll(mask & ((1ull << lane) - 1)); // this lane's place among them
     const int mx = (int) (int16_t) (key & 0xffff), my = key >> 16;
@@ -630,7 +641,7 @@ template <class Ctx>
 __device__ __forceinline__ unsigned subpel_probes(const Ctx &c, FastLds &S, int fpelx, int fpely, int bx, int by, int bw, int bh, const Quad &a, bool act, int qi,
                                                   int qj, const Psy &psy, unsigned &dirs)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     int v4[4];
     Quad aw;
     {
@@ -729,7 +740,7 @@ __device__ __forceinline__ uint32_t avg4_b4(uint32_t a, uint32_t b, uint32_t c, 
 template <class Ctx>
 __device__ __forceinline__ unsigned subpel_probes_patch(const Ctx &c, int fpelx, int fpely, int bx, int by, const Quad &a, int qi, int qj, const Psy &psy, unsigned &dirs)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const DPlane &ref = c.ref[0];
     typedef const __attribute__((address_space(1))) uint8_t *gb_t;
     typedef const __attribute__((address_space(1))) uint2v_t *gu2_t; // (may be unaligned: the hardware splits the access)
@@ -839,7 +850,7 @@ __device__ __forceinline__ unsigned subpel_probes_patch(const Ctx &c, int fpelx,
 __device__ __forceinline__ unsigned subpel_decide(const CostCtx &cc, int effort, unsigned mr, unsigned dirs, int &sub_x, int &sub_y, int fpelx, int fpely,
                                                   unsigned best, int bw, int bh)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const unsigned yarea = (unsigned) (bw * bh);
     const int area_ratio = (int) div_nn(8u * 256u, yarea), iarea_ratio = (int) (8 * yarea / 256);
     best = best * (unsigned) area_ratio >> 3;
@@ -914,7 +925,7 @@ struct RowAcc {
     bool par_open = false, par_inl = false; // (par_inl: per lane)
     __device__ __forceinline__ void flush(int *counters)
     {
-        if ((threadIdx.x & 63) == 0) {
+        if (hme_lane() == 0) {
             if (intra) {
                 atomicAdd(&counters[0], intra);
             }
@@ -959,14 +970,15 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
 // 0 = 4:4:4 (16x16 like the luma: every lane owns the quad (qi, qj) of U and of V),
 // 2 = 4:2:2 (8 wide, 16 high: 4 x 8 quads a plane -- lanes 0..31 own U's, lanes 32..63 V's)
 template <int CS, bool SPLIT, class Ctx>
-__device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
+__device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const Quad &a,
                                   bool act, int qi, int qj, int bx, int by, int bw, int bh, int lax, int lay, int motion_bias, bool good_enough,
                                   unsigned best, unsigned var_src, unsigned avg_src, const Psy &psy, const NbPre &pre, bool sp_done, unsigned sp_mr,
                                   unsigned sp_dirs)
 {
-    const int lane = threadIdx.x & 63;
+    Ctx c = fenced(c_in, 0);
+    const int lane = hme_lane();
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 16, y_h = 16;
-    const DPlane &ref0 = c.ref[0];
+    DPlane ref0 = c.ref[0];
     const int qw = bw >> 1, qh = bh >> 1;
     int fpelx = mv.u.mv.x, fpely = mv.u.mv.y, sx = 0, sy = 0;
     bool found_sub = false;
@@ -1023,6 +1035,8 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
     }
 
     HME_MARK(S, 5);
+    c = fenced(c_in, 0);
+    ref0 = c.ref[0];
     // ---- operands of the mode decision, one load round ----
     constexpr int CSH = CS == 0 ? 0 : 1, CSV = CS == 1 ? 1 : 0; // chroma shifts: horizontal, vertical
     const int cbx = (i * 16) >> CSH, cby = (j * 16) >> CSV;   // 16x16 luma blocks
@@ -1278,6 +1292,8 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
             }
         }
         HME_MARK(S, 6);
+        c = fenced(c_in, 0);
+        ref0 = c.ref[0];
         // ---- test_subblock_intra_y (hme.c:891), all four sub-blocks evaluated together ----
         {
             int rx = mv.u.mv.x, ry = mv.u.mv.y;
@@ -1360,6 +1376,8 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c, int i, int j, FastLds 
             }
         }
         HME_MARK(S, 7);
+        c = fenced(c_in, 0);
+        ref0 = c.ref[0];
         // ---- test_subblock_intra_c (hme.c:987) ----
         if (c.effort >= 6) {
             unsigned detail_c = (unsigned) div_nn(ipolvar, bw * bh);
@@ -1502,7 +1520,7 @@ __device__ __forceinline__ bool parent_average(bool pvalid, int pvx, int pvy, in
 // entry with that vector is a duplicate of it.  key: both components, int16 each.  Returns "this lane's entry is a duplicate".
 __device__ __forceinline__ bool dedup_lanes(bool exist, int key)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     bool dup = false;
     for (unsigned long long rest = __ballot(exist); rest;) {
         const int m = __ffsll((long long) rest) - 1;
@@ -1519,7 +1537,7 @@ template <bool L0, int NQ>
 __device__ __forceinline__ void refine_fpel(const DPlane &ref, const SrcBlk<NQ> &B, int level, const Psy &psy, const CostCtx &cc, unsigned qthresh, int &dx,
                                             int &dy, unsigned &best, bool &good_enough, FastLds &S)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const int bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
     const int step = 1 << level;
     unsigned metr0 = 0xffffffffu, metr1 = 0xffffffffu, metr2 = 0xffffffffu, metr3 = 0xffffffffu;
@@ -1594,7 +1612,7 @@ __device__ __forceinline__ void refine_fpel(const DPlane &ref, const SrcBlk<NQ> 
 // finished: its head is still in registers (acc.left_head).
 __device__ __forceinline__ MvHead load_neighbour_heads(DSV_MV *mvf, DSV_MV *out, int i, int j, int step, int nxb, int *counters, RowAcc &acc, bool &nb_ok)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const bool need_i = lane != 4, need_j = lane != 3;
     nb_ok = lane >= 3 && lane <= 5 && (!need_i || i > 0) && (!need_j || j > 0);
     const DSV_MV *np = nb_ok ? &mvf[(i - (need_i ? step : 0)) + (j - (need_j ? step : 0)) * nxb] : out;
@@ -1639,7 +1657,7 @@ __device__ __forceinline__ MvHead load_neighbour_heads(DSV_MV *mvf, DSV_MV *out,
 template <bool FULL, int NQ>
 __device__ __forceinline__ SrcBlk<NQ> load_src_blk(const DPlane &src, int bx, int by, int bw, int bh, int level, bool with_other, const DPlane &oth, Quad (&o)[NQ])
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     SrcBlk<NQ> B;
     B.bx = bx;
     B.by = by;
@@ -1675,14 +1693,16 @@ template <bool FULL, int NQ> __device__ __forceinline__ SrcBlk<NQ> load_src_blk(
 }
 
 template <bool FULL, int NQ, class Ctx>
-__device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+__device__ __forceinline__ void hme_block_lx_t(const Ctx &c_in, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
-    const int lane = threadIdx.x & 63;
+    Ctx c = fenced(c_in, level);
+    const int lane = hme_lane();
     const int qi = lane & 7, qj = lane >> 3;
     constexpr int BS = NQ == 4 ? 32 : 16;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = BS, y_h = BS;
     const int step = 1 << level;
-    const DPlane &src = c.src[level], &ref = c.ref[level], &ogr = c.ogr[level];
+    const DPlane src = c.src[level], ogr = c.ogr[level];
+    DPlane ref = c.ref[level];
     DSV_MV *mvf = c.mvf[level];
     const DSV_MV *parent = level < c.pyr_levels ? c.mvf[level + 1] : nullptr;
     DSV_MV *out = &mvf[i + j * nxb];
@@ -1837,6 +1857,8 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c, int level, int i, i
         }
     }
     if (!good_enough) {
+        c = fenced(c_in, level);
+        ref = c.ref[level];
         refine_fpel<false, NQ>(ref, B, level, psy, cc, qthresh, dx, dy, best, good_enough, S);
     }
     mv.u.mv.x = (int16_t) (dx * step);
@@ -1884,7 +1906,7 @@ constexpr unsigned long long kL0PreLanes = 0x1ffffc3ull; // lanes that own a pre
 
 template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block_t(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, uint32_t *rec)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const int qi = lane & 7, qj = lane >> 3;
     const int nxb = c.a.nbh, nyb = c.a.nbv;
     const DPlane &src = c.src[0], &ref = c.ref[0];
@@ -2006,12 +2028,14 @@ template <class Ctx> __device__ __forceinline__ void hme_l0_pre_block(const Ctx 
 // one kernel does everything, less work in total (no record, one set of loads) but a longer chain per block.  Which is better
 // depends on what the GPU is short of: with many pictures per launch and several lockstep groups it is work, with a few it is the chain.
 template <bool FULL, int CS, bool SPLIT, class Ctx>
-__device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+__device__ __forceinline__ void hme_block_l0_t(const Ctx &c_in, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
-    const int lane = threadIdx.x & 63;
+    Ctx c = fenced(c_in, 0);
+    const int lane = hme_lane();
     const int qi = lane & 7, qj = lane >> 3;
     const int nxb = c.a.nbh, nyb = c.a.nbv;
-    const DPlane &src = c.src[0], &ref = c.ref[0];
+    const DPlane src = c.src[0];
+    DPlane ref = c.ref[0];
     DSV_MV *mvf = c.mvf[0];
     DSV_MV *out = &mvf[i + j * nxb];
     DSV_MV mv = {};
@@ -2221,6 +2245,8 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c, int i, int j, int g
         }
     }
     HME_MARK(S, 3);
+    c = fenced(c_in, 0);
+    ref = c.ref[0];
     if (!good_enough) {
         refine_fpel<true, 1>(ref, B, 0, psy, cc, qthresh, dx, dy, best, good_enough, S);
     }

@@ -15,7 +15,7 @@
 // left / upper neighbour is the last quad column / row of the quadrant next door
 __device__ __forceinline__ void blk_grad_partials(const Quad (&q)[4], const bool (&act)[4], int qi, int qj, int &sum, int &sh, int &sv)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     sum = sh = sv = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -43,7 +43,7 @@ __device__ __forceinline__ void blk_grad_partials(const Quad (&q)[4], const bool
 template <class Ctx>
 __device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, int fpelx, int fpely, const SrcBlk<4> &B, const Psy &psy, unsigned &dirs)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = hme_lane();
     const int qi = B.qi, qj = B.qj, bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
     const DPlane &src = c.src[0], &ref = c.ref[0];
     int v4[4] = {0, 0, 0, 0};
@@ -116,14 +116,15 @@ __device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, in
 
 // sub-pel refinement + mode decision of a 32 x 32 block, 4:2:0 (hme.c:1598-1821): hme_l0_tail's arithmetic on four quadrants
 template <bool FULL, class Ctx>
-__device__ __forceinline__ void hme_l0_tail32(const Ctx &c, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const SrcBlk<4> &B,
+__device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const SrcBlk<4> &B,
                                               int lax, int lay, int motion_bias, bool good_enough, unsigned best, unsigned var_src, unsigned avg_src,
                                               const Psy &psy, const NbPre &pre)
 {
-    const int lane = threadIdx.x & 63;
+    Ctx c = fenced(c_in, 0);
+    const int lane = hme_lane();
     const int qi = B.qi, qj = B.qj, bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
     const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 32, y_h = 32;
-    const DPlane &ref0 = c.ref[0];
+    DPlane ref0 = c.ref[0];
     const int qw = bw >> 1, qh = bh >> 1;
     int fpelx = mv.u.mv.x, fpely = mv.u.mv.y, sx = 0, sy = 0;
     bool found_sub = false;
@@ -164,6 +165,8 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c, int i, int j, FastLd
         ratio = udiv_fast(best << 5, best_fp + !best_fp);
     }
     HME_MARK(S, 5);
+    c = fenced(c_in, 0);
+    ref0 = c.ref[0];
     // ---- operands of the mode decision, one load round ----
     const int cbx = (i * 32) >> 1, cby = (j * 32) >> 1;
     const int cbmx = cbx + sarx(fpelx, 1), cbmy = cby + sarx(fpely, 1);
@@ -382,6 +385,8 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c, int i, int j, FastLd
             }
         }
         HME_MARK(S, 6);
+        c = fenced(c_in, 0);
+        ref0 = c.ref[0];
         // ---- test_subblock_intra_y (hme.c:891), all four sub-blocks evaluated together ----
         {
             int rx = mv.u.mv.x, ry = mv.u.mv.y;
@@ -477,6 +482,8 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c, int i, int j, FastLd
             }
         }
         HME_MARK(S, 7);
+        c = fenced(c_in, 0);
+        ref0 = c.ref[0];
         // ---- test_subblock_intra_c (hme.c:987) ----
         if (c.effort >= 6) {
             unsigned detail_c = (unsigned) div_nn(ipolvar, bw * bh);
@@ -549,11 +556,13 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c, int i, int j, FastLd
 }
 
 // the block of the row pipeline (hme_block_l0_t's in-place form) for a 32 x 32 block
-template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_t(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_t(const Ctx &c_in, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
-    const int lane = threadIdx.x & 63;
+    Ctx c = fenced(c_in, 0);
+    const int lane = hme_lane();
     const int nxb = c.a.nbh, nyb = c.a.nbv;
-    const DPlane &src = c.src[0], &ref = c.ref[0];
+    const DPlane src = c.src[0];
+    DPlane ref = c.ref[0];
     DSV_MV *mvf = c.mvf[0];
     DSV_MV *out = &mvf[i + j * nxb];
     DSV_MV mv = {};
@@ -689,6 +698,8 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_
         }
     }
     HME_MARK(S, 3);
+    c = fenced(c_in, 0);
+    ref = c.ref[0];
     if (!good_enough) {
         refine_fpel<true, 4>(ref, B, 0, psy, cc, qthresh, dx, dy, best, good_enough, S);
     }
