@@ -1036,9 +1036,12 @@ def main():
         # bytes of SURVEY.md 8(d) moved in that span
         per_unit = {STAGES[i]: (stage_ms[i] / stage_units[i] if stage_units[i] else 0.0) for i in range(NST)}
         total_ms = {STAGES[i]: stage_ms[i] for i in range(8)}
-        dom = max(total_ms, key=lambda k: total_ms[k])
-        if dom == "hme":
-            dom = "hme_level0"  # the dominant KERNEL: the level-0 launch of the search (its span is measured on its own)
+        # The dominant KERNEL is the level-0 launch of the search (its span is measured on its own): the largest single kernel of
+        # the rocprofv3 summary of this command (profiles/r05_rocprof_kernel_stats.txt).  The largest STAGE span is reported beside
+        # it -- a stage is several kernels (quantise + compact + entropy is ~25 launches per plane class), and under four
+        # concurrent groups its span is mostly the other groups' kernels sharing the chip.
+        largest_stage = max(total_ms, key=lambda k: total_ms[k])
+        dom = "hme_level0"
         i = STAGES.index(dom)
         nl = max(1, stage_launches[i])
         avg_launch_ms = stage_ms[i] / nl
@@ -1072,6 +1075,7 @@ def main():
                               "launches_per_step": round(nl / prof_steps * G, 1),
                               "algorithmic_bytes_per_launch": round(bytes_per_launch),
                               "stage_us_per_frame": {k: round(1e3 * v, 2) for k, v in per_unit.items()},
+                              "largest_stage_span": largest_stage,
                               "whole_frame_algorithmic_GBps": round(frame_bytes * fps / 1e9, 1),
                               "note": "the search is an integer kernel bound by instruction issue and dependent latencies, not by bandwidth: "
                                       "see roofline.issue for the roofline that binds the pipeline"}

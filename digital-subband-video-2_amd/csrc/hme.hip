@@ -1556,6 +1556,19 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
 // lockstep groups' streaming kernels -- whose bandwidth is their bytes in flight, i.e. their resident wavefronts -- then live
 // in what is left).  A row still only waits for a lower ticket, which a RUNNING worker holds (a worker takes its next ticket
 // after finishing its row), so the progress argument is unchanged.
+// The launch's arguments, read again from the kernel-argument segment for every row: six values that would otherwise sit in
+// scalar registers (or their spill lanes) through the whole persistent loop, with the reciprocals take_row derives from them.
+struct HmeRowsArgs {
+    const HmeDev *tab;
+    int level, nbx, parts, nstreams, nrows;
+};
+__device__ __forceinline__ HmeRowsArgs hme_rows_args()
+{
+    typedef const __attribute__((address_space(4))) HmeRowsArgs *ArgsK;
+    ArgsK p = (ArgsK) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return HmeRowsArgs{p->tab, p->level, p->nbx, p->parts, p->nstreams, p->nrows};
+}
 #ifdef DSV2_HME_WMAX
 #define HME_WMAX(W) DSV2_HME_WMAX
 #else
@@ -1563,10 +1576,14 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
 #endif
 #define HME_ROWS_P(NAME, WAVES, LEVEL_EXPR, ...)                                                                         \
     __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, HME_WMAX(WAVES)))) void NAME(                       \
-        const HmeDev *__restrict__ tab, int level, int nbx, int parts, int nstreams, int nrows)                          \
+        const HmeDev *__restrict__, int, int, int, int, int)                                                             \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
         for (;;) {                                                                                                       \
+            const HmeRowsArgs a_ = hme_rows_args();                                                                      \
+            const HmeDev *tab = a_.tab;                                                                                  \
+            const int level = a_.level, nbx = a_.nbx, parts = a_.parts, nstreams = a_.nstreams, nrows = a_.nrows;        \
+            (void) level;                                                                                                \
             const RowTicket t_ = take_row(tab, LEVEL_EXPR, nstreams, nrows, parts);                                      \
             if (t_.row < 0) {                                                                                            \
                 return;                                                                                                  \
