@@ -71,8 +71,8 @@ def stage_bytes(w, h, fmt):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSV2_STREAMS", "768")),
                     help="independent closed-GOP streams (encoder instances) per GPU")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("DSV2_GROUPS", "4")),
@@ -907,6 +907,9 @@ def main():
         thr1 = thread_cpu()
         rows = sorted(((thr1[t][1] - thr0.get(t, (None, 0.0))[1], thr1[t][0], t) for t in thr1), reverse=True)
         sys.stderr.write("[bench] host CPU by thread over %.2f s: %s\n" % (elapsed, ", ".join("%s/%d %.2f" % (nm, t, d) for d, nm, t in rows[:24] if d > 0.005)))
+    if os.environ.get("DSV2_BENCH_STEP_SERIES"):  # drift inside the timed region: mean step time of each group, per dozen steps
+        for g, ser in enumerate(run.step_ms):
+            sys.stderr.write("[bench] group %d step ms per dozen: %s\n" % (g, " ".join("%.1f" % (sum(ser[i:i + 12]) / max(1, len(ser[i:i + 12]))) for i in range(0, len(ser), 12))))
     step_ms = sorted(x for g in run.step_ms for x in g)
     in_call_share = [round(x / elapsed, 3) for x in run.in_call_s]
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
