@@ -1301,7 +1301,7 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     return cfgs
 
 
-BATCH_POINTS = [(1, 1), (8, 4), (16, 4), (48, 4), (192, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets
+BATCH_POINTS = [(1, 1), (8, 4), (16, 4), (48, 4), (192, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets (groups: 4 re-measured against 1 - 24 per point, tools/probe/few_streams_groups.sh -- every lockstep group adds its ~100 launches per step to ONE submission path: 8 streams in 8 groups deliver 0.6 x what they do in 4)
 
 
 def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks):

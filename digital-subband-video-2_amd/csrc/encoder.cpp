@@ -1462,11 +1462,12 @@ struct TaskCpu {
 };
 TaskCpu g_task_cpu;
 
-// The search token.  The motion search runs at a fixed two wavefronts per SIMD and is bound by how many of those slots it
-// holds for how long; every other kernel of a step lives in the other half of the register file.  Lockstep groups that
-// reach their search phase together share the slots (each search takes twice as long) and then reach their G2 phases
-// together too, with the search slots idle meanwhile: a convoy, and a stable one.  With the token at most
-// DSV2_SEARCH_SLOTS groups (default 1; 0 = unlimited) have a search in flight; the others wait with their pre-search work
+// The search token.  The motion search runs at a fixed number of wavefronts per SIMD (3 072 persistent workers: three) and is
+// bound by how many of those slots it holds for how long; every other kernel of a step lives in the rest of the register file.
+// Lockstep groups that reach their search phase together share the slots (each search takes twice as long) and then reach their
+// G2 phases together too, with the search slots idle meanwhile: a convoy, and a stable one.  With the token at most
+// ONE group has a search in flight (re-measured with the round-5 kernels: without it 8 780 against 8 950 frames/s; the coarse
+// levels outside it: 8 810); the others wait with their pre-search work
 // (ingest, pyramids) already enqueued, and the searches of the groups follow one another back to back while the rest of
 // each step runs beside them.
 struct SearchToken {
@@ -1826,12 +1827,12 @@ static void enc_batch_step(Job *jobs, int n)
         hme_run_batch(bs, hf.data(), hp.data(), (int) pjobs.size(), sc.h_hme, sc.d_hme, nullptr, -1, 0, HME_PREPARE);
     }
     prof.end(bs, ST_INGEST, n);
-    // (only launches that keep the chip's 2 048 search slots full for most of their length take the token: a row-pipelined
+    // (only launches that keep the chip's search slots -- 3 072 persistent workers -- full for most of their length take the token: a row-pipelined
     // launch ramps up and down over one picture's critical path, ~2 ms whatever the batch, and launches of a few dozen
     // pictures hide each other's ramps when they overlap)
     // (Until the end of round 4 the bound was 8 192 rows.  Re-measured with the persistent kernels: 4 groups of 3 264 rows -- 192
     // streams -- gain 3 % from the token, 6 880 -> 7 090 frames/s, 4 groups of 6 528 rows 3.4 %; at 2 176 rows a group the token
-    // costs 3 %, at 816 it makes no difference.  One and a half sets of the 2 048 persistent workers it is.)
+    // costs 3 %, at 816 it makes no difference.  3 072 rows it is: one set of the persistent workers.)
     constexpr int min_rows = 3072;
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
     SearchTokenGuard token;

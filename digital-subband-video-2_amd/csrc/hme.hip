@@ -2226,7 +2226,12 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     for (int level = level_hi; (phases & HME_LEVELS) && level >= level_lo; level--) {
         const int step = 1 << level;
         const int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
-        const int workers = std::min(g_hme_persist > 0 ? g_hme_persist : 3072, n * nby);
+        // (three workers per SIMD for the kernels whose wavefronts are small enough to share a SIMD with the other groups' kernels;
+        // the 32 x 32 forms and the general routine hold 123 - 224 registers -- two per SIMD is all that fits, and a third set of
+        // workers only queues: 2160p 1 480 -> 1 360 frames/s with 3 072)
+        const bool two_per_simd = (b32 && fast_level(level)) || !fast_level(level);
+        const int persist = g_hme_persist > 0 ? g_hme_persist : 3072;
+        const int workers = std::min(two_per_simd ? std::min(persist, 2048) : persist, n * nby);
         if (level == 0 && g.pyr_levels == 0 && split) { // (no level above: the pre-pass has nothing to wait for)
             DSV2_LAUNCH(k_hme_l0_pre_b, dim3((nbx * nby + 1) / 2, n), dim3(64), 0, s, tab, nbx, nby, 2);
         }

@@ -157,7 +157,7 @@ print(json.dumps(T.run_once(hip, frames, 32, 2, pinned)))
 def test_alternative_forms_agree(env_extra):
     """the same streams in a process where a stage runs its other form: the search with the general block routine at every level
     (the reference's block loop with wave-cooperative primitives: no pre-passes, no fast routines); the row pipeline with 64
-    persistent workers instead of 2 048 (rows queue for workers: the ticket order is all that keeps it moving); the in-loop
+    persistent workers instead of 3 072 (rows queue for workers: the ticket order is all that keeps it moving); the in-loop
     filter's luma sweep with a lane per cell / a lane pair per cell whatever the batch; the in-loop filters' global-memory
     kernels (no LDS ring)"""
     frames = gen_inputs()
