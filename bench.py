@@ -840,7 +840,7 @@ def main():
     if extras:
         specs += [(1280, 720, "420", 101 + k, 24) for k in range(4)]
         specs += [(W_, H_, "444", 201, 12)]
-        specs += [(3840, 2160, "420", 301 + k, 10) for k in range(2)]
+        specs += [(3840, 2160, "420", 301 + k, 16) for k in range(2)]
     t_gen = time.perf_counter()
     under_profiler = under_profiler_()
     gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(16, ncpu_box // (1 if locality["bound"] else max(1, world)))))
@@ -1293,10 +1293,10 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     leg("c4_1080p_444_lossless", r4, 2, 8, 10, {"frames": "P frames 2..9 of each stream (4:4:4 instance of the fast level-0 search)"})
     cfgs["c4_1080p_444_lossless"]["round_trip"] = lossless_round_trip(hip, A, r4, vids[NV + 4])
     r4.free()
-    # 3840x2160 4:2:0: 32 x 32 blocks (dsv_encoder.c:1203-1211) -- level 0 of the search takes the GENERAL block routine
-    # (csrc/hme.hip k_hme_rows_b_w2: hme_block on operands staged in LDS; no fast form for 32-pixel blocks yet); every stream from its first (intra) picture
-    r5 = EncodeRun(hip, A, torch, 3840, 2160, "420", 60, 48, 10, min(32, S), min(4, args.groups), vids[NV + 5:NV + 7], False, seeds=[301, 302])
-    leg("c_2160p_420_qp60_gop48", r5, 2, 6, 8, {"frames": "P frames 2..7 of each stream; 32 x 32 blocks: general level-0 block routine"})
+    # 3840x2160 4:2:0: 32 x 32 blocks (dsv_encoder.c:1203-1211) -- the search's 32 x 32 forms (csrc/hme_fast32.h: k_hme_rows_l0_32, k_hme_rows_lx32);
+    # every stream from its first (intra) picture; 64 streams = 16 pictures per launch in four groups
+    r5 = EncodeRun(hip, A, torch, 3840, 2160, "420", 60, 48, 10, min(64, S), min(4, args.groups), vids[NV + 5:NV + 7], False, seeds=[301, 302])
+    leg("c_2160p_420_qp60_gop48", r5, 2, 12, 8, {"frames": "P frames 2..13 of each stream; 32 x 32 blocks: the search's 32 x 32 block routines"})
     r5.free()
     return cfgs
 

@@ -1558,10 +1558,13 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
 // after finishing its row), so the progress argument is unchanged.
 // The launch's arguments, read again from the kernel-argument segment for every row: six values that would otherwise sit in
 // scalar registers (or their spill lanes) through the whole persistent loop, with the reciprocals take_row derives from them.
-struct HmeRowsArgs {
+struct HmeRowsArgs { // (the HME_ROWS_P kernels' parameter list, in its order: the kernel-argument segment is read AS this struct)
     const HmeDev *tab;
     int level, nbx, parts, nstreams, nrows;
 };
+static_assert(offsetof(HmeRowsArgs, tab) == 0 && offsetof(HmeRowsArgs, level) == 8 && offsetof(HmeRowsArgs, nbx) == 12 && offsetof(HmeRowsArgs, parts) == 16 &&
+                  offsetof(HmeRowsArgs, nstreams) == 20 && offsetof(HmeRowsArgs, nrows) == 24,
+              "HmeRowsArgs: not the layout of (const HmeDev *, int, int, int, int, int) in the kernel-argument segment");
 __device__ __forceinline__ HmeRowsArgs hme_rows_args()
 {
     typedef const __attribute__((address_space(4))) HmeRowsArgs *ArgsK;
@@ -1592,14 +1595,20 @@ __device__ __forceinline__ HmeRowsArgs hme_rows_args()
             __syncthreads();                                                                                             \
         }                                                                                                                \
     }
+#ifndef DSV2_HME32_L0_WAVES
+#define DSV2_HME32_L0_WAVES 3
+#define DSV2_HME32_LX_WAVES 4
+#endif
 HME_ROWS_P(k_hme_rows_l0, 4, 0, ROW_FAST_L0, 1, false)
 HME_ROWS_P(k_hme_rows_l0_444, 4, 0, ROW_FAST_L0, 0, false)
 HME_ROWS_P(k_hme_rows_l0_422, 4, 0, ROW_FAST_L0, 2, false)
 HME_ROWS_P(k_hme_rows_l0s, 4, 0, ROW_FAST_L0, 1, true) // ... with the neighbour-independent half from the pre-pass (k_hme_l0_pre_b)
 HME_ROWS_P(k_hme_rows_l0s_444, 4, 0, ROW_FAST_L0, 0, true)
 HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
-HME_ROWS_P(k_hme_rows_l0_32, 2, 0, ROW_FAST_L0_32)
-HME_ROWS_P(k_hme_rows_lx32, 2, level, ROW_FAST_LX32) // (36 reference quads live in a refinement round: two wavefronts per SIMD, as the general kernel)
+// (the 32 x 32 forms: 143 and 123 registers -- three and four wavefronts per SIMD; at two each, as until late in round 5, the
+// 2160p leg ran 5 % slower: 1 850 against 1 940 frames/s at 64 streams)
+HME_ROWS_P(k_hme_rows_l0_32, DSV2_HME32_L0_WAVES, 0, ROW_FAST_L0_32)
+HME_ROWS_P(k_hme_rows_lx32, DSV2_HME32_LX_WAVES, level, ROW_FAST_LX32)
 HME_ROWS_P(k_hme_rows_general, 2, level, ROW_GENERAL)
 static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 3072;
 // DSV2_HME_SPLIT: level 0 with its neighbour-independent half in an unordered pre-pass (1) or in place (0); default: by launch size
@@ -2227,9 +2236,8 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         const int step = 1 << level;
         const int nbx = (g.a.nbh + step - 1) / step, nby = (g.a.nbv + step - 1) / step;
         // (three workers per SIMD for the kernels whose wavefronts are small enough to share a SIMD with the other groups' kernels;
-        // the 32 x 32 forms and the general routine hold 123 - 224 registers -- two per SIMD is all that fits, and a third set of
-        // workers only queues: 2160p 1 480 -> 1 360 frames/s with 3 072)
-        const bool two_per_simd = (b32 && fast_level(level)) || !fast_level(level);
+        // the general routine holds 224 registers -- two per SIMD is all that fits, a third set of workers would only queue)
+        const bool two_per_simd = !fast_level(level);
         const int persist = g_hme_persist > 0 ? g_hme_persist : 3072;
         const int workers = std::min(two_per_simd ? std::min(persist, 2048) : persist, n * nby);
         if (level == 0 && g.pyr_levels == 0 && split) { // (no level above: the pre-pass has nothing to wait for)
