@@ -2345,21 +2345,6 @@ __global__ __launch_bounds__(256) void k_inter_filters_g(const McJob *__restrict
     }
 }
 
-// the two chroma planes of a batch on their own (no LDS: beside the ring kernels' luma-only launch)
-__global__ __launch_bounds__(256) void k_chroma_filters_b(const McJob *__restrict__ tab)
-{
-    DSV2_KERNEL_PRIO();
-    const McJob &jb = tab[blockIdx.x];
-    const int c = 1 + (int) blockIdx.y;
-    const DPlane dp = jb.res.p[c];
-    const FilterParams f = jb.f;
-    const DSV_MV *vecs = jb.mvs;
-    if (f.lossless) {
-        return;
-    }
-    sweep_fronts(f.nbh, f.nbv, [&](int i, int j) { chroma_block(dp, f, vecs, i, j); });
-}
-
 __global__ __launch_bounds__(256) void k_intra_filter_g(const McJob *__restrict__ tab)
 {
     const McJob &jb = tab[blockIdx.x];
@@ -2536,24 +2521,6 @@ void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nb
     }
 }
 
-#ifndef DSV2_FILT_LDS_PAD
-#define DSV2_FILT_LDS_PAD 0
-#endif
-#ifndef DSV2_FILT_SPLIT_CHROMA
-#define DSV2_FILT_SPLIT_CHROMA 0
-#endif
-// the lane-per-cell ring sweep of a batch (the many-pictures form)
-static void launch_inter_filters_b(hipStream_t s, const McJob *d_tab, int n, unsigned lds)
-{
-    const unsigned req = DSV2_FILT_LDS_PAD && n <= 256 && lds < DSV2_FILT_LDS_PAD ? (unsigned) DSV2_FILT_LDS_PAD : lds;
-    if (DSV2_FILT_SPLIT_CHROMA) {
-        DSV2_LAUNCH(k_inter_filters_b, dim3(n, 1), dim3(256), req, s, d_tab, lds);
-        DSV2_LAUNCH(k_chroma_filters_b, dim3(n, 2), dim3(256), 0, s, d_tab);
-    } else {
-        DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), req, s, d_tab, lds);
-    }
-}
-
 void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_w, int blk_h)
 {
     if (n > 0) {
@@ -2568,7 +2535,7 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
             } else if (filter_pair(n)) {
                 DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), lds, s, d_tab, lds);
             } else {
-                launch_inter_filters_b(s, d_tab, n, lds);
+                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), lds, s, d_tab, lds);
             }
         }
     }
@@ -2589,7 +2556,7 @@ void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, 
             } else if (filter_pair(n)) {
                 DSV2_LAUNCH(k_inter_filters_b2, dim3(n, 3), dim3(512), lds, s, d_filt, lds);
             } else {
-                launch_inter_filters_b(s, d_filt, n, lds);
+                DSV2_LAUNCH(k_inter_filters_b, dim3(n, 3), dim3(256), lds, s, d_filt, lds);
             }
         }
     }
