@@ -406,6 +406,60 @@ template <class JobT> class Coalescer {
     Stats st_;
 };
 
+// A first-come-first-served token with a bounded wait (the encoder's search token, encoder.cpp).  A waiter that gives up RETIRES
+// its ticket: `serving` never stops at a ticket nobody is waiting with, so one time-out fails one call and the next waiter still
+// gets the token when the holder lets go (advisor, round 5: the abandoned ticket parked every later waiter for good).
+// CPU harness: tests/coalescer_harness.cpp ("token_timeout").
+struct FifoToken {
+    struct TimedOut {};
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_slots = 1;
+    unsigned long long next_ticket = 0, serving = 0;
+    std::vector<unsigned long long> retired; // tickets beyond `serving` whose waiters gave up
+    void skip_retired() // (mu held)
+    {
+        for (;;) {
+            auto it = std::find(retired.begin(), retired.end(), serving);
+            if (it == retired.end()) {
+                return;
+            }
+            retired.erase(it);
+            serving++;
+        }
+    }
+    template <class Rep, class Period> void acquire(std::chrono::duration<Rep, Period> patience)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long mine = next_ticket++;
+        if (!cv.wait_for(lk, patience, [&] { return free_slots > 0 && serving == mine; })) {
+            if (serving == mine) {
+                serving++;
+                skip_retired();
+            } else {
+                retired.push_back(mine);
+            }
+            lk.unlock();
+            cv.notify_all(); // whoever is next in line may have been waiting for this ticket only
+            throw TimedOut{};
+        }
+        serving++;
+        skip_retired();
+        free_slots--;
+        if (free_slots > 0) {
+            cv.notify_all(); // (more than one slot: the next in line may go as well)
+        }
+    }
+    void release()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_slots++;
+        }
+        cv.notify_all();
+    }
+};
+
 template <class F> inline void parallel_for(int n, F fn)
 {
     if (n == 1) {

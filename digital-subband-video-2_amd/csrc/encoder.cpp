@@ -1073,8 +1073,26 @@ ScratchPool g_scratch_pool;
 thread_local BatchScratch *t_last_scratch = nullptr;
 struct ScratchLease {
     BatchScratch *sc = g_scratch_pool.acquire(t_last_scratch);
+    const int unwinding = std::uncaught_exceptions();
     ScratchLease() { t_last_scratch = sc; }
-    ~ScratchLease() { g_scratch_pool.release(sc); }
+    ~ScratchLease()
+    {
+        // A step that FAILS (StepFailed) leaves with work enqueued or running on this scratch's streams, reading the pinned and
+        // device job tables: they are drained before another group may overwrite the tables; a scratch whose streams do not
+        // drain is never handed out again (leaked on purpose: its owner's encoders are dead, the process is not).
+        if (std::uncaught_exceptions() > unwinding) {
+            bool ok = true;
+            for (hipStream_t s : {sc->main, sc->aux[0], sc->aux[1], sc->copy_stream}) {
+                ok = ok && (!s || hipStreamSynchronize(s) == hipSuccess);
+            }
+            if (!ok) {
+                fprintf(stderr, "[dsv2hip] a failed step's streams did not drain: its batch scratch is retired\n");
+                t_last_scratch = nullptr;
+                return;
+            }
+        }
+        g_scratch_pool.release(sc);
+    }
 };
 
 // A step that cannot finish (the search token never comes, a search reports a time-out) fails the CALLS that are part of it --
@@ -1470,48 +1488,19 @@ TaskCpu g_task_cpu;
 // levels outside it: 8 810); the others wait with their pre-search work
 // (ingest, pyramids) already enqueued, and the searches of the groups follow one another back to back while the rest of
 // each step runs beside them.
-struct SearchToken {
-    std::mutex mu;
-    std::condition_variable cv;
-    int free_slots = 1;
-    const bool on = true;
-    // first come, first served (DSV2_SEARCH_FIFO=0: whoever the condition variable wakes first): a group that has waited longest
-    // searches next, so the groups keep their rotation and none of them falls a step behind the others
-    const bool fifo = true;
-    unsigned long long next_ticket = 0, serving = 0;
+struct SearchToken { // first come, first served: the group that has waited longest searches next, so the groups keep their rotation
+    FifoToken tok;
     void acquire()
     {
-        if (!on) {
-            return;
-        }
-        std::unique_lock<std::mutex> lk(mu);
-        const unsigned long long mine = next_ticket++;
         // bounded: a holder that never lets go (a search that hangs, a bug between acquire and release) must not park every
-        // other lockstep group of the process silently
-        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return free_slots > 0 && (!fifo || serving == mine); })) {
+        // other lockstep group of the process silently; the waiter that gives up retires its ticket (batch.h)
+        try {
+            tok.acquire(std::chrono::seconds(120));
+        } catch (const FifoToken::TimedOut &) {
             throw StepFailed{"search token not released within 120 s (another lockstep group's motion search never finished)"};
         }
-        if (fifo) {
-            serving++;
-        } else {
-            serving = next_ticket;
-        }
-        free_slots--;
-        if (fifo && free_slots > 0) {
-            cv.notify_all(); // (more than one slot: the next in line may go as well)
-        }
     }
-    void release()
-    {
-        if (!on) {
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            free_slots++;
-        }
-        cv.notify_all();
-    }
+    void release() { tok.release(); }
 };
 SearchToken g_search_token;
 struct SearchTokenGuard { // releases on every way out of the scope that took the token
@@ -1542,21 +1531,35 @@ static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") 
 static std::atomic<long> g_list_growths{0}; // pictures that had more symbols than their stream's compaction lists (dsv2hip_enc_list_growths)
 static const bool kFusedCount = true;
 
+// tests: fail the next step of this process on purpose (dsv2hip_test_fail_next_step): 1 = as a search that did not deliver its
+// counters (thrown behind H1a, the search drained), 2 = as a search token that never came (thrown with the step's ingest,
+// pyramids and source pre-pass still enqueued on the stream)
+static std::atomic<int> g_fail_next_step{0};
+void dsv2hip_test_fail_next_step(int how) { g_fail_next_step.store(how); }
+
 static void enc_batch_step(Job *jobs, int n);
-void enc_batch(Job *jobs, int n)
+bool enc_batch_ok(Job *jobs, int n)
 {
     try {
         enc_batch_step(jobs, n);
+        return true;
     } catch (const StepFailed &e) {
+        // (the step's scratch has drained its streams on the way here: ScratchLease)
         fprintf(stderr, "[dsv2hip] encode step of %d stream(s) FAILED: %s; these encoders return no packets from now on\n", n, e.what);
         for (int k = 0; k < n; k++) {
             jobs[k].nbuf = 0;
+            if (jobs[k].frame) { // not yet released by the step (dsv_encoder.c:1457 releases it on every path)
+                dsv_frame_ref_dec(jobs[k].frame);
+                jobs[k].frame = nullptr;
+            }
             if (jobs[k].enc->ref) {
                 ((EncImpl *) jobs[k].enc->ref)->dead = true;
             }
         }
+        return false;
     }
 }
+void enc_batch(Job *jobs, int n) { (void) enc_batch_ok(jobs, n); }
 
 static void enc_batch_step(Job *jobs, int n)
 {
@@ -1836,6 +1839,9 @@ static void enc_batch_step(Job *jobs, int n)
     constexpr int min_rows = 3072;
     const bool searching = !pjobs.empty() && (int) pjobs.size() * nbv >= min_rows;
     SearchTokenGuard token;
+    if (g_fail_next_step.load() == 2 && g_fail_next_step.exchange(0) == 2) {
+        throw StepFailed{"search token not released (test hook)"};
+    }
     if (searching) {
         // the token is for the search alone: what precedes it on the stream (this step's upload, ingest, pyramids) is waited
         // for BEFORE taking it, or the holder would sit on the token while its own pictures are still crossing PCIe.
@@ -1900,11 +1906,15 @@ static void enc_batch_step(Job *jobs, int n)
     for (int k = 0; k < n; k++) {
         if (jobs[k].frame) {
             dsv_frame_ref_dec(jobs[k].frame); // the caller's pixels are in HBM now (dsv_encoder.c:1457)
+            jobs[k].frame = nullptr;
         }
     }
 
     // ---- H1 ----
     parallel_for(n, [&](int k) { g_task_cpu.run(0, [&] { phase_h1a(jobs[k]); }); });
+    if (g_fail_next_step.load() == 1 && g_fail_next_step.exchange(0) == 1) {
+        jobs[0].failed = 2;
+    }
     for (int k = 0; k < n; k++) {
         if (jobs[k].failed) {
             throw StepFailed{jobs[k].failed == 1 ? "motion estimation row pipeline timed out (a row waited > 4 s for the row above)"
@@ -2516,11 +2526,11 @@ int dsv2hip_enc_batch(int n, DSV_ENCODER **encs, const void *const *dev_planar, 
         jobs[(size_t) k].dev_planar = (const uint8_t *) dev_planar[k];
         jobs[(size_t) k].bufs = bufs + 4 * k;
     }
-    enc_batch(jobs.data(), n);
+    const bool ok = enc_batch_ok(jobs.data(), n);
     for (int k = 0; k < n; k++) {
         nbufs[k] = jobs[(size_t) k].nbuf;
     }
-    return 0;
+    return ok ? 0 : -1; // a failed step: every nbufs[k] is 0, the encoders are dead
 }
 
 /* the same with the pictures in HOST memory (packed planar Y, U, V).  host_planar[k]: stream k's picture of this
@@ -2549,11 +2559,11 @@ int dsv2hip_enc_batch_host(int n, DSV_ENCODER **encs, const void *const *host_pl
         jobs[(size_t) k].host_next = host_next ? (const uint8_t *) host_next[k] : nullptr;
         jobs[(size_t) k].bufs = bufs + 4 * k;
     }
-    enc_batch(jobs.data(), n);
+    const bool ok = enc_batch_ok(jobs.data(), n);
     for (int k = 0; k < n; k++) {
         nbufs[k] = jobs[(size_t) k].nbuf;
     }
-    return 0;
+    return ok ? 0 : -1; // a failed step: every nbufs[k] is 0, the encoders are dead
 }
 
 /* packed pictures handed to this encoder (dsv2hip_enc_device_frame / _batch / _batch_host) are interleaved UYVY 4:2:2

@@ -743,7 +743,6 @@ __device__ __forceinline__ unsigned subpel_probes_patch(const Ctx &c, int fpelx,
     const int lane = hme_lane();
     const DPlane &ref = c.ref[0];
     typedef const __attribute__((address_space(1))) uint8_t *gb_t;
-    typedef const __attribute__((address_space(1))) uint2v_t *gu2_t; // (may be unaligned: the hardware splits the access)
     uint32_t lo[6], hi[6];
     {
         gb_t g = (gb_t) at(ref, bx + fpelx - 2, by + fpely - 2);
@@ -1913,7 +1912,6 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_l0_pre_block
     const DSV_MV *parent = c.pyr_levels > 0 ? c.mvf[1] : nullptr;
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
-    const int qw = bw >> 1, qh = bh >> 1;
     const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0);
     const bool act = B.act[0];
     const Quad a = B.a[0];
@@ -2042,7 +2040,6 @@ __device__ __forceinline__ void hme_block_l0_t(const Ctx &c_in, int i, int j, in
     HME_COUNT(S, 10, 1);
     const int bx = i * 16, by = j * 16;
     const int bw = FULL ? 16 : min(src.w - bx, 16), bh = FULL ? 16 : min(src.h - by, 16);
-    const int qw = bw >> 1, qh = bh >> 1;
     const SrcBlk<1> B = load_src_blk<FULL, 1>(src, bx, by, bw, bh, 0);
     const bool act = B.act[0];
     const Quad a = B.a[0];

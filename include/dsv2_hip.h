@@ -411,6 +411,11 @@ long dsv2hip_enc_list_growths(void);
 /* Device allocations that did not fit their instance's one-block arena (the block's size is an estimate): 0 unless the estimate has
  * drifted from the allocations it stands for. */
 long dsv2hip_arena_fallbacks(void);
+/* Test hook: the NEXT lockstep step of this process fails on purpose -- how = 1: as a motion search that did not deliver its
+ * counters (the search has drained), how = 2: as a search token that never came (ingest / pyramids still enqueued).  The
+ * failed step drains its streams before its job tables go back to the pool, releases the callers' frames, marks its encoders
+ * dead; dsv_enc returns 0, the batch calls return -1 with every nbufs[k] = 0 (tests/test_gpu_robustness.py). */
+void dsv2hip_test_fail_next_step(int how);
 /* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
  * off at any time (resets the totals).  dsv2hip_prof_read fills 9 entries (ingest+pyramid, HME,
  * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend, and -- inside HME -- the level-0

@@ -9,10 +9,13 @@
  *   - one independent work item per block, written as straight-line control code over a
  *     small set of block primitives (metric / SSE / statistics), which the GPU evaluates
  *     cooperatively across one wavefront;
- *   - blocks of a level are visited in ANTI-DIAGONAL order (all blocks with equal
- *     i/step + j/step form a front): a block only reads the vectors of its left, top and
- *     top-left neighbours at the same level (candidate list :1218-1226, MV predictor
- *     dsv.c:375, neighbour difference dsv.c:404), so the fronts reproduce the raster order;
+ *   - the ORDER in which blocks of a level may be evaluated: a block only reads the vectors of
+ *     its left, top and top-left neighbours at the same level (candidate list :1218-1226, MV
+ *     predictor dsv.c:375, neighbour difference dsv.c:404).  This restatement walks the
+ *     anti-diagonal fronts (all blocks with equal i/step + j/step), one legal order; the
+ *     kernels (csrc/hme.hip: k_hme_rows_*) walk another -- a ROW PIPELINE: one wavefront per
+ *     block row, left to right, each block waiting for the heads of its top / top-left
+ *     neighbours.  Both reproduce the reference's raster order;
  *   - the half/quarter-pel search never materialises the 68x68 quarter-pel image: every
  *     quarter-pel sample is derived on the fly from the 34x34 half-pel image.
  */

@@ -171,6 +171,76 @@ static Result silent_leaver()
     return r;
 }
 
+// the search token (batch.h: FifoToken): a holder that keeps it, a waiter that gives up after 50 ms, three more in line behind it.
+// When the holder lets go every one of the three gets the token, in the order they asked (advisor finding, round 5: the ticket
+// the first waiter abandoned was never served and every later waiter timed out too).
+static Result token_timeout()
+{
+    FifoToken tok;
+    std::atomic<int> timed_out{0}, got{0}, order_wrong{0};
+    std::atomic<int> last{-1};
+    const auto t0 = std::chrono::steady_clock::now();
+    tok.acquire(std::chrono::seconds(1)); // the holder
+    std::thread quitter([&] {
+        try {
+            tok.acquire(std::chrono::milliseconds(50));
+            got++;
+            tok.release();
+        } catch (const FifoToken::TimedOut &) {
+            timed_out++;
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    std::vector<std::thread> later;
+    for (int t = 0; t < 3; t++) {
+        later.emplace_back([&, t] {
+            try {
+                tok.acquire(std::chrono::seconds(5));
+                order_wrong += last.exchange(t) != t - 1;
+                got++;
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                tok.release();
+            } catch (const FifoToken::TimedOut &) {
+                timed_out++;
+            }
+        });
+        std::this_thread::sleep_for(std::chrono::milliseconds(10)); // (tickets in thread order)
+    }
+    quitter.join();                                              // gave up at ~50 ms, the holder still holding
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    tok.release();
+    for (auto &x : later) {
+        x.join();
+    }
+    // and a waiter that is FIRST in line when it gives up (its ticket == serving) must not stop the line either
+    tok.acquire(std::chrono::seconds(1));
+    std::thread front([&] {
+        try {
+            tok.acquire(std::chrono::milliseconds(20));
+            got++;
+            tok.release();
+        } catch (const FifoToken::TimedOut &) {
+            timed_out++;
+        }
+    });
+    front.join();
+    tok.release();
+    try {
+        tok.acquire(std::chrono::milliseconds(200));
+        got++;
+        tok.release();
+    } catch (const FifoToken::TimedOut &) {
+        timed_out++;
+    }
+    Result r{};
+    r.calls = (unsigned long long) got.load();       // 3 in line + the last one = 4
+    r.steps = (unsigned long long) timed_out.load(); // the two quitters = 2
+    r.wrong = order_wrong.load();
+    r.largest = tok.retired.size();                  // nothing left behind
+    r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return r;
+}
+
 static void print(const char *name, const Result &r, bool last)
 {
     printf("\"%s\": {\"calls\": %llu, \"steps\": %llu, \"largest\": %llu, \"waited_us\": %llu, \"wrong\": %d, \"mixed\": %d, \"seconds\": %.4f, "
@@ -188,7 +258,8 @@ int main(int argc, char **argv)
     print("two_keys", scenario(6, 30, {1, 1, 1, 2, 2, 2}, -1, 0), false);
     print("one_leaves", scenario(2, 60, {1, 1}, 1, 5), false);
     print("one_thread_four_instances", one_thread_many(4, 20), false);
-    print("silent_leaver", silent_leaver(), true);
+    print("silent_leaver", silent_leaver(), false);
+    print("token_timeout", token_timeout(), true);
     printf("}\n");
     return 0;
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/streams.json by running the REAL reference CLI (oracle/_ref/dsv2_ref, built
 from /root/reference/src) on the committed deterministic generator (digital-subband-video-2_amd/synth.py).
-Only hashes and sizes are stored.  Run in the build container:  python tests/make_golden.py
+Only hashes and sizes are stored.  Run in the build container:  python tests/make_golden.py [entry names: only these, the
+rest of the file is kept]
 """
 import hashlib
 import json
@@ -33,6 +34,8 @@ CONFIGS = [
     dict(name="x_720p_effort7", w=1280, h=720, fmt="420", seed=15, n=8, flags=["-qp=60", "-gop=48", "-effort=7"]),
     # 32 x 32 blocks (dsv_encoder.c:1203-1211): the four-quadrant block routine
     dict(name="x_2160p_ip", w=3840, h=2160, fmt="420", seed=16, n=3, flags=["-qp=60", "-gop=48"]),
+    # 32 x 16 blocks: wider than 1280 and not "mostly square" (dsv_encoder.c:1203-1209) -- cinema crops, 21:9
+    dict(name="x_1920x800_ip", w=1920, h=800, fmt="420", seed=17, n=6, flags=["-qp=60", "-gop=48"]),
 ]
 
 
@@ -42,9 +45,13 @@ def md5(b):
 
 def main():
     pkg = load_pkg()
-    out = {}
+    only = set(sys.argv[1:])
+    path = os.path.join(HERE, "golden", "streams.json")
+    out = json.load(open(path)) if only else {}
     with tempfile.TemporaryDirectory() as td:
         for c in CONFIGS:
+            if only and c["name"] not in only:
+                continue
             v = pkg.synth.SynthVideo(c["w"], c["h"], c["fmt"], seed=c["seed"])
             y4m = os.path.join(td, "in.y4m")
             pkg.synth.write_y4m(y4m, v, c["n"])
@@ -57,7 +64,7 @@ def main():
             out[c["name"]] = dict(c, input_md5=md5(src), dsv_bytes=len(stream), dsv_md5=md5(stream), decoded_md5=md5(dec),
                                   decoded_bytes=len(dec))
             print(c["name"], len(stream), md5(stream))
-    json.dump(out, open(os.path.join(HERE, "golden", "streams.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -29,6 +29,8 @@ def report(tmp_path_factory):
 
 def test_every_caller_gets_its_own_result_and_keys_never_mix(report):
     for name, r in report.items():
+        if name == "token_timeout":
+            continue
         assert r["wrong"] == 0, name
         assert r["mixed"] == 0, name
 
@@ -74,3 +76,14 @@ def test_an_instance_that_went_silent_ages_out_while_other_steps_run(report):
     own = r["calls"]  # (the other key's calls are counted too: the 40 calls of this key are what must not have waited)
     assert own >= 40
     assert r["waited_us"] < 40 * 100
+
+
+def test_a_token_waiter_that_gave_up_does_not_stop_the_line(report):
+    """advisor finding (round 5): SearchToken::acquire threw after its time-out with its FIFO ticket still in line; `serving`
+    never passed it and every later search step of the process waited 120 s and failed.  csrc/batch.h: FifoToken retires it."""
+    r = report["token_timeout"]
+    assert r["steps"] == 2    # the two waiters that were meant to time out, and nobody else
+    assert r["calls"] == 4    # everybody behind them got the token once the holder let go
+    assert r["wrong"] == 0    # in the order they asked
+    assert r["largest"] == 0  # no retired ticket left behind
+    assert r["seconds"] < 2.0

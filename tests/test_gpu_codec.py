@@ -106,6 +106,8 @@ OPTION_CASES = [
     dict(skip_block_thresh=-1),
     dict(skip_block_thresh=8),
     dict(block_size_override_x=1, block_size_override_y=1),   # 32x32 blocks on a small picture
+    dict(block_size_override_x=1, block_size_override_y=0),   # 32x16 blocks (dsv_encoder.c:1213-1220)
+    dict(block_size_override_x=0, block_size_override_y=1),   # 16x32 blocks
     dict(variable_i_interval=1, gop=4),
     dict(do_temporal_aq=0, do_dark_intra_boost=0),
     dict(pyramid_levels=3),

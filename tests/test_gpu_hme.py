@@ -25,6 +25,9 @@ def run_lib(lib, sc, quant, effort, skip_thresh=0):
     (1920, 1080, A.SUBSAMP_420, 7, 172, 10, True),
     (640, 360, A.SUBSAMP_422, 8, 172, 10, True),     # 4:2:2: the general block routine at level 0
     (3840, 2160, A.SUBSAMP_420, 9, 172, 10, True),   # 32 x 32 blocks (dsv_encoder.c:1203-1211)
+    (1920, 800, A.SUBSAMP_420, 10, 172, 10, True),   # 32 x 16 blocks: wider than 1280, not "mostly square" (dsv_encoder.c:1203-1209)
+    (2560, 1080, A.SUBSAMP_420, 11, 172, 10, True),  # 32 x 16 blocks
+    (1920, 816, A.SUBSAMP_420, 12, 300, 7, False),   # 32 x 16, effort 7 (no quarter-pel), no previous field
 ])
 def test_hme_matches_reference(w, h, subsamp, seed, quant, effort, prev):
     ref, hip = A.load_ref(), A.load_hip()

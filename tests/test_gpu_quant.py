@@ -25,7 +25,7 @@ def decode_plane(lib, data, cw, ch, q, plane, isP, params, blockdata):
     return ok, coefs, bs.pos
 
 
-@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420)])
+@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (1920, 800, A.SUBSAMP_420)])  # (1920 x 800: 32 x 16 blocks)
 @pytest.mark.parametrize("isP,lossless,q,do_psy", [(0, 0, 180, 0xff), (1, 0, 172, 0xff), (0, 0, 40, 0),
                                                     (1, 0, 900, 0x1), (0, 1, 1, 0xff), (1, 1, 1, 0xff)])
 def test_encode_decode_plane_match_reference(w, h, subsamp, isP, lossless, q, do_psy):

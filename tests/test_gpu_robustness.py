@@ -187,3 +187,50 @@ def test_mixed_geometries_in_one_batch_are_refused_and_arenas_hold_their_instanc
     assert hip.dsv2hip_arena_fallbacks() == 0
     for e in encs:
         hip.dsv_enc_free(C.byref(e))
+
+
+@pytest.mark.parametrize("how", [1, 2])
+def test_a_failed_step_fails_its_calls_and_nothing_else(how):
+    """advisor finding (round 5): the StepFailed path had no test, the batch calls returned 0 after a failed step and the step's
+    job tables went back to the pool with work still enqueued on its stream.  The hook fails ONE step (how = 1: a search without
+    counters, how = 2: the token never came, with the step's first kernels still enqueued): the batch call returns -1 with no
+    packets, the encoders of that step are dead (later calls: -1 / 0 packets), a fresh encoder of the same geometry -- which
+    takes the same scratch, tables and streams -- then encodes exactly what the reference encodes."""
+    from codec_run import configure_encoder, encode_stream
+    ref, hip = A.load_ref(), A.load_hip()
+    pkg = load_pkg()
+    w, h = 352, 288
+    v = pkg.synth.SynthVideo(w, h, "420", seed=21)
+    frames = [v.frame_bytes(t) for t in range(3)]
+    hip.dsv2hip_enc_batch_host.argtypes = [C.c_int, C.POINTER(C.POINTER(A.ENCODER)), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(A.BUF), C.POINTER(C.c_int)]
+    hip.dsv2hip_enc_batch_host.restype = C.c_int
+    hip.dsv2hip_test_fail_next_step.argtypes = [C.c_int]
+    encs = [A.ENCODER(), A.ENCODER()]
+    for e in encs:
+        configure_encoder(hip, e, A.mk_meta(w, h, A.SUBSAMP_420), qp=60, gop=48)
+    gp = (C.POINTER(A.ENCODER) * 2)(*[C.pointer(e) for e in encs])
+    bufs = (A.BUF * 8)()
+    nb = (C.c_int * 2)()
+    pics = [np.frombuffer(f, dtype=np.uint8).copy() for f in frames]
+
+    def step(t):
+        nb[0] = nb[1] = 7
+        return hip.dsv2hip_enc_batch_host(2, gp, (C.c_void_p * 2)(pics[t].ctypes.data, pics[t].ctypes.data), None, bufs, nb)
+
+    assert step(0) == 0 and nb[0] >= 1 and nb[1] >= 1  # the intra picture
+    for k in range(2):
+        for i in range(nb[k]):
+            hip.dsv_buf_free(C.byref(bufs[4 * k + i]))
+    hip.dsv2hip_test_fail_next_step(how)
+    assert step(1) == -1 and nb[0] == 0 and nb[1] == 0  # the failed step (a P picture: it searches)
+    assert step(2) == -1                                 # dead encoders are refused
+    hip.dsv_mk_frame.restype = C.POINTER(A.FRAME)
+    hip.dsv_enc.restype = C.c_int
+    fr = hip.dsv_mk_frame(A.SUBSAMP_420, w, h, 1)
+    assert hip.dsv_enc(C.byref(encs[0]), fr, bufs) == 0
+    for e in encs:
+        hip.dsv_enc_free(C.byref(e))
+    # the library is healthy: same scratch, same streams, same geometry
+    want, _ = encode_stream(ref, frames, w, h, A.SUBSAMP_420, eos=False, qp=60, gop=48)
+    got, _ = encode_stream(hip, frames, w, h, A.SUBSAMP_420, eos=False, qp=60, gop=48)
+    assert want == got

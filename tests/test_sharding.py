@@ -110,7 +110,11 @@ def test_gather_unpadded_chunked(tmp_path, nseg, chunk):
     assert open(tmp_path / "g.bin", "rb").read() == want
 
 
-def _stream_worker(rank, world, port, outdir, nseg, chunk, corrupt):
+def _seg_len(s, big):
+    return (s * 97771) % 500000 if big else (s * 977) % 5000
+
+
+def _stream_worker(rank, world, port, outdir, nseg, chunk, corrupt, big=False):
     import numpy as np
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -121,7 +125,7 @@ def _stream_worker(rank, world, port, outdir, nseg, chunk, corrupt):
 
     def seg_bytes(s):
         calls.append(s)
-        b = np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8)
+        b = np.random.RandomState(s).randint(0, 256, size=_seg_len(s, big), dtype=np.uint8)
         # a producer whose second pass (the one that ships) differs from what it announced: rank 0 must notice
         if corrupt and s == corrupt and calls.count(s) > 1 and len(b):
             b[len(b) // 2] ^= 1
@@ -159,6 +163,23 @@ def test_streaming_gather_verifies_every_segment_above_a_tiny_cap(tmp_path, worl
     want = b"".join(np.random.RandomState(s).randint(0, 256, size=(s * 977) % 5000, dtype=np.uint8).tobytes() for s in range(nseg))
     assert res["segments"] == nseg and res["segments_verified"] == nseg and res["bytes"] == len(want)
     assert res["peak_piece"] <= max(chunk, max((s * 977) % 5000 for s in range(0, nseg, world)))  # (rank 0's own segments arrive whole)
+    assert open(tmp_path / "s.bin", "rb").read() == want
+
+
+def test_streaming_gather_world_8(tmp_path):
+    """the shape of the first real 8-GPU run (review, round 5): eight ranks, 64 segments of up to 0.5 MB (16 MB in all) through a
+    1 MB cap -- every segment of the job verified on rank 0, seven of eight over the wire, rank 0 never holding more than its two
+    receive buffers"""
+    import json
+    import numpy as np
+    world, nseg, chunk = 8, 64, 1 << 20
+    port = _free_port()
+    mp.spawn(_stream_worker, args=(world, port, str(tmp_path), nseg, chunk, 0, True), nprocs=world, join=True)
+    res = json.load(open(tmp_path / "res.json"))
+    want = b"".join(np.random.RandomState(s).randint(0, 256, size=_seg_len(s, True), dtype=np.uint8).tobytes() for s in range(nseg))
+    assert res["segments"] == nseg and res["segments_verified"] == nseg and res["bytes"] == len(want)
+    assert res["segments_over_the_wire"] == nseg - nseg // world
+    assert res["peak_bytes_held"] <= 2 * chunk
     assert open(tmp_path / "s.bin", "rb").read() == want
 
 
