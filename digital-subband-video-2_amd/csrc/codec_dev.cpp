@@ -251,8 +251,10 @@ void CodecDev::init(int format_, int w_, int h_, int blk_w_, int blk_h_, int pyr
         HIPCHK(dev_alloc((void **) &d_mvf[l], nb * sizeof(DSV_MV)));
     }
     HIPCHK(dev_alloc((void **) &d_counters, hme_counter_words(nbv) * sizeof(int)));
-    HIPCHK(dev_alloc(&d_src_stats, hme_src_stats_bytes(nbh, nbv)));
-    HIPCHK(dev_alloc(&d_l0_pre, hme_l0_pre_bytes(nbh, nbv)));
+    if (encoder) { // the search's pre-pass records: nothing a decoder ever reads (advisor, round 5: 2 MB per 1080p decoder)
+        HIPCHK(dev_alloc(&d_src_stats, hme_src_stats_bytes(nbh, nbv)));
+        HIPCHK(dev_alloc(&d_l0_pre, hme_l0_pre_bytes(nbh, nbv)));
+    }
     for (int i = 0; i < 2; i++) {
         HIPCHK(dev_alloc((void **) &d_intra_map[i], nb));
         dev_zero(d_intra_map[i], nb);
@@ -353,6 +355,7 @@ void CodecDev::destroy()
     dev_release(d_counters);
     dev_release(d_src_stats);
     dev_release(d_l0_pre);
+    d_src_stats = d_l0_pre = nullptr;
     for (int i = 0; i < 2; i++) {
         if (d_intra_map[i]) {
             dev_release(d_intra_map[i]);

@@ -403,3 +403,55 @@ void SbtScratch::release()
 }
 
 } // namespace dsv2
+
+// ---- residency census (prio.h; `make census`): host registry of the per-translation-unit tallies ---------------------------------
+// The product build has no tallies: the two entry points exist (one ABI for every build) and report nothing.
+namespace dsv2 {
+namespace census {
+struct Tally {
+    unsigned long long ticks, groups, waves, line;
+};
+typedef void (*read_fn)(Tally *out);
+typedef void (*reset_fn)();
+struct Unit {
+    const char *file;
+    read_fn rd;
+    reset_fn rs;
+};
+static Unit g_units[16];
+static int g_nunits = 0;
+void register_tu(const char *file, read_fn rd, reset_fn rs)
+{
+    if (g_nunits < 16) {
+        g_units[g_nunits++] = Unit{file, rd, rs};
+    }
+}
+} // namespace census
+} // namespace dsv2
+
+extern "C" {
+void dsv2hip_census_reset(void)
+{
+    for (int u = 0; u < dsv2::census::g_nunits; u++) {
+        dsv2::census::g_units[u].rs();
+    }
+}
+/* one text line per kernel site that ran: "<file> <line> <ticks of the 100 MHz clock x wavefronts> <workgroups> <wavefronts>";
+ * returns the number of bytes written (0: this build carries no census) */
+int dsv2hip_census_read(char *out, int cap)
+{
+    int at = 0;
+    for (int u = 0; u < dsv2::census::g_nunits; u++) {
+        dsv2::census::Tally t[64];
+        dsv2::census::g_units[u].rd(t);
+        const char *f = strrchr(dsv2::census::g_units[u].file, '/');
+        f = f ? f + 1 : dsv2::census::g_units[u].file;
+        for (int s = 0; s < 64; s++) {
+            if (t[s].groups && at < cap - 160) {
+                at += snprintf(out + at, (size_t) (cap - at), "%s %llu %llu %llu %llu\n", f, t[s].line, t[s].ticks, t[s].groups, t[s].waves);
+            }
+        }
+    }
+    return at;
+}
+}

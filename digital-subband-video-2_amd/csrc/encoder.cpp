@@ -1535,7 +1535,6 @@ static const bool kFusedCount = true;
 // counters (thrown behind H1a, the search drained), 2 = as a search token that never came (thrown with the step's ingest,
 // pyramids and source pre-pass still enqueued on the stream)
 static std::atomic<int> g_fail_next_step{0};
-void dsv2hip_test_fail_next_step(int how) { g_fail_next_step.store(how); }
 
 static void enc_batch_step(Job *jobs, int n);
 bool enc_batch_ok(Job *jobs, int n)
@@ -2473,6 +2472,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs) // dsv_encoder.c:
 
 /* what the submit queue of dsv_enc did so far: [0] calls, [1] lockstep steps they were run as, [2] the largest step, [3] total
  * microseconds leaders spent waiting for expected callers; reset != 0 clears the counts afterwards */
+void dsv2hip_test_fail_next_step(int how) { g_fail_next_step.store(how); }
 long dsv2hip_enc_list_growths(void) { return g_list_growths.load(); }
 long dsv2hip_arena_fallbacks(void) { return dsv2::arena_fallbacks(); }
 

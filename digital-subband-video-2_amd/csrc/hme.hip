@@ -21,6 +21,7 @@
 #include "blockstat.h"
 #include "codec.h"
 #include "hme.h"
+#include "prio.h"
 
 namespace dsv2 {
 
@@ -1582,6 +1583,7 @@ __device__ __forceinline__ HmeRowsArgs hme_rows_args()
         const HmeDev *__restrict__, int, int, int, int, int)                                                             \
     {                                                                                                                    \
         __shared__ FastLds S;                                                                                            \
+        DSV2_CENSUS_SCOPE();                                                                                             \
         for (;;) {                                                                                                       \
             const HmeRowsArgs a_ = hme_rows_args();                                                                      \
             const HmeDev *tab = a_.tab;                                                                                  \
@@ -1622,6 +1624,7 @@ constexpr int kSplitMaxRows = 2048;
 // that level's finished field and its global motion) and before the level-0 launch.
 __global__ __launch_bounds__(64) void k_hme_l0_pre_b(const HmeDev *__restrict__ tab, int nbx, int nby, int per_wg)
 {
+    DSV2_CENSUS_SCOPE();
     __shared__ FastLds S;
     const HmeDev &c = tab[blockIdx.y];
     const HmeCtx x = make_ctx(uni_ptr(&c), 0);
@@ -1677,6 +1680,7 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
 // level < 0: blockIdx.z enumerates the levels (row pipeline: one clear for the whole search)
 __global__ __launch_bounds__(256) void k_hme_clear_b(const HmeDev *__restrict__ tab, int level, int nwords, int clear_counters)
 {
+    DSV2_CENSUS_SCOPE();
     const HmeDev &c = tab[blockIdx.y];
     bool first = level >= 0 || blockIdx.z == 0;
     if (level < 0) {
@@ -1709,6 +1713,7 @@ __device__ __forceinline__ int bs_seg_bits(int v) // dsv.c:344
 // grid = (ceil(nblocks / 256), streams); one thread per block
 __global__ __launch_bounds__(256) void k_block_stats_b(const BlockStatsJob *__restrict__ tab, int nbh, int nbv)
 {
+    DSV2_CENSUS_SCOPE();
     const BlockStatsJob &J = tab[blockIdx.y];
     const int nblk = nbh * nbv;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1871,6 +1876,7 @@ int hme_estimate(hipStream_t s, CodecDev &dv, const PicSet &cur, const PicSet &r
 __global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int fb0x, int fb0y,
                                                         int fb1x, int fb1y, int per_wg)
 {
+    DSV2_CENSUS_SCOPE();
     // [0, fbx) x [0, fby) of a level is left to k_hme_src_stats4_b; what is enumerated here is the strip of block rows below it,
     // then the strip of block columns to its right (fb = 0: every block)
     __shared__ int hist[16];
@@ -1918,6 +1924,7 @@ __global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict
 // and in no order, so its cost is not the search's.
 __global__ __launch_bounds__(64) void k_hme_src_stats32_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int per_wg)
 {
+    DSV2_CENSUS_SCOPE();
     __shared__ int hist[16];
     __shared__ alignas(4) uint8_t sblk[32 * 32], oblk[32 * 36];
     const HmeDev &c = tab[blockIdx.y];
@@ -1986,6 +1993,7 @@ __device__ __forceinline__ int row16_max(int v)
 typedef unsigned uint4v_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void k_hme_src_stats4_b(const HmeDev *__restrict__ tab, int nb0x, int nb1x, int fb0x, int fb0y, int fb1x, int fb1y)
 {
+    DSV2_CENSUS_SCOPE();
     __shared__ int hist[2][4][16];
     const HmeDev &c = tab[blockIdx.y];
     const int lane = threadIdx.x & 63, blk = lane >> 4, r = lane & 15;

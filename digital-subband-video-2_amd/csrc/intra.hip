@@ -8,12 +8,14 @@
 #include "blockstat.h"
 #include "bmc.h"
 #include "hme.h"
+#include "prio.h"
 
 namespace dsv2 {
 
 // tab == nullptr: the single picture `one`; otherwise blockIdx.z indexes a device table of pictures
 __global__ __launch_bounds__(64) void k_intra_analysis(const IntraJob *__restrict__ tab, IntraJob one, AnalysisParams p)
 {
+    DSV2_CENSUS_SCOPE();
     __shared__ int hist[16];
     const IntraJob &job = tab ? tab[blockIdx.z] : one;
     const Planes3 &src = job.src;

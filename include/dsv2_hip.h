@@ -416,6 +416,12 @@ long dsv2hip_arena_fallbacks(void);
  * failed step drains its streams before its job tables go back to the pool, releases the callers' frames, marks its encoders
  * dead; dsv_enc returns 0, the batch calls return -1 with every nbufs[k] = 0 (tests/test_gpu_robustness.py). */
 void dsv2hip_test_fail_next_step(int how);
+/* Residency census of a `make census` build (csrc/prio.h): resident wavefront-time of every kernel site, measured inside the
+ * kernels while the lockstep groups share the chip.  dsv2hip_census_read writes one text line per site that ran -- "<file> <line>
+ * <ticks of the 100 MHz clock x wavefronts> <workgroups> <wavefronts>" -- and returns the bytes written; the product build
+ * carries no census and returns 0. */
+void dsv2hip_census_reset(void);
+int dsv2hip_census_read(char *out, int cap);
 /* stage timing with HIP events on the stream each lockstep step runs on.  May be switched on and
  * off at any time (resets the totals).  dsv2hip_prof_read fills 9 entries (ingest+pyramid, HME,
  * predict, fwd SBT, quant+compact, inv SBT, reconstruct+filters, extend, and -- inside HME -- the level-0

@@ -1,16 +1,20 @@
 #!/bin/bash
-# Round-5 profile artefacts (GPU box, repo root; run through gpurun).  Raw output under gpurun_out/prof5/, summarised into
-# profiles/r05_* by tools/summarise_r05.py.  Parts (pick with PARTS="trace pmc excl insts", default all):
+# A round's profile artefacts (GPU box, repo root; run through gpurun).  ROUND=<n> (default 6): raw output under gpurun_out/prof<n>/,
+# summarised into profiles/r0<n>_* by tools/summarise_round.py <n>.  Parts (pick with PARTS="trace pmc excl insts occ census", default all):
 #   trace  rocprofv3 --kernel-trace --stats of the headline command -> kernel_stats.csv + kernel_trace.csv.gz
 #   pmc    FETCH_SIZE / WRITE_SIZE of the level-0 search launch in the bench's own layout (separate passes)
 #   excl   one lockstep group of 96 streams alone: exclusive kernel durations
 #   insts  SQ_INSTS_VALU / SQ_INSTS_SALU / LDS / VMEM of every kernel (32 streams, 1 intra + 5 inter)
+#   occ    what the machine is short of: SQ wave / busy / issue counters of EVERY kernel in the headline's own four-group command
+#          (rocprofv3 --pmc runs the dispatches one at a time: each kernel is seen in the headline's launch shape, ALONE on the chip),
+#          joined by summarise_round.py with the un-serialised trace of part `trace` (the same kernels sharing the chip)
+#   census resident wavefront-time per kernel measured INSIDE the kernels with all four groups running (the census build of the library)
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof5
+out=gpurun_out/prof${ROUND:-6}
 mkdir -p $out
-parts=${PARTS:-trace pmc excl insts}
+parts=${PARTS:-trace pmc excl insts occ census}
 L0=k_hme_rows_l0
 for p in $parts; do case $p in
 trace)
@@ -35,5 +39,15 @@ insts)
     cp $out/insts/*/*_counter_collection.csv $out/insts.csv
     gzip -f $out/insts.csv
     rm -rf $out/insts ;;
+occ)
+    # (8 SQ slots, 2 GRBM slots; GRBM_GUI_ACTIVE = clocks summed over the 8 XCDs)
+    timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/occ -- python3 bench.py --steps 4 --warmup 2 --gen-procs 1 --no-cpu-baseline --no-profile --no-extras > $out/occ.json 2> $out/occ.err
+    cp $out/occ/*/*_counter_collection.csv $out/occ.csv; gzip -f $out/occ.csv
+    gzip -c $out/occ/*/*_kernel_trace.csv > $out/occ_kernel_trace.csv.gz
+    rm -rf $out/occ
+    for o in digital-subband-video-2_amd/csrc/build/*.hip.o; do tools/codeobj.sh $o; done > $out/kernel_registers.txt 2>/dev/null ;;
+census)
+    # residency UNDER LOAD, measured inside the kernels (csrc/prio.h; `make -C digital-subband-video-2_amd/csrc census` beforehand): no profiler, nothing serialised
+    DSV2HIP_LIB=$PWD/digital-subband-video-2_amd/libdsv2hip_census.so DSV2_CENSUS=1 timeout 900 python3 bench.py --no-cpu-baseline --no-extras --no-profile --steps 48 > $out/census.json 2> $out/census.err ;;
 esac; done
 ls -la $out
