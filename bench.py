@@ -710,8 +710,8 @@ def decode_leg(hip, A, run, nsteps, nstreams, groups, check):
            "mpix_per_s": round(n / elapsed * run.w * run.h / 1e6, 1),
            "host_cpu_cores_busy": round(host_cpu_s / elapsed, 2),
            "note": "lockstep batch decoder (dsv2hip_dec_batch) over this run's own packets, pictures delivered to host memory as DSV_FRAMEs; "
-                   "host_cpu_cores_busy includes the serial entropy parse of every plane section (hzcc.c:451-585), the one per-coefficient loop "
-                   "the decoder keeps on the host"}
+                   "host_cpu_cores_busy includes the serial entropy parse of the plane sections (hzcc.c:451-585) where the host does it "
+                   "(plane_sections_parsed_on; csrc/dec_parse_dev.hip is the device form)"}
     if prof_steps:
         t0 = min(nfr - prof_steps, warm + nsteps)
         hip.dsv2hip_prof_enable(1)
@@ -1183,7 +1183,25 @@ def main():
     dec_md5 = {}
     if (extras or args.decode_too) and not args.only_batch_curve and not args.only_api_legs:
         try:
-            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, 256, 4, sel if (extras and not args.no_cpu_baseline) else [])
+            # (DSV2_DEC_GROUPS / DSV2_DEC_STREAMS: experiments with the decode leg's shape)
+            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, int(os.environ.get("DSV2_DEC_STREAMS", "256")), int(os.environ.get("DSV2_DEC_GROUPS", "4")),
+                                                   sel if (extras and not args.no_cpu_baseline) else [])
+            # the same leg with the P pictures' plane sections parsed on the DEVICE (csrc/dec_parse_dev.hip): the operating point of a
+            # host with few cores per GPU -- what the library picks by itself below 12 usable cores (the 2-core re-run below takes it)
+            hip.dsv2hip_dec_parse_mode.restype = C.c_int
+            mode0 = hip.dsv2hip_dec_parse_mode()
+            result["decode"]["plane_sections_parsed_on"] = ["host", "device (P pictures)", "device"][mode0]
+            if mode0 == 0 and extras:
+                hip.dsv2hip_dec_set_parse_mode(1)
+                try:
+                    leg, md5b = decode_leg(hip, A, run, 32, int(os.environ.get("DSV2_DEC_STREAMS", "256")), int(os.environ.get("DSV2_DEC_GROUPS", "4")),
+                                           sel if (extras and not args.no_cpu_baseline) else [])
+                    leg["plane_sections_parsed_on"] = "device (P pictures)"
+                    leg["pictures_equal_to_the_host_parsed_leg"] = bool(md5b == dec_md5)
+                    leg.pop("roofline", None)
+                    result["decode_device_parse"] = leg
+                finally:
+                    hip.dsv2hip_dec_set_parse_mode(-1)
         except Exception as e:  # noqa: BLE001
             result["decode"] = {"error": repr(e)}
     run.free()
@@ -1239,6 +1257,9 @@ def main():
         except (OSError, AssertionError, ValueError) as e:  # the reference side failed: say so beside the headline
             result["parity_checked"]["vs_reference_error"] = repr(e)
             rc = 5
+    if isinstance(result.get("decode_device_parse"), dict) and result["decode_device_parse"].get("pictures_equal_to_the_host_parsed_leg") is False:
+        sys.stderr.write("[bench] pictures decoded with the device parser DIFFER from the host-parsed ones\n")
+        rc = rc or 9
     print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

@@ -248,7 +248,14 @@ inline int parse_head(BitReader &br, DSV_DECODER *d, PictureHead &hd)
     return kParsePicture;
 }
 
+// a plane section whose symbols are NOT parsed here (the device does it: dec_parse_dev.hip): what the section's head says
+struct PlaneHead {
+    uint32_t data_bitpos = 0, end_byte = 0; // first bit of the first run; section start + plane length
+    int runs = 0;                           // symbol count of the header (24 bits)
+};
+
 struct PictureBody {
+    PlaneHead head[3];
     int do_filter = 0, quant = 0, lossless = 0;
     int ok[3] = {0, 0, 0};
     int seg[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -258,8 +265,11 @@ struct PictureBody {
 
 // the rest of a picture packet: statistics bits, per-block side information, the three planes' symbols (one after the other
 // in pos / val, which are grown to the planes' scan lengths)
+// heads_only: the planes' symbols stay unparsed -- out.head[c] says where they are; ok[c] is -1 for a section whose length field
+// is implausible (exactly the test, and the reader position afterwards, of entropy_decode_plane) and 1 otherwise: whether the
+// section is damaged further in is found by whoever parses it
 inline void parse_body(BitReader &br, const uint8_t *pkt, int has_ref, int nbh, int nbv, const ScanGeom scan[3], SideBufs &side,
-                       std::vector<uint32_t> &pos, std::vector<int32_t> &val, PictureBody &out)
+                       std::vector<uint32_t> &pos, std::vector<int32_t> &val, PictureBody &out, bool heads_only = false)
 {
     const size_t nb = (size_t) nbh * nbv;
     br.align();
@@ -290,6 +300,30 @@ inline void parse_body(BitReader &br, const uint8_t *pkt, int has_ref, int nbh, 
         read_intra_meta(&side, br, pkt, stats);
     }
     br.align();
+    if (heads_only) {
+        for (int c = 0; c < 3; c++) {
+            out.LL[c] = 0;
+            out.ok[c] = -1;
+            out.seg[c][0] = out.seg[c][1] = out.seg[c][2] = out.seg[c][3] = 0;
+            br.align();
+            const unsigned plen = br.get_bits(32);
+            br.align();
+            if (!(plen > 0 && plen < (unsigned) scan[c].w * scan[c].h * sizeof(int32_t) * 2)) {
+                continue; // "plane length was strange" (hzcc.c:645): the next section is looked for right behind the length field
+            }
+            const unsigned start = br.byte_pos();
+            out.LL[c] = br.get_seg();
+            br.align();
+            out.head[c].runs = (int) br.get_bits(24);
+            br.align();
+            out.head[c].data_bitpos = br.pos;
+            out.head[c].end_byte = start + plen;
+            out.ok[c] = 1;
+            br.seek(((uint64_t) start + plen) * 8);
+        }
+        out.nsym = 0;
+        return;
+    }
     size_t cap = (size_t) scan[0].base[10] + (size_t) scan[1].base[10] + (size_t) scan[2].base[10];
     if (pos.size() < cap) {
         pos.resize(cap);

@@ -5,9 +5,11 @@
 // the device pipeline: symbol scatter + dequantisation -> inverse SBT -> intra filter, or
 // motion-compensated prediction + reconstruction + in-loop filters -> border extension of
 // reference pictures.  Entropy *parsing* is serial adaptive-state work and stays on the host.
+#include <sched.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -15,6 +17,7 @@
 #include "batch.h"
 #include "codec.h"
 #include "dec_parse.h"
+#include "dec_parse_dev.h"
 
 using namespace dsv2;
 using namespace dsv2::decparse;
@@ -58,6 +61,10 @@ struct DecJob {
     int32_t LL[3] = {0, 0, 0};
     size_t sym_first[3] = {0, 0, 0}; // first symbol of each plane within the decoder's list
     size_t nsym = 0, stage_off = 0;
+    bool dev_parse = false;          // the plane sections' symbols are parsed on the device (dec_parse_dev.hip)
+    PlaneHead head[3];               // ... from here
+    int cap[3] = {0, 0, 0};          // ... into lists of this many entries (min(header count, coefficients of the plane))
+    size_t pkt_off = 0;              // ... out of the packet as staged at this offset of the round's stage block
     DSV_FRAME *of = nullptr; // output picture: a bordered frame on pinned memory the device writes directly
 };
 
@@ -158,6 +165,27 @@ struct DecClock { // DSV2_TRACE=2: wall-clock split of a lockstep decode step, p
 };
 thread_local DecClock t_dec_clock;
 
+// Where a picture's plane sections are parsed: DSV2_DEC_DEVICE_PARSE = 0: on the host (one pool task per picture: ~2 ms of a
+// core per 1080p P picture -- the fastest decoder while there are ~16 host cores per GPU to burn); 1: P pictures on the device, one
+// wavefront per section (dec_parse_dev.hip) -- slower per step, the section being one dependency chain, but with ~1.4 host cores
+// per GPU instead of ~15 -- and intra pictures (1 in a GOP, ten times the symbols: a 0.4 s chain on a wavefront) on the host; 2:
+// everything on the device (tests).  Unset: by the host budget of this process -- the device parses when fewer than 12 cores are
+// usable (DSV2_DEC_PARSE_AUTO_CORES), e.g. eight ranks of an 8-GPU node on a 64-core host, or a rank pinned to two cores.
+static int dev_parse_mode()
+{
+    if (const char *e = getenv("DSV2_DEC_DEVICE_PARSE")) {
+        return atoi(e);
+    }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const int need = getenv("DSV2_DEC_PARSE_AUTO_CORES") ? atoi(getenv("DSV2_DEC_PARSE_AUTO_CORES")) : 12;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) < need) {
+        return 1;
+    }
+    return 0;
+}
+static std::atomic<int> g_dev_parse{dev_parse_mode()};
+
 // phase A: everything dsv_dec does before it touches the device (dsv_decoder.c:393-503).  The bit parsing itself is
 // dec_parse.h (device-free: fuzzed on the CPU under AddressSanitizer by tests/parser_fuzz.cpp); here: the private copy of
 // the packet, the device instance of the stream's geometry, the pinned mirrors the device reads.
@@ -210,7 +238,9 @@ void dec_parse(DecJob &jb)
     }
     CodecDev &dv = im->dev;
     PictureBody body;
-    parse_body(br, pkt, hd.has_ref, dv.nbh, dv.nbv, dv.scan, im->side, im->pos, im->val, body);
+    const int dev_mode = g_dev_parse.load(std::memory_order_relaxed);
+    jb.dev_parse = dev_mode >= 2 || (dev_mode == 1 && hd.has_ref);
+    parse_body(br, pkt, hd.has_ref, dv.nbh, dv.nbv, dv.scan, im->side, im->pos, im->val, body, jb.dev_parse);
     jb.do_filter = body.do_filter;
     jb.quant = body.quant;
     jb.lossless = body.lossless;
@@ -223,10 +253,22 @@ void dec_parse(DecJob &jb)
         }
     }
     jb.nsym = body.nsym;
-    // the device reads the symbols straight from pinned host memory (each is read exactly once)
-    dv.ensure_host_syms(body.nsym);
-    memcpy(dv.h_pos, im->pos.data(), body.nsym * sizeof(uint32_t));
-    memcpy(dv.h_val, im->val.data(), body.nsym * sizeof(int32_t));
+    if (jb.dev_parse) {
+        // the symbol lists live in device memory; their sizes come from the (untrusted) header counts, bounded by the planes' coefficient counts
+        size_t at = 0;
+        for (int c = 0; c < 3; c++) {
+            jb.head[c] = body.head[c];
+            jb.sym_first[c] = at;
+            jb.cap[c] = jb.ok[c] > 0 ? std::min(std::max(body.head[c].runs, 0), dv.scan[c].base[10]) : 0;
+            at += (size_t) jb.cap[c];
+        }
+        dv.ensure_dev_syms(at);
+    } else {
+        // the device reads the symbols straight from pinned host memory (each is read exactly once)
+        dv.ensure_host_syms(body.nsym);
+        memcpy(dv.h_pos, im->pos.data(), body.nsym * sizeof(uint32_t));
+        memcpy(dv.h_val, im->val.data(), body.nsym * sizeof(int32_t));
+    }
     *jb.fn = jb.fno;
     if (jb.has_ref && !im->have_ref) {
         jb.ret = DSV_DEC_ERROR; /* reference frame not found (dsv_decoder.c:535) */
@@ -249,13 +291,25 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     sc.tabs.reserve((size_t) n * 8192 + 65536);
 
     // stage layout: per stream {motion field, block flags}
+    // stage layout: per stream {motion field, block flags}, then -- for pictures whose sections the device parses -- the packets,
+    // each 16-byte aligned with 64 zero bytes behind it (the parser reads a 2 KB window: the block ends with that much slack)
     size_t total = 0;
+    int n_dev = 0;
     for (int i = 0; i < n; i++) {
         DecJob &jb = jobs[ids[(size_t) i]];
         jb.stage_off = total;
         total += mv_bytes + bd_bytes;
     }
-    sc.ensure_stage(total);
+    for (int i = 0; i < n; i++) {
+        DecJob &jb = jobs[ids[(size_t) i]];
+        if (jb.dev_parse) {
+            jb.pkt_off = total;
+            total += ((size_t) jb.buf->len + 64 + 15) & ~(size_t) 15;
+            n_dev++;
+        }
+    }
+    const size_t stage_used = total;
+    sc.ensure_stage(total + (n_dev ? 4096 : 0));
     parallel_for(n, [&](int i) {
         DecJob &jb = jobs[ids[(size_t) i]];
         DecImpl *im = jb.im;
@@ -264,6 +318,11 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
             memcpy(h, im->mvs.data(), mv_bytes);
         }
         memcpy(h + mv_bytes, im->blockdata.data(), nb);
+        if (jb.dev_parse) {
+            uint8_t *p = sc.h_stage + jb.pkt_off;
+            memcpy(p, jb.buf->data, jb.buf->len);
+            memset(p + jb.buf->len, 0, (((size_t) jb.buf->len + 64 + 15) & ~(size_t) 15) - jb.buf->len);
+        }
     });
 
     t_dec_clock.lap(1);
@@ -297,6 +356,14 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     CopyJob *h_zfail = sc.tabs.take<CopyJob>(3 * (size_t) n, &d_zfail);
     const To420Job *d_to420;
     To420Job *h_to420 = sc.tabs.take<To420Job>(3 * (size_t) n, &d_to420);
+    // device-parsed sections: one job each; a damaged one raises its flag and the plane's residual is zeroed behind the inverse transform
+    const DecParseJob *d_parse;
+    DecParseJob *h_parse = sc.tabs.take<DecParseJob>(3 * (size_t) n, &d_parse);
+    const CopyJob *d_zcond;
+    CopyJob *h_zcond = sc.tabs.take<CopyJob>(3 * (size_t) n, &d_zcond);
+    const int *d_fail;
+    int *h_fail = sc.tabs.take<int>(3 * (size_t) n, &d_fail);
+    int n_parse = 0;
     int nP = 0, nI = 0, nIf = 0, n_ext = 0, n_zfail = 0, n_out = 0, n_to420 = 0;
     size_t max_plane_bytes = 0;
     bool any_filter = false;
@@ -332,11 +399,38 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
             max_coef_bytes = cbytes > max_coef_bytes ? cbytes : max_coef_bytes;
             DequantJob &dq = h_dq[c][i];
             dq.coefs = dv.coefs[c];
-            dq.pos = d_pos + jb.sym_first[c];
-            dq.val = d_val + jb.sym_first[c];
-            for (int k = 0; k < 4; k++) {
-                dq.seg[k] = jb.seg[c][k];
-                sl.max_seg[c][k] = jb.seg[c][k] > sl.max_seg[c][k] ? jb.seg[c][k] : sl.max_seg[c][k];
+            if (jb.dev_parse) {
+                dq.pos = dv.d_sym_pos + jb.sym_first[c];
+                dq.val = dv.d_sym_val + jb.sym_first[c];
+                for (int k = 0; k < 4; k++) { // (the counts are written into the device copy of this record by the parse kernel)
+                    dq.seg[k] = 0;
+                    sl.max_seg[c][k] = jb.cap[c] > sl.max_seg[c][k] ? jb.cap[c] : sl.max_seg[c][k];
+                }
+                if (jb.ok[c] > 0) {
+                    DecParseJob &pj = h_parse[n_parse];
+                    pj.pkt = sc.d_stage + jb.pkt_off;
+                    pj.data_bitpos = jb.head[c].data_bitpos;
+                    pj.limit_bits = (jb.buf->len + 8) * 8;
+                    pj.end_byte = jb.head[c].end_byte;
+                    pj.runs = jb.head[c].runs;
+                    pj.cap = jb.cap[c];
+                    pj.chroma = c != 0;
+                    pj.pos = dv.d_sym_pos + jb.sym_first[c];
+                    pj.val = dv.d_sym_val + jb.sym_first[c];
+                    pj.seg_out = (int *) ((uint8_t *) const_cast<DequantJob *>(d_dq[c]) + (size_t) i * sizeof(DequantJob) + offsetof(DequantJob, seg));
+                    pj.fail = const_cast<int *>(d_fail) + n_parse;
+                    h_fail[n_parse] = 0;
+                    h_zcond[n_parse] = CopyJob{nullptr, resid.alloc + resid.plane_off[c], resid.plane_len[c]};
+                    max_plane_bytes = resid.plane_len[c] > max_plane_bytes ? resid.plane_len[c] : max_plane_bytes;
+                    n_parse++;
+                }
+            } else {
+                dq.pos = d_pos + jb.sym_first[c];
+                dq.val = d_val + jb.sym_first[c];
+                for (int k = 0; k < 4; k++) {
+                    dq.seg[k] = jb.seg[c][k];
+                    sl.max_seg[c][k] = jb.seg[c][k] > sl.max_seg[c][k] ? jb.seg[c][k] : sl.max_seg[c][k];
+                }
             }
             dq.bd = d_bd;
             dq.LL = jb.LL[c];
@@ -407,9 +501,17 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     // encoder's stage names: QUANT = zero + scatter + dequantise, INV_SBT, RECON_FILTER = intra filter / motion-compensated
     // reconstruction + in-loop filters, EXTEND = borders + the picture's way into the caller's frame)
     static thread_local StageProf prof;
-    HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, total, hipMemcpyHostToDevice, bs));
+    HIPCHK(hipMemcpyAsync(sc.d_stage, sc.h_stage, stage_used, hipMemcpyHostToDevice, bs));
     sc.tabs.upload(bs);
     prof.begin(bs, ST_QUANT);
+    if (n_parse) {
+        DecScanBases sb_l, sb_c;
+        for (int k = 0; k < 11; k++) {
+            sb_l.base[k] = dv0.scan[0].base[k];
+            sb_c.base[k] = dv0.scan[1].base[k];
+        }
+        dec_parse_planes(bs, d_parse, n_parse, sb_l, sb_c);
+    }
     zero_linear_batch(bs, d_zero, 3 * n, max_coef_bytes);
     for (const Slice &sl : slices) {
         for (int c = 0; c < 3; c++) {
@@ -426,6 +528,7 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     prof.end(bs, ST_INV_SBT, n);
     prof.begin(bs, ST_RECON_FILTER);
     zero_linear_batch(bs, d_zfail, n_zfail, max_plane_bytes);
+    zero_linear_if_batch(bs, d_zcond, d_fail, n_parse, max_plane_bytes);
     intra_filter_batch(bs, d_mc_intra, nIf, dv0.w, dv0.h);
     mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter, dv0.w, dv0.h);
     prof.end(bs, ST_RECON_FILTER, n);
@@ -563,6 +666,16 @@ int dsv2hip_dec_set_out420p(DSV_DECODER *d, int on)
     }
     ((DecImpl *) d->ref)->out420p = on != 0;
     return 0;
+}
+
+int dsv2hip_dec_parse_mode(void) { return g_dev_parse.load(); }
+int dsv2hip_dec_set_parse_mode(int mode)
+{
+    if (mode < 0) {
+        mode = dev_parse_mode(); // back to the environment / the host budget
+    }
+    g_dev_parse.store(mode > 2 ? 2 : mode);
+    return g_dev_parse.load();
 }
 
 // lockstep decode: packet bufs[k] on decoder decs[k]; ret[k], out[k], fn[k] are what dsv_dec would return

@@ -394,6 +394,11 @@ void dsv2hip_host_free(void *p);
  * and fn[k] are exactly what dsv_dec(decs[k], &bufs[k], &out[k], &fn[k]) would have produced (packets are
  * consumed the same way).  All pictures of a step run through one set of kernel launches. */
 int dsv2hip_dec_batch(int n, DSV_DECODER **decs, DSV_BUF *bufs, DSV_FRAME **out, DSV_FNUM *fn, int *ret);
+/* where the decoder parses the plane sections of the pictures it is given from now on (hzcc.c:451-585): 0 on the host (fastest with
+ * ~16 host cores per GPU), 1 P pictures on the device (one wavefront per section: ~1.4 host cores per GPU), 2 every picture on the
+ * device; -1 (the default when DSV2_DEC_DEVICE_PARSE is unset): by the number of cores the process may use.  Returns the mode in force. */
+int dsv2hip_dec_parse_mode(void);
+int dsv2hip_dec_set_parse_mode(int mode); /* 0 / 1 / 2 as above, < 0: back to the default; for pictures handed over after the call */
 /* Submit queue behind dsv_enc / dsv_dec.  The reference's interface is one synchronous call per frame
  * (dsv_encoder.h:190-199, dsv_decoder.h:54-61); its own parallel recipe is one encoder per process
  * (parallel_encode_yuv.sh:31-52).  Threads that each loop dsv_enc (or dsv_dec) on an instance of their own are run

@@ -65,7 +65,27 @@ int parse_packet(DSV_DECODER *d, const uint8_t *data, unsigned len, Stats &st)
     static std::vector<uint32_t> pos;
     static std::vector<int32_t> val;
     PictureBody body;
-    parse_body(br, pkt, hd.has_ref, nbh, nbv, scan, side, pos, val, body);
+    // the heads-only form (what runs when the device parses the sections: dec_parse_dev.hip) must agree with the full parse on
+    // every plane's verdict on the length field, its DC, and -- for sections it accepts -- place the section inside the limit
+    {
+        BitReader br2 = br;
+        static SideBufs side2;
+        PictureBody heads;
+        parse_body(br2, pkt, hd.has_ref, nbh, nbv, scan, side2, pos, val, heads, true);
+        BitReader br3 = br;
+        parse_body(br3, pkt, hd.has_ref, nbh, nbv, scan, side, pos, val, body);
+        for (int c = 0; c < 3; c++) {
+            if ((heads.ok[c] < 0) != (body.ok[c] < 0) || (heads.ok[c] > 0 && heads.LL[c] != body.LL[c])) {
+                fprintf(stderr, "heads-only parse disagrees with the full parse on plane %d\n", c);
+                abort();
+            }
+            if (heads.ok[c] > 0 && (heads.head[c].data_bitpos > br.limit || heads.head[c].runs < 0 || heads.head[c].runs >= (1 << 24))) {
+                fprintf(stderr, "heads-only parse: section %d outside the packet's limit\n", c);
+                abort();
+            }
+        }
+        br = br3;
+    }
     st.parsed++;
     for (int c = 0; c < 3; c++) {
         (body.ok[c] > 0 ? st.planes_ok : st.planes_bad)++;
