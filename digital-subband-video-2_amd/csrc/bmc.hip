@@ -301,11 +301,18 @@ __device__ __forceinline__ uint32_t resid4_pk(uint32_t s4, s16x2 p01, s16x2 p23,
     return __builtin_amdgcn_perm(u32_of(o23), u32_of(o01), 0x06040200u);
 }
 
-struct WaveLds { // (alignas(16) on both: the packed sub-pel path reads and writes hz rows as 8-byte words, for every wave of L[4])
-    alignas(16) uint8_t win[35 * 36];
-    alignas(16) int16_t hz[35 * 32];
+// A wavefront's scratch for the luma sub-pel path: the block's (bw + 3) x (bh + 3) window as row dwords (36-byte rows) and the
+// horizontally filtered intermediate (32 int16 a row).  Sized BY THE LAUNCH's block height (dynamic LDS): 19 rows for 16-pixel
+// blocks = 1.9 KB a wavefront, 7.6 KB a workgroup.  Until round 6 it was a static 35 rows (3.5 KB, 14 KB a workgroup) whatever the
+// geometry -- and LDS is what the chip runs out of first under the headline's load: two in-loop filter sweeps (2 x 70 KB rings)
+// and the motion search's twelve wavefronts (19 KB) fill a compute unit's 160 KB, and the kernels that need LDS (this one, the
+// scatter, the entropy coder's emit) were the ones that stretched most beside them (profiles/r06_occupancy.txt).
+struct WaveLds {
+    uint8_t *win;
+    int16_t *hz;
 };
-static_assert(sizeof(WaveLds) % 16 == 0 && offsetof(WaveLds, hz) % 16 == 0, "WaveLds: hz rows must stay 8-byte aligned in every element of an array");
+__host__ __device__ constexpr unsigned wave_lds_win_bytes(int rows) { return ((unsigned) rows * 36u + 15u) & ~15u; }
+__host__ __device__ constexpr unsigned wave_lds_bytes(int rows) { return wave_lds_win_bytes(rows) + (unsigned) rows * 64u; }
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -667,17 +674,19 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
     }
 }
 
-template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab)
+template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab, int lds_rows)
 {
     DSV2_KERNEL_PRIO();
-    __shared__ WaveLds L[4];
+    extern __shared__ __align__(16) uint8_t predict_lds[];
     const McJob &jb = tab[blockIdx.z];
     // (the wavefront's index told to the compiler as wave-uniform: the block's origin, its vector and every base address
     // then live in scalar registers)
     const int w = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     int i = (int) blockIdx.x * 4 + w, j = blockIdx.y;
     if (i < jb.p.nbh) {
-        predict_block_wave<MODE>(jb, i, j, L[w]);
+        uint8_t *mine = predict_lds + (unsigned) w * wave_lds_bytes(lds_rows);
+        WaveLds L{mine, (int16_t *) (mine + wave_lds_win_bytes(lds_rows))};
+        predict_block_wave<MODE>(jb, i, j, L);
     }
 }
 
@@ -2514,10 +2523,11 @@ static bool filter_pair(int n)
 }
 
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
-void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv)
+void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, int blk_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH((k_predict_w<MC_SUBTRACT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_tab);
+        const int rows = blk_h + 3; // the luma window of the launch's blocks (chroma blocks are no taller)
+        DSV2_LAUNCH((k_predict_w<MC_SUBTRACT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows);
     }
 }
 
@@ -2542,10 +2552,11 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
 }
 
 // decoder: d_pred jobs {ref, pred = output picture, res = residual}; d_filt jobs {res = output picture}
-void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h)
+void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_h)
 {
     if (n > 0) {
-        DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 0, s, d_pred);
+        const int rows = blk_h + 3;
+        DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_pred, rows);
         if (any_filter) {
             bool wide = false;
             const unsigned lds = ring_lds_bytes(luma_w, luma_h, &wide);

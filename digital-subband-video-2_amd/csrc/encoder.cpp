@@ -2097,7 +2097,7 @@ static void enc_batch_step(Job *jobs, int n)
     copy_linear_batch(bs, d_mvcopy, n_mvcopy, mv_bytes);
     copy_linear_batch(bs, d_copy, n_copy, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
-    mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv);
+    mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv, dv0.blk_h);
     prof.end(bs, ST_PREDICT, nP);
     struct Slice {
         int first, count, isP, lossless;
@@ -2230,7 +2230,7 @@ static void enc_batch_step(Job *jobs, int n)
             h_k2->total = sc.d_totals + ti;
             sc.tabs.upload(bs);
             if (isP) {
-                mc_sub_pred_batch(bs, d_m2, 1, nbh, nbv);
+                mc_sub_pred_batch(bs, d_m2, 1, nbh, nbv, dv0.blk_h);
             } else {
                 copy_linear_batch(bs, d_c2, 1, cur.src.bytes);
             }

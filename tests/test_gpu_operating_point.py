@@ -120,6 +120,22 @@ def test_many_streams_concurrent_groups_repeated():
         hip.dsv2hip_host_free(p)
 
 
+def test_the_headline_768_streams_in_four_groups():
+    """the headline's own operating point (review, round 5: it was only checked inside bench.py): 768 encoder instances in four
+    lockstep groups of 192, every launch carrying 192 pictures, the four groups passing the search token round -- every one of the
+    768 streams against the reference encode of its input (63 GB of encoder instances: the test frees them before it returns)"""
+    hip = A.load_hip()
+    bind(hip)
+    frames = gen_inputs()
+    want = reference_digests(frames)
+    pinned = pin(hip, frames)
+    got = run_once(hip, frames, 768, 4, pinned)
+    bad = [s for s in range(768) if got[s] != want[s % NSEED]]
+    assert not bad, "768 streams / 4 groups: streams %s differ from the reference" % bad[:8]
+    for p in pinned:
+        hip.dsv2hip_host_free(p)
+
+
 def test_192_pictures_per_launch_with_search_token():
     """the bench's launch size: 192 streams in ONE lockstep group (every kernel launch carries 192 pictures: 13 056 block rows
     in the level-0 search launch), then 384 streams in two groups of 192 that pass the search token back and
