@@ -342,28 +342,15 @@ __global__ __launch_bounds__(256) void k_quant_level(const PlaneJob *__restrict_
 // values, one parent pair and one grandparent for the four, the block's flags and vector fetched once when the four share
 // a block (levels 0 and 1 of the 16-pixel-block geometries).  A thread whose fourth coefficient is a dependent of the
 // last column, and any job whose buffers are not 16-byte aligned, goes cell by cell.
+// kQRows rows per thread (rows y, y + 4, ... of the workgroup's band), every row's 16-byte load issued before the first is looked at:
+// beside three other lockstep groups a streaming kernel holds one or two wavefronts per SIMD, not the six it holds alone
+// (profiles/r06_occupancy.txt), and a workgroup's life is a chain of round trips -- kernel arguments, job record, data; throughput
+// under load is (resident wavefronts) x (bytes in flight per wavefront) / latency, and the middle factor is the kernel's to choose.
+constexpr int kQRows = 4;
 template <int MODE>
-__global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
+__device__ __forceinline__ void quant_row4(const PlaneJob &J, const QuantCfg &c, const LevelArgs &a, int si, int x, int y, int4 *cell, const int4 cv)
 {
-    DSV2_KERNEL_PRIO();
-    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int si = blockIdx.z % 3;
-    const PlaneJob &J = tab ? tab[blockIdx.z / 3] : one;
-    if (x >= a.sw || y >= a.sh || (((si + 1) & 2) && a.ydep && y == a.sh - 1)) {
-        return;
-    }
-    const bool coldep = ((si + 1) & 1) && a.xdep && x + 4 == a.sw;
-    const bool aligned = ((((uintptr_t) J.coefs) | ((uintptr_t) J.qv)) & 15) == 0 && (J.qv_base & 3u) == 0;
-    if (c.lossless || coldep || !aligned) {
-        for (int k = 0; k < (coldep ? 3 : 4); k++) {
-            quant_cell(J, c, a, si, x + k, y);
-        }
-        return;
-    }
     int32_t *coefs = J.coefs;
-    int4 *cell = (int4 *) (coefs + a.off[si] + (size_t) y * c.w + x);
-    const int4 cv = *cell;
     if (MODE == QM_P_PLAIN || MODE == QM_P_PSY) {
         // A P picture's step is at least 6/8 of the subband's (tmq_for_P) and its dead-zone offset is never negative (hzcc.c:364-380):
         // a coefficient below 6/8 of the step quantises to zero whatever its parent, its block's flags and vector say.  Most of a
@@ -435,6 +422,48 @@ __global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void k_quant_level4(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
+{
+    DSV2_KERNEL_PRIO();
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int yb = blockIdx.y * (4 * kQRows) + threadIdx.y;
+    const int si = blockIdx.z % 3;
+    const PlaneJob &J = tab ? tab[blockIdx.z / 3] : one;
+    if (x >= a.sw || yb >= a.sh) {
+        return;
+    }
+    const int ylim = (((si + 1) & 2) && a.ydep) ? a.sh - 1 : a.sh; // (the last row's dependents are phase B's)
+    const bool coldep = ((si + 1) & 1) && a.xdep && x + 4 == a.sw;
+    const bool aligned = ((((uintptr_t) J.coefs) | ((uintptr_t) J.qv)) & 15) == 0 && (J.qv_base & 3u) == 0;
+    if (c.lossless || coldep || !aligned) {
+        for (int r = 0; r < kQRows; r++) {
+            const int y = yb + 4 * r;
+            if (y < ylim) {
+                for (int k = 0; k < (coldep ? 3 : 4); k++) {
+                    quant_cell(J, c, a, si, x + k, y);
+                }
+            }
+        }
+        return;
+    }
+    int4 *cell[kQRows];
+    int4 cv[kQRows];
+#pragma unroll
+    for (int r = 0; r < kQRows; r++) { // (wave-uniform: a wavefront is one row segment)
+        const int y = yb + 4 * r;
+        cell[r] = (int4 *) (J.coefs + a.off[si] + (size_t) (y < ylim ? y : yb) * c.w + x);
+        cv[r] = *cell[r];
+    }
+#pragma unroll
+    for (int r = 0; r < kQRows; r++) {
+        const int y = yb + 4 * r;
+        if (y < ylim) {
+            quant_row4<MODE>(J, c, a, si, x, y, cell[r], cv[r]);
+        }
+    }
+}
+
 // phase B: the dependents (last column, then last row without the shared corner); blockIdx.y = subband - 1
 __global__ __launch_bounds__(256) void k_quant_level_dep(const PlaneJob *__restrict__ tab, PlaneJob one, QuantCfg c, LevelArgs a)
 {
@@ -496,7 +525,7 @@ static void quant_launch(hipStream_t s, const PlaneJob *tab, const PlaneJob &one
             a.vec = a.vec && (a.off[si] & 3) == 0 && (a.base[si] & 3) == 0 && (a.par[si] & 1) == 0;
         }
         if (a.vec) {
-            const dim3 grid4((a.sw / 4 + 63) / 64, (a.sh + 3) / 4, 3 * nz);
+            const dim3 grid4((a.sw / 4 + 63) / 64, (a.sh + 4 * kQRows - 1) / (4 * kQRows), 3 * nz);
             switch (quant_mode(cfg)) { // (a lossless launch goes cell by cell inside the kernel: any instance will do)
                 case QM_P_PLAIN: DSV2_LAUNCH(k_quant_level4<QM_P_PLAIN>, grid4, blk, 0, s, tab, one, cfg, a); break;
                 case QM_P_PSY: DSV2_LAUNCH(k_quant_level4<QM_P_PSY>, grid4, blk, 0, s, tab, one, cfg, a); break;

@@ -406,44 +406,60 @@ __global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ t
 // level 1 from the 8-bit picture, four 2x2 quads (eight pixels of two rows) per thread: two 8-byte loads, four 16-byte
 // stores (one per band).  Launched when the level's half width and the row stride are multiples of four; threads at the
 // picture's right / bottom edge, and jobs whose images are not 16-byte aligned, go quad by quad.
+constexpr int kHaarRows = 4; // output rows per thread (jy, jy + 4, ...): every row pair's loads are issued before the first is used
 __global__ __launch_bounds__(256) void k_fwd_haar_u8x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel, int ovf)
 {
     DSV2_KERNEL_PRIO();
     const PlaneJob &J = pick_job(tab, one);
     const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int jy = blockIdx.y * 4 + threadIdx.y;
-    if (idx >= g.hw || jy >= g.hh) {
+    const int jy0 = blockIdx.y * (4 * kHaarRows) + threadIdx.y;
+    if (idx >= g.hw || jy0 >= g.hh) {
         return;
     }
     int32_t *D = img(J, d_sel), *C = J.coefs;
-    const int x = 2 * idx, y = 2 * jy;
-    const bool fast = x + 8 <= min(g.sw, J.pic.w) && y + 2 <= min(g.sh, J.pic.h) &&
-                      ((((uintptr_t) D) | ((uintptr_t) C)) & 15) == 0 && (((uintptr_t) J.pic.data | (uintptr_t) J.pic.stride) & 7) == 0;
-    if (!fast) {
-        for (int q = 0; q < 4 && idx + q < g.hw; q++) {
-            fwd_haar_quad<true>(J, g, idx + q, jy, 0, d_sel, ovf);
-        }
-        return;
-    }
-    const uint8_t *r0 = J.pic.data + (size_t) y * J.pic.stride + x;
-    const uint2 a = *(const uint2 *) r0, b = *(const uint2 *) (r0 + J.pic.stride);
-    const uint32_t aw[2] = {a.x, a.y}, bw[2] = {b.x, b.y};
-    int ll[4], lh[4], hl[4], hh[4];
+    const int x = 2 * idx;
+    const bool fastx = x + 8 <= min(g.sw, J.pic.w) && ((((uintptr_t) D) | ((uintptr_t) C)) & 15) == 0 &&
+                       (((uintptr_t) J.pic.data | (uintptr_t) J.pic.stride) & 7) == 0;
+    uint2 a[kHaarRows], b[kHaarRows];
+    bool fast[kHaarRows];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t wa = aw[q >> 1] >> (16 * (q & 1)), wb = bw[q >> 1] >> (16 * (q & 1));
-        const int x0 = (int) (wa & 0xffu) - 128, x1 = (int) ((wa >> 8) & 0xffu) - 128;
-        const int x2 = (int) (wb & 0xffu) - 128, x3 = (int) ((wb >> 8) & 0xffu) - 128;
-        ll[q] = ovf ? (x0 + x1 + x2 + x3) / 2 : (x0 + x1 + x2 + x3);
-        lh[q] = x0 - x1 + x2 - x3;
-        hl[q] = x0 + x1 - x2 - x3;
-        hh[q] = x0 - x1 - x2 + x3;
+    for (int r = 0; r < kHaarRows; r++) {
+        const int jy = jy0 + 4 * r, y = 2 * jy;
+        fast[r] = fastx && jy < g.hh && y + 2 <= min(g.sh, J.pic.h);
+        const uint8_t *r0 = J.pic.data + (size_t) (fast[r] ? y : 2 * jy0) * J.pic.stride + x;
+        a[r] = fastx ? *(const uint2 *) r0 : make_uint2(0u, 0u);
+        b[r] = fast[r] ? *(const uint2 *) (r0 + J.pic.stride) : make_uint2(0u, 0u);
     }
-    const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
-    *(int4 *) (D + oLL) = make_int4(ll[0], ll[1], ll[2], ll[3]);
-    *(int4 *) (C + oLL + g.hw) = make_int4(lh[0], lh[1], lh[2], lh[3]);
-    *(int4 *) (C + oHL) = make_int4(hl[0], hl[1], hl[2], hl[3]);
-    *(int4 *) (C + oHL + g.hw) = make_int4(hh[0], hh[1], hh[2], hh[3]);
+#pragma unroll
+    for (int r = 0; r < kHaarRows; r++) {
+        const int jy = jy0 + 4 * r;
+        if (jy >= g.hh) {
+            break;
+        }
+        if (!fast[r]) {
+            for (int q = 0; q < 4 && idx + q < g.hw; q++) {
+                fwd_haar_quad<true>(J, g, idx + q, jy, 0, d_sel, ovf);
+            }
+            continue;
+        }
+        const uint32_t aw[2] = {a[r].x, a[r].y}, bw[2] = {b[r].x, b[r].y};
+        int ll[4], lh[4], hl[4], hh[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t wa = aw[q >> 1] >> (16 * (q & 1)), wb = bw[q >> 1] >> (16 * (q & 1));
+            const int x0 = (int) (wa & 0xffu) - 128, x1 = (int) ((wa >> 8) & 0xffu) - 128;
+            const int x2 = (int) (wb & 0xffu) - 128, x3 = (int) ((wb >> 8) & 0xffu) - 128;
+            ll[q] = ovf ? (x0 + x1 + x2 + x3) / 2 : (x0 + x1 + x2 + x3);
+            lh[q] = x0 - x1 + x2 - x3;
+            hl[q] = x0 + x1 - x2 - x3;
+            hh[q] = x0 - x1 - x2 + x3;
+        }
+        const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+        *(int4 *) (D + oLL) = make_int4(ll[0], ll[1], ll[2], ll[3]);
+        *(int4 *) (C + oLL + g.hw) = make_int4(lh[0], lh[1], lh[2], lh[3]);
+        *(int4 *) (C + oHL) = make_int4(hl[0], hl[1], hl[2], hl[3]);
+        *(int4 *) (C + oHL + g.hw) = make_int4(hh[0], hh[1], hh[2], hh[3]);
+    }
 }
 
 __device__ __forceinline__ int round2(int v) { return (v + (v < 0 ? -1 : 1)) / 2; }
@@ -918,7 +934,7 @@ static void fwd_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
         switch (filter) {
             case F_HAAR:
                 if (u8 && (g.hw & 3) == 0 && (g.w & 3) == 0) {
-                    DSV2_LAUNCH(k_fwd_haar_u8x4, grid3(g.hw / 4, g.hh, b), kBlk, 0, s, b.tab, b.one, g, d_sel, ovf);
+                    DSV2_LAUNCH(k_fwd_haar_u8x4, grid3(g.hw / 4, (g.hh + kHaarRows - 1) / kHaarRows, b), kBlk, 0, s, b.tab, b.one, g, d_sel, ovf);
                 } else if (u8) {
                     DSV2_LAUNCH((k_fwd_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
                 } else {
