@@ -177,11 +177,11 @@ def insts_part():
               open(os.path.join(dst, "instruction_volume.json"), "w"))
 
 
-def decode_part():
+def decode_part(tag="decode", mode="w"):
     """kernels of the decode leg: everything the traced process launched after its last encoder kernel (k_ent_out)"""
-    line = json.loads([l for l in open(os.path.join(src, "decode.json")) if l.startswith("{")][-1])
+    line = json.loads([l for l in open(os.path.join(src, tag + ".json")) if l.startswith("{")][-1])
     tr = []
-    for r in csv.DictReader(io.TextIOWrapper(gzip.open(os.path.join(src, "decode_kernel_trace.csv.gz")))):
+    for r in csv.DictReader(io.TextIOWrapper(gzip.open(os.path.join(src, tag + "_kernel_trace.csv.gz")))):
         tr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     tr.sort()
     last_enc = max(e for s, e, n in tr if "k_ent_out" in n)
@@ -192,7 +192,9 @@ def decode_part():
         by[n] += e - s
         cnt[n] += 1
     d = line.get("decode", {})
-    with open(os.path.join(dst, TAG + "_decode_kernel_stats.txt"), "w") as f:
+    with open(os.path.join(dst, TAG + "_decode_kernel_stats.txt"), mode) as f:
+        if mode == "a":
+            f.write("\n\n==== the same leg with DSV2_DEC_DEVICE_PARSE=1: the P pictures' plane sections parsed on the device (k_dec_parse, csrc/dec_parse_dev.hip) ====\n")
         f.write("rocprofv3 --kernel-trace -- python3 bench.py --no-extras --decode-too --streams 256 --groups 4 --steps 24 (tools/profile_decode.sh): the kernels launched\n"
                 "after the last encoder kernel = the decode leg (warm-up, %d timed pictures, the stage-event steps); 256 decoders in 4 lockstep groups\n" % d.get("frames", 0))
         f.write("decode leg under the profiler: %s frames/s, host_cpu_cores_busy %s; roofline object of the line: %s\n"
@@ -343,4 +345,6 @@ if have("insts.csv.gz"):
     insts_part()
 if have("decode_kernel_trace.csv.gz") and have("decode.json"):
     decode_part()
+    if have("decode_dev_kernel_trace.csv.gz") and have("decode_dev.json"):
+        decode_part("decode_dev", "a")
 print("summarised into", dst)
