@@ -651,12 +651,17 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const CompactJob *_
     }
 }
 
+// kScatterTiles tiles per workgroup.  Three tiles in four of a P picture hold nothing, and a workgroup per tile spent its life on the
+// round trips that tell it so (kernel arguments, job record, two tile bases) -- 3 038 workgroups a picture, 9 x slower under load than
+// alone (round 6).  Now the first nine threads fetch the nine bases of eight tiles at once and the workgroup walks the tiles that hold something.
+constexpr int kScatterTiles = 8;
 __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ tab, CompactJob one)
 {
     DSV2_KERNEL_PRIO();
     __shared__ int wsum[4];
     __shared__ uint32_t spos[kTile];
     __shared__ int32_t sval[kTile];
+    __shared__ int tbs[kScatterTiles + 1];
     const CompactJob &J = tab ? tab[blockIdx.y] : one;
     const int32_t *qv = J.qv;
     int n = J.n;
@@ -665,60 +670,72 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
     uint32_t *host_pos = J.host_pos;
     int32_t *host_val = J.host_val;
     int host_cap = host_pos ? J.host_cap : 0;
-    int base = blockIdx.x * kTile;
-    // the scan of the tile counts tells which tiles hold nothing (most of the finest level of a P picture): not read at all
-    const int tb = J.tile_base[blockIdx.x];
-    const int tb_next = (base + kTile < n) ? J.tile_base[blockIdx.x + 1] : *J.total;
-    if (tb_next == tb) {
+    const int ntiles = (n + kTile - 1) / kTile;
+    const int t0 = blockIdx.x * kScatterTiles;
+    if (t0 >= ntiles) {
         return;
     }
-    int vals[4];
-    int cnt = 0;
-    const int i0 = base + threadIdx.x * 4;
-    if (i0 + 3 < n && (((uintptr_t) qv) & 15) == 0) {
-        const int4 q4 = *(const int4 *) (qv + i0);
-        vals[0] = q4.x, vals[1] = q4.y, vals[2] = q4.z, vals[3] = q4.w;
-    } else {
+    // the scan of the tile counts tells which tiles hold nothing (most of the finest level of a P picture): not read at all
+    if (threadIdx.x <= kScatterTiles) {
+        const int t = t0 + (int) threadIdx.x;
+        tbs[threadIdx.x] = t < ntiles ? J.tile_base[t] : *J.total;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < kScatterTiles && t0 + k < ntiles; k++) {
+        const int tb = tbs[k], tb_next = tbs[k + 1];
+        if (tb_next == tb) {
+            continue; // (uniform over the workgroup)
+        }
+        const int base = (t0 + k) * kTile;
+        int vals[4];
+        int cnt = 0;
+        const int i0 = base + threadIdx.x * 4;
+        if (i0 + 3 < n && (((uintptr_t) qv) & 15) == 0) {
+            const int4 q4 = *(const int4 *) (qv + i0);
+            vals[0] = q4.x, vals[1] = q4.y, vals[2] = q4.z, vals[3] = q4.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                vals[j] = (i0 + j < n) ? qv[i0 + j] : 0;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            vals[j] = (i0 + j < n) ? qv[i0 + j] : 0;
+            cnt += vals[j] != 0;
         }
-    }
+        int inc = wave_incl_scan(cnt, lane);
+        if (lane == 63) {
+            wsum[wv] = inc;
+        }
+        __syncthreads();
+        int o = inc - cnt;
+        for (int w = 0; w < wv; w++) {
+            o += wsum[w];
+        }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        cnt += vals[j] != 0;
-    }
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int inc = wave_incl_scan(cnt, lane);
-    if (lane == 63) {
-        wsum[wv] = inc;
-    }
-    __syncthreads();
-    int o = inc - cnt;
-    for (int k = 0; k < wv; k++) {
-        o += wsum[k];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (vals[j] != 0) {
-            spos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
-            sval[o] = vals[j];
-            o++;
+        for (int j = 0; j < 4; j++) {
+            if (vals[j] != 0) {
+                spos[o] = (uint32_t) (base + threadIdx.x * 4 + j);
+                sval[o] = vals[j];
+                o++;
+            }
         }
-    }
-    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    for (int k = threadIdx.x; k < total; k += 256) {
-        uint32_t p = spos[k];
-        int32_t v = sval[k];
-        if (tb + k < J.list_cap) { // (a picture with more symbols than the lists hold: the host sees it in *total and has it redone)
-            out_pos[tb + k] = p;
-            out_val[tb + k] = v;
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        for (int q = threadIdx.x; q < total; q += 256) {
+            uint32_t p = spos[q];
+            int32_t v = sval[q];
+            if (tb + q < J.list_cap) { // (a picture with more symbols than the lists hold: the host sees it in *total and has it redone)
+                out_pos[tb + q] = p;
+                out_val[tb + q] = v;
+            }
+            if (tb + q < host_cap) {
+                host_pos[tb + q] = p;
+                host_val[tb + q] = v;
+            }
         }
-        if (tb + k < host_cap) {
-            host_pos[tb + k] = p;
-            host_val[tb + k] = v;
-        }
+        __syncthreads(); // (wsum / spos / sval are the next tile's)
     }
 }
 
@@ -782,7 +799,7 @@ void Compactor::run(hipStream_t s, const int32_t *qv, size_t n)
     int ntiles = (int) ((n + kTile - 1) / kTile);
     DSV2_LAUNCH(k_count, dim3(ntiles), dim3(256), 0, s, nullptr, one);
     DSV2_LAUNCH(k_scan_tiles, dim3(1), dim3(kScanThreads), 0, s, nullptr, one, 1); // counts always left at zero
-    DSV2_LAUNCH(k_scatter, dim3(ntiles), dim3(256), 0, s, nullptr, one);
+    DSV2_LAUNCH(k_scatter, dim3((ntiles + kScatterTiles - 1) / kScatterTiles), dim3(256), 0, s, nullptr, one);
     HIPCHK(hipMemcpyAsync(h_total, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
 }
@@ -797,7 +814,7 @@ void compact_jobs(hipStream_t s, const CompactJob *d_jobs, int njobs, size_t n, 
         DSV2_LAUNCH(k_count, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     }
     DSV2_LAUNCH(k_scan_tiles, dim3(1, njobs), dim3(kScanThreads), 0, s, d_jobs, CompactJob{}, counted ? 1 : 0);
-    DSV2_LAUNCH(k_scatter, dim3(ntiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
+    DSV2_LAUNCH(k_scatter, dim3((ntiles + kScatterTiles - 1) / kScatterTiles, njobs), dim3(256), 0, s, d_jobs, CompactJob{});
     HIPCHK(hipGetLastError());
 }
 
