@@ -138,31 +138,47 @@ __global__ __launch_bounds__(256) void k_ds2x(const PlanePair *__restrict__ tab,
 // the same, four output samples per thread: two 8-byte loads (rows 2y, 2y + 1), byte-lane sums, one dword store.
 // Needs 16-byte aligned plane origins and strides (every plane made by dframe_alloc); the last partial group of a row
 // goes sample by sample.
+constexpr int kDsRows = 4; // output rows per thread (y, y + 4, ...): all eight 8-byte loads issued before the first average
 __global__ __launch_bounds__(256) void k_ds2x4(const PlanePair *__restrict__ tab, PlanePair one)
 {
     DSV2_KERNEL_PRIO();
     const PlanePair &pp = tab ? tab[blockIdx.z] : one;
-    int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= pp.dst.w || y >= pp.dst.h) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = blockIdx.y * (4 * kDsRows) + threadIdx.y;
+    if (x >= pp.dst.w || y0 >= pp.dst.h) {
         return;
     }
-    int sstride = pp.src.stride;
-    const uint8_t *sp = pp.src.data + (size_t) (2 * y) * sstride + 2 * x;
-    uint8_t *dp = pp.dst.data + (size_t) y * pp.dst.stride + x;
-    if (x + 4 <= pp.dst.w) {
-        const uint2 a = *(const uint2 *) sp, b = *(const uint2 *) (sp + sstride);
-        const uint32_t m = 0x00ff00ffu;
-        // per 32-bit word: bytes (p0 p1 p2 p3) -> 16-bit fields (p0 + p1, p2 + p3)
-        uint32_t lo = (a.x & m) + ((a.x >> 8) & m) + (b.x & m) + ((b.x >> 8) & m) + 0x00020002u;
-        uint32_t hi = (a.y & m) + ((a.y >> 8) & m) + (b.y & m) + ((b.y >> 8) & m) + 0x00020002u;
-        lo = (lo >> 2) & m; // outputs 0, 1 in bytes 0 and 2
-        hi = (hi >> 2) & m; // outputs 2, 3
-        *(uint32_t *) dp = (lo & 0xffu) | ((lo >> 8) & 0xff00u) | ((hi & 0xffu) << 16) | ((hi >> 16) << 24);
-    } else {
-        for (int i = 0; x + i < pp.dst.w; i++) {
-            const uint8_t *q = sp + 2 * i;
-            dp[i] = (uint8_t) ((q[0] + q[1] + q[sstride] + q[sstride + 1] + 2) >> 2);
+    const int sstride = pp.src.stride;
+    const bool whole = x + 4 <= pp.dst.w;
+    uint2 a[kDsRows], b[kDsRows];
+#pragma unroll
+    for (int r = 0; r < kDsRows; r++) {
+        const int y = y0 + 4 * r < pp.dst.h ? y0 + 4 * r : y0;
+        const uint8_t *sp = pp.src.data + (size_t) (2 * y) * sstride + 2 * x;
+        a[r] = whole ? *(const uint2 *) sp : make_uint2(0u, 0u);
+        b[r] = whole ? *(const uint2 *) (sp + sstride) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < kDsRows; r++) {
+        const int y = y0 + 4 * r;
+        if (y >= pp.dst.h) {
+            break;
+        }
+        const uint8_t *sp = pp.src.data + (size_t) (2 * y) * sstride + 2 * x;
+        uint8_t *dp = pp.dst.data + (size_t) y * pp.dst.stride + x;
+        if (whole) {
+            const uint32_t m = 0x00ff00ffu;
+            // per 32-bit word: bytes (p0 p1 p2 p3) -> 16-bit fields (p0 + p1, p2 + p3)
+            uint32_t lo = (a[r].x & m) + ((a[r].x >> 8) & m) + (b[r].x & m) + ((b[r].x >> 8) & m) + 0x00020002u;
+            uint32_t hi = (a[r].y & m) + ((a[r].y >> 8) & m) + (b[r].y & m) + ((b[r].y >> 8) & m) + 0x00020002u;
+            lo = (lo >> 2) & m; // outputs 0, 1 in bytes 0 and 2
+            hi = (hi >> 2) & m; // outputs 2, 3
+            *(uint32_t *) dp = (lo & 0xffu) | ((lo >> 8) & 0xff00u) | ((hi & 0xffu) << 16) | ((hi >> 16) << 24);
+        } else {
+            for (int i = 0; x + i < pp.dst.w; i++) {
+                const uint8_t *q = sp + 2 * i;
+                dp[i] = (uint8_t) ((q[0] + q[1] + q[sstride] + q[sstride + 1] + 2) >> 2);
+            }
         }
     }
 }
@@ -186,7 +202,7 @@ void ds2x_planes4(hipStream_t s, const PlanePair *d_pairs, int n, int dst_w, int
     if (n <= 0) {
         return;
     }
-    DSV2_LAUNCH(k_ds2x4, dim3((dst_w + 255) / 256, (dst_h + 3) / 4, n), dim3(64, 4), 0, s, d_pairs, PlanePair{});
+    DSV2_LAUNCH(k_ds2x4, dim3((dst_w + 255) / 256, (dst_h + 4 * kDsRows - 1) / (4 * kDsRows), n), dim3(64, 4), 0, s, d_pairs, PlanePair{});
 }
 
 // visible pixels of all planes, device to device (frame.c:186-203 without the extension)
