@@ -403,6 +403,66 @@ __global__ __launch_bounds__(256) void k_fwd_haar(const PlaneJob *__restrict__ t
     fwd_haar_quad<U8>(J, g, idx, jy, s_sel, d_sel, ovf);
 }
 
+// levels above 1, four quads per thread (round 6): the int32 image's two rows as four 16-byte loads, one 16-byte store per band,
+// two quad rows per thread with every load issued up front.  The quad-per-thread kernel above moved 4 bytes per lane and load:
+// at a third of level 1's work the levels 2 .. 3 took as long under load.  Launched when the level's half width and the row
+// stride are multiples of four; edge threads and unaligned jobs go quad by quad.
+constexpr int kHaarRowsI = 1;
+__global__ __launch_bounds__(256) void k_fwd_haar_i32x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int s_sel, int d_sel, int ovf)
+{
+    DSV2_KERNEL_PRIO();
+    const PlaneJob &J = pick_job(tab, one);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int jy0 = blockIdx.y * (4 * kHaarRowsI) + threadIdx.y;
+    if (idx >= g.hw || jy0 >= g.hh) {
+        return;
+    }
+    int32_t *D = img(J, d_sel), *C = J.coefs;
+    const int32_t *S = img(J, s_sel);
+    const int x = 2 * idx;
+    const bool fastx = x + 8 <= g.sw && ((((uintptr_t) D) | ((uintptr_t) C) | ((uintptr_t) S)) & 15) == 0;
+    int4 a0[kHaarRowsI], a1[kHaarRowsI], b0[kHaarRowsI], b1[kHaarRowsI];
+    const int4 z4 = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < kHaarRowsI; r++) {
+        const int jy = jy0 + 4 * r, y = 2 * jy;
+        const bool f = fastx && jy < g.hh && y + 2 <= g.sh;
+        const int32_t *r0 = S + (size_t) (f ? y : 0) * g.w + x;
+        a0[r] = f ? *(const int4 *) r0 : z4;
+        a1[r] = f ? *(const int4 *) (r0 + 4) : z4;
+        b0[r] = f ? *(const int4 *) (r0 + g.w) : z4;
+        b1[r] = f ? *(const int4 *) (r0 + g.w + 4) : z4;
+    }
+#pragma unroll
+    for (int r = 0; r < kHaarRowsI; r++) {
+        const int jy = jy0 + 4 * r, y = 2 * jy;
+        if (jy >= g.hh) {
+            // (nothing: past the level's last quad row)
+        } else if (!(fastx && y + 2 <= g.sh)) {
+            for (int q = 0; q < 4 && idx + q < g.hw; q++) {
+                fwd_haar_quad<false>(J, g, idx + q, jy, s_sel, d_sel, ovf);
+            }
+        } else {
+        const int ta[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
+        const int tb[8] = {b0[r].x, b0[r].y, b0[r].z, b0[r].w, b1[r].x, b1[r].y, b1[r].z, b1[r].w};
+        int ll[4], lh[4], hl[4], hh[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x0 = ta[2 * q], x1 = ta[2 * q + 1], x2 = tb[2 * q], x3 = tb[2 * q + 1];
+            ll[q] = ovf ? (x0 + x1 + x2 + x3) / 2 : (x0 + x1 + x2 + x3);
+            lh[q] = x0 - x1 + x2 - x3;
+            hl[q] = x0 + x1 - x2 - x3;
+            hh[q] = x0 - x1 - x2 + x3;
+        }
+        const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+        *(int4 *) (D + oLL) = make_int4(ll[0], ll[1], ll[2], ll[3]);
+        *(int4 *) (C + oLL + g.hw) = make_int4(lh[0], lh[1], lh[2], lh[3]);
+        *(int4 *) (C + oHL) = make_int4(hl[0], hl[1], hl[2], hl[3]);
+        *(int4 *) (C + oHL + g.hw) = make_int4(hh[0], hh[1], hh[2], hh[3]);
+        }
+    }
+}
+
 // level 1 from the 8-bit picture, four 2x2 quads (eight pixels of two rows) per thread: two 8-byte loads, four 16-byte
 // stores (one per band).  Launched when the level's half width and the row stride are multiples of four; threads at the
 // picture's right / bottom edge, and jobs whose images are not 16-byte aligned, go quad by quad.
@@ -628,6 +688,62 @@ __global__ __launch_bounds__(256) void k_inv_haar_u8x4(const PlaneJob *__restric
     uint8_t *r0 = J.pic.data + (size_t) y * J.pic.stride + x;
     *(uint2 *) r0 = make_uint2(r0w[0], r0w[1]);
     *(uint2 *) (r0 + J.pic.stride) = make_uint2(r1w[0], r1w[1]);
+}
+
+// levels above 1, four quads per thread to the int32 image (round 6): k_inv_haar_u8x4's loads, four 16-byte stores.  Interior
+// threads only; the rest goes quad by quad.
+__global__ __launch_bounds__(256) void k_inv_haar_i32x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int ll_sel, int d_sel, int ovf,
+                                                        int filtered, int hdiv)
+{
+    DSV2_KERNEL_PRIO();
+    const PlaneJob &J = pick_job(tab, one);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int jy = blockIdx.y * 4 + threadIdx.y;
+    if (idx >= g.hw || jy >= g.hh) {
+        return;
+    }
+    const int32_t *LLp = img(J, ll_sel), *C = J.coefs;
+    int32_t *O = J.t[d_sel];
+    const int x = 2 * idx, y = 2 * jy;
+    const bool fast = idx > 0 && idx + 4 < g.hw && jy > 0 && jy + 1 < g.hh && x + 8 <= g.sw && y + 2 <= g.sh &&
+                      ((((uintptr_t) LLp) | ((uintptr_t) C) | ((uintptr_t) O)) & 15) == 0;
+    if (!fast) {
+        for (int q = 0; q < 4 && idx + q < g.hw; q++) {
+            inv_haar_quad<false>(J, g, idx + q, jy, ll_sel, d_sel, ovf, filtered, hdiv);
+        }
+        return;
+    }
+    const int hqp = J.q / hdiv;
+    const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
+    const int4 l4 = *(const int4 *) (LLp + oLL), lh4 = *(const int4 *) (C + oLL + g.hw), hl4 = *(const int4 *) (C + oHL),
+               hh4 = *(const int4 *) (C + oHL + g.hw);
+    const int sc = 1 << ovf;
+    const int L[6] = {filtered ? LLp[oLL - 1] * sc : 0, l4.x * sc, l4.y * sc, l4.z * sc, l4.w * sc, filtered ? LLp[oLL + 4] * sc : 0};
+    int LH[4] = {lh4.x, lh4.y, lh4.z, lh4.w}, HL[4] = {hl4.x, hl4.y, hl4.z, hl4.w};
+    const int HH[4] = {hh4.x, hh4.y, hh4.z, hh4.w};
+    if (filtered) {
+        const int4 u4 = *(const int4 *) (LLp + oLL - g.w), d4 = *(const int4 *) (LLp + oLL + g.w);
+        const int U[4] = {u4.x * sc, u4.y * sc, u4.z * sc, u4.w * sc}, Dn[4] = {d4.x * sc, d4.y * sc, d4.z * sc, d4.w * sc};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            LH[q] = nudge(L[q + 1], L[q], L[q + 2], LH[q], hqp);
+            HL[q] = nudge(L[q + 1], U[q], Dn[q], HL[q], hqp);
+        }
+    }
+    int r0v[8], r1v[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int LL = L[q + 1];
+        r0v[2 * q] = (LL + LH[q] + HL[q] + HH[q]) / 4;
+        r0v[2 * q + 1] = (LL - LH[q] + HL[q] - HH[q]) / 4;
+        r1v[2 * q] = (LL + LH[q] - HL[q] - HH[q]) / 4;
+        r1v[2 * q + 1] = (LL - LH[q] - HL[q] + HH[q]) / 4;
+    }
+    int32_t *r0 = O + (size_t) y * g.w + x;
+    *(int4 *) r0 = make_int4(r0v[0], r0v[1], r0v[2], r0v[3]);
+    *(int4 *) (r0 + 4) = make_int4(r0v[4], r0v[5], r0v[6], r0v[7]);
+    *(int4 *) (r0 + g.w) = make_int4(r1v[0], r1v[1], r1v[2], r1v[3]);
+    *(int4 *) (r0 + g.w + 4) = make_int4(r1v[4], r1v[5], r1v[6], r1v[7]);
 }
 
 // ---- the Haar tail of a plane in ONE launch --------------------------------------------------------------------
@@ -937,6 +1053,8 @@ static void fwd_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
                     DSV2_LAUNCH(k_fwd_haar_u8x4, grid3(g.hw / 4, (g.hh + kHaarRows - 1) / kHaarRows, b), kBlk, 0, s, b.tab, b.one, g, d_sel, ovf);
                 } else if (u8) {
                     DSV2_LAUNCH((k_fwd_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
+                } else if ((g.hw & 3) == 0 && (g.w & 3) == 0) {
+                    DSV2_LAUNCH(k_fwd_haar_i32x4, grid3(g.hw / 4, (g.hh + kHaarRowsI - 1) / kHaarRowsI, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
                 } else {
                     DSV2_LAUNCH((k_fwd_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, s_sel, d_sel, ovf);
                 }
@@ -980,6 +1098,8 @@ static void inv_levels(hipStream_t s, const Batch &b, int cw, int ch, int plane_
                 } else if (u8) {
                     DSV2_LAUNCH((k_inv_haar<true>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
                                        filtered, hdiv);
+                } else if ((g.hw & 3) == 0 && (g.w & 3) == 0) {
+                    DSV2_LAUNCH(k_inv_haar_i32x4, grid3(g.hw / 4, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf, filtered, hdiv);
                 } else {
                     DSV2_LAUNCH((k_inv_haar<false>), grid3(g.hw, g.hh, b), kBlk, 0, s, b.tab, b.one, g, ll_sel, d_sel, ovf,
                                        filtered, hdiv);
