@@ -1536,6 +1536,9 @@ static const bool kFusedCount = true;
 // pyramids and source pre-pass still enqueued on the stream)
 static std::atomic<int> g_fail_next_step{0};
 
+// workgroups per (picture, plane) of the entropy coder's chunk kernels; each walks its share of the plane's 1 024-symbol chunks
+static const int kEntSlots = getenv("DSV2_ENT_SLOTS") ? atoi(getenv("DSV2_ENT_SLOTS")) : 32; // (192 until round 6: four in five of those workgroups found no chunk)
+
 static void enc_batch_step(Job *jobs, int n);
 bool enc_batch_ok(Job *jobs, int n)
 {
@@ -2131,9 +2134,9 @@ static void enc_batch_step(Job *jobs, int n)
         if (kAuxStreams & 1) {
             sc.ensure_aux();
             sc.fork(bs, 0);
-            entropy_gpu_jobs(sc.aux[0], d_ent, n, ent_geom(dv0.qv_off, dv0.scan), 192);
+            entropy_gpu_jobs(sc.aux[0], d_ent, n, ent_geom(dv0.qv_off, dv0.scan), kEntSlots);
         } else {
-            entropy_gpu_jobs(bs, d_ent, n, ent_geom(dv0.qv_off, dv0.scan), 192);
+            entropy_gpu_jobs(bs, d_ent, n, ent_geom(dv0.qv_off, dv0.scan), kEntSlots);
         }
     }
     prof.end(bs, ST_QUANT, n);
