@@ -1525,7 +1525,7 @@ static const bool kGpuEntropy = !(getenv("DSV2_GPU_ENTROPY") && atoi(getenv("DSV
 // side streams within a step: bit 0 entropy coder, bit 1 intra filter; unset: the entropy kernels of a SMALL batch (fewer than
 // 12 streams: the step is a chain of latency-bound launches on a mostly idle GPU) run beside inverse transform /
 // reconstruction / filters, a large batch keeps one chain (no throughput gain there, more host work)
-static const int kAuxStreamsEnv = -1;
+static const int kAuxStreamsEnv = -1; // (re-measured in round 6 with 192-picture launches: 1 -> -0.6 %, 3 -> +0.2 %: a group's chain in parallel with itself buys nothing)
 static const bool kEntForceFallback = getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK") && atoi(getenv("DSV2_GPU_ENTROPY_FORCE_FALLBACK")) != 0; // (tests)
 // the quantiser tallies nonzeros per compaction tile while it writes the values (DSV2_FUSED_COUNT=0: separate pass)
 static std::atomic<long> g_list_growths{0}; // pictures that had more symbols than their stream's compaction lists (dsv2hip_enc_list_growths)

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar_i32x4(const PlaneJob *__restri
 // level 1 from the 8-bit picture, four 2x2 quads (eight pixels of two rows) per thread: two 8-byte loads, four 16-byte
 // stores (one per band).  Launched when the level's half width and the row stride are multiples of four; threads at the
 // picture's right / bottom edge, and jobs whose images are not 16-byte aligned, go quad by quad.
-constexpr int kHaarRows = 4; // output rows per thread (jy, jy + 4, ...): every row pair's loads are issued before the first is used
+constexpr int kHaarRows = 2; // output rows per thread (jy, jy + 4): both row pairs' loads are issued before the first is used (four rows: 60 registers, a wavefront per SIMD fewer under load, no faster)
 __global__ __launch_bounds__(256) void k_fwd_haar_u8x4(const PlaneJob *__restrict__ tab, PlaneJob one, LevelGeom g, int d_sel, int ovf)
 {
     DSV2_KERNEL_PRIO();
