@@ -270,36 +270,13 @@ __device__ __forceinline__ LaneStep lane_neg(uint64_t w)
     return lane_finish(w, sign ? -mag : mag, l + 1, ok1 && l + 1 <= 40, false);
 }
 
-// DSV2_DEC_PARSE_STATS=1: [0] rounds, [1] symbols out of rounds, [2] symbols of the serial step
-__device__ unsigned long long g_parse_stats[4];
-
-// the (position, value) pairs leave through the lanes: pair n sits in lane n % 64 and the wavefront stores 64 at a time
-struct PairOut {
-    uint32_t *pos;
-    int32_t *val;
-    int vp, vv; // this lane's pending pair
-    __device__ __forceinline__ void put(int n, uint32_t p, int v) // n: wave-uniform index of the pair
-    {
-        const bool mine = (int) threadIdx.x == (n & 63); // (a compare and two selects: no exec-mask juggling)
-        vp = mine ? (int) p : vp;
-        vv = mine ? v : vv;
-        if ((n & 63) == 63) {
-            pos[(n & ~63) + (int) threadIdx.x] = (uint32_t) vp;
-            val[(n & ~63) + (int) threadIdx.x] = vv;
-        }
-    }
-    __device__ __forceinline__ void flush(int n) // n pairs in all
-    {
-        if ((int) threadIdx.x < (n & 63)) {
-            pos[(n & ~63) + (int) threadIdx.x] = (uint32_t) vp;
-            val[(n & ~63) + (int) threadIdx.x] = vv;
-        }
-    }
-};
+// DSV2_DEC_PARSE_STATS=1: [0] rounds, [1] symbols out of rounds, [2] symbols of the serial step; =2: [3] luma sections, [4..7] shader clocks (lanes, walk, commit, all)
+__device__ unsigned long long g_parse_stats[8];
 
 __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict__ tab, DecScanBases luma, DecScanBases chroma, int lane_rounds, int stats)
 {
     unsigned st_rounds = 0, st_lane = 0, st_exact = 0;
+    unsigned long long cy_lane = 0, cy_walk = 0, cy_commit = 0, cy_t0 = 0, cy_all0 = __builtin_readcyclecounter();
     DSV2_CENSUS_SCOPE();
     // one wavefront, one dependency chain, and a whole step waits for the longest of them: it issues ahead of the streaming kernels'
     // wavefronts it shares a SIMD with (DSV2_DEC_PARSE_PRIO=0: default priority)
@@ -316,7 +293,6 @@ __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict_
     br.limit = J.limit_bits;
     br.overrun = false;
     br.start_at(J.data_bitpos);
-    PairOut out{J.pos, J.val, 0, 0};
     int runs = J.runs;
     int vk = 0, n = 0, ok = 1;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0; // symbols in {LL region, level 0, 1, 2}
@@ -378,6 +354,9 @@ __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict_
                 const bool up = rice && (hiA - vk) < (vk - loA) && kA < 31;
                 const int kB = rice ? (up ? kA + 1 : kA - 1) : -1; // (-1: no second guess)
                 const int loB = kB >= 0 ? kB << damp : 1, hiB = kB >= 0 ? (kB >= 31 ? 0x7fffffff : loB + (1 << damp) - 1) : 0;
+                if (stats >= 2) {
+                    cy_t0 = __builtin_readcyclecounter();
+                }
                 if ((P >> 3) < br.base || (P >> 3) + 40 > br.base + kWinBytes) {
                     br.refill(P >> 3);
                 }
@@ -390,49 +369,107 @@ __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict_
                     sA = lane_neg(w);
                     sB = sA;
                 }
-                // ---- the true chain through the lanes' answers ----
+                // ---- the true chain through the lanes' answers, in two phases ----
+                // Phase 1, scalar, as little as a step allows: ONE lane read (the two guesses' lengths / flags, packed), the guess that
+                // vk picks, a bit set in two 64-bit masks -- which lanes START a step, which of them take the second guess -- vk moved,
+                // the next start lane.  (Measured before this form: with the step's bookkeeping in vector registers the walk was 55 %
+                // of a section's clocks, 400 a step.)  It stops at an undecodable lane, when neither guess holds, after 64 bits, or at the
+                // step count the section / the list allows.
+                const unsigned pk2 = sA.pack | (sB.pack << 16);
+                if (stats >= 2) {
+                    const unsigned long long t = __builtin_readcyclecounter();
+                    cy_lane += t - cy_t0 + (unsigned long long) (__builtin_amdgcn_readfirstlane((int) pk2) & 0); // (after the lanes' answers exist)
+                    cy_t0 = t;
+                }
+                const int max_steps = min(min(runs - 1, J.cap - n), 64);
+                const int vk0 = vk;
                 unsigned j = 0;
-                int steps = 0;
-                for (;;) {
-                    bool useB = false;
+                int T = 0;
+                unsigned long long starts = 0, selB = 0;
+                bool bad_lane = false;
+                while (T < max_steps && j < 64) {
+                    unsigned sel = 0;
                     if (rice && (vk < loA || vk > hiA)) {
                         if (vk < loB || vk > hiB) {
                             break; // neither guess: a new round
                         }
-                        useB = true;
+                        sel = 1;
                     }
-                    const unsigned pk = (unsigned) __builtin_amdgcn_readlane((int) (useB ? sB.pack : sA.pack), (int) j);
+                    const unsigned pk = ((unsigned) __builtin_amdgcn_readlane((int) pk2, (int) j) >> (16 * sel)) & 0x1ffu;
                     if (!(pk & kStepValid)) {
-                        left = true;
+                        bad_lane = true;
                         break;
                     }
-                    const int v = __builtin_amdgcn_readlane(useB ? sB.v : sA.v, (int) j);
-                    const unsigned nr = (unsigned) __builtin_amdgcn_readlane((int) (useB ? sB.run : sA.run), (int) j);
+                    starts |= 1ull << j;
+                    selB |= (unsigned long long) sel << j;
                     if (rice) {
                         vk += (pk & kStepQnz) ? 1 : (vk > 0 ? -1 : 0);
                     }
-                    out.put(n, p, v);
-                    n++;
-                    steps++;
-                    cur = p + 1;
-                    run = nr;
-                    runs--;
                     j += pk & 127u;
-                    if (run >= seg_end - cur) {
-                        break; // another subband (its coding / damping may differ) or off the plane: the top of the round loop sorts it out
-                    }
-                    p = cur + run;
-                    if (j >= 64 || runs < 2 || n >= J.cap) {
-                        left = runs < 2 || n >= J.cap;
-                        break;
-                    }
+                    T++;
                 }
-                c0 += seg == 0 ? steps : 0;
-                c1 += seg >= 1 && seg <= 3 ? steps : 0;
-                c2 += seg >= 4 && seg <= 6 ? steps : 0;
-                c3 += seg >= 7 ? steps : 0;
-                st_lane += (unsigned) steps;
+                if (stats >= 2) {
+                    const unsigned long long t = __builtin_readcyclecounter();
+                    cy_walk += t - cy_t0;
+                    cy_t0 = t;
+                }
+                // Phase 2, in the start lanes themselves: a start lane holds its step's value and run; its scan position is p plus the
+                // sum of (run + 1) over the start lanes before it (a DPP scan: no LDS), its place in the list its rank among them; the
+                // first step that leaves the subband (or the plane) ends the round before it.
+                int Tc = T; // steps committed
+                if (T > 0) {
+                    const int lane = (int) threadIdx.x;
+                    const bool isS = (starts >> lane) & 1ull, useB = (selB >> lane) & 1ull;
+                    const int v = useB ? sB.v : sA.v;
+                    const unsigned nr = useB ? sB.run : sA.run;
+                    const unsigned inc = isS ? min(nr, total) + 1u : 0u; // (a run that reaches the plane's end is as good as any larger one: the sums stay inside 32 bits)
+                    int x = (int) inc;
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1 .. 8: inclusive scan inside each row of 16
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+                    const unsigned pt = p + ((unsigned) x - inc);
+                    const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (starts >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) starts, 0u));
+                    unsigned long long committed = starts;
+                    const unsigned long long over = __ballot(isS && pt >= seg_end);
+                    if (over) { // (never lane 0: step 0's position was checked above)
+                        const int jo = __ffsll((long long) over) - 1;
+                        committed = starts & ((1ull << jo) - 1ull);
+                        Tc = __popcll(committed);
+                        // the round ended early: the bit position of the step that left, and vk as it was before it (re-walked: once per subband)
+                        j = (unsigned) jo;
+                        vk = vk0;
+                        if (rice) {
+                            for (unsigned long long m = committed; m; m &= m - 1) {
+                                const int jl = __ffsll((long long) m) - 1;
+                                const unsigned pkl = ((unsigned) __builtin_amdgcn_readlane((int) pk2, jl) >> (16 * (int) ((selB >> jl) & 1ull))) & 0x1ffu;
+                                vk += (pkl & kStepQnz) ? 1 : (vk > 0 ? -1 : 0);
+                            }
+                        }
+                        bad_lane = false;
+                    }
+                    if (isS && rank < Tc) {
+                        J.pos[n + rank] = pt;
+                        J.val[n + rank] = v;
+                    }
+                    const int lastl = 63 - __builtin_clzll(committed);
+                    cur = (uint32_t) __builtin_amdgcn_readlane((int) pt, lastl) + 1;
+                    run = (uint32_t) __builtin_amdgcn_readlane((int) nr, lastl);
+                    n += Tc;
+                    runs -= Tc;
+                }
+                left = bad_lane || runs < 2 || n >= J.cap;
+                c0 += seg == 0 ? Tc : 0;
+                c1 += seg >= 1 && seg <= 3 ? Tc : 0;
+                c2 += seg >= 4 && seg <= 6 ? Tc : 0;
+                c3 += seg >= 7 ? Tc : 0;
+                st_lane += (unsigned) Tc;
                 P += j;
+                if (stats >= 2) {
+                    cy_commit += __builtin_readcyclecounter() - cy_t0 + (unsigned long long) (__builtin_amdgcn_readfirstlane((int) cur) & 0);
+                }
             }
             br.start_at(P);
         }
@@ -462,7 +499,10 @@ __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict_
             truncated = true;
             break;
         }
-        out.put(__builtin_amdgcn_readfirstlane(n), (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) p), __builtin_amdgcn_readfirstlane(v));
+        if (threadIdx.x == 0) {
+            J.pos[n] = (uint32_t) p;
+            J.val[n] = v;
+        }
         n++;
         c0 += seg == 0;
         c1 += seg >= 1 && seg <= 3;
@@ -470,7 +510,6 @@ __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict_
         c3 += seg >= 7;
         cur = (uint32_t) p + 1;
     }
-    out.flush(__builtin_amdgcn_readfirstlane(n));
     if (!truncated) {
         br.align();
         if (br.get_bits(8) != 0x55) {
@@ -491,6 +530,13 @@ __global__ __launch_bounds__(64) void k_dec_parse(const DecParseJob *__restrict_
             atomicAdd(&g_parse_stats[0], (unsigned long long) st_rounds);
             atomicAdd(&g_parse_stats[1], (unsigned long long) st_lane);
             atomicAdd(&g_parse_stats[2], (unsigned long long) st_exact);
+            if (stats >= 2 && J.chroma == 0) { // shader clocks of a luma section: the lanes' answers, the scalar walk, the commit, everything
+                atomicAdd(&g_parse_stats[4], cy_lane);
+                atomicAdd(&g_parse_stats[5], cy_walk);
+                atomicAdd(&g_parse_stats[6], cy_commit);
+                atomicAdd(&g_parse_stats[7], __builtin_readcyclecounter() - cy_all0);
+                atomicAdd(&g_parse_stats[3], 1ull);
+            }
         }
     }
 }
@@ -523,10 +569,14 @@ void dec_parse_planes(hipStream_t s, const DecParseJob *d_jobs, int n, const Dec
             static struct AtExit {
                 ~AtExit()
                 {
-                    unsigned long long h[4];
+                    unsigned long long h[8];
                     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_parse_stats), sizeof(h)) == hipSuccess) {
                         fprintf(stderr, "[dec parse] lane-parallel rounds %llu, symbols out of them %llu (%.1f a round), serial steps %llu\n", h[0], h[1],
                                 h[0] ? (double) h[1] / (double) h[0] : 0.0, h[2]);
+                        if (h[3]) { // DSV2_DEC_PARSE_STATS=2
+                            fprintf(stderr, "[dec parse] shader clocks of a luma section (mean of %llu): all %.0f k; in rounds: the lanes' answers %.0f k, the walk %.0f k, "
+                                            "the commit %.0f k\n", h[3], h[7] / 1e3 / h[3], h[4] / 1e3 / h[3], h[5] / 1e3 / h[3], h[6] / 1e3 / h[3]);
+                        }
                     }
                 }
             } at_exit;
