@@ -14,6 +14,16 @@ import time
 from .common import *  # noqa: F401,F403
 from .reference import RefCheck  # noqa: F401
 
+def decode_traffic(stage, pictures_per_launch):
+    """HBM-side counter bytes of one launch group of the decode leg's dominant stage: committed PMC passes (profiles/pmc_traffic_decode.json:
+    FETCH_SIZE + WRITE_SIZE per decoded picture and stage) x the pictures a group's step carries; None without the file"""
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_decode.json")))
+        return int(pt["bytes_per_picture_by_stage"][stage] * pictures_per_launch)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def decode_leg(hip, A, run, nsteps, nstreams, groups, check):
     """lockstep batch decoder over the packets the encode run produced: every decoder starts at its stream's first packet.
     The streams in `check` (the ones the reference re-encodes AND decodes) are among the decoders; their pictures are
@@ -119,7 +129,7 @@ def decode_leg(hip, A, run, nsteps, nstreams, groups, check):
             steps_prof = max(1, fr.value)  # lockstep steps (all groups) the events cover
             ach = per[dom]["GBps"]
             out["roofline"] = {"bound": "hbm", "stage": dom, "kernel": dkern[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": decode_traffic(dom, D // G),
                                "avg_stage_span_us": round(1e3 * per[dom]["ms"] / steps_prof, 1),
                                "algorithmic_bytes_per_frame": dbytes[dom], "pictures_per_step_per_group": D // G,
                                "stage_us_per_frame": {k: v["us_per_frame"] for k, v in per.items()},

@@ -18,3 +18,11 @@ ls -la $out
 DSV2_DEC_DEVICE_PARSE=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/dec -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --decode-too --no-profile --streams 256 --groups 4 --steps 24 --warmup 4 > $out/decode_dev.json 2> $out/decode_dev.err
 gzip -c $out/dec/*/*_kernel_trace.csv > $out/decode_dev_kernel_trace.csv.gz
 rm -rf $out/dec
+# HBM-side counter traffic of the decode leg's kernels (host-parsed leg): FETCH_SIZE and WRITE_SIZE in separate passes (the TCC block cannot
+# hold both), each with the kernel trace of the same run for the dispatch order and the grids -> profiles/pmc_traffic_decode.json
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/dec -- python3 bench.py --gen-procs 1 --no-cpu-baseline --no-extras --decode-too --no-profile --streams 256 --groups 4 --steps 8 --warmup 2 > /dev/null 2> $out/decode_pmc_$c.err
+    cp $out/dec/*/*_counter_collection.csv $out/decode_pmc_$c.csv; gzip -f $out/decode_pmc_$c.csv
+    gzip -c $out/dec/*/*_kernel_trace.csv > $out/decode_pmc_${c}_trace.csv.gz
+    rm -rf $out/dec
+done

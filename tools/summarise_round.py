@@ -331,6 +331,50 @@ def census_part():
     json.dump(oc, open(p, "w"), indent=1)
 
 
+def decode_pmc_part():
+    """profiles/pmc_traffic_decode.json: counter traffic (FETCH_SIZE + WRITE_SIZE, separate passes) of the decode leg's kernels per decoded picture,
+    by stage of bench.py's decode roofline.  The decode phase = the dispatches behind the last encoder kernel (k_ent_out); pictures = the rows of the
+    k_copy_linear launches (one row per picture delivered)."""
+    WIDE16 = ("k_inv_haar_u8x4", "k_copy_linear", "k_zero_linear", "k_inv_haar_i32x4", "k_inv_haar_tail")  # 16-byte loads: FETCH_SIZE counts half (gfx950)
+    stage_of = [("k_zero_linear_if", "recon_filters"), ("k_zero_linear", "quant_compact"), ("k_dequant", "quant_compact"), ("k_dec_parse", "quant_compact"),
+                ("k_inv_", "inv_sbt"), ("k_predict_w", "recon_filters"), ("k_inter_filters", "recon_filters"), ("k_intra_filter", "recon_filters"),
+                ("k_extend", "extend"), ("k_copy_linear", "extend"), ("k_copy_plane", "extend"), ("k_to420", "extend")]
+    per_stage = collections.defaultdict(float)
+    per_kernel = collections.defaultdict(lambda: [0.0, 0.0])
+    pictures = None
+    for ci, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+        tr = list(csv.DictReader(io.TextIOWrapper(gzip.open(os.path.join(src, "decode_pmc_%s_trace.csv.gz" % c)))))
+        tr.sort(key=lambda r: int(r["Dispatch_Id"]))
+        last_enc = max(int(r["Dispatch_Id"]) for r in tr if "k_ent_out" in r["Kernel_Name"])
+        if pictures is None:
+            pictures = sum(int(r["Grid_Size_Y"]) for r in tr if int(r["Dispatch_Id"]) > last_enc and short(r["Kernel_Name"]).startswith("k_copy_linear"))
+        for r in csv.DictReader(io.TextIOWrapper(gzip.open(os.path.join(src, "decode_pmc_%s.csv.gz" % c)))):
+            if r["Counter_Name"] != c or int(r["Dispatch_Id"]) <= last_enc:
+                continue
+            k = short(r["Kernel_Name"])
+            v = float(r["Counter_Value"]) * 1024.0  # KiB as reported
+            if c == "FETCH_SIZE" and k.startswith(WIDE16):
+                v *= 2.0
+            per_kernel[k][ci] += v
+            for pre, st in stage_of:
+                if k.startswith(pre):
+                    per_stage[st] += v
+                    break
+    pictures = max(1, pictures or 1)
+    out = {"pictures": pictures, "bytes_per_picture_by_stage": {k: round(v / pictures) for k, v in per_stage.items()},
+           "bytes_per_picture_by_kernel": {k: [round(a / pictures), round(b / pictures)] for k, (a, b) in sorted(per_kernel.items(), key=lambda kv: -sum(kv[1]))[:16]},
+           "note": "FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes) of the decode leg's dispatches, 256 decoders in 4 groups, plane sections parsed on "
+                   "the host; FETCH_SIZE doubled for the kernels whose loads are 16 bytes per lane (gfx950 tallies their 128-byte requests at 64 B)",
+           "source": "tools/profile_decode.sh -> tools/summarise_round.py"}
+    json.dump(out, open(os.path.join(dst, "pmc_traffic_decode.json"), "w"), indent=1)
+    with open(os.path.join(dst, TAG + "_decode_kernel_stats.txt"), "a") as f:
+        f.write("\n\n==== counter traffic of the decode leg (profiles/pmc_traffic_decode.json), bytes per decoded picture ====\n")
+        for k, v in sorted(out["bytes_per_picture_by_stage"].items(), key=lambda kv: -kv[1]):
+            f.write("  stage %-16s %12d\n" % (k, v))
+        for k, (a, b) in out["bytes_per_picture_by_kernel"].items():
+            f.write("  %-40s fetched %12d written %12d\n" % (k[:40], a, b))
+
+
 have = lambda f: os.path.exists(os.path.join(src, f))
 traced = trace_part() if have("kernel_trace.csv.gz") else None
 if traced and have("pmc_FETCH_SIZE.csv") and have("kernel_source_sha16.txt"):
@@ -347,4 +391,6 @@ if have("decode_kernel_trace.csv.gz") and have("decode.json"):
     decode_part()
     if have("decode_dev_kernel_trace.csv.gz") and have("decode_dev.json"):
         decode_part("decode_dev", "a")
+    if have("decode_pmc_FETCH_SIZE.csv.gz") and have("decode_pmc_WRITE_SIZE.csv.gz"):
+        decode_pmc_part()
 print("summarised into", dst)
