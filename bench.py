@@ -424,22 +424,34 @@ def main():
     dec_md5 = {}
     if (extras or args.decode_too) and not args.only_batch_curve and not args.only_api_legs:
         try:
-            # (DSV2_DEC_GROUPS / DSV2_DEC_STREAMS: experiments with the decode leg's shape)
-            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, int(os.environ.get("DSV2_DEC_STREAMS", "256")), int(os.environ.get("DSV2_DEC_GROUPS", "4")),
-                                                   sel if (extras and not args.no_cpu_baseline) else [])
-            # the same leg with the P pictures' plane sections parsed on the DEVICE (csrc/dec_parse_dev.hip): the operating point of a
-            # host with few cores per GPU -- what the library picks by itself below 12 usable cores (the 2-core re-run below takes it)
+            # The decode leg's shape: 256 decoders in 4 groups where the HOST parses the plane sections (16 cores' worth of parsing: more
+            # decoders do not help); as many decoders as the run has streams (768) in 8 groups where the DEVICE parses them -- a section is one
+            # wavefront's 40 ms chain whatever the batch, so that path's throughput is the decoders in flight.
+            # (DSV2_DEC_GROUPS / DSV2_DEC_STREAMS: experiments.)
             hip.dsv2hip_dec_parse_mode.restype = C.c_int
             mode0 = hip.dsv2hip_dec_parse_mode()
+            want = sel if (extras and not args.no_cpu_baseline) else []
+
+            def leg_shape(on_device):
+                d = int(os.environ.get("DSV2_DEC_STREAMS", str(min(S, 768) if on_device else 256)))
+                g = int(os.environ.get("DSV2_DEC_GROUPS", "8" if on_device else "4"))
+                return d, g
+            d0, g0 = leg_shape(mode0 != 0)
+            result["decode"], dec_md5 = decode_leg(hip, A, run, 32, d0, g0, want)
             result["decode"]["plane_sections_parsed_on"] = ["host", "device (P pictures)", "device"][mode0]
+            # the other parser on the same packets: the device's where the library chose the host (a box with >= 12 usable cores), at its
+            # own shape and at the host leg's 256 decoders; the pictures of the streams the reference checks must be identical
             if mode0 == 0 and extras:
                 hip.dsv2hip_dec_set_parse_mode(1)
                 try:
-                    leg, md5b = decode_leg(hip, A, run, 32, int(os.environ.get("DSV2_DEC_STREAMS", "256")), int(os.environ.get("DSV2_DEC_GROUPS", "4")),
-                                           sel if (extras and not args.no_cpu_baseline) else [])
+                    d1, g1 = leg_shape(True)
+                    leg, md5b = decode_leg(hip, A, run, 32, d1, g1, want)
                     leg["plane_sections_parsed_on"] = "device (P pictures)"
                     leg["pictures_equal_to_the_host_parsed_leg"] = bool(md5b == dec_md5)
                     leg.pop("roofline", None)
+                    small, md5c = decode_leg(hip, A, run, 32, d0, g0, want)
+                    leg["pictures_equal_to_the_host_parsed_leg"] = leg["pictures_equal_to_the_host_parsed_leg"] and bool(md5c == dec_md5)
+                    leg["at_the_host_legs_shape"] = {k: small.get(k) for k in ("value", "decoders", "groups", "host_cpu_cores_busy")}
                     result["decode_device_parse"] = leg
                 finally:
                     hip.dsv2hip_dec_set_parse_mode(-1)
