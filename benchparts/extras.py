@@ -182,7 +182,7 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     return cfgs
 
 
-BATCH_POINTS = [(1, 1), (8, 4), (16, 4), (48, 4), (192, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets (groups: 4 re-measured against 1 - 24 per point, tools/probe/few_streams_groups.sh -- every lockstep group adds its ~100 launches per step to ONE submission path: 8 streams in 8 groups deliver 0.6 x what they do in 4)
+BATCH_POINTS = [(1, 1), (8, 4), (16, 4), (48, 4), (192, 4), (1536, 4)]  # (streams, lockstep groups): what a node that has fewer streams than the headline gets -- and, last, twice as many (126 GB of encoder instances: deeper launches, +4 ... 5 % frames/s at twice the time a frame waits) (groups: 4 re-measured against 1 - 24 per point, tools/probe/few_streams_groups.sh -- every lockstep group adds its ~100 launches per step to ONE submission path: 8 streams in 8 groups deliver 0.6 x what they do in 4)
 
 
 def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, checks):
@@ -192,7 +192,7 @@ def batch_curve(hip, A, torch, args, vids, NV, seeds, W_, H_, QP, GOP, effort, c
     out = []
     for S, G in BATCH_POINTS:
         G = min(G, S)
-        k = 48
+        k = 48 if S < 1000 else 24
         run = EncodeRun(hip, A, torch, W_, H_, "420", QP, GOP, effort, S, G, vids[:min(NV, 8)], not args.no_stagger, seeds=seeds, phase_align=not args.no_phase_align,
                         mix=None if (args.no_mix or S < 20) else MIX, timed_from=(GOP if not args.no_stagger else 0) + 4, timed_steps=k)
         f, e, ms = timed_leg(run, 4, k)
