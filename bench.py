@@ -151,6 +151,7 @@ def main():
         specs += [(1280, 720, "420", 101 + k, 24) for k in range(4)]
         specs += [(W_, H_, "444", 201, 12)]
         specs += [(3840, 2160, "420", 301 + k, 16) for k in range(2)]
+        specs += [(1920, 800, "420", 401 + k, 16) for k in range(2)]
     t_gen = time.perf_counter()
     under_profiler = under_profiler_()
     gen_procs = args.gen_procs if args.gen_procs > 0 else (1 if under_profiler else max(1, min(16, ncpu_box // (1 if locality["bound"] else max(1, world)))))

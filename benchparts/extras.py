@@ -179,6 +179,11 @@ def other_configs(hip, A, torch, args, vids, NV, S, W_, H_, seeds, checks):
     r5 = EncodeRun(hip, A, torch, 3840, 2160, "420", 60, 48, 10, min(64, S), min(4, args.groups), vids[NV + 5:NV + 7], False, seeds=[301, 302])
     leg("c_2160p_420_qp60_gop48", r5, 2, 12, 8, {"frames": "P frames 2..13 of each stream; 32 x 32 blocks: the search's 32 x 32 block routines"})
     r5.free()
+    # 1920x800 4:2:0 (a 2.40:1 crop of 1080p): 32 x 16 blocks (dsv_encoder.c:1203-1211: wider than 1280 and at least twice as wide as high)
+    # -- the search's two-quadrant forms (k_hme_rows_l0_32w, k_hme_rows_lx32w; until late in round 6 the general block routine)
+    r6 = EncodeRun(hip, A, torch, 1920, 800, "420", 60, 48, 10, min(192, S), min(4, args.groups), vids[NV + 7:NV + 9], False, seeds=[401, 402])
+    leg("c_1920x800_420_qp60_gop48", r6, 2, 12, 8, {"frames": "P frames 2..13 of each stream; 32 x 16 blocks: the search's 32 x 16 block routines"})
+    r6.free()
     return cfgs
 
 

@@ -1474,17 +1474,25 @@ __device__ __forceinline__ void hme_level_epilogue(const HmeDev &c, int level, i
 
 // KIND: which block routine walks the row -- the general one (any geometry: blocks up to 32 x 32, any chroma format, odd
 // clipped sizes), the fast one of the coarser levels, or the fast one of level 0 (CS: chroma shift, 1 = 4:2:0, 0 = 4:4:4)
-enum { ROW_GENERAL = 0, ROW_FAST_LX = 1, ROW_FAST_L0 = 2, ROW_FAST_LX32 = 3 /* the coarser levels' routine for 32 x 32 blocks */, ROW_FAST_L0_32 = 4 /* level 0 for 32 x 32 blocks, 4:2:0 */ };
+enum {
+    ROW_GENERAL = 0,
+    ROW_FAST_LX = 1,
+    ROW_FAST_L0 = 2,
+    ROW_FAST_LX32 = 3,  // the coarser levels' routine for 32 x 32 blocks
+    ROW_FAST_L0_32 = 4, // level 0 for 32 x 32 blocks, 4:2:0
+    ROW_FAST_LX32W = 5, // the same two for 32 x 16 blocks (hme_fast32.h with two quadrants)
+    ROW_FAST_L0_32W = 6
+};
 template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ void hme_row(const HmeDev &c, int bj, int level_rt, int nbx, int nby, FastLds &S)
 {
-    const int level = (KIND == ROW_FAST_L0 || KIND == ROW_FAST_L0_32) ? 0 : level_rt;
+    const int level = (KIND == ROW_FAST_L0 || KIND == ROW_FAST_L0_32 || KIND == ROW_FAST_L0_32W) ? 0 : level_rt;
     int gx = uni(c.counters[4]), gy = uni(c.counters[5]);
     int j = bj << level;
     const HmeCtx x = make_ctx(uni_ptr(&c), level);
 #ifdef DSV2_HME_PROF
     if (hme_lane() == 0) {
         S.prof_on = level == 0;
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < 32; k++) {
             S.prof_acc[k] = 0;
         }
         S.prof_t = __builtin_amdgcn_s_memtime();
@@ -1507,11 +1515,15 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
             if constexpr (KIND == ROW_FAST_L0) {
                 hme_block_l0<CS, SPLIT>(x, i, j, gx, gy, S, acc);
             } else if constexpr (KIND == ROW_FAST_L0_32) {
-                hme_block_l0_32(x, i, j, gx, gy, S, acc);
+                hme_block_l0_32<4>(x, i, j, gx, gy, S, acc);
+            } else if constexpr (KIND == ROW_FAST_L0_32W) {
+                hme_block_l0_32<2>(x, i, j, gx, gy, S, acc);
             } else if constexpr (KIND == ROW_FAST_LX) {
                 hme_block_lx<1>(x, level, i, j, gx, gy, S, acc);
             } else if constexpr (KIND == ROW_FAST_LX32) {
                 hme_block_lx<4>(x, level, i, j, gx, gy, S, acc);
+            } else if constexpr (KIND == ROW_FAST_LX32W) {
+                hme_block_lx<2>(x, level, i, j, gx, gy, S, acc);
             } else {
                 hme_block(c, level, i, j, gx, gy, S.hist, S.sp);
                 // the general routine reads its LEFT neighbour back from memory (the fast ones carry it in registers): this
@@ -1531,7 +1543,7 @@ template <int KIND, int CS = 1, bool SPLIT = false> __device__ __forceinline__ v
     }
 #ifdef DSV2_HME_PROF
     if (hme_lane() == 0 && S.prof_on) {
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < 32; k++) {
             atomicAdd(&g_hme_prof[k], S.prof_acc[k]);
         }
     }
@@ -1611,6 +1623,9 @@ HME_ROWS_P(k_hme_rows_lx, 4, level, ROW_FAST_LX)
 // 2160p leg ran 5 % slower: 1 850 against 1 940 frames/s at 64 streams)
 HME_ROWS_P(k_hme_rows_l0_32, DSV2_HME32_L0_WAVES, 0, ROW_FAST_L0_32)
 HME_ROWS_P(k_hme_rows_lx32, DSV2_HME32_LX_WAVES, level, ROW_FAST_LX32)
+// (32 x 16 blocks -- 1920 x 800, 2560 x 1080: two quadrants a block; 97 and 75 registers)
+HME_ROWS_P(k_hme_rows_l0_32w, 4, 0, ROW_FAST_L0_32W)
+HME_ROWS_P(k_hme_rows_lx32w, 4, level, ROW_FAST_LX32W)
 HME_ROWS_P(k_hme_rows_general, 2, level, ROW_GENERAL)
 static int g_hme_persist = getenv("DSV2_HME_PERSIST") ? atoi(getenv("DSV2_HME_PERSIST")) : 3072;
 // DSV2_HME_SPLIT: level 0 with its neighbour-independent half in an unordered pre-pass (1) or in place (0); default: by launch size
@@ -1657,22 +1672,25 @@ static bool level_all_fast(const AnalysisParams &a, const DPlane &src, int level
     // the chroma planes only enter at level 0 (mode decision): 4:2:0 and 4:4:4 have a block routine there, the coarser
     // levels take any format
     const bool c420 = a.hshift == 1 && a.vshift == 1, c444 = a.hshift == 0 && a.vshift == 0, c422 = a.hshift == 1 && a.vshift == 0;
-    const int bs = a.blk_w;
-    if ((bs != 16 && bs != 32) || a.blk_h != bs || (level == 0 && !c420 && !c444 && !(c422 && bs == 16))) {
+    const int bs = a.blk_w, bsh = a.blk_h; // 16 x 16, 32 x 32 or 32 x 16
+    const bool wide = bs == 32 && bsh == 16;
+    if ((bs != 16 && bs != 32) || (bsh != bs && !wide) || (level == 0 && !c420 && !c444 && !(c422 && bs == 16))) {
         return false;
     }
-    if (bs == 32 && level == 0 && !c420) { // (32 x 32 blocks at level 0: the 4:2:0 routine of hme_fast32.h)
+    if (bs == 32 && level == 0 && !c420) { // (32-wide blocks at level 0: the 4:2:0 routine of hme_fast32.h)
         return false;
     }
     int step = 1 << level;
     int nbx = (a.nbh + step - 1) / step, nby = (a.nbv + step - 1) / step;
-    int lx = ((nbx - 1) * step * bs) >> level, ly = ((nby - 1) * step * bs) >> level; // origin of the last block column / row
+    int lx = ((nbx - 1) * step * bs) >> level, ly = ((nby - 1) * step * bsh) >> level; // origin of the last block column / row
     if (lx >= src.w || ly >= src.h) {
         return false;
     }
-    int bw = src.w - lx < bs ? src.w - lx : bs, bh = src.h - ly < bs ? src.h - ly : bs;
+    int bw = src.w - lx < bs ? src.w - lx : bs, bh = src.h - ly < bsh ? src.h - ly : bsh;
     if (level == 0 && bs == 32) {
-        return (bw & 15) == 0 && (bh & 15) == 0; // (a clipped block's sub-blocks must not straddle a quadrant seam)
+        // (a clipped block's sub-blocks must not straddle a quadrant seam; a 32 x 16 block has no seam across its height, and its
+        // chroma sub-blocks are whole quads down to a height of 8)
+        return (bw & 15) == 0 && (bh & (wide ? 7 : 15)) == 0;
     }
     return level == 0 ? ((bw & 7) == 0 && (bh & 7) == 0) : (level > 1 || (!(bw & 1) && !(bh & 1)));
 }
@@ -1922,7 +1940,8 @@ __global__ __launch_bounds__(64) void k_hme_src_stats_b(const HmeDev *__restrict
 // ---- the same statistics for 32 x 32 blocks (2160p and up), one block per wavefront ------------------------------------------------
 // The general routine's own formulation (hme_block: wave-cooperative loops over a copy of the block in LDS) -- it runs once per block
 // and in no order, so its cost is not the search's.
-__global__ __launch_bounds__(64) void k_hme_src_stats32_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int per_wg)
+// (blk_h: 32, or 16 for the 32 x 16 blocks of wide pictures)
+__global__ __launch_bounds__(64) void k_hme_src_stats32_b(const HmeDev *__restrict__ tab, int nb0x, int nb0y, int nb1x, int nb1y, int per_wg, int blk_h)
 {
     DSV2_CENSUS_SCOPE();
     __shared__ int hist[16];
@@ -1939,8 +1958,8 @@ __global__ __launch_bounds__(64) void k_hme_src_stats32_b(const HmeDev *__restri
         const int e = l1 ? b - n0 : b, nbx = l1 ? nb1x : nb0x;
         const int bj = e / nbx, bi = e - bj * nbx;
         const DPlane src = l1 ? src1 : src0, ogr = l1 ? ogr1 : ogr0;
-        const int bx = bi * 32, by = bj * 32;
-        const int bw = min(src.w - bx, 32), bh = min(src.h - by, 32);
+        const int bx = bi * 32, by = bj * blk_h;
+        const int bw = min(src.w - bx, 32), bh = min(src.h - by, blk_h);
         if (bw <= 0 || bh <= 0) {
             continue;
         }
@@ -1949,7 +1968,7 @@ __global__ __launch_bounds__(64) void k_hme_src_stats32_b(const HmeDev *__restri
         const unsigned var_src = (unsigned) ws_block_detail(sblk, 32, bw, bh, avg_src);
         int tvar = (int) (var_src + SQR(var_src >> 10));
         tvar = (8 * tvar * quant >> 9) / (bw * bh);
-        int bias_raw = 32 * 32;
+        int bias_raw = 32 * blk_h; // hme.c:1444
         if (tvar) { // hme.c:1405-1417
             const int hvar = (int) ws_hist_var(sblk, 32, bw, bh, hist);
             const int qtex = ws_quant_tex(sblk, 32, bw, bh);
@@ -2188,8 +2207,8 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
     // The fast block routines: 16 x 16 blocks, one geometry per pyramid level (make_ctx), the source statistics and the level-0
     // records of the pre-passes (memory for both handed in by the caller).  Anything else takes the general routine.
     // (A function of the jobs alone: a call that only runs the levels, behind a separate HME_PREPARE call, comes to the same answer.)
-    const bool b16 = g.a.blk_w == 16 && g.a.blk_h == 16, b32 = g.a.blk_w == 32 && g.a.blk_h == 32;
-    bool fast = g_hme_fast != 0 && (b16 || b32);
+    const bool b16 = g.a.blk_w == 16 && g.a.blk_h == 16, b32 = g.a.blk_w == 32 && g.a.blk_h == 32, b32w = g.a.blk_w == 32 && g.a.blk_h == 16;
+    bool fast = g_hme_fast != 0 && (b16 || b32 || b32w);
     for (int k = 0; k < n; k++) {
         fast = fast && uniform_geometry(f[k], g.pyr_levels) && f[k].src_stats != nullptr && f[k].l0_pre != nullptr;
     }
@@ -2205,9 +2224,9 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
             }
         }
         HIPCHK(hipMemcpyAsync(d_table, h_table, (size_t) n * sizeof(HmeDev), hipMemcpyHostToDevice, s));
-        if (fast && b32) {
+        if (fast && (b32 || b32w)) {
             const int per_wg = 2, total = nb0x * nb0y + nb1x * nb1y;
-            DSV2_LAUNCH(k_hme_src_stats32_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, per_wg);
+            DSV2_LAUNCH(k_hme_src_stats32_b, dim3((total + per_wg - 1) / per_wg, n), dim3(64), 0, s, tab, nb0x, nb0y, nb1x, nb1y, per_wg, g.a.blk_h);
         }
         if (fast && b16) {
             // whole blocks four to a wavefront, clipped blocks of the last block row / column one to a wavefront
@@ -2254,13 +2273,13 @@ int hme_run_batch(hipStream_t s, const HmeFrames *f, const HmeParams *hp, int n,
         if (prof && level == 0) {
             prof->begin(s, ST_HME_L0);
         }
-        if (level == 0 && b32 && fast_level(0)) {
-            DSV2_LAUNCH(k_hme_rows_l0_32, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
+        if (level == 0 && (b32 || b32w) && fast_level(0)) {
+            DSV2_LAUNCH(b32 ? k_hme_rows_l0_32 : k_hme_rows_l0_32w, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else if (level == 0 && fast_level(0)) {
             auto pk = c422 ? k_hme_rows_l0_422 : g.a.hshift == 0 ? (split ? k_hme_rows_l0s_444 : k_hme_rows_l0_444) : (split ? k_hme_rows_l0s : k_hme_rows_l0);
             DSV2_LAUNCH(pk, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else if (level > 0 && fast_level(level)) {
-            DSV2_LAUNCH(b32 ? k_hme_rows_lx32 : k_hme_rows_lx, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
+            DSV2_LAUNCH(b32 ? k_hme_rows_lx32 : b32w ? k_hme_rows_lx32w : k_hme_rows_lx, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         } else {
             DSV2_LAUNCH(k_hme_rows_general, dim3(workers), dim3(64), 0, s, tab, level, nbx, parts, n, nby);
         }
@@ -2312,9 +2331,9 @@ int hme_run(hipStream_t s, const HmeFrames &f_in, const HmeParams &hp)
 
 #ifdef DSV2_HME_PROF
 // debugging build only: cumulative phase clocks of the level-0 search (see HME_MARK)
-extern "C" void dsv2hip_debug_hme_prof(unsigned long long out[16])
+extern "C" void dsv2hip_debug_hme_prof(unsigned long long out[32])
 {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dsv2::g_hme_prof), 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dsv2::g_hme_prof), 32 * sizeof(unsigned long long)));
 }
 #endif

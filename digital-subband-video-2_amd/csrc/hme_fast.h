@@ -236,7 +236,7 @@ struct FastLds {
     int hist[16];
     SubpelLds sp;
 #ifdef DSV2_HME_PROF
-    unsigned long long prof_t, prof_acc[16];
+    unsigned long long prof_t, prof_acc[32];
     int prof_on;
 #endif
 };
@@ -244,7 +244,7 @@ struct FastLds {
 // phase clock of a debugging build (-DDSV2_HME_PROF): shader-clock ticks per phase of the level-0 search,
 // summed over all wavefronts into g_hme_prof[]
 #ifdef DSV2_HME_PROF
-__device__ unsigned long long g_hme_prof[16];
+__device__ unsigned long long g_hme_prof[32];
 #define HME_MARK(S, k)                                                                                                \
     do {                                                                                                              \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                        \
@@ -465,7 +465,7 @@ template <int NT> struct VecSet {
 
 // A lane's share of the source block.  NQ = 1: a 16 x 16 block, the lane (qi, qj) owns its 2x2 quad (qi, qj).  NQ = 4: a
 // 32 x 32 block (dsv_encoder.c:1203-1211: every picture of 2160p and up) as FOUR 16 x 16 quadrants -- quadrant k at (16 (k & 1),
-// 16 (k >> 1)) -- of which the lane owns quad (qi, qj) each: every per-quad primitive of the 16 x 16 routine is used as it is,
+// 16 (k >> 1)) -- of which the lane owns quad (qi, qj) each (NQ = 2: the upper two of them, a 32 x 16 block): every per-quad primitive of the 16 x 16 routine is used as it is,
 // once per quadrant, with the sums combined before the metric's square root; the mode decision's four sub-block sums are the
 // quadrants' own.  act[k]: the quad takes part in the level's metric (a clipped block's quads beyond its edge do not);
 // smask[k]: bytes of the quad inside the block (all four, except in the half quads of an odd last row / column at the
@@ -478,6 +478,12 @@ template <int NQ> struct SrcBlk {
 };
 // byte offset of quadrant k's origin from the block's, for a plane of row stride `stride`
 __device__ __forceinline__ unsigned quadrant_off(int k, int stride) { return (unsigned) (16 * (k & 1) + 16 * (k >> 1) * stride); }
+// nominal block size of a SrcBlk<NQ>: 16 x 16 (one quadrant), 32 x 16 (two, side by side: the 32 x 16 blocks dsv_encoder.c:1203-1211
+// gives wide pictures -- 1920 x 800, 2560 x 1080), 32 x 32 (four)
+template <int NQ> struct BlkDim {
+    static_assert(NQ == 1 || NQ == 2 || NQ == 4, "a block is one, two or four 16 x 16 quadrants");
+    static constexpr int W = NQ == 1 ? 16 : 32, H = NQ == 4 ? 32 : 16;
+};
 
 template <int NT, int NQ>
 __device__ __forceinline__ unsigned score_set(const VecSet<NT> &vs, int cnt, bool safe, const DPlane &ref, const SrcBlk<NQ> &B, int level, const Psy &psy)
@@ -1013,6 +1019,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
             if (!run) {
                 continue;
             }
+            HME_COUNT(S, 21 + pass, 1);
             if (best_fp != 0) {
                 best = subpixel_me_fast(c, S, cc, sx, sy, ccx, ccy, best_fp, bx, by, bw, bh, a, act, qi, qj, psy);
             }
@@ -1062,6 +1069,9 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
     // (the zero-motion operands are only looked at by the skip test: hme.c:1686)
     const bool skip_test = (good_enough || (fpelx | fpely | sx | sy) == 0) && c.skip_block_thresh >= 0 && !c.lossless;
     rz.w = 0;
+    HME_COUNT(S, 16, skip_test ? 1 : 0);
+    HME_COUNT(S, 23, good_enough ? 1 : 0);
+    HME_COUNT(S, 27, ((mv.u.mv.x | mv.u.mv.y) & 3) ? 1 : 0);
     if (skip_test) {
         rz = ldq(at(ref0, bx, by), ref0.stride, qi, qj, act);
     }
@@ -1240,6 +1250,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
             mv.u.all = 0;
             mv.err = 0;
             skipped = true;
+            HME_COUNT(S, 17, 1);
         }
     }
     int add_err = 0, add_ndiff = 0;
@@ -1247,6 +1258,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
         if (!oob && !c.lossless) {
             bool y_prereq = avg_y_dif <= 2, c_prereq = !cpsy.greyish && avg_c_dif <= 2;
             if (y_prereq || c_prereq) {
+                HME_COUNT(S, 18, 1);
                 // round 3: sub-block metrics at the chosen full-pel motion (hme.c:1741)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1307,6 +1319,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
             int sbw = bw / 2, sbh = bh / 2;
             bool run = !(mv.u.all && neidif < 3 && abs(rx - mv.u.mv.x) < 3 && abs(ry - mv.u.mv.y) < 3) && sbw != 0 && sbh != 0;
             if (run) {
+                HME_COUNT(S, 19, 1);
                 int ss, sh, sv2;
                 quad_grad_partials(a, act, qi, qj, (kq & 1) ? (qw >> 1) : 0, (kq & 2) ? (qh >> 1) : 0, ss, sh, sv2);
                 int rsum = act ? r.p1() + r.p2() + r.p3() + r.p4() : 0;
@@ -1383,6 +1396,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
             unsigned thr = (mv.flags & (1u << DSV_MV_BIT_INTRA)) ? detail_c : SQR(detail_c);
             int sbw = cbw / 2, sbh = cbh / 2;
             if (!(sbw == 0 || sbh == 0 || mad <= thr || thr > 64 || (abs((int) mv.u.mv.x) < 4 && abs((int) mv.u.mv.y) < 4))) {
+                HME_COUNT(S, 20, 1);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if constexpr (CS == 1) {
@@ -1431,6 +1445,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
         add_ndiff = (ogrmad > 11) + (avg_c_dif >= 32);
     }
     int is_intra = 0;
+    HME_COUNT(S, 24, (mv.flags & (1u << DSV_MV_BIT_INTRA)) ? 1 : 0);
     if (mv.flags & (1u << DSV_MV_BIT_INTRA)) {
         int merged = (mv.dc & DSV_SRC_DC_PRED) ? eprmd : eprmi;
         if (mv.submask != DSV_MASK_ALL_INTRA) {
@@ -1697,8 +1712,7 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c_in, int level, int i
     Ctx c = fenced(c_in, level);
     const int lane = hme_lane();
     const int qi = lane & 7, qj = lane >> 3;
-    constexpr int BS = NQ == 4 ? 32 : 16;
-    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = BS, y_h = BS;
+    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = BlkDim<NQ>::W, y_h = BlkDim<NQ>::H;
     const int step = 1 << level;
     const DPlane src = c.src[level], ogr = c.ogr[level];
     DPlane ref = c.ref[level];
@@ -1871,10 +1885,10 @@ __device__ __forceinline__ void hme_block_lx_t(const Ctx &c_in, int level, int i
 
 template <int NQ, class Ctx> __device__ __forceinline__ void hme_block_lx(const Ctx &c, int level, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
-    constexpr int BS = NQ == 4 ? 32 : 16;
+    constexpr int BW = BlkDim<NQ>::W, BH = BlkDim<NQ>::H;
     const DPlane &src = c.src[level];
-    int bx = (i * BS) >> level, by = (j * BS) >> level;
-    if (src.w - bx >= BS && src.h - by >= BS) {
+    int bx = (i * BW) >> level, by = (j * BH) >> level;
+    if (src.w - bx >= BW && src.h - by >= BH) {
         hme_block_lx_t<true, NQ>(c, level, i, j, gx, gy, S, acc);
     } else {
         hme_block_lx_t<false, NQ>(c, level, i, j, gx, gy, S, acc);

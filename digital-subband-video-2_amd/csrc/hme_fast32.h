@@ -1,11 +1,13 @@
-// hme_fast32.h -- level 0 of the fast block routine for 32 x 32 blocks (dsv_encoder.c:1203-1211: every picture of 2160p and up), 4:2:0.
+// hme_fast32.h -- level 0 of the fast block routine for 32 x 32 blocks (dsv_encoder.c:1203-1211: every picture of 2160p and up) and
+// for 32 x 16 blocks (the same lines: pictures wider than 1280 and at least twice as wide as high -- 1920 x 800, 2560 x 1080), 4:2:0.
 // Included by hme.hip behind hme_fast.h, whose per-quad primitives it uses unchanged.
 //
-// Layout (SrcBlk<4>): the block is FOUR 16 x 16 quadrants, quadrant k at (16 (k & 1), 16 (k >> 1)); lane (qi, qj) owns quad (qi, qj) of
-// each.  A block sum is the sum of the quadrants' sums before the metric's square root; first-difference sums add the differences
+// Layout (SrcBlk<NQ>): the block is FOUR 16 x 16 quadrants (NQ = 4), quadrant k at (16 (k & 1), 16 (k >> 1)), or the upper TWO of them
+// (NQ = 2: 32 x 16); lane (qi, qj) owns quad (qi, qj) of each.  A block sum is the sum of the quadrants' sums before the metric's square root; first-difference sums add the differences
 // ACROSS the quadrant seams (blk_grad_partials); the mode decision's four luma sub-blocks (hme.c:370, :891) are the quadrants
-// themselves for a whole block, and for a clipped one -- sizes are multiples of 16 here -- halves of the quadrants that exist
-// (sub_of).  The chroma block is 16 x 16: a quad per lane, its four sub-blocks by lane as in the 4:4:4 form of the 16 x 16 routine.
+// themselves for a whole 32 x 32 block; for a clipped one -- widths are multiples of 16 here, heights of 16 (NQ = 4) or 8 (NQ = 2) --
+// and for a 32 x 16 block (sub-blocks of 16 x 8: the halves of a quadrant) they are found per quad (sub_of).  The chroma block is
+// 16 x 16 (16 x 8): a quad per lane, its four sub-blocks by lane as in the 4:4:4 form of the 16 x 16 routine.
 // The sub-pel search works on the centred 16 x 16 window whatever the block size (hme.c:1100-1108): subpel_probes' LDS image, with
 // the four neighbours' squared errors summed over the quadrants.
 #pragma once
@@ -13,12 +15,12 @@
 // pixel sum and horizontal / vertical first-difference sums of the lane's quads of a 32 x 32 (or clipped) block: the quadrants'
 // own partials (neighbours inside a quadrant come from the neighbouring lanes) + the differences across the seams, where the
 // left / upper neighbour is the last quad column / row of the quadrant next door
-__device__ __forceinline__ void blk_grad_partials(const Quad (&q)[4], const bool (&act)[4], int qi, int qj, int &sum, int &sh, int &sv)
+template <int NQ> __device__ __forceinline__ void blk_grad_partials(const Quad (&q)[NQ], const bool (&act)[NQ], int qi, int qj, int &sum, int &sh, int &sv)
 {
     const int lane = hme_lane();
     sum = sh = sv = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NQ; k++) {
         int s, h, v;
         quad_grad_partials(q[k], act[k], qi, qj, 0, 0, s, h, v);
         sum += s;
@@ -40,8 +42,8 @@ __device__ __forceinline__ void blk_grad_partials(const Quad (&q)[4], const bool
 }
 
 // the four neighbour errors + the half-pel image of the centred window: subpel_probes (hme_fast.h) with the errors over four quadrants
-template <class Ctx>
-__device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, int fpelx, int fpely, const SrcBlk<4> &B, const Psy &psy, unsigned &dirs)
+template <int NQ, class Ctx>
+__device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, int fpelx, int fpely, const SrcBlk<NQ> &B, const Psy &psy, unsigned &dirs)
 {
     const int lane = hme_lane();
     const int qi = B.qi, qj = B.qj, bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
@@ -50,11 +52,11 @@ __device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, in
     Quad aw;
     {
         const int dxs[4] = {1, -1, 0, 0}, dys[4] = {0, 0, 1, -1};
-        QuadRaw b4[4][4];
+        QuadRaw b4[4][NQ];
 #pragma unroll
         for (int n = 0; n < 4; n++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NQ; k++) {
                 b4[n][k] = ldq_raw(at(ref, bx + fpelx + dxs[n] + 16 * (k & 1), by + fpely + dys[n] + 16 * (k >> 1)), ref.stride, qi, qj, B.act[k]);
             }
         }
@@ -66,7 +68,7 @@ __device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, in
 #pragma unroll
         for (int n = 0; n < 4; n++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NQ; k++) {
                 v4[n] += B.act[k] ? (int) qsse(B.a[k], ldq_finish(b4[n][k], B.act[k])) : 0;
             }
         }
@@ -114,16 +116,16 @@ __device__ __forceinline__ unsigned subpel_probes32(const Ctx &c, FastLds &S, in
     return metric_return(acc, 16, 16);
 }
 
-// sub-pel refinement + mode decision of a 32 x 32 block, 4:2:0 (hme.c:1598-1821): hme_l0_tail's arithmetic on four quadrants
-template <bool FULL, class Ctx>
-__device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const SrcBlk<4> &B,
+// sub-pel refinement + mode decision of a 32 x 32 / 32 x 16 block, 4:2:0 (hme.c:1598-1821): hme_l0_tail's arithmetic on four / two quadrants
+template <bool FULL, int NQ, class Ctx>
+__device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, FastLds &S, RowAcc &acc, DSV_MV *out, DSV_MV mv, const CostCtx &cc, const SrcBlk<NQ> &B,
                                               int lax, int lay, int motion_bias, bool good_enough, unsigned best, unsigned var_src, unsigned avg_src,
                                               const Psy &psy, const NbPre &pre)
 {
     Ctx c = fenced(c_in, 0);
     const int lane = hme_lane();
     const int qi = B.qi, qj = B.qj, bx = B.bx, by = B.by, bw = B.bw, bh = B.bh;
-    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = 32, y_h = 32;
+    const int nxb = c.a.nbh, nyb = c.a.nbv, y_w = BlkDim<NQ>::W, y_h = BlkDim<NQ>::H;
     DPlane ref0 = c.ref[0];
     const int qw = bw >> 1, qh = bh >> 1;
     int fpelx = mv.u.mv.x, fpely = mv.u.mv.y, sx = 0, sy = 0;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
             }
             if (best_fp != 0) {
                 unsigned dirs;
-                const unsigned mr = subpel_probes32(c, S, ccx, ccy, B, psy, dirs);
+                const unsigned mr = subpel_probes32<NQ>(c, S, ccx, ccy, B, psy, dirs);
                 best = subpel_decide(cc, c.effort, mr, dirs, sx, sy, ccx, ccy, best_fp, bw, bh);
             }
             if (pass == 0) {
@@ -168,14 +170,14 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
     c = fenced(c_in, 0);
     ref0 = c.ref[0];
     // ---- operands of the mode decision, one load round ----
-    const int cbx = (i * 32) >> 1, cby = (j * 32) >> 1;
+    const int cbx = (i * y_w) >> 1, cby = (j * y_h) >> 1;
     const int cbmx = cbx + sarx(fpelx, 1), cbmy = cby + sarx(fpely, 1);
     const int cbw = bw >> 1, cbh = bh >> 1;
-    const bool actc = qi < (cbw >> 1) && qj < (cbh >> 1); // the lane's quad of the (up to) 16 x 16 chroma blocks
+    const bool actc = qi < (cbw >> 1) && qj < (cbh >> 1); // the lane's quad of the (up to) 16 x 16 (NQ = 2: 16 x 8) chroma blocks
     const bool skip_test = (good_enough || (fpelx | fpely | sx | sy) == 0) && c.skip_block_thresh >= 0 && !c.lossless;
-    Quad r[4], o[4], rz[4];
+    Quad r[NQ], o[NQ], rz[NQ];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NQ; k++) {
         const int ox = 16 * (k & 1), oy = 16 * (k >> 1);
         r[k] = ldq(at(ref0, bx + fpelx + ox, by + fpely + oy), ref0.stride, qi, qj, B.act[k]);
         o[k] = ldq(at(c.ogr[0], bx + fpelx + ox, by + fpely + oy), c.ogr[0].stride, qi, qj, B.act[k]);
@@ -195,21 +197,23 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
         vzq = ldq(at(c.refc[1], cbx, cby), c.refc[1].stride, qi, qj, actc);
     }
     // which of the block's four sub-blocks (bw / 2 x bh / 2 each) a quad belongs to; the sub-block's first quad column / row in
-    // lane coordinates (block sizes are multiples of 16: a sub-block never straddles a quadrant seam)
-    int sub_of[4], sqi0[4], sqj0[4];
+    // lane coordinates (widths are multiples of 16, and so are the heights of 32-high blocks: a sub-block never straddles a
+    // quadrant seam; a whole 32 x 32 block's sub-blocks ARE its quadrants)
+    constexpr bool kSubIsQuadrant = FULL && NQ == 4;
+    int sub_of[NQ], sqi0[NQ], sqj0[NQ];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NQ; k++) {
         const int xq = 8 * (k & 1) + qi, yq = 8 * (k >> 1) + qj;
-        sub_of[k] = FULL ? k : ((xq >= (qw >> 1) ? 1 : 0) | (yq >= (qh >> 1) ? 2 : 0));
-        sqi0[k] = FULL ? 0 : max(((sub_of[k] & 1) ? (qw >> 1) : 0) - 8 * (k & 1), 0);
-        sqj0[k] = FULL ? 0 : max(((sub_of[k] & 2) ? (qh >> 1) : 0) - 8 * (k >> 1), 0);
+        sub_of[k] = kSubIsQuadrant ? k : ((xq >= (qw >> 1) ? 1 : 0) | (yq >= (qh >> 1) ? 2 : 0));
+        sqi0[k] = kSubIsQuadrant ? 0 : max(((sub_of[k] & 1) ? (qw >> 1) : 0) - 8 * (k & 1), 0);
+        sqj0[k] = kSubIsQuadrant ? 0 : max(((sub_of[k] & 2) ? (qh >> 1) : 0) - 8 * (k >> 1), 0);
     }
     const int kqc = (qi >= (cbw >> 2) ? 1 : 0) | (qj >= (cbh >> 2) ? 2 : 0); // chroma sub-block of this lane's chroma quad
     // sum over the lane's quads of f(k) that lie in luma sub-block kk
     auto lum_sub = [&](int kk, auto f) {
         int t = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NQ; k++) {
             t += (B.act[k] && sub_of[k] == kk) ? (int) f(k) : 0;
         }
         return t;
@@ -219,10 +223,10 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
     int v[16];
     {
         int rs, rh, rv;
-        blk_grad_partials(r, B.act, qi, qj, rs, rh, rv);
+        blk_grad_partials<NQ>(r, B.act, qi, qj, rs, rh, rv);
         v[0] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NQ; k++) {
             v[0] += B.act[k] ? (int) qmetric(B.a[k], o[k], psy) : 0;
         }
         v[1] = rs;
@@ -250,7 +254,7 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
     {
         int dev = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NQ; k++) {
             dev += quad_absdev(r[k], B.act[k], (int) avg_ref);
         }
         if (skip_test) {
@@ -295,7 +299,7 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
         int as128 = (int) avg_src - 128, ar128 = (int) avg_ref - 128;
         int ci = 0, cd = 0, cr = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NQ; k++) {
             if (B.act[k]) {
                 const Quad &a = B.a[k];
                 cr |= (((a.p1() - r[k].p1()) + 128) | ((a.p2() - r[k].p2()) + 128) | ((a.p3() - r[k].p3()) + 128) | ((a.p4() - r[k].p4()) + 128)) & ~0xff;
@@ -402,9 +406,9 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
             bool run = !(mv.u.all && neidif < 3 && abs(rx - mv.u.mv.x) < 3 && abs(ry - mv.u.mv.y) < 3) && sbw != 0 && sbh != 0;
             if (run) {
                 // per quad: the source's sum / first differences inside its sub-block, the reference's sum
-                int ss[4], sh[4], sv2[4], rsum[4];
+                int ss[NQ], sh[NQ], sv2[NQ], rsum[NQ];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < NQ; k++) {
                     quad_grad_partials(B.a[k], B.act[k], qi, qj, sqi0[k], sqj0[k], ss[k], sh[k], sv2[k]);
                     rsum[k] = B.act[k] ? r[k].p1() + r[k].p2() + r[k].p3() + r[k].p4() : 0;
                 }
@@ -422,7 +426,7 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
                     w16[t] = 0;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < NQ; k++) {
                     // the quad's own sub-block's averages (per lane: a clipped block's sub-blocks are not the quadrants)
                     const int my_avg_local = div_nn(bcastL<16>(R, 4 * sub_of[k] + 0), sbw * sbh);
                     const int my_avg_sub = div_nn(bcastL<16>(R, 4 * sub_of[k] + 1), sbw * sbh);
@@ -555,8 +559,8 @@ __device__ __forceinline__ void hme_l0_tail32(const Ctx &c_in, int i, int j, Fas
     acc.err += add_err;
 }
 
-// the block of the row pipeline (hme_block_l0_t's in-place form) for a 32 x 32 block
-template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_t(const Ctx &c_in, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+// the block of the row pipeline (hme_block_l0_t's in-place form) for a 32 x 32 (NQ = 4) / 32 x 16 (NQ = 2) block
+template <bool FULL, int NQ, class Ctx> __device__ __forceinline__ void hme_block_l0_32_t(const Ctx &c_in, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
     Ctx c = fenced(c_in, 0);
     const int lane = hme_lane();
@@ -567,9 +571,10 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_
     DSV_MV *out = &mvf[i + j * nxb];
     DSV_MV mv = {};
     HME_COUNT(S, 10, 1);
-    const int bx = i * 32, by = j * 32;
-    const int bw = FULL ? 32 : min(src.w - bx, 32), bh = FULL ? 32 : min(src.h - by, 32);
-    const SrcBlk<4> B = load_src_blk<FULL, 4>(src, bx, by, bw, bh, 0);
+    constexpr int BW = BlkDim<NQ>::W, BH = BlkDim<NQ>::H;
+    const int bx = i * BW, by = j * BH;
+    const int bw = FULL ? BW : min(src.w - bx, BW), bh = FULL ? BH : min(src.h - by, BH);
+    const SrcBlk<NQ> B = load_src_blk<FULL, NQ>(src, bx, by, bw, bh, 0);
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) v4i_t *cv4i_t;
     typedef const __attribute__((address_space(1))) uint32_t *gu32p_t;
@@ -661,7 +666,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_
     const bool keep = exist && !dedup_lanes(exist, key);
     const int mx = (int) (int16_t) (key & 0xffff), my = key >> 16;
     HME_COUNT(S, 14, __popcll(__ballot(keep)));
-    const unsigned raw0 = metric_return(score_lanes<4>(__ballot(keep), key, ref, B, 0, psy), bw, bh);
+    const unsigned raw0 = metric_return(score_lanes<NQ>(__ballot(keep), key, ref, B, 0, psy), bw, bh);
     HME_MARK(S, 2);
     int dx, dy;
     unsigned best, score_zero;
@@ -701,7 +706,7 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_
     c = fenced(c_in, 0);
     ref = c.ref[0];
     if (!good_enough) {
-        refine_fpel<true, 4>(ref, B, 0, psy, cc, qthresh, dx, dy, best, good_enough, S);
+        refine_fpel<true, NQ>(ref, B, 0, psy, cc, qthresh, dx, dy, best, good_enough, S);
     }
     HME_MARK(S, 4);
     mv.u.mv.x = (int16_t) dx;
@@ -713,15 +718,16 @@ template <bool FULL, class Ctx> __device__ __forceinline__ void hme_block_l0_32_
     pre.t_flags = (uint32_t) __builtin_amdgcn_readlane((int) nbv.flags, 4);
     pre.colo = colo;
     pre.colo_ok = colo_ok;
-    hme_l0_tail32<FULL>(c, i, j, S, acc, out, mv, cc, B, lax, lay, motion_bias, good_enough, best, var_src, avg_src, psy, pre);
+    hme_l0_tail32<FULL, NQ>(c, i, j, S, acc, out, mv, cc, B, lax, lay, motion_bias, good_enough, best, var_src, avg_src, psy, pre);
 }
 
-template <class Ctx> __device__ __forceinline__ void hme_block_l0_32(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
+template <int NQ, class Ctx> __device__ __forceinline__ void hme_block_l0_32(const Ctx &c, int i, int j, int gx, int gy, FastLds &S, RowAcc &acc)
 {
+    constexpr int BW = BlkDim<NQ>::W, BH = BlkDim<NQ>::H;
     const DPlane &src = c.src[0];
-    if (src.w - i * 32 >= 32 && src.h - j * 32 >= 32) {
-        hme_block_l0_32_t<true>(c, i, j, gx, gy, S, acc);
+    if (src.w - i * BW >= BW && src.h - j * BH >= BH) {
+        hme_block_l0_32_t<true, NQ>(c, i, j, gx, gy, S, acc);
     } else {
-        hme_block_l0_32_t<false>(c, i, j, gx, gy, S, acc);
+        hme_block_l0_32_t<false, NQ>(c, i, j, gx, gy, S, acc);
     }
 }

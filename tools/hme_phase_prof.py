@@ -14,7 +14,7 @@ import bench  # noqa: E402
 sys.argv = ["bench.py", "--no-cpu-baseline", "--no-profile", "--no-extras"] + sys.argv[1:]
 bench.main()
 lib = ctypes.CDLL(PROF_SO)
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 lib.dsv2hip_debug_hme_prof(out)
 names = ["wait row above", "first load round", "list + scores", "best candidate + good-enough", "refinement",
          "sub-pel", "mode decision A", "intra sub-block luma", "intra sub-block chroma + rest", "store + publish"]
@@ -27,3 +27,6 @@ if out[15]:
 blocks = float(out[10]) or 1.0
 print(f"blocks {out[10]}  refined {out[11] / blocks:.3f}  refinement rounds/block {out[12] / blocks:.3f}  "
       f"sub-pel searches/block {out[13] / blocks:.3f}  vectors scored/block {out[14] / blocks:.2f}  ticks/block {tot / blocks:.0f}", file=sys.stderr)
+print("per block: " + "  ".join(f"{nm} {out[k] / blocks:.3f}" for k, nm in [
+    (23, "good-enough before the tail"), (21, "sub-pel pass 0"), (22, "sub-pel pass 1"), (27, "sub-pel vector"), (16, "skip test"), (17, "skipped"),
+    (18, "sub-block metrics at the vector (round 3)"), (19, "intra test luma"), (20, "intra test chroma"), (24, "intra")]), file=sys.stderr)
