@@ -28,6 +28,9 @@ def run_lib(lib, sc, quant, effort, skip_thresh=0):
     (1920, 800, A.SUBSAMP_420, 10, 172, 10, True),   # 32 x 16 blocks: wider than 1280, not "mostly square" (dsv_encoder.c:1203-1209)
     (2560, 1080, A.SUBSAMP_420, 11, 172, 10, True),  # 32 x 16 blocks
     (1920, 816, A.SUBSAMP_420, 12, 300, 7, False),   # 32 x 16, effort 7 (no quarter-pel), no previous field
+    (1936, 808, A.SUBSAMP_420, 13, 172, 10, True),   # 32 x 16 with a clipped last column (16 wide) and row (8 high): still the fast 32 x 16 routine
+    (1928, 804, A.SUBSAMP_420, 14, 61, 10, True),    # 32 x 16 clipped to 8 wide / 4 high: the general routine at level 0, the fast one above it
+    (2048, 860, A.SUBSAMP_444, 15, 172, 10, True),   # 32 x 16 in 4:4:4: level 0 on the general routine (the 32-wide level-0 form is 4:2:0)
 ])
 def test_hme_matches_reference(w, h, subsamp, seed, quant, effort, prev):
     ref, hip = A.load_ref(), A.load_hip()
