@@ -53,9 +53,10 @@ void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, c
 void intra_filter_luma(hipStream_t s, const uint8_t *d_bd, const MCParams &p, int q, const DPlane &luma);
 
 // lockstep batches over n streams (job tables resident on the device)
-void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, int blk_h);
+void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, int blk_w, int blk_h, bool c420);
 void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_w, int blk_h);
-void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_h);
+void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_w,
+                       int blk_h, bool c420);
 void intra_filter_batch(hipStream_t s, const McJob *d_tab, int n, int luma_w, int luma_h); // luma size: whether / how large the LDS ring
 
 // dsv_post_process (bmc.c:340): de-gradient sharpen of every interior 4x4 cell

@@ -85,155 +85,10 @@ __device__ __forceinline__ uint8_t recon_px(int rv, int pv, uint32_t flags, int 
     return plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2);
 }
 
-// One workgroup (256 threads) forms the prediction of one block of one plane.
-// MODE MC_SUBTRACT: pred <- prediction, res <- residual(res - pred)      (dsv_sub_pred)
-// MODE MC_RECONSTRUCT: out(=pred plane) <- recon(prediction, res)        (dsv_add_pred: prediction is
-//                      formed straight into the output frame, then overwritten by the reconstruction)
-// A luma block with a fractional vector stages its (bw+3) x (bh+3) reference window in LDS once and
-// runs the two filter passes of luma_qp (bmc.c:662-727) from there: horizontal into a 16-bit image,
-// then vertical -- the same arithmetic per pixel as evaluating both passes from its own 4x4 window.
-struct PredLds {
-    int qsum[4];
-    uint8_t win[35 * 36];
-    int16_t hz[35 * 32];
-};
-
-template <int MODE>
-__device__ __forceinline__ void predict_block(const DSV_MV *__restrict__ mvs, const MCParams &p, const DPlane &rp, const DPlane &dp,
-                                              const DPlane &sp, int i, int j, int c, PredLds &L)
-{
-    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
-    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
-    DSV_MV mv = mvs[i + j * p.nbh];
-    int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
-    uint32_t flags = mv.flags;
-    bool intra = flags & (1u << DSV_MV_BIT_INTRA);
-    int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
-    int x = i * bw, y = j * bh;
-    int px = x + sar(mvx, 2 + sh), py = y + sar(mvy, 2 + sv);
-    int sbw = bw >> 1, sbh = bh >> 1;
-    bool subpel_luma = (c == 0) && !intra && ((mvx | mvy) & 3);
-    if (subpel_luma) {
-        px = clampi(px - 1, -kBorder, limx);
-        py = clampi(py - 1, -kBorder, limy);
-    } else {
-        px = clampi(px, -kBorder, limx);
-        py = clampi(py, -kBorder, limy);
-    }
-    const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
-    bool need_mean = intra && !(c == 0 && mv.dc);
-    int dcq[4] = {0, 0, 0, 0};
-    if (intra) {
-        if (need_mean) {
-            if (threadIdx.x < 4) {
-                L.qsum[threadIdx.x] = 0;
-            }
-            __syncthreads();
-            int part[4] = {0, 0, 0, 0};
-            for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
-                int m = idx % bw, n = idx / bw;
-                int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
-                part[k] += rbase[(ptrdiff_t) n * rp.stride + m];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (part[k]) {
-                    atomicAdd(&L.qsum[k], part[k]);
-                }
-            }
-            __syncthreads();
-            if (mv.submask == DSV_MASK_ALL_INTRA) {
-                int all = (L.qsum[0] + L.qsum[1] + L.qsum[2] + L.qsum[3]) / (bw * bh); // bmc.c:857
-                dcq[0] = dcq[1] = dcq[2] = dcq[3] = all;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    dcq[k] = L.qsum[k] / (sbw * sbh); // bmc.c:884
-                }
-            }
-        } else {
-            dcq[0] = dcq[1] = dcq[2] = dcq[3] = mv.dc; // transmitted DC, luma only (bmc.c:854,881)
-        }
-    }
-    int fx = 0, fy = 0;
-    bool soft_x = false, soft_y = false;
-    int f0 = 0, f1 = 0, f2 = 0, f3 = 0, sf = 0, af = 0;
-    bool chroma_frac = false;
-    if (subpel_luma) {
-        bool large = abs(mvx) >= 8 || abs(mvy) >= 8; // bmc.c:674-679
-        fx = mvx & 3;
-        fy = mvy & 3;
-        soft_x = large || !(fx & 1) || (p.temporal_mc & 1);
-        soft_y = large || !(fy & 1) || (p.temporal_mc & 1);
-        int ww = bw + 3, wh = bh + 3;
-        for (int idx = threadIdx.x; idx < ww * wh; idx += 256) {
-            int r = idx / ww, cc = idx % ww;
-            L.win[r * 36 + cc] = rbase[(ptrdiff_t) r * rp.stride + cc];
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < wh * bw; idx += 256) {
-            int r = idx / bw, m = idx % bw;
-            const uint8_t *q = &L.win[r * 36 + m];
-            int a = q[0], b = q[1], cc = q[2], d = q[3];
-            L.hz[r * 32 + m] = (int16_t) qp_blend(hp_tap(a, b, cc, d, soft_x), b, cc, fx);
-        }
-        __syncthreads();
-    } else if (c != 0 && !intra) {
-        int hb = 2 + sh, vb = 2 + sv, hf = 1 << hb, vf = 1 << vb; // bmc.c:778-798
-        int dx = mvx & (hf - 1), dy = mvy & (vf - 1);
-        chroma_frac = (dx | dy) != 0;
-        f0 = (hf - dx) * (vf - dy);
-        f1 = dx * (vf - dy);
-        f2 = (hf - dx) * dy;
-        f3 = dx * dy;
-        sf = hb + vb;
-        af = 1 << (sf - 1);
-    }
-    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
-        int m = idx % bw, n = idx / bw;
-        const uint8_t *r = rbase + (ptrdiff_t) n * rp.stride + m;
-        int pv;
-        if (intra) {
-            int k = (m >= sbw ? 1 : 0) | (n >= sbh ? 2 : 0);
-            bool fill = (mv.submask == DSV_MASK_ALL_INTRA) || (mv.submask & (1 << k));
-            pv = fill ? (dcq[k] & 0xff) : r[0];
-        } else if (subpel_luma) {
-            const int16_t *t = &L.hz[n * 32 + m];
-            pv = clamp_u8(qp_blend(hp_tap(t[0], t[32], t[64], t[96], soft_y), t[32], t[64], fy));
-        } else if (chroma_frac) {
-            pv = (f0 * r[0] + f1 * r[1] + f2 * r[rp.stride] + f3 * r[rp.stride + 1] + af) >> sf;
-            pv &= 0xff;
-        } else {
-            pv = r[0];
-        }
-        ptrdiff_t o = (ptrdiff_t) (y + n) * dp.stride + (x + m);
-        if (MODE == MC_SUBTRACT) {
-            dp.data[o] = (uint8_t) pv;
-            ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
-            sp.data[so] = residual_px(sp.data[so], pv, flags, c, p.lossless);
-        } else if (MODE == MC_RECONSTRUCT) {
-            ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
-            dp.data[o] = recon_px(sp.data[so], pv, flags, p.lossless);
-        } else {
-            dp.data[o] = (uint8_t) pv;
-        }
-    }
-}
-
-// grid = (nblocks_h, nblocks_v, 3)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_predict(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 refp, Planes3 predp,
-                                                 Planes3 resp)
-{
-    __shared__ PredLds L;
-    int c = blockIdx.z;
-    predict_block<MODE>(mvs, p, refp.p[c], predp.p[c], resp.p[c], blockIdx.x, blockIdx.y, c, L);
-}
-
 // ---- lockstep-batch forms: one WAVEFRONT per block (all three planes), four pixels per lane ---------------------
 // grid = (ceil(nblocks_h / 4), nblocks_v, n streams), 256 threads = 4 wavefronts = 4 horizontally adjacent blocks.
 // Pixels move as aligned dwords (block origins and widths are multiples of 4); the reference window of a
-// fractional luma vector is staged per wavefront in LDS and filtered in two passes like predict_block().
+// fractional luma vector is staged per wavefront in LDS and filtered in two passes (rows, then columns: bmc.c:702-760).
 struct __attribute__((packed)) U32u {
     uint32_t v;
 };
@@ -337,8 +192,11 @@ __device__ __forceinline__ int wave_sum_i(int v)
 // one plane of one block.  CC >= 0 fixes the plane AND the geometry at compile time (16x16 luma blocks, 4:2:0: 8x8 chroma):
 // loop bounds, shifts and the lane -> pixel mapping fold to constants, which removes about a third of the kernel's scalar and
 // a fifth of its vector instructions; CC < 0 is the general form (plane c, sizes from the job).
-template <int MODE, int CC>
-__device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p, const DSV_MV &mv, int i, int j, WaveLds &L, int c_rt)
+// TILED (with CC >= 0): the 16 x 16 (8 x 8) piece at luma offset (ox, oy) of an INTER block of 32 x 32, 32 x 16 or 16 x 32 -- a block's prediction
+// is per pixel once the block's reference position is known, so the piece takes the whole block's position (clamped with the
+// whole block's size, bmc.c:700-707) plus its own offset.
+template <int MODE, int CC, bool TILED = false>
+__device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p, const DSV_MV &mv, int i, int j, WaveLds &L, int c_rt, int ox = 0, int oy = 0)
 {
     const int lane = threadIdx.x & 63;
     const int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
@@ -350,13 +208,15 @@ __device__ __forceinline__ void predict_plane(const McJob &jb, const MCParams &p
         const int sh = CC >= 0 ? (CC ? 1 : 0) : (c ? p.hshift : 0), sv = CC >= 0 ? (CC ? 1 : 0) : (c ? p.vshift : 0);
         const int bw = CC >= 0 ? (CC ? 8 : 16) : (p.blk_w >> sh), bh = CC >= 0 ? (CC ? 8 : 16) : (p.blk_h >> sv);
         const DPlane rp = jb.ref.p[c], dp = jb.pred.p[c], sp = jb.res.p[c];
-        const int limx = (dp.w - bw) + kBorder - 1, limy = (dp.h - bh) + kBorder - 1;
-        const int x = i * bw, y = j * bh;
-        int px = x + sar(mvx, 2 + sh), py = y + sar(mvy, 2 + sv);
+        const int Bw = TILED ? (p.blk_w >> sh) : bw, Bh = TILED ? (p.blk_h >> sv) : bh; // the block the vector belongs to
+        const int tox = TILED ? (ox >> sh) : 0, toy = TILED ? (oy >> sv) : 0;
+        const int limx = (dp.w - Bw) + kBorder - 1, limy = (dp.h - Bh) + kBorder - 1;
+        const int x = i * Bw + tox, y = j * Bh + toy;
+        int px = i * Bw + sar(mvx, 2 + sh), py = j * Bh + sar(mvy, 2 + sv);
         const int sbw = bw >> 1, sbh = bh >> 1;
         const bool subpel_luma = (c == 0) && !intra && ((mvx | mvy) & 3);
-        px = clampi(subpel_luma ? px - 1 : px, -kBorder, limx);
-        py = clampi(subpel_luma ? py - 1 : py, -kBorder, limy);
+        px = clampi(subpel_luma ? px - 1 : px, -kBorder, limx) + tox;
+        py = clampi(subpel_luma ? py - 1 : py, -kBorder, limy) + toy;
         const uint8_t *rbase = rp.data + (ptrdiff_t) py * rp.stride + px;
         // block sizes are powers of two (16 << e, halved by the chroma shifts): lane -> (row, column) by shifts, not by the
         // 32-bit divide sequence (a dozen of them per block otherwise)
@@ -549,8 +409,8 @@ __device__ __forceinline__ int row16_sum_i(int v)
 #define DSV2_CHROMA_PAIR 1
 #endif
 constexpr bool kChromaPair = DSV2_CHROMA_PAIR != 0; // (build switch for A/B: make EXTRA=-DDSV2_CHROMA_PAIR=0)
-template <int MODE>
-__device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCParams &p, const DSV_MV &mv, int i, int j)
+template <int MODE, bool TILED = false>
+__device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCParams &p, const DSV_MV &mv, int i, int j, int ox = 0, int oy = 0)
 {
     const int lane = threadIdx.x & 63;
     const int mvx = mv.u.mv.x, mvy = mv.u.mv.y;
@@ -562,9 +422,11 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
     const DPlane rp1 = jb.ref.p[1], dp1 = jb.pred.p[1], sp1 = jb.res.p[1];
     const uint8_t *rdata = v_plane ? jb.ref.p[2].data : rp1.data;
     uint8_t *ddata = v_plane ? jb.pred.p[2].data : dp1.data, *sdata = v_plane ? jb.res.p[2].data : sp1.data;
-    const int limx = (dp1.w - bw) + kBorder - 1, limy = (dp1.h - bh) + kBorder - 1;
-    const int x = i * bw, y = j * bh;
-    const int px = clampi(x + sar(mvx, 3), -kBorder, limx), py = clampi(y + sar(mvy, 3), -kBorder, limy);
+    const int Bw = TILED ? (p.blk_w >> 1) : bw, Bh = TILED ? (p.blk_h >> 1) : bh; // (see predict_plane)
+    const int tox = TILED ? (ox >> 1) : 0, toy = TILED ? (oy >> 1) : 0;
+    const int limx = (dp1.w - Bw) + kBorder - 1, limy = (dp1.h - Bh) + kBorder - 1;
+    const int x = i * Bw + tox, y = j * Bh + toy;
+    const int px = clampi(i * Bw + sar(mvx, 3), -kBorder, limx) + tox, py = clampi(j * Bh + sar(mvy, 3), -kBorder, limy) + toy;
     const uint8_t *rbase = rdata + (ptrdiff_t) py * rp1.stride + px;
     const int g = lane & 15, m = (g & 1) * 4, n = g >> 1; // 16 groups of 4 pixels, two per row
     typedef const __attribute__((address_space(1))) uint8_t *gbr_t;
@@ -654,9 +516,22 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
     }
 }
 
-template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int i, int j, WaveLds &L)
+// tiles: 0 = a wavefront per block; (tw | th << 8) = a wavefront per 16 x 16 piece of a block of tw x th pieces (4:2:0, the host's
+// choice: mc_tiles) -- (ti, tj) is then the piece's place in the picture
+template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int ti, int tj, WaveLds &L, int tiles)
 {
     const MCParams p = jb.p;
+    int i = ti, j = tj, ox = 0, oy = 0;
+    if (tiles) {
+        const int tw = tiles & 0xff, th = tiles >> 8; // 1 or 2 each
+        i = tw == 2 ? ti >> 1 : ti;
+        j = th == 2 ? tj >> 1 : tj;
+        ox = tw == 2 ? 16 * (ti & 1) : 0;
+        oy = th == 2 ? 16 * (tj & 1) : 0;
+    }
+    if (i >= p.nbh) {
+        return;
+    }
     const DSV_MV mv = jb.mvs[i + j * p.nbh];
     if (p.blk_w == 16 && p.blk_h == 16 && p.hshift == 1 && p.vshift == 1) { // (uniform over the launch)
         predict_plane<MODE, 0>(jb, p, mv, i, j, L, 0);
@@ -666,6 +541,11 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
             predict_plane<MODE, 1>(jb, p, mv, i, j, L, 1);
             predict_plane<MODE, 2>(jb, p, mv, i, j, L, 2);
         }
+    } else if (tiles && !(mv.flags & (1u << DSV_MV_BIT_INTRA))) {
+        predict_plane<MODE, 0, true>(jb, p, mv, i, j, L, 0, ox, oy);
+        predict_chroma_pair<MODE, true>(jb, p, mv, i, j, ox, oy);
+    } else if (tiles && (ox | oy)) {
+        // (an intra block -- sub-block means over the whole block -- is its first piece's work, in the general form below)
     } else {
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
@@ -674,7 +554,7 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
     }
 }
 
-template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab, int lds_rows)
+template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab, int lds_rows, int tiles)
 {
     DSV2_KERNEL_PRIO();
     extern __shared__ __align__(16) uint8_t predict_lds[];
@@ -683,10 +563,10 @@ template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJ
     // then live in scalar registers)
     const int w = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     int i = (int) blockIdx.x * 4 + w, j = blockIdx.y;
-    if (i < jb.p.nbh) {
+    {
         uint8_t *mine = predict_lds + (unsigned) w * wave_lds_bytes(lds_rows);
         WaveLds L{mine, (int16_t *) (mine + wave_lds_win_bytes(lds_rows))};
-        predict_block_wave<MODE>(jb, i, j, L);
+        predict_block_wave<MODE>(jb, i, j, L, tiles);
     }
 }
 
@@ -2467,13 +2347,46 @@ static Planes3 planes_of(const DFrame &f)
     return p;
 }
 
-void mc_sub_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DFrame &pred, const DFrame &resd, const DFrame &ref)
+// Blocks larger than 16 x 16 in 4:2:0 (32 x 32: 2160p; 32 x 16: 1920 x 800, 2560 x 1080) are predicted a 16 x 16 piece per wavefront through
+// the 16 x 16 routine (predict_plane<.., TILED>): tw | th << 8 pieces a block, 0 = a wavefront per block (16 x 16 itself; other formats)
+static int mc_tiles(int blk_w, int blk_h, bool c420)
 {
-    DSV2_LAUNCH((k_predict<MC_SUBTRACT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(pred),
-                       planes_of(resd));
-    HIPCHK(hipGetLastError());
+    const bool big = (blk_w == 32 || blk_h == 32) && (blk_w == 16 || blk_w == 32) && (blk_h == 16 || blk_h == 32);
+    return (c420 && big) ? ((blk_w / 16) | ((blk_h / 16) << 8)) : 0;
+}
+template <int MODE> static void launch_predict(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, int blk_w, int blk_h, bool c420)
+{
+    const int tiles = mc_tiles(blk_w, blk_h, c420);
+    const int tw = tiles ? (tiles & 0xff) : 1, th = tiles ? (tiles >> 8) : 1;
+    // the luma window of a wavefront's piece: the launch's block height + 3, or a 16-high piece's 19 (an intra block of a tiled
+    // launch takes the general form, which only stages a window for sub-pel vectors -- an intra block has none)
+    const int rows = (tiles ? 16 : blk_h) + 3;
+    DSV2_LAUNCH((k_predict_w<MODE>), dim3((nbh * tw + 3) / 4, nbv * th, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows, tiles);
+}
+// the single-call seam (dsv_sub_pred, dsv_add_pred): the batch kernel over a table of ONE job, so that the stage tests exercise
+// the kernel the encoder and the decoder run.  (The seam serialises its callers and drains the stream before it returns: one
+// table is enough.)
+template <int MODE> static void predict_one(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DFrame &ref, const DFrame &pred, const DFrame &resd)
+{
+    static McJob *d_job = nullptr;
+    if (d_job == nullptr) {
+        HIPCHK(hipMalloc(&d_job, sizeof(McJob)));
+    }
+    McJob jb{};
+    jb.mvs = d_mvs;
+    jb.p = p;
+    jb.ref = planes_of(ref);
+    jb.pred = planes_of(pred);
+    jb.res = planes_of(resd);
+    HIPCHK(hipMemcpyAsync(d_job, &jb, sizeof(McJob), hipMemcpyHostToDevice, s)); // (pageable source: staged before the call returns)
+    launch_predict<MODE>(s, d_job, 1, p.nbh, p.nbv, p.blk_w, p.blk_h, p.hshift == 1 && p.vshift == 1);
 }
 
+void mc_sub_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DFrame &pred, const DFrame &resd, const DFrame &ref)
+{
+    predict_one<MC_SUBTRACT>(s, d_mvs, p, ref, pred, resd);
+    HIPCHK(hipGetLastError());
+}
 void mc_add_res(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &pred, int do_filter,
                 int inter_sharpen)
 {
@@ -2488,8 +2401,7 @@ void mc_add_res(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, co
 void mc_add_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &out, const DFrame &ref,
                  int do_filter, int inter_sharpen)
 {
-    DSV2_LAUNCH((k_predict<MC_RECONSTRUCT>), dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(ref), planes_of(out),
-                       planes_of(resd));
+    predict_one<MC_RECONSTRUCT>(s, d_mvs, p, ref, out, resd);
     if (!p.lossless) {
         DSV2_LAUNCH(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
                            planes_of(out));
@@ -2539,11 +2451,10 @@ static bool filter_pair(int n)
 }
 
 // ---- lockstep batch drivers: `d_tab` holds n McJob records already resident on the device ----
-void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, int blk_h)
+void mc_sub_pred_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv, int blk_w, int blk_h, bool c420)
 {
     if (n > 0) {
-        const int rows = blk_h + 3; // the luma window of the launch's blocks (chroma blocks are no taller)
-        DSV2_LAUNCH((k_predict_w<MC_SUBTRACT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows);
+        launch_predict<MC_SUBTRACT>(s, d_tab, n, nbh, nbv, blk_w, blk_h, c420);
     }
 }
 
@@ -2568,11 +2479,11 @@ void mc_add_res_batch(hipStream_t s, const McJob *d_tab, int n, int nbh, int nbv
 }
 
 // decoder: d_pred jobs {ref, pred = output picture, res = residual}; d_filt jobs {res = output picture}
-void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_h)
+void mc_add_pred_batch(hipStream_t s, const McJob *d_pred, const McJob *d_filt, int n, int nbh, int nbv, bool any_filter, int luma_w, int luma_h, int blk_w,
+                       int blk_h, bool c420)
 {
     if (n > 0) {
-        const int rows = blk_h + 3;
-        DSV2_LAUNCH((k_predict_w<MC_RECONSTRUCT>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_pred, rows);
+        launch_predict<MC_RECONSTRUCT>(s, d_pred, n, nbh, nbv, blk_w, blk_h, c420);
         if (any_filter) {
             bool wide = false;
             const unsigned lds = ring_lds_bytes(luma_w, luma_h, &wide);

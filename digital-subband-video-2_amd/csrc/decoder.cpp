@@ -530,7 +530,8 @@ void dec_device_round(DecJob *jobs, const std::vector<int> &ids)
     zero_linear_batch(bs, d_zfail, n_zfail, max_plane_bytes);
     zero_linear_if_batch(bs, d_zcond, d_fail, n_parse, max_plane_bytes);
     intra_filter_batch(bs, d_mc_intra, nIf, dv0.w, dv0.h);
-    mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter, dv0.w, dv0.h, dv0.blk_h);
+    mc_add_pred_batch(bs, d_mc_pred, d_mc_filt, nP, dv0.nbh, dv0.nbv, any_filter, dv0.w, dv0.h, dv0.blk_w, dv0.blk_h,
+                      DSV_FORMAT_H_SHIFT(dv0.format) == 1 && DSV_FORMAT_V_SHIFT(dv0.format) == 1);
     prof.end(bs, ST_RECON_FILTER, n);
     prof.begin(bs, ST_EXTEND);
     for (int c = 0; c < 3; c++) {

@@ -2100,7 +2100,7 @@ static void enc_batch_step(Job *jobs, int n)
     copy_linear_batch(bs, d_mvcopy, n_mvcopy, mv_bytes);
     copy_linear_batch(bs, d_copy, n_copy, dv0.pics[0].src.bytes);
     prof.begin(bs, ST_PREDICT);
-    mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv, dv0.blk_h);
+    mc_sub_pred_batch(bs, sc.d_mc, nP, nbh, nbv, dv0.blk_w, dv0.blk_h, DSV_FORMAT_H_SHIFT(dv0.format) == 1 && DSV_FORMAT_V_SHIFT(dv0.format) == 1);
     prof.end(bs, ST_PREDICT, nP);
     struct Slice {
         int first, count, isP, lossless;
@@ -2233,7 +2233,7 @@ static void enc_batch_step(Job *jobs, int n)
             h_k2->total = sc.d_totals + ti;
             sc.tabs.upload(bs);
             if (isP) {
-                mc_sub_pred_batch(bs, d_m2, 1, nbh, nbv, dv0.blk_h);
+                mc_sub_pred_batch(bs, d_m2, 1, nbh, nbv, dv0.blk_w, dv0.blk_h, DSV_FORMAT_H_SHIFT(dv0.format) == 1 && DSV_FORMAT_V_SHIFT(dv0.format) == 1);
             } else {
                 copy_linear_batch(bs, d_c2, 1, cur.src.bytes);
             }

@@ -12,7 +12,9 @@ from test_oracle_sbt import rand_frame
 pytestmark = [pytest.mark.gpu]  # (a GPU box without oracle/_ref FAILS these tests: conftest.py)
 
 
-@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (2560, 1440, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420)])
+# (2560 x 1440: 32 x 32 blocks; 1920 x 800, 16384 x 64: 32 x 16 -- in 4:2:0 those are predicted a 16 x 16 piece per wavefront, intra blocks whole)
+@pytest.mark.parametrize("w,h,subsamp", CASES + [(1920, 1080, A.SUBSAMP_420), (2560, 1440, A.SUBSAMP_420), (16384, 64, A.SUBSAMP_420), (1920, 800, A.SUBSAMP_420),
+                                             (2560, 1440, A.SUBSAMP_444)])
 @pytest.mark.parametrize("lossless,tmc,do_filter,q", [(0, 0, 1, 700), (0, 1, 1, 172), (0, 1, 0, 2500), (1, 0, 1, 1)])
 def test_motion_compensation_and_filters(w, h, subsamp, lossless, tmc, do_filter, q):
     ref, hip = A.load_ref(), A.load_hip()
