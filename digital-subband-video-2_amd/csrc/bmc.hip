@@ -59,32 +59,6 @@ __device__ __forceinline__ int luma_subpel_px(const uint8_t *r, int rs, int fx, 
 
 enum { MC_PREDICT_ONLY = 0, MC_SUBTRACT = 1, MC_RECONSTRUCT = 2 };
 
-__device__ __forceinline__ uint8_t residual_px(int s, int pv, uint32_t flags, int c, int lossless) // bmc.c:1015-1050
-{
-    if (lossless) {
-        return (uint8_t) (s - pv + 128);
-    }
-    bool intra = flags & (1u << DSV_MV_BIT_INTRA), skip = flags & (1u << DSV_MV_BIT_SKIP);
-    bool noxmit = c == 0 ? (flags & (1u << DSV_MV_BIT_NOXMITY)) : (flags & (1u << DSV_MV_BIT_NOXMITC));
-    if (!intra && (skip || noxmit)) {
-        return 128;
-    }
-    if (flags & (1u << DSV_MV_BIT_EPRM)) {
-        return clamp_u8((s - pv + 256) >> 1);
-    }
-    return clamp_u8(s - pv + 128);
-}
-
-__device__ __forceinline__ uint8_t recon_px(int rv, int pv, uint32_t flags, int lossless) // bmc.c:953-983
-{
-    if (lossless) {
-        return (uint8_t) (pv + rv - 128);
-    }
-    bool plain = !(flags & (1u << DSV_MV_BIT_EPRM)) ||
-                 (!(flags & (1u << DSV_MV_BIT_INTRA)) && (flags & (1u << DSV_MV_BIT_SKIP)));
-    return plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2);
-}
-
 // ---- lockstep-batch forms: one WAVEFRONT per block (all three planes), four pixels per lane ---------------------
 // grid = (ceil(nblocks_h / 4), nblocks_v, n streams), 256 threads = 4 wavefronts = 4 horizontally adjacent blocks.
 // Pixels move as aligned dwords (block origins and widths are multiples of 4); the reference window of a
@@ -516,13 +490,19 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
     }
 }
 
-// tiles: 0 = a wavefront per block; (tw | th << 8) = a wavefront per 16 x 16 piece of a block of tw x th pieces (4:2:0, the host's
-// choice: mc_tiles) -- (ti, tj) is then the piece's place in the picture
-template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int ti, int tj, WaveLds &L, int tiles)
+// TILED (a kernel of its own: k_predict_w<MODE, PRED_TILED> -- the 16 x 16 kernel's code is what a 1080p launch keeps in the
+// instruction cache beside every other group's kernels, and it measured 26 - 34 % slower under load with this form folded in):
+// tiles = (tw | th << 8), a wavefront per 16 x 16 piece of a block of tw x th pieces (4:2:0, the host's choice: mc_tiles);
+// (ti, tj) is then the piece's place in the picture.  Otherwise a wavefront per block.
+// FORM: PRED_ANY = whatever the job's geometry asks for; PRED_16 = 16 x 16 blocks in 4:2:0 and nothing else (the host's promise: the kernel
+// carries no other form's code or registers); PRED_TILED as above.
+enum { PRED_ANY = 0, PRED_16 = 1, PRED_TILED = 2 };
+template <int MODE, int FORM> __device__ __forceinline__ void predict_block_wave(const McJob &jb, int ti, int tj, WaveLds &L, int tiles)
 {
+    constexpr bool TILED = FORM == PRED_TILED;
     const MCParams p = jb.p;
     int i = ti, j = tj, ox = 0, oy = 0;
-    if (tiles) {
+    if (TILED) {
         const int tw = tiles & 0xff, th = tiles >> 8; // 1 or 2 each
         i = tw == 2 ? ti >> 1 : ti;
         j = th == 2 ? tj >> 1 : tj;
@@ -533,7 +513,7 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
         return;
     }
     const DSV_MV mv = jb.mvs[i + j * p.nbh];
-    if (p.blk_w == 16 && p.blk_h == 16 && p.hshift == 1 && p.vshift == 1) { // (uniform over the launch)
+    if (FORM == PRED_16 || (FORM == PRED_ANY && p.blk_w == 16 && p.blk_h == 16 && p.hshift == 1 && p.vshift == 1)) { // (uniform over the launch)
         predict_plane<MODE, 0>(jb, p, mv, i, j, L, 0);
         if (kChromaPair) {
             predict_chroma_pair<MODE>(jb, p, mv, i, j);
@@ -541,12 +521,12 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
             predict_plane<MODE, 1>(jb, p, mv, i, j, L, 1);
             predict_plane<MODE, 2>(jb, p, mv, i, j, L, 2);
         }
-    } else if (tiles && !(mv.flags & (1u << DSV_MV_BIT_INTRA))) {
+    } else if (TILED && !(mv.flags & (1u << DSV_MV_BIT_INTRA))) {
         predict_plane<MODE, 0, true>(jb, p, mv, i, j, L, 0, ox, oy);
         predict_chroma_pair<MODE, true>(jb, p, mv, i, j, ox, oy);
-    } else if (tiles && (ox | oy)) {
+    } else if (TILED && (ox | oy)) {
         // (an intra block -- sub-block means over the whole block -- is its first piece's work, in the general form below)
-    } else {
+    } else if constexpr (FORM != PRED_16) {
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             predict_plane<MODE, -1>(jb, p, mv, i, j, L, c);
@@ -554,7 +534,7 @@ template <int MODE> __device__ __forceinline__ void predict_block_wave(const McJ
     }
 }
 
-template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab, int lds_rows, int tiles)
+template <int MODE, int FORM> __global__ __launch_bounds__(256) void k_predict_w(const McJob *__restrict__ tab, int lds_rows, int tiles)
 {
     DSV2_KERNEL_PRIO();
     extern __shared__ __align__(16) uint8_t predict_lds[];
@@ -563,24 +543,34 @@ template <int MODE> __global__ __launch_bounds__(256) void k_predict_w(const McJ
     // then live in scalar registers)
     const int w = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     int i = (int) blockIdx.x * 4 + w, j = blockIdx.y;
+#ifdef DSV2_PRED_PAD // (experiment: the 16 x 16 kernel's code with the general kernel's register allocation)
+    asm volatile("v_mov_b32 v55, 0" ::: "v55");
+#endif
     {
         uint8_t *mine = predict_lds + (unsigned) w * wave_lds_bytes(lds_rows);
         WaveLds L{mine, (int16_t *) (mine + wave_lds_win_bytes(lds_rows))};
-        predict_block_wave<MODE>(jb, i, j, L, tiles);
+        predict_block_wave<MODE, FORM>(jb, i, j, L, tiles);
     }
 }
 
 // res <- recon(pred, res) over the block grid of every plane: grid = (x groups, rows, 3 n), one dword per thread
+// (recon_px, bmc.c:953-983, two pixels an instruction: the residual's weight -- 1 for a plain block, 2 for an expanded-range one --
+// is a per-lane multiplier, not a branch; (rv - 128) * 2 + pv stays inside 16 bits)
 __device__ __forceinline__ uint32_t recon4(uint32_t rv4, uint32_t pv4, bool plain, int lossless)
 {
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int rv = (int) ((rv4 >> (8 * k)) & 0xff), pv = (int) ((pv4 >> (8 * k)) & 0xff);
-        int o = lossless ? ((pv + rv - 128) & 0xff) : (plain ? clamp_u8(pv + rv - 128) : clamp_u8(pv + (rv - 128) * 2));
-        out |= (uint32_t) o << (8 * k);
+    const s16x2 r01 = pk_of(__builtin_amdgcn_perm(0u, rv4, 0x0c010c00u)) - spl16s(128), r23 = pk_of(__builtin_amdgcn_perm(0u, rv4, 0x0c030c02u)) - spl16s(128);
+    const s16x2 p01 = pk_of(__builtin_amdgcn_perm(0u, pv4, 0x0c010c00u)), p23 = pk_of(__builtin_amdgcn_perm(0u, pv4, 0x0c030c02u));
+    const s16x2 lo = spl16s(0), hi = spl16s(255);
+    s16x2 o01, o23;
+    if (lossless) { // (uniform over the launch)
+        o01 = (p01 + r01) & hi;
+        o23 = (p23 + r23) & hi;
+    } else {
+        const s16x2 m = spl16s(plain ? 1 : 2);
+        o01 = __builtin_elementwise_min(__builtin_elementwise_max(p01 + r01 * m, lo), hi);
+        o23 = __builtin_elementwise_min(__builtin_elementwise_max(p23 + r23 * m, lo), hi);
     }
-    return out;
+    return __builtin_amdgcn_perm(u32_of(o23), u32_of(o01), 0x06040200u);
 }
 
 // sixteen pixels of a row per thread (one 16-byte load of the residual and of the prediction, one 16-byte store); a
@@ -595,6 +585,9 @@ __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__
     int c = blockIdx.z % 3;
     int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
     int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
+    // (block sizes are powers of two -- 16 << e, halved by the chroma shifts: pixel -> block by a shift; the compiler's integer
+    // division of a runtime divisor is ~30 instructions, and this kernel made five of them per thread)
+    const int lbw = 31 - __builtin_clz((unsigned) bw), lbh = 31 - __builtin_clz((unsigned) bh);
     const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16, y0 = blockIdx.y * (4 * kReconRows) + (threadIdx.x >> 6);
     const int xlim = p.nbh * bw, ylim = p.nbv * bh;
     if (x >= xlim || y0 >= ylim) {
@@ -606,7 +599,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__
 #pragma unroll
     for (int r = 0; r < kReconRows; r++) { // (a row past the plane's end re-reads row y0: harmless, never stored)
         const int y = y0 + 4 * r < ylim ? y0 + 4 * r : y0;
-        const DSV_MV *row = jb.mvs + (y / bh) * p.nbh;
+        const DSV_MV *row = jb.mvs + (y >> lbh) * p.nbh;
         const uint8_t *spx = sp.data + (ptrdiff_t) y * sp.stride + x;
         const uint8_t *dpx = dp.data + (ptrdiff_t) y * dp.stride + x;
         if (whole) {
@@ -623,7 +616,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__
         }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            fl[r][g] = row[min((x + 4 * g) / bw, p.nbh - 1)].flags;
+            fl[r][g] = row[min((x + 4 * g) >> lbw, p.nbh - 1)].flags;
         }
     }
 #pragma unroll
@@ -650,22 +643,6 @@ __global__ __launch_bounds__(256) void k_reconstruct_w(const McJob *__restrict__
                 }
             }
         }
-    }
-}
-
-// encoder-side reconstruction in place: res <- recon(pred, res)   (dsv_add_res, bmc.c:1082)
-__global__ __launch_bounds__(256) void k_reconstruct(const DSV_MV *__restrict__ mvs, MCParams p, Planes3 predp, Planes3 resp)
-{
-    int i = blockIdx.x, j = blockIdx.y, c = blockIdx.z;
-    int sh = c ? p.hshift : 0, sv = c ? p.vshift : 0;
-    int bw = p.blk_w >> sh, bh = p.blk_h >> sv;
-    const DPlane dp = predp.p[c], sp = resp.p[c];
-    uint32_t flags = mvs[i + j * p.nbh].flags;
-    int x = i * bw, y = j * bh;
-    for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
-        int m = idx % bw, n = idx / bw;
-        ptrdiff_t so = (ptrdiff_t) (y + n) * sp.stride + (x + m);
-        sp.data[so] = recon_px(sp.data[so], dp.data[(ptrdiff_t) (y + n) * dp.stride + (x + m)], flags, p.lossless);
     }
 }
 
@@ -2361,7 +2338,13 @@ template <int MODE> static void launch_predict(hipStream_t s, const McJob *d_tab
     // the luma window of a wavefront's piece: the launch's block height + 3, or a 16-high piece's 19 (an intra block of a tiled
     // launch takes the general form, which only stages a window for sub-pel vectors -- an intra block has none)
     const int rows = (tiles ? 16 : blk_h) + 3;
-    DSV2_LAUNCH((k_predict_w<MODE>), dim3((nbh * tw + 3) / 4, nbv * th, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows, tiles);
+    if (tiles) {
+        DSV2_LAUNCH((k_predict_w<MODE, PRED_TILED>), dim3((nbh * tw + 3) / 4, nbv * th, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows, tiles);
+    } else if (blk_w == 16 && blk_h == 16 && c420) {
+        DSV2_LAUNCH((k_predict_w<MODE, PRED_16>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows, 0);
+    } else {
+        DSV2_LAUNCH((k_predict_w<MODE, PRED_ANY>), dim3((nbh + 3) / 4, nbv, n), dim3(256), 4 * wave_lds_bytes(rows), s, d_tab, rows, 0);
+    }
 }
 // the single-call seam (dsv_sub_pred, dsv_add_pred): the batch kernel over a table of ONE job, so that the stage tests exercise
 // the kernel the encoder and the decoder run.  (The seam serialises its callers and drains the stream before it returns: one
@@ -2390,7 +2373,19 @@ void mc_sub_pred(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, const DF
 void mc_add_res(hipStream_t s, const DSV_MV *d_mvs, const MCParams &p, int q, const DFrame &resd, const DFrame &pred, int do_filter,
                 int inter_sharpen)
 {
-    DSV2_LAUNCH(k_reconstruct, dim3(p.nbh, p.nbv, 3), dim3(256), 0, s, d_mvs, p, planes_of(pred), planes_of(resd));
+    { // (the batch kernel over a table of one: see predict_one)
+        static McJob *d_job = nullptr;
+        if (d_job == nullptr) {
+            HIPCHK(hipMalloc(&d_job, sizeof(McJob)));
+        }
+        McJob jb{};
+        jb.mvs = d_mvs;
+        jb.p = p;
+        jb.pred = planes_of(pred);
+        jb.res = planes_of(resd);
+        HIPCHK(hipMemcpyAsync(d_job, &jb, sizeof(McJob), hipMemcpyHostToDevice, s));
+        DSV2_LAUNCH(k_reconstruct_w, dim3((p.nbh * p.blk_w / 16 + 63) / 64, (p.nbv * p.blk_h + 4 * kReconRows - 1) / (4 * kReconRows), 3), dim3(256), 0, s, d_job);
+    }
     if (!p.lossless) {
         DSV2_LAUNCH(k_inter_filters, dim3(3), dim3(256), 0, s, d_mvs, make_filter_params(p, q, do_filter, inter_sharpen),
                            planes_of(resd));
