@@ -58,6 +58,7 @@ def issue_roofline(fps, world):
     # (tools/probe/issue_rate.cpp; the guide says 4): two peaks -- what the SIMDs can issue with enough wavefronts each, and what
     # they can with one
     peak2, peak4 = simds * clock / 2 / 1e9, simds * clock / 5.4 / 1e9
+    peak_meas = simds * clock * 0.39 / 1e9  # tools/probe/issue_rate_chip.cpp: 0.36 - 0.39 vector instructions per nominal clock per SIMD from 3 - 4 wavefronts up
     ach = iv["vector_per_frame"] * fps / max(1, world) / 1e9
     occ = {}
     try:  # tools/profile_round.sh part `occ`: resident wavefronts per SIMD and issue shares of the four-group mix (committed passes)
@@ -69,7 +70,9 @@ def issue_roofline(fps, world):
     return {**occ, "bound": "vector issue", "vector_inst_per_frame": iv["vector_per_frame"], "scalar_inst_per_frame": iv.get("scalar_per_frame"),
             "achieved": round(ach, 1), "peak": round(peak2, 1), "unit": "G wave-instructions/s per GPU", "frac": round(ach / peak2, 4),
             "peak_one_wave_per_simd": round(peak4, 1), "frac_of_one_wave_rate": round(ach / peak4, 4),
+            "peak_measured": round(peak_meas, 1), "frac_of_measured_peak": round(ach / peak_meas, 4),
             "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 clocks per wave64 vector instruction (enough wavefronts per SIMD); / 5.4 clocks "
                          "is what ONE wavefront per SIMD was measured to issue (9 when each instruction waits for the one before: tools/probe/issue_rate.cpp) "
-                         "-- the search runs at three per SIMD and is parked on memory counters 43 % of its wave-cycles",
+                         "-- the search runs at three per SIMD and is parked on memory counters 43 % of its wave-cycles; peak_measured: every CU running streams of "
+                         "v_add_u32 saturates at 0.36 - 0.39 instructions per nominal clock per SIMD from three to four wavefronts up (tools/probe/issue_rate_chip.cpp)",
             "source": "committed PMC passes, not this run: " + iv.get("source", "profiles/instruction_volume.json")}
