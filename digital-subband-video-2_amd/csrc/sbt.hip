@@ -522,8 +522,10 @@ __global__ __launch_bounds__(256) void k_fwd_haar_u8x4(const PlaneJob *__restric
     }
 }
 
-__device__ __forceinline__ int round2(int v) { return (v + (v < 0 ? -1 : 1)) / 2; }
-__device__ __forceinline__ int round4(int v) { return (v + (v < 0 ? -2 : 2)) / 4; }
+// (v + (v < 0 ? -1 : 1)) / 2 and (v + (v < 0 ? -2 : 2)) / 4 with C's truncating division (sbt.c:94-104), as three instructions
+// each: for v < 0 the truncated quotient of v - r is the floored quotient of v + r - 1
+__device__ __forceinline__ int round2(int v) { return (v + 1 + (v >> 31)) >> 1; }
+__device__ __forceinline__ int round4(int v) { return (v + 2 + (v >> 31)) >> 2; }
 
 __device__ __forceinline__ int nudge(int LL, int lp, int ln, int band, int hqp) // sbt.c:723-741
 {
@@ -542,6 +544,10 @@ __device__ __forceinline__ int nudge(int LL, int lp, int ln, int band, int hqp) 
     }
     return band;
 }
+
+// v * (1 << ovf) (sbt.c:717: the LL band's overflow guard) as a shift: a 32-bit vector multiply is a quarter-rate instruction, and the
+// four-quad kernels scale fourteen values per thread
+__device__ __forceinline__ int shl_ovf(int v, int ovf) { return (int) ((unsigned) v << ovf); }
 
 __device__ __forceinline__ uint8_t to_px(int v) { return (uint8_t) clampi(v + 128, 0, 255); }
 
@@ -663,13 +669,14 @@ __global__ __launch_bounds__(256) void k_inv_haar_u8x4(const PlaneJob *__restric
     const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
     const int4 l4 = *(const int4 *) (LLp + oLL), lh4 = *(const int4 *) (C + oLL + g.hw), hl4 = *(const int4 *) (C + oHL),
                hh4 = *(const int4 *) (C + oHL + g.hw);
-    const int sc = 1 << ovf;
-    const int L[6] = {filtered ? LLp[oLL - 1] * sc : 0, l4.x * sc, l4.y * sc, l4.z * sc, l4.w * sc, filtered ? LLp[oLL + 4] * sc : 0};
+    const int L[6] = {filtered ? shl_ovf(LLp[oLL - 1], ovf) : 0, shl_ovf(l4.x, ovf), shl_ovf(l4.y, ovf), shl_ovf(l4.z, ovf), shl_ovf(l4.w, ovf),
+                      filtered ? shl_ovf(LLp[oLL + 4], ovf) : 0};
     int LH[4] = {lh4.x, lh4.y, lh4.z, lh4.w}, HL[4] = {hl4.x, hl4.y, hl4.z, hl4.w};
     const int HH[4] = {hh4.x, hh4.y, hh4.z, hh4.w};
     if (filtered) {
         const int4 u4 = *(const int4 *) (LLp + oLL - g.w), d4 = *(const int4 *) (LLp + oLL + g.w);
-        const int U[4] = {u4.x * sc, u4.y * sc, u4.z * sc, u4.w * sc}, Dn[4] = {d4.x * sc, d4.y * sc, d4.z * sc, d4.w * sc};
+        const int U[4] = {shl_ovf(u4.x, ovf), shl_ovf(u4.y, ovf), shl_ovf(u4.z, ovf), shl_ovf(u4.w, ovf)};
+        const int Dn[4] = {shl_ovf(d4.x, ovf), shl_ovf(d4.y, ovf), shl_ovf(d4.z, ovf), shl_ovf(d4.w, ovf)};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             LH[q] = nudge(L[q + 1], L[q], L[q + 2], LH[q], hqp);
@@ -717,13 +724,14 @@ __global__ __launch_bounds__(256) void k_inv_haar_i32x4(const PlaneJob *__restri
     const size_t oLL = (size_t) jy * g.w + idx, oHL = (size_t) (g.hh + jy) * g.w + idx;
     const int4 l4 = *(const int4 *) (LLp + oLL), lh4 = *(const int4 *) (C + oLL + g.hw), hl4 = *(const int4 *) (C + oHL),
                hh4 = *(const int4 *) (C + oHL + g.hw);
-    const int sc = 1 << ovf;
-    const int L[6] = {filtered ? LLp[oLL - 1] * sc : 0, l4.x * sc, l4.y * sc, l4.z * sc, l4.w * sc, filtered ? LLp[oLL + 4] * sc : 0};
+    const int L[6] = {filtered ? shl_ovf(LLp[oLL - 1], ovf) : 0, shl_ovf(l4.x, ovf), shl_ovf(l4.y, ovf), shl_ovf(l4.z, ovf), shl_ovf(l4.w, ovf),
+                      filtered ? shl_ovf(LLp[oLL + 4], ovf) : 0};
     int LH[4] = {lh4.x, lh4.y, lh4.z, lh4.w}, HL[4] = {hl4.x, hl4.y, hl4.z, hl4.w};
     const int HH[4] = {hh4.x, hh4.y, hh4.z, hh4.w};
     if (filtered) {
         const int4 u4 = *(const int4 *) (LLp + oLL - g.w), d4 = *(const int4 *) (LLp + oLL + g.w);
-        const int U[4] = {u4.x * sc, u4.y * sc, u4.z * sc, u4.w * sc}, Dn[4] = {d4.x * sc, d4.y * sc, d4.z * sc, d4.w * sc};
+        const int U[4] = {shl_ovf(u4.x, ovf), shl_ovf(u4.y, ovf), shl_ovf(u4.z, ovf), shl_ovf(u4.w, ovf)};
+        const int Dn[4] = {shl_ovf(d4.x, ovf), shl_ovf(d4.y, ovf), shl_ovf(d4.z, ovf), shl_ovf(d4.w, ovf)};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             LH[q] = nudge(L[q + 1], L[q], L[q + 2], LH[q], hqp);
