@@ -490,6 +490,24 @@ __device__ __forceinline__ void predict_chroma_pair(const McJob &jb, const MCPar
     }
 }
 
+// A block's record through the SCALAR cache (the address is wave-uniform and an earlier launch wrote the field): the vector, the
+// flags and everything decoded from them then live in scalar registers, and every "is this block intra / skipped / sub-pel" is a
+// scalar branch.  (Loaded through a generic pointer the compiler makes it a per-lane load of the same 16 bytes: the decode runs on
+// the vector unit and each such test becomes a compare, an exec-mask save and a branch.)
+__device__ __forceinline__ DSV_MV load_mv_uniform(const DSV_MV *p)
+{
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) v4u_t *cv4u_t;
+    const v4u_t w = *(cv4u_t) p;
+    DSV_MV mv;
+    mv.u.all = (int32_t) w.x;
+    mv.flags = w.y;
+    mv.err = (uint16_t) (w.z & 0xffffu);
+    mv.dc = (uint16_t) (w.z >> 16);
+    mv.submask = (uint8_t) (w.w & 0xffu);
+    return mv;
+}
+
 // TILED (a kernel of its own: k_predict_w<MODE, PRED_TILED> -- the 16 x 16 kernel's code is what a 1080p launch keeps in the
 // instruction cache beside every other group's kernels, and it measured 26 - 34 % slower under load with this form folded in):
 // tiles = (tw | th << 8), a wavefront per 16 x 16 piece of a block of tw x th pieces (4:2:0, the host's choice: mc_tiles);
@@ -512,7 +530,7 @@ template <int MODE, int FORM> __device__ __forceinline__ void predict_block_wave
     if (i >= p.nbh) {
         return;
     }
-    const DSV_MV mv = jb.mvs[i + j * p.nbh];
+    const DSV_MV mv = load_mv_uniform(&jb.mvs[i + j * p.nbh]);
     if (FORM == PRED_16 || (FORM == PRED_ANY && p.blk_w == 16 && p.blk_h == 16 && p.hshift == 1 && p.vshift == 1)) { // (uniform over the launch)
         predict_plane<MODE, 0>(jb, p, mv, i, j, L, 0);
         if (kChromaPair) {
