@@ -46,6 +46,25 @@ struct DPlane {
     int w, h;
 };
 
+// A launch's job record: entry i of the table (the host wrote it before the launch; nothing writes it during) or, for the
+// single-call forms, the copy in the kernel arguments -- BY VALUE, THROUGH THE SCALAR CACHE, into scalar registers.
+// `tab ? tab[i] : one` bound to a reference is a pointer into one of two address spaces: the compiler then fetches every field with a
+// per-lane (flat) load of the same address, the record's pointers and strides live in vector registers, and every address the kernel
+// forms from them is a 64-bit vector multiply-add instead of a scalar base plus a 32-bit lane offset.  (For the small records only --
+// planes, plane pairs, the compaction's job: the 144-byte PlaneJob with its arrays ends up in scratch when copied this way, which costs
+// more than the flat loads did; the transform and quantiser kernels keep the reference.)
+#ifdef __HIPCC__
+template <class T> __device__ __forceinline__ T job_of(const T *tab, unsigned i, const T &one)
+{
+    if (tab == nullptr) {
+        return one;
+    }
+    T j;
+    __builtin_memcpy(&j, (const __attribute__((address_space(4))) void *) (tab + i), sizeof(T));
+    return j;
+}
+#endif
+
 struct DFrame {
     uint8_t *alloc = nullptr;
     size_t bytes = 0;

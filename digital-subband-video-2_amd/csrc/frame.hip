@@ -96,7 +96,7 @@ static int extend_items(int w, int h) { return 16 * h + 2 * kBorder * ((w + 3) >
 __global__ __launch_bounds__(256) void k_extend(const DPlane *__restrict__ tab, DPlane one)
 {
     DSV2_KERNEL_PRIO();
-    const DPlane &pl = tab ? tab[blockIdx.y] : one;
+    const DPlane pl = job_of(tab, blockIdx.y, one);
     extend_item(pl, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
@@ -124,7 +124,7 @@ void extend_planes(hipStream_t s, const DPlane *d_planes, int n, int max_w, int 
 // 2x2 rounded mean decimation of the luma plane (frame.c:211-234)
 __global__ __launch_bounds__(256) void k_ds2x(const PlanePair *__restrict__ tab, PlanePair one)
 {
-    const PlanePair &pp = tab ? tab[blockIdx.z] : one;
+    const PlanePair pp = job_of(tab, blockIdx.z, one);
     int x = blockIdx.x * 64 + threadIdx.x;
     int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= pp.dst.w || y >= pp.dst.h) {
@@ -142,7 +142,7 @@ constexpr int kDsRows = 4; // output rows per thread (y, y + 4, ...): all eight 
 __global__ __launch_bounds__(256) void k_ds2x4(const PlanePair *__restrict__ tab, PlanePair one)
 {
     DSV2_KERNEL_PRIO();
-    const PlanePair &pp = tab ? tab[blockIdx.z] : one;
+    const PlanePair pp = job_of(tab, blockIdx.z, one);
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y0 = blockIdx.y * (4 * kDsRows) + threadIdx.y;
     if (x >= pp.dst.w || y0 >= pp.dst.h) {

@@ -581,7 +581,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 __global__ __launch_bounds__(256) void k_count(const CompactJob *__restrict__ tab, CompactJob one)
 {
     __shared__ int wsum[4];
-    const CompactJob &J = tab ? tab[blockIdx.y] : one;
+    const CompactJob J = job_of(tab, blockIdx.y, one);
     const int32_t *qv = J.qv;
     int n = J.n;
     int *tile_count = J.tile_count;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const CompactJob *_
 {
     DSV2_KERNEL_PRIO();
     __shared__ int wsum[kScanThreads / 64];
-    const CompactJob &J = tab ? tab[blockIdx.y] : one;
+    const CompactJob J = job_of(tab, blockIdx.y, one);
     const int *tile_count = J.tile_count;
     int ntiles = (J.n + kTile - 1) / kTile;
     int *tile_base = J.tile_base, *total = J.total;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_scatter(const CompactJob *__restrict__ 
     __shared__ uint32_t spos[kTile];
     __shared__ int32_t sval[kTile];
     __shared__ int tbs[kScatterTiles + 1];
-    const CompactJob &J = tab ? tab[blockIdx.y] : one;
+    const CompactJob J = job_of(tab, blockIdx.y, one);
     const int32_t *qv = J.qv;
     int n = J.n;
     uint32_t *out_pos = J.pos;
