@@ -54,6 +54,18 @@ struct DPlane {
 // planes, plane pairs, the compaction's job: the 144-byte PlaneJob with its arrays ends up in scratch when copied this way, which costs
 // more than the flat loads did; the transform and quantiser kernels keep the reference.)
 #ifdef __HIPCC__
+// a value / pointer every lane holds alike, told to the compiler as such: it moves to scalar registers and what is computed from it
+// (addresses above all) to the scalar unit
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    unsigned long long v = (unsigned long long) p;
+    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    return (T *) (((unsigned long long) hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ DPlane uni(const DPlane &p) { return DPlane{uni_ptr(p.data), uni(p.stride), uni(p.w), uni(p.h)}; }
+
 template <class T> __device__ __forceinline__ T job_of(const T *tab, unsigned i, const T &one)
 {
     if (tab == nullptr) {

@@ -44,15 +44,7 @@ struct HmeDev {
 // sits in global memory, and after every hand-off fence its fields would otherwise be reloaded (vector loads, in
 // front of each block).  Same member names as HmeDev; src[] / ref[] / ogr[] answer for this level and for
 // level 0, mvf[] for this level and its parent; the chroma planes are picked by select, not by indexing.
-template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
-{
-    unsigned long long v = (unsigned long long) p;
-    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
-    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
-    return (T *) (((unsigned long long) hi << 32) | lo);
-}
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ DPlane uni(const DPlane &p) { return DPlane{uni_ptr(p.data), uni(p.stride), uni(p.w), uni(p.h)}; }
+// (uni / uni_ptr: dev.h)
 
 struct HmeCtx {
     struct Planes {
