@@ -968,6 +968,21 @@ __device__ __forceinline__ void neighbordif2_pre(const NbPre &p, int x, int y, i
     dy = abs(tx - cx) + abs(ty - cy);
 }
 
+// Sub-block sums of a WHOLE 16 x 16 block in 4:2:0 without the sixteen-entry transposing reduction: a sub-block is a set of lanes
+// that differ in fixed lane bits, so its sum is a butterfly over the OTHER bits and every lane ends up with its own sub-block's
+// total.  Luma (lane = qi | qj << 3, sub-block = {qi >= 4, qj >= 4} = lane bits 2 and 5): folds over bits 0, 1, 3, 4; the totals of
+// sub-blocks 0..3 sit on lanes 0, 4, 32, 36.  Chroma quads (lanes 0..31: plane = bit 4, cqi = lane & 3, cqj = (lane >> 2) & 3,
+// sub-block = {cqi >= 2, cqj >= 2} = bits 1 and 3): folds over bits 0 and 2; U's totals on lanes 0, 2, 8, 10, V's on 16, 18, 24, 26.
+// (Integer sums: any order gives the reference's value.)  ~12 instructions for the twelve sums the mode decision asks for, against
+// twelve selects and a ~46-instruction reduceN<16>.
+__device__ __forceinline__ int subblock_sums_luma(int v) { return fold_xor<16>(fold_xor<8>(fold_xor<2>(fold_xor<1>(v)))); }
+__device__ __forceinline__ int subblock_sums_chroma(int v) { return fold_xor<4>(fold_xor<1>(v)); }
+__device__ __forceinline__ unsigned max4_lanes(int r, int l0, int l1, int l2, int l3)
+{
+    return max(max((unsigned) __builtin_amdgcn_readlane(r, l0), (unsigned) __builtin_amdgcn_readlane(r, l1)),
+               max((unsigned) __builtin_amdgcn_readlane(r, l2), (unsigned) __builtin_amdgcn_readlane(r, l3)));
+}
+
 // level-0 tail of the block routine: sub-pel refinement + mode decision (hme.c:1598-1821)
 // (sp_done, sp_mr, sp_dirs): the pixel half of the FIRST sub-pel search (around the parent average), from the pre-pass
 // (subpel_probes; sp_done = it was run: effort >= 4 and the block at the parent average has a rim of four inside the padded plane)
@@ -1158,7 +1173,15 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
     // round 2: reference deviation + -- for the skip test -- the zero-motion sub-block metrics
     int ref_dev;
     unsigned zsub[3] = {0u, 0u, 0u};
-    if (skip_test) {
+    constexpr bool kWhole420 = CS == 1; // (with bw == bh == 16: a compile-time fact in the whole-block instantiation)
+    if (skip_test && kWhole420 && bw == 16 && bh == 16) {
+        ref_dev = wave_sum(quad_absdev(r, true, (int) avg_ref)) >> 1;
+        const int ys = subblock_sums_luma((int) qmetric(a, rz, psy));
+        const int cs_ = subblock_sums_chroma(lane < 32 ? (int) qmetric(cs, cz, psy) : 0);
+        zsub[0] = max4_lanes(ys, 0, 4, 32, 36);
+        zsub[1] = max4_lanes(cs_, 0, 2, 8, 10);
+        zsub[2] = max4_lanes(cs_, 16, 18, 24, 26);
+    } else if (skip_test) {
         v[0] = quad_absdev(r, act, (int) avg_ref);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1260,6 +1283,14 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
             if (y_prereq || c_prereq) {
                 HME_COUNT(S, 18, 1);
                 // round 3: sub-block metrics at the chosen full-pel motion (hme.c:1741)
+                unsigned bsub[3];
+                if (kWhole420 && bw == 16 && bh == 16) {
+                    const int ys = subblock_sums_luma((int) qmetric(a, r, psy));
+                    const int cs_ = subblock_sums_chroma(lane < 32 ? (int) qmetric(cs, cm, psy) : 0);
+                    bsub[0] = max4_lanes(ys, 0, 4, 32, 36) * ratio >> 5;
+                    bsub[1] = max4_lanes(cs_, 0, 2, 8, 10) * ratio >> 5;
+                    bsub[2] = max4_lanes(cs_, 16, 18, 24, 26) * ratio >> 5;
+                } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     v[k] = (act && kq == k) ? (int) qmetric(a, r, psy) : 0;
@@ -1276,12 +1307,12 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
                     v[12 + k] = 0;
                 }
                 R = reduceN<16>(v);
-                unsigned bsub[3];
 #pragma unroll
                 for (int z = 0; z < 3; z++) {
                     unsigned m0 = (unsigned) bcastN<16>(R, 4 * z), m1 = (unsigned) bcastN<16>(R, 4 * z + 1);
                     unsigned m2 = (unsigned) bcastN<16>(R, 4 * z + 2), m3 = (unsigned) bcastN<16>(R, 4 * z + 3);
                     bsub[z] = max(max(m0, m1), max(m2, m3)) * ratio >> 5;
+                }
                 }
                 unsigned xth = skipt * yarea;
                 int carea = 4 * cbw * cbh;
