@@ -1225,19 +1225,21 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
     ChromaPsy cpsy = chroma_analysis((int) avg_src, uavg_src, vavg_src);
     unsigned avg_y_dif = (unsigned) abs((int) avg_src - (int) avg_ref);
     unsigned avg_c_dif = (unsigned) AVG2(abs(uavg_src - uavg_ref), abs(vavg_src - vavg_ref));
-    int eprmi, eprmd, eprmr;
+    // expanded-range votes (hme.c:1790-1821): against the reference block here; against the reference's / the source's mean only if the
+    // block ends up intra (one block in 250 of the headline's content) -- worked out there
+    int eprmr;
     {
-        int as128 = (int) avg_src - 128, ar128 = (int) avg_ref - 128;
-        int ci = 0, cd = 0, cr = 0;
+        int cr = 0;
         if (act) {
             cr = (((a.p1() - r.p1()) + 128) | ((a.p2() - r.p2()) + 128) | ((a.p3() - r.p3()) + 128) | ((a.p4() - r.p4()) + 128)) & ~0xff;
-            ci = ((a.p1() - ar128) | (a.p2() - ar128) | (a.p3() - ar128) | (a.p4() - ar128)) & ~0xff;
-            cd = ((a.p1() - as128) | (a.p2() - as128) | (a.p3() - as128) | (a.p4() - as128)) & ~0xff;
         }
-        eprmi = __any(ci != 0) ? 1 : 0;
-        eprmd = __any(cd != 0) ? 1 : 0;
         eprmr = __any(cr != 0) ? 1 : 0;
     }
+    auto eprm_against_mean = [&](int mean) {
+        const int m128 = mean - 128;
+        const int cm_ = act ? (((a.p1() - m128) | (a.p2() - m128) | (a.p3() - m128) | (a.p4() - m128)) & ~0xff) : 0;
+        return __any(cm_ != 0) ? 1 : 0;
+    };
     bool oob;
     {
         int px = i * y_w + sarx(mv.u.mv.x, 2), py = j * y_h + sarx(mv.u.mv.y, 2);
@@ -1478,7 +1480,7 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
     int is_intra = 0;
     HME_COUNT(S, 24, (mv.flags & (1u << DSV_MV_BIT_INTRA)) ? 1 : 0);
     if (mv.flags & (1u << DSV_MV_BIT_INTRA)) {
-        int merged = (mv.dc & DSV_SRC_DC_PRED) ? eprmd : eprmi;
+        int merged = eprm_against_mean((mv.dc & DSV_SRC_DC_PRED) ? (int) avg_src : (int) avg_ref);
         if (mv.submask != DSV_MASK_ALL_INTRA) {
             merged |= eprmr;
         }
@@ -1488,8 +1490,8 @@ __device__ __forceinline__ void hme_l0_tail(const Ctx &c_in, int i, int j, FastL
         mv.u.mv.y = (int16_t) (fpely * 4);
     } else {
         int merged = eprmr;
-        if (mv.submask) {
-            merged |= eprmi;
+        if (mv.submask) { // (never: a sub-block mask sets the intra flag with it; kept as the reference has it, hme.c:1815)
+            merged |= eprm_against_mean((int) avg_ref);
         }
         mv.flags = (mv.flags & ~(1u << DSV_MV_BIT_EPRM)) | (merged ? (1u << DSV_MV_BIT_EPRM) : 0u);
     }
